@@ -1,0 +1,80 @@
+/*
+ * qnnpack_gfx950.h -- MI355X-specific extensions that sit BESIDE the unchanged
+ * qnnpack.h API. Nothing here is required by a drop-in caller; these entry
+ * points exist for callers that own device memory and streams (frameworks,
+ * bench.py, the parity tests).
+ *
+ * The reference has no counterpart for any of these: its only execution
+ * resource is the pthreadpool argument of qnnp_run_operator
+ * (include/qnnpack.h:327-329, src/operator-run.c:639), which this build ignores.
+ *
+ * All functions are plain C ABI: pointers and sizes only, no HIP types. A HIP
+ * stream is passed as the opaque `void*` value of a hipStream_t.
+ */
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "qnnpack.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Select the HIP device ordinal the library binds to. Must be called before
+ * qnnp_initialize (otherwise invalid_parameter). Default: env QNNP_GFX950_DEVICE,
+ * else the calling thread's current HIP device. One process drives one GPU;
+ * multi-GPU = one process per GPU with the batch sharded by the caller. */
+enum qnnp_status qnnp_gfx950_set_device(int device);
+int qnnp_gfx950_get_device(void);
+
+/* Stream all subsequent qnnp_run_operator launches (and host-pointer staging
+ * copies) are enqueued on. NULL = the device's default stream. */
+enum qnnp_status qnnp_gfx950_set_stream(void* hip_stream);
+
+/* async = 1: qnnp_run_operator only enqueues work and returns; the caller
+ * synchronises (qnnp_gfx950_synchronize or its own stream sync). Requires device
+ * pointers for input/output (host pointers force a synchronous staged run).
+ * async = 0 (default): reference semantics, outputs complete on return. */
+enum qnnp_status qnnp_gfx950_set_async(int async);
+enum qnnp_status qnnp_gfx950_synchronize(void);
+
+/* Device memory helpers for C callers without HIP headers. */
+void* qnnp_gfx950_malloc(size_t bytes);
+void qnnp_gfx950_free(void* device_ptr);
+enum qnnp_status qnnp_gfx950_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes);
+enum qnnp_status qnnp_gfx950_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes);
+enum qnnp_status qnnp_gfx950_memset(void* dst_device, int value, size_t bytes);
+
+/* Time `iters` back-to-back qnnp_run_operator launches of one operator with
+ * hipEvents recorded on the library's stream, after `warmup` untimed launches.
+ * Writes the AVERAGE milliseconds per launch. Device pointers only. */
+enum qnnp_status qnnp_gfx950_time_operator(
+    qnnp_operator_t op, int warmup, int iters, float* avg_ms_out);
+
+/* Same, but rotates through `nsets` (input, output) device buffer pairs between
+ * launches so the working set exceeds the 256 MiB Infinity Cache when an HBM
+ * bandwidth figure is claimed. inputs/outputs: arrays of nsets device pointers. */
+enum qnnp_status qnnp_gfx950_time_operator_rotating(
+    qnnp_operator_t op, size_t nsets, const void* const* inputs, void* const* outputs,
+    int warmup, int iters, float* avg_ms_out);
+
+/* Kernel-variant control for A/B measurement and tests. Keys:
+ *   "gemm_kernel":   0 = auto, 1 = generic MFMA implicit-GEMM kernel, 2 = 256x256 LDS-DMA MFMA kernel
+ *   "dwconv_kernel": 0 = auto, 1 = generic direct kernel, 2 = LDS-tiled kernel
+ * Unknown key -> invalid_parameter. Applies to operators set up afterwards. */
+enum qnnp_status qnnp_gfx950_set_option(const char* key, int value);
+
+/* Name of the HIP kernel the operator's last setup selected (static string), or
+ * NULL. Lets tests assert that the intended kernel actually ran. */
+const char* qnnp_gfx950_operator_kernel(qnnp_operator_t op);
+
+/* Device properties as seen by the library: gcnArchName copied into `arch`
+ * (NUL-terminated, truncated to arch_len), CU count, clock in kHz. */
+enum qnnp_status qnnp_gfx950_device_info(
+    char* arch, size_t arch_len, int* compute_units, int* clock_khz, size_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,114 @@
+/*
+ * oracle_q8.h -- CPU restatement ("O1") of QNNPACK's uint8 GEMM / conv2d /
+ * depthwise hot path, used ONLY as the checker for the gfx950 HIP path.
+ *
+ * TEST INFRASTRUCTURE. Nothing under qnnpack_amd/ (the product) may include,
+ * link or call this. Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * the pytorch/QNNPACK tree). The restatement is scalar on purpose: it follows
+ * the arithmetic the reference's own test harnesses use as ground truth
+ * (naive int32 accumulate, then qnnp_q31_requantize), not the SSE2/NEON
+ * microkernels.
+ *
+ * Parity pinning: tests/test_oracle_requant.py re-hosts the reference's
+ * deterministic known-answer tests (test/requantization-tester.h:84-246 as
+ * driven for Q31 in test/requantization.cc:250-296); tests/golden/ holds
+ * outputs of the compiled reference library (oracle/_ref, built from
+ * /root/reference by oracle/Makefile) on seeded inputs, which this oracle
+ * must reproduce byte-for-byte.
+ */
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/qnnpack/params.h:94-104 (scalar member of qnnp_q31_requantization_params) */
+struct oracle_q31_params {
+  int32_t multiplier;
+  int32_t remainder_mask;
+  int32_t remainder_threshold;
+  uint32_t shift;
+  int32_t min_less_zero_point;
+  int32_t max_less_zero_point;
+  int32_t zero_point;
+};
+
+/* src/qnnpack/requantization.h:22-54. Returns 0, or -1 if scale is outside
+ * [2^-32, 1) (the reference asserts). */
+int oracle_q31_params_init(
+    float scale, uint8_t zero_point, uint8_t qmin, uint8_t qmax,
+    struct oracle_q31_params* params);
+
+/* src/qnnpack/requantization.h:464-480 (normative rounding). */
+uint8_t oracle_q31_requantize(int32_t n, const struct oracle_q31_params* params);
+
+/* Same contract as qnnp_requantize_q31__scalar, src/requantization/q31-scalar.c:17-138. */
+int oracle_q31_requantize_array(
+    size_t n, const int32_t* input, float scale, uint8_t zero_point,
+    uint8_t qmin, uint8_t qmax, uint8_t* output);
+
+/* test/gemm-microkernel-tester.h:213-226 / test/fully-connected-operator-tester.h:133-146:
+ * acc[m*N + n] = bias[n] + sum_k (a[m*a_stride + k] - izp) * (w[n*K + k] - kzp). */
+void oracle_gemm_acc(
+    size_t M, size_t N, size_t K,
+    const uint8_t* a, size_t a_stride,
+    const uint8_t* w, const int32_t* bias,
+    uint8_t izp, uint8_t kzp, int32_t* acc);
+
+struct oracle_conv_shape {
+  size_t batch, input_height, input_width;
+  uint32_t pad_top, pad_right, pad_bottom, pad_left;
+  uint32_t kernel_height, kernel_width;
+  uint32_t stride_height, stride_width;
+  uint32_t dilation_height, dilation_width;
+  uint32_t groups;
+  size_t group_input_channels, group_output_channels;
+  size_t input_pixel_stride;
+};
+
+/* src/convolution.c:29-37 */
+size_t oracle_conv_output_dim(size_t padded_input, size_t kernel, size_t dilation, size_t stride);
+
+/* test/convolution-operator-tester.h:367-403 (7-loop direct convolution).
+ * kernel layout [g][oc][ky][kx][ic]; acc layout [n][oy][ox][g*GOC + oc]. */
+void oracle_conv2d_acc(
+    const struct oracle_conv_shape* s,
+    const uint8_t* input, const uint8_t* kernel, const int32_t* bias,
+    uint8_t izp, uint8_t kzp, int32_t* acc);
+
+/* Requantize a [rows][cols] accumulator matrix into out rows of out_stride bytes. */
+int oracle_requantize_rows(
+    size_t rows, size_t cols, const int32_t* acc,
+    float scale, uint8_t ozp, uint8_t omin, uint8_t omax,
+    uint8_t* out, size_t out_stride);
+
+/* Whole operators = the two steps above, with scale = in_scale*k_scale/out_scale
+ * (src/convolution.c:161, src/fully-connected.c:71). Return 0 / -1 (bad scale). */
+int oracle_fully_connected_q8(
+    size_t batch, size_t input_channels, size_t output_channels,
+    uint8_t izp, float input_scale, uint8_t kzp, float kernel_scale,
+    const uint8_t* kernel, const int32_t* bias,
+    uint8_t ozp, float output_scale, uint8_t omin, uint8_t omax,
+    const uint8_t* input, size_t input_stride,
+    uint8_t* output, size_t output_stride);
+
+int oracle_convolution2d_q8(
+    const struct oracle_conv_shape* s,
+    uint8_t izp, float input_scale, uint8_t kzp, float kernel_scale,
+    const uint8_t* kernel, const int32_t* bias,
+    uint8_t ozp, float output_scale, uint8_t omin, uint8_t omax,
+    const uint8_t* input, uint8_t* output, size_t output_pixel_stride);
+
+/* OpenMP thread count used by the loops above (cpu_baseline "cores"). */
+void oracle_set_threads(int n);
+int oracle_get_threads(void);
+
+#ifdef __cplusplus
+}
+#endif

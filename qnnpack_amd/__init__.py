@@ -1,0 +1,61 @@
+"""qnnpack_amd -- MI355X (gfx950) native build of QNNPACK's uint8 conv/GEMM hot path.
+
+The product is the C-ABI shared library ``libqnnpack_gfx950.so`` (plain-C host
+code + hand-written HIP kernels, sources under ``qnnpack_amd/csrc``) exporting
+the reference's ``include/qnnpack.h`` entry points. This Python package is only
+the thin ctypes loader used by tests, ``bench.py`` and ``__graft_entry__.py``.
+
+There is no CPU fallback anywhere in this package: if the library has not been
+built, or no gfx950 device is usable, loading / ``qnnp_initialize`` fails loudly.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+from .binding import Gfx950Library, QnnpackError, QnnpackLibrary, Status, address_of
+
+__all__ = [
+    "Gfx950Library", "QnnpackLibrary", "QnnpackError", "Status", "address_of",
+    "library_path", "build", "load",
+]
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libqnnpack_gfx950.so"
+_loaded = None
+
+
+def library_path() -> str:
+    return os.path.join(_PKG_DIR, _LIB_NAME)
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the C host code and the gfx950 HIP kernels in-tree (needs hipcc, no GPU)."""
+    cmd = ["make", "-C", os.path.join(_PKG_DIR, "csrc"), "-j8"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        sys.stderr.write(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError(f"building {_LIB_NAME} failed (exit {res.returncode})")
+    return library_path()
+
+
+def load() -> Gfx950Library:
+    """Load the built product library (once per process).
+
+    If torch is already imported its bundled HIP runtime (same SONAME) is
+    resident and the library binds to it, so torch device tensors and this
+    library share one HIP context. Otherwise the ROCm runtime from the library's
+    rpath (/opt/rocm/lib) is used.
+    """
+    global _loaded
+    if _loaded is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: the HIP extension has not been built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C qnnpack_amd/csrc`. "
+                "There is no CPU fallback.")
+        _loaded = Gfx950Library(path)
+    return _loaded

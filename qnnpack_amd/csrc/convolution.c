@@ -1,0 +1,396 @@
+/*
+ * convolution.c -- qnnp_create_convolution2d_nhwc_q8 / qnnp_setup_convolution2d_nhwc_q8
+ * for the gfx950 build.
+ *
+ * Replaces reference src/convolution.c:39-378 (create) and :380-492 (setup):
+ * same argument validation and status codes, same operator-type selection idea,
+ * but the products of create/setup are device-resident:
+ *   create: weights re-laid-out as MFMA operand fragments (or a tap-major int16
+ *           image for depthwise) with both zero points folded into an int32 bias,
+ *           uploaded once; Q31 requantization parameters.
+ *   setup : output geometry; for general convolutions a batch-invariant int32
+ *           offset table (pixel x tap -> byte offset inside one image, -1 = padding)
+ *           instead of the reference's per-image table of absolute host pointers
+ *           (src/indirection.c:18-79) -- im2col is never materialised and the
+ *           table does not depend on the input pointer or the batch size.
+ */
+#include <math.h>
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <qnnpack.h>
+
+#include "hip/qnnp_hip.h"
+#include "indirection.h"
+#include "log.h"
+#include "operator.h"
+#include "pack.h"
+#include "requantization.h"
+#include "state.h"
+
+/* reference src/convolution.c:29-37 */
+static inline size_t compute_output_dimension(
+    size_t padded_input, size_t kernel, size_t dilation, size_t subsampling)
+{
+  const size_t effective_kernel = (kernel - 1) * dilation + 1;
+  return (padded_input - effective_kernel) / subsampling + 1;
+}
+
+static inline bool scale_is_valid(float scale)
+{
+  return scale > 0.0f && isnormal(scale);
+}
+
+enum qnnp_status qnnp_create_convolution2d_nhwc_q8(
+    uint32_t input_padding_top,
+    uint32_t input_padding_right,
+    uint32_t input_padding_bottom,
+    uint32_t input_padding_left,
+    uint32_t kernel_height,
+    uint32_t kernel_width,
+    uint32_t subsampling_height,
+    uint32_t subsampling_width,
+    uint32_t dilation_height,
+    uint32_t dilation_width,
+    uint32_t groups,
+    size_t group_input_channels,
+    size_t group_output_channels,
+    uint8_t input_zero_point,
+    float input_scale,
+    uint8_t kernel_zero_point,
+    float kernel_scale,
+    const uint8_t* kernel,
+    const int32_t* bias,
+    uint8_t output_zero_point,
+    float output_scale,
+    uint8_t output_min,
+    uint8_t output_max,
+    uint32_t flags,
+    qnnp_operator_t* convolution_out)
+{
+  (void) flags; /* accepted and ignored, as in the reference (convolution.c:63) */
+  qnnp_operator_t op = NULL;
+  void* host_weights = NULL;
+  int32_t* host_bias = NULL;
+  enum qnnp_status status = qnnp_status_uninitialized;
+
+  /* reference convolution.c:69-72 */
+  if (!qnnp_state.initialized) {
+    qnnp_log_error("qnnp_create_convolution2d_nhwc_q8 failed because QNNPACK is not properly initialized");
+    goto error;
+  }
+
+  /* reference convolution.c:74-115 */
+  status = qnnp_status_invalid_parameter;
+  if (kernel_width == 0 || kernel_height == 0) {
+    qnnp_log_error("failed to create convolution with %" PRIu32 "x%" PRIu32 " kernel: kernel dimensions must be non-zero",
+        kernel_width, kernel_height);
+    goto error;
+  }
+  if (subsampling_width == 0 || subsampling_height == 0) {
+    qnnp_log_error("failed to create convolution with %" PRIu32 "x%" PRIu32 " subsampling: subsampling dimensions must be non-zero",
+        subsampling_width, subsampling_height);
+    goto error;
+  }
+  if (dilation_width == 0 || dilation_height == 0) {
+    qnnp_log_error("failed to create convolution with %" PRIu32 "x%" PRIu32 " dilation: dilation dimensions must be non-zero",
+        dilation_width, dilation_height);
+    goto error;
+  }
+  if (!scale_is_valid(input_scale)) {
+    qnnp_log_error("failed to create convolution with %.7g input scale: scale must be finite and positive", input_scale);
+    goto error;
+  }
+  if (!scale_is_valid(kernel_scale)) {
+    qnnp_log_error("failed to create convolution with %.7g kernel scale: scale must be finite and positive", kernel_scale);
+    goto error;
+  }
+  if (!scale_is_valid(output_scale)) {
+    qnnp_log_error("failed to create convolution with %.7g output scale: scale must be finite and positive", output_scale);
+    goto error;
+  }
+  if (groups == 0 || group_input_channels == 0 || group_output_channels == 0 || kernel == NULL || bias == NULL) {
+    qnnp_log_error("failed to create convolution: groups, channel counts, kernel and bias must be non-zero");
+    goto error;
+  }
+
+  /* reference convolution.c:117-168 (the "inefficiency" notes are informational there) */
+  status = qnnp_status_unsupported_parameter;
+  const float convolution_scale = input_scale * kernel_scale / output_scale;
+  if (convolution_scale >= 1.0f) {
+    qnnp_log_error(
+        "failed to create convolution with %.7g input scale, %.7g kernel scale, and %.7g output scale: "
+        "convolution scale %.7g is greater or equal to 1.0",
+        input_scale, kernel_scale, output_scale, convolution_scale);
+    goto error;
+  }
+  if (!(convolution_scale >= 0x1.0p-32f)) {
+    /* the reference's parameter builder asserts this range (requantization.h:28, :139) */
+    qnnp_log_error("failed to create convolution: convolution scale %.7g is below 2**-32", convolution_scale);
+    goto error;
+  }
+  const size_t kernel_size = (size_t) kernel_height * kernel_width;
+  if (kernel_size * group_input_channels > (size_t) UINT32_MAX / 4 ||
+      (size_t) groups * group_output_channels > (size_t) UINT32_MAX / 4) {
+    qnnp_log_error("failed to create convolution: channel / kernel extents exceed the 32-bit index range of the device kernels");
+    goto error;
+  }
+
+  status = qnnp_status_out_of_memory;
+  op = calloc(1, sizeof(struct qnnp_operator));
+  if (op == NULL) {
+    qnnp_log_error("failed to allocate %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
+    goto error;
+  }
+
+  /*
+   * Operator-type selection. Reference convolution.c:180-189 sends 3x3 / 5x5
+   * depthwise to dwconv, unpadded stride-1 1x1 to gemm and the rest to conv.
+   * The device depthwise kernel is not limited to 9 or 25 taps, so every
+   * depthwise convolution (one input and one output channel per group) takes
+   * it; results are identical, only the kernel differs.
+   */
+  const bool any_padding =
+      (input_padding_left | input_padding_top | input_padding_right | input_padding_bottom) != 0;
+  enum qnnp_ukernel_type ukernel_type;
+  if (group_input_channels == 1 && group_output_channels == 1 && groups > 1) {
+    ukernel_type = qnnp_ukernel_type_dwconv;
+  } else if (kernel_size == 1 && subsampling_height == 1 && subsampling_width == 1 && !any_padding) {
+    ukernel_type = qnnp_ukernel_type_gemm;
+  } else {
+    ukernel_type = qnnp_ukernel_type_conv;
+  }
+
+  if (ukernel_type == qnnp_ukernel_type_dwconv) {
+    const uint32_t c_pad = qnnp_round_up_u32(groups, 16);
+    const size_t w_bytes = sizeof(int16_t) * kernel_size * c_pad;
+    const size_t b_bytes = sizeof(int32_t) * c_pad;
+    host_weights = malloc(w_bytes);
+    host_bias = malloc(b_bytes);
+    if (host_weights == NULL || host_bias == NULL) {
+      qnnp_log_error("failed to allocate %zu bytes for packed weights", w_bytes + b_bytes);
+      goto error;
+    }
+    qnnp_pack_dwconv_w(groups, c_pad, kernel_height, kernel_width,
+        input_zero_point, kernel_zero_point, kernel, bias, (int16_t*) host_weights, host_bias);
+    op->c_pad = c_pad;
+    op->d_weights = qnnp_hip_alloc(w_bytes);
+    op->d_bias = (int32_t*) qnnp_hip_alloc(b_bytes);
+    if (op->d_weights == NULL || op->d_bias == NULL ||
+        qnnp_hip_h2d(op->d_weights, host_weights, w_bytes, 0) != QNNP_HIP_OK ||
+        qnnp_hip_h2d(op->d_bias, host_bias, b_bytes, 0) != QNNP_HIP_OK) {
+      qnnp_log_error("failed to place %zu bytes of packed depthwise weights on the device", w_bytes + b_bytes);
+      goto error;
+    }
+  } else {
+    const uint32_t k_total = (uint32_t) (kernel_size * group_input_channels);
+    const uint32_t n_pad = qnnp_round_up_u32((uint32_t) group_output_channels, 32);
+    const uint32_t k_pad = qnnp_round_up_u32(k_total, 64);
+    const size_t w_bytes = qnnp_igemm_packed_weights_size(groups, n_pad, k_pad);
+    const size_t b_bytes = sizeof(int32_t) * (size_t) groups * n_pad;
+    host_weights = malloc(w_bytes);
+    host_bias = malloc(b_bytes);
+    if (host_weights == NULL || host_bias == NULL) {
+      qnnp_log_error("failed to allocate %zu bytes for packed weights", w_bytes + b_bytes);
+      goto error;
+    }
+    qnnp_pack_igemm_w(groups, (uint32_t) group_output_channels, k_total, n_pad, k_pad,
+        input_zero_point, kernel_zero_point, kernel, bias, (int8_t*) host_weights, host_bias);
+    op->n_pad = n_pad;
+    op->k_pad = k_pad;
+    op->d_weights = qnnp_hip_alloc(w_bytes);
+    op->d_bias = (int32_t*) qnnp_hip_alloc(b_bytes);
+    if (op->d_weights == NULL || op->d_bias == NULL ||
+        qnnp_hip_h2d(op->d_weights, host_weights, w_bytes, 0) != QNNP_HIP_OK ||
+        qnnp_hip_h2d(op->d_bias, host_bias, b_bytes, 0) != QNNP_HIP_OK) {
+      qnnp_log_error("failed to place %zu bytes of packed weights on the device", w_bytes + b_bytes);
+      goto error;
+    }
+  }
+  free(host_weights);
+  free(host_bias);
+  host_weights = NULL;
+  host_bias = NULL;
+
+  op->input_padding_top = input_padding_top;
+  op->input_padding_right = input_padding_right;
+  op->input_padding_bottom = input_padding_bottom;
+  op->input_padding_left = input_padding_left;
+  op->kernel_height = kernel_height;
+  op->kernel_width = kernel_width;
+  op->stride_height = subsampling_height;
+  op->stride_width = subsampling_width;
+  op->dilation_height = dilation_height;
+  op->dilation_width = dilation_width;
+  op->groups = groups;
+  op->group_input_channels = group_input_channels;
+  op->group_output_channels = group_output_channels;
+  op->input_zero_point = input_zero_point;
+  op->kernel_zero_point = kernel_zero_point;
+  op->requant = qnnp_compute_requant(convolution_scale, output_zero_point, output_min, output_max);
+  op->ukernel_type = ukernel_type;
+
+  /* reference convolution.c:372: the handle is written only on success */
+  *convolution_out = op;
+  return qnnp_status_success;
+
+error:
+  free(host_weights);
+  free(host_bias);
+  qnnp_delete_operator(op);
+  return status;
+}
+
+/* Decide where a caller pointer lives and (re)size the staging buffer that a
+ * host pointer needs. Returns 0 on success. */
+static int bind_endpoint(const void* ptr, size_t span, int* on_device, void** stage, size_t* capacity)
+{
+  *on_device = qnnp_hip_is_device_pointer(ptr);
+  if (*on_device) return 0;
+  if (*capacity < span) {
+    qnnp_hip_free(*stage);
+    *capacity = 0;
+    *stage = qnnp_hip_alloc(span);
+    if (*stage == NULL) return -1;
+    *capacity = span;
+  }
+  return 0;
+}
+
+enum qnnp_status qnnp_setup_convolution2d_nhwc_q8(
+    qnnp_operator_t op,
+    size_t batch_size,
+    size_t input_height,
+    size_t input_width,
+    const uint8_t* input,
+    size_t input_pixel_stride,
+    uint8_t* output,
+    size_t output_pixel_stride,
+    pthreadpool_t threadpool)
+{
+  (void) threadpool; /* unused by the reference's setup too (convolution.c:389) */
+
+  /* reference convolution.c:391-394 */
+  if (!qnnp_state.initialized) {
+    qnnp_log_error("qnnp_setup_convolution2d_nhwc_q8 failed because QNNPACK is not properly initialized");
+    return qnnp_status_uninitialized;
+  }
+  if (op == NULL) {
+    return qnnp_status_invalid_parameter;
+  }
+
+  /* reference convolution.c:396-399 */
+  if (batch_size == 0) {
+    op->batch_size = 0;
+    return qnnp_status_success;
+  }
+
+  /* reference convolution.c:401-407 */
+  if (input_width == 0 || input_height == 0) {
+    qnnp_log_error("failed to setup convolution with %zux%zu input: input dimensions must be non-zero",
+        input_width, input_height);
+    return qnnp_status_invalid_parameter;
+  }
+  const size_t in_channels = (size_t) op->groups * op->group_input_channels;
+  const size_t out_channels = (size_t) op->groups * op->group_output_channels;
+  if (input == NULL || output == NULL || input_pixel_stride < in_channels || output_pixel_stride < out_channels) {
+    qnnp_log_error("failed to setup convolution: NULL tensor or pixel stride smaller than the channel count");
+    return qnnp_status_invalid_parameter;
+  }
+  const size_t eff_kh = (size_t) (op->kernel_height - 1) * op->dilation_height + 1;
+  const size_t eff_kw = (size_t) (op->kernel_width - 1) * op->dilation_width + 1;
+  if (op->input_padding_top + input_height + op->input_padding_bottom < eff_kh ||
+      op->input_padding_left + input_width + op->input_padding_right < eff_kw) {
+    qnnp_log_error("failed to setup convolution with %zux%zu input: padded input is smaller than the dilated kernel",
+        input_width, input_height);
+    return qnnp_status_invalid_parameter;
+  }
+
+  /* reference convolution.c:409-426 */
+  op->batch_size = batch_size;
+  op->input_height = input_height;
+  op->input_width = input_width;
+  op->input = input;
+  op->input_pixel_stride = input_pixel_stride;
+  op->output_height = compute_output_dimension(
+      op->input_padding_top + input_height + op->input_padding_bottom,
+      op->kernel_height, op->dilation_height, op->stride_height);
+  op->output_width = compute_output_dimension(
+      op->input_padding_left + input_width + op->input_padding_right,
+      op->kernel_width, op->dilation_width, op->stride_width);
+  op->output = output;
+  op->output_pixel_stride = output_pixel_stride;
+
+  const size_t output_size = op->output_height * op->output_width;
+  const size_t input_size = input_height * input_width;
+  if (batch_size * output_size > (size_t) UINT32_MAX / 2 || input_size * input_pixel_stride > (size_t) INT32_MAX) {
+    qnnp_log_error("failed to setup convolution: %zu output pixels / %zu-byte images exceed the device kernels' index range",
+        batch_size * output_size, input_size * input_pixel_stride);
+    return qnnp_status_unsupported_parameter;
+  }
+
+  op->input_span = (batch_size * input_size - 1) * input_pixel_stride + in_channels;
+  op->output_span = (batch_size * output_size - 1) * output_pixel_stride + out_channels;
+  if (bind_endpoint(input, op->input_span, &op->input_on_device, &op->d_stage_in, &op->stage_in_capacity) != 0 ||
+      bind_endpoint(output, op->output_span, &op->output_on_device, &op->d_stage_out, &op->stage_out_capacity) != 0) {
+    qnnp_log_error("failed to allocate device staging for host tensors (%zu + %zu bytes)",
+        op->input_span, op->output_span);
+    return qnnp_status_out_of_memory;
+  }
+
+  switch (op->ukernel_type) {
+    case qnnp_ukernel_type_gemm:
+      /* maps directly to GEMM, no table (reference convolution.c:429-431) */
+      op->variant = qnnp_state.opt_gemm_kernel;
+      return qnnp_status_success;
+    case qnnp_ukernel_type_dwconv:
+      /* the depthwise kernels derive tap coordinates arithmetically */
+      op->variant = qnnp_state.opt_dwconv_kernel;
+      return qnnp_status_success;
+    case qnnp_ukernel_type_conv:
+    {
+      op->variant = qnnp_state.opt_gemm_kernel;
+      const size_t kernel_size = (size_t) op->kernel_height * op->kernel_width;
+      const size_t entries = output_size * kernel_size;
+      const bool same_geometry = op->d_offsets != NULL &&
+          op->offsets_in_h == input_height && op->offsets_in_w == input_width &&
+          op->offsets_in_stride == input_pixel_stride;
+      if (same_geometry) {
+        return qnnp_status_success;  /* table is pointer- and batch-invariant */
+      }
+      int32_t* host_table = (int32_t*) malloc(sizeof(int32_t) * entries);
+      if (host_table == NULL) {
+        qnnp_log_error("failed to allocate %zu bytes for the offset table", sizeof(int32_t) * entries);
+        return qnnp_status_out_of_memory;
+      }
+      if (op->offsets_capacity < entries) {
+        qnnp_hip_free(op->d_offsets);
+        op->offsets_capacity = 0;
+        op->d_offsets = (int32_t*) qnnp_hip_alloc(sizeof(int32_t) * entries);
+        if (op->d_offsets == NULL) {
+          free(host_table);
+          qnnp_log_error("failed to allocate %zu bytes for the device offset table", sizeof(int32_t) * entries);
+          return qnnp_status_out_of_memory;
+        }
+        op->offsets_capacity = entries;
+      }
+      qnnp_indirection_init_conv2d_offsets(op, host_table);
+      const int rc = qnnp_hip_h2d(op->d_offsets, host_table, sizeof(int32_t) * entries, 0);
+      free(host_table);
+      if (rc != QNNP_HIP_OK) {
+        op->offsets_in_h = 0;
+        qnnp_log_error("failed to upload the offset table");
+        return qnnp_status_out_of_memory;
+      }
+      op->offsets_in_h = input_height;
+      op->offsets_in_w = input_width;
+      op->offsets_in_stride = input_pixel_stride;
+      return qnnp_status_success;
+    }
+    default:
+      return qnnp_status_invalid_parameter;
+  }
+}

@@ -1,0 +1,67 @@
+/*
+ * debug-hooks.c -- exports the create/setup-time HOST logic (weight packing,
+ * offset-table construction, requantization parameters) as plain C-ABI functions
+ * so the CPU-only test tier can check it without a GPU (tests/test_host_logic.py
+ * replays the device kernels' documented index arithmetic in numpy on these
+ * images and compares with the oracle). No compute path uses these entry points.
+ *
+ * Reference counterparts of the logic under test: src/qnnpack/pack.h:12-91,
+ * 135-167; src/indirection.c:18-79; src/qnnpack/requantization.h:122-198.
+ */
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "indirection.h"
+#include "operator.h"
+#include "pack.h"
+#include "requantization.h"
+
+void qnnp_debug_pack_igemm_w(
+    uint32_t groups, uint32_t n, uint32_t k_total, uint32_t n_pad, uint32_t k_pad,
+    uint8_t izp, uint8_t kzp, const uint8_t* kernel, const int32_t* bias,
+    int8_t* packed, int32_t* bias2)
+{
+  qnnp_pack_igemm_w(groups, n, k_total, n_pad, k_pad, izp, kzp, kernel, bias, packed, bias2);
+}
+
+void qnnp_debug_pack_dwconv_w(
+    uint32_t channels, uint32_t c_pad, uint32_t kh, uint32_t kw,
+    uint8_t izp, uint8_t kzp, const uint8_t* kernel, const int32_t* bias,
+    int16_t* wadj, int32_t* bias1)
+{
+  qnnp_pack_dwconv_w(channels, c_pad, kh, kw, izp, kzp, kernel, bias, wadj, bias1);
+}
+
+void qnnp_debug_conv2d_offsets(
+    size_t input_height, size_t input_width, size_t input_pixel_stride,
+    size_t output_height, size_t output_width,
+    uint32_t kernel_height, uint32_t kernel_width,
+    uint32_t stride_height, uint32_t stride_width,
+    uint32_t dilation_height, uint32_t dilation_width,
+    uint32_t pad_top, uint32_t pad_left,
+    int32_t* table)
+{
+  struct qnnp_operator op;
+  memset(&op, 0, sizeof(op));
+  op.input_height = input_height;
+  op.input_width = input_width;
+  op.input_pixel_stride = input_pixel_stride;
+  op.output_height = output_height;
+  op.output_width = output_width;
+  op.kernel_height = kernel_height;
+  op.kernel_width = kernel_width;
+  op.stride_height = stride_height;
+  op.stride_width = stride_width;
+  op.dilation_height = dilation_height;
+  op.dilation_width = dilation_width;
+  op.input_padding_top = pad_top;
+  op.input_padding_left = pad_left;
+  qnnp_indirection_init_conv2d_offsets(&op, table);
+}
+
+void qnnp_debug_compute_requant(
+    float scale, uint8_t zero_point, uint8_t qmin, uint8_t qmax, struct qnnp_hip_requant* out)
+{
+  *out = qnnp_compute_requant(scale, zero_point, qmin, qmax);
+}

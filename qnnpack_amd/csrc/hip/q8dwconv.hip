@@ -1,0 +1,313 @@
+/*
+ * q8dwconv.hip -- uint8 depthwise convolution, NHWC, fused Q31 requantization.
+ *
+ * Replaces, as whole-operator launches, the reference's per-output-row CPU
+ * microkernels
+ *   q8dwconv_ukernel_up8x9__sse2  (src/q8dwconv/up8x9-sse2.c:14-372, 3x3 unipass)
+ *   q8dwconv_ukernel_mp8x25__sse2 (src/q8dwconv/mp8x25-sse2.c:14-742, 5x5 multipass)
+ * their pthreadpool fan-out compute_dwconv_unipass / _multiipass
+ * (src/operator-run.c:238-284, 675-679) and the pointer indirection buffer of
+ * qnnp_indirection_init_dwconv2d (src/indirection.c:81-132), which is not needed:
+ * tap coordinates are computed in-kernel.
+ *
+ * Arithmetic (exact int32, same folding as pack_q8dw_w, src/qnnpack/pack.h:146-159):
+ *   out[c] = requant( bias1[c] + sum_taps a(tap, c) * (w(tap, c) - kzp) ),
+ *   bias1 = bias + taps*izp*kzp - izp*sum_taps w,   padding taps read a = izp.
+ *
+ * This is not a dense contraction (one input channel per output channel), so it
+ * does not go to the matrix cores; it is an HBM-streaming kernel whose work is
+ * the coalesced NHWC traffic plus the per-element requantization.
+ *
+ * Kernel A  q8_dwconv_lds_kernel<KH, KW, VECL>   (3x3 and 5x5, C % 4 == 0)
+ *   workgroup = one image x a band of output rows x all output columns x a channel
+ *   slab. The input band (with halo, padding materialised as the zero point) is
+ *   staged into LDS with 16-byte (or 4-byte) coalesced loads along C; each thread
+ *   owns one 4-channel group (its tap weights live in registers as int16 pairs)
+ *   and walks output positions, reading dwords from LDS, pairing taps with
+ *   v_perm_b32 and accumulating two taps per v_dot2_i32_i16; one coalesced dword
+ *   store of 4 requantized channels per position.
+ *
+ * Kernel B  q8_dwconv_direct_kernel   (any kernel size / channel count / stride)
+ *   one thread per output element, channels fastest; byte loads through L1/L2.
+ *   Correctness fallback for shapes kernel A does not take.
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "qnnp_hip.h"
+#include "requant.cuh"
+
+extern "C" void* qnnp_hip_get_stream(void);
+
+namespace {
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+struct DwParams {
+  const uint8_t* input;
+  uint8_t* output;
+  const int16_t* wadj;
+  const int32_t* bias1;
+  uint32_t batch;
+  uint32_t H, W, OH, OW;
+  uint32_t C, c_pad;
+  uint32_t KH, KW;
+  uint32_t sh, sw, dh, dw;
+  uint32_t pad_top, pad_left;
+  uint32_t in_stride, out_stride;
+  uint32_t izp;
+  // LDS-tiled kernel geometry
+  uint32_t CS;        // channels per slab (multiple of 4, divides C)
+  uint32_t TOH;       // output rows per band
+  uint32_t IR, IC;    // staged input rows / columns per band
+  uint32_t bands;     // ceil(OH / TOH)
+  uint32_t slabs;     // C / CS
+  qnnp_hip_requant rq;
+};
+
+// --------------------------------------------------------------------------
+// Kernel B: generic direct
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void q8_dwconv_direct_kernel(const DwParams p)
+{
+  const uint64_t total = static_cast<uint64_t>(p.batch) * p.OH * p.OW * p.C;
+  for (uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+       idx += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const uint32_t c = static_cast<uint32_t>(idx % p.C);
+    const uint64_t pix = idx / p.C;
+    const uint32_t ox = static_cast<uint32_t>(pix % p.OW);
+    const uint64_t t = pix / p.OW;
+    const uint32_t oy = static_cast<uint32_t>(t % p.OH);
+    const uint32_t n = static_cast<uint32_t>(t / p.OH);
+    int32_t acc = p.bias1[c];
+    for (uint32_t ky = 0; ky < p.KH; ky++) {
+      const uint32_t iy = oy * p.sh + ky * p.dh - p.pad_top;   // unsigned wrap = out of range
+      for (uint32_t kx = 0; kx < p.KW; kx++) {
+        const uint32_t ix = ox * p.sw + kx * p.dw - p.pad_left;
+        int32_t a = static_cast<int32_t>(p.izp);
+        if (iy < p.H && ix < p.W) {
+          a = p.input[((static_cast<uint64_t>(n) * p.H + iy) * p.W + ix) * p.in_stride + c];
+        }
+        acc += a * static_cast<int32_t>(p.wadj[(ky * p.KW + kx) * p.c_pad + c]);
+      }
+    }
+    p.output[pix * p.out_stride + c] = static_cast<uint8_t>(qnnp::q31_requantize(acc, p.rq));
+  }
+}
+
+// --------------------------------------------------------------------------
+// Kernel A: LDS-tiled
+// --------------------------------------------------------------------------
+constexpr int kDwThreads = 512;
+
+template <int KH, int KW, int VECL>
+__global__ __launch_bounds__(kDwThreads)
+void q8_dwconv_lds_kernel(const DwParams p)
+{
+  constexpr int TAPS = KH * KW;
+  constexpr int PAIRS = (TAPS + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) uint8_t tile[];   // [IR][IC][CS]
+
+  const uint32_t tid = threadIdx.x;
+  // block -> (image, band, slab); slab fastest so that the blocks sharing input
+  // cache lines (same pixels, neighbouring channel slabs) are dispatched together
+  uint32_t b = blockIdx.x;
+  const uint32_t slab = b % p.slabs; b /= p.slabs;
+  const uint32_t band = b % p.bands;
+  const uint32_t n = b / p.bands;
+  const uint32_t c0 = slab * p.CS;
+  const uint32_t oy0 = band * p.TOH;
+  const uint32_t toh = min(p.TOH, p.OH - oy0);
+  const uint32_t ir = (toh - 1) * p.sh + (KH - 1) * p.dh + 1;   // rows actually needed
+
+  // ---- stage the input band: coalesced VECL-byte vectors along C ----
+  {
+    const uint32_t vpp = p.CS / VECL;                 // vectors per pixel
+    const uint32_t nvec = ir * p.IC * vpp;
+    const int32_t iy_base = static_cast<int32_t>(oy0 * p.sh) - static_cast<int32_t>(p.pad_top);
+    const int32_t ix_base = -static_cast<int32_t>(p.pad_left);
+    const uint8_t* img = p.input + static_cast<uint64_t>(n) * p.H * p.W * p.in_stride + c0;
+    const uint32_t fill = p.izp * 0x01010101u;
+    for (uint32_t v = tid; v < nvec; v += kDwThreads) {
+      const uint32_t cv = v % vpp;
+      const uint32_t px = v / vpp;
+      const uint32_t ixl = px % p.IC;
+      const uint32_t iyl = px / p.IC;
+      const int32_t iy = iy_base + static_cast<int32_t>(iyl);
+      const int32_t ix = ix_base + static_cast<int32_t>(ixl);
+      const bool inb = iy >= 0 && iy < static_cast<int32_t>(p.H) && ix >= 0 && ix < static_cast<int32_t>(p.W);
+      uint8_t* dst = tile + (iyl * p.IC + ixl) * p.CS + cv * VECL;
+      const uint8_t* src = img;   // only dereferenced in bounds
+      if (inb) {
+        src += (static_cast<uint64_t>(static_cast<uint32_t>(iy)) * p.W + static_cast<uint32_t>(ix)) * p.in_stride + cv * VECL;
+      }
+      if constexpr (VECL == 16) {
+        uint4 val = make_uint4(fill, fill, fill, fill);
+        if (inb) val = *reinterpret_cast<const uint4*>(src);
+        *reinterpret_cast<uint4*>(dst) = val;
+      } else {
+        uint32_t val = fill;
+        if (inb) val = *reinterpret_cast<const uint32_t*>(src);
+        *reinterpret_cast<uint32_t*>(dst) = val;
+      }
+    }
+  }
+
+  // ---- per-thread channel group: weights as (tap 2i, tap 2i+1) int16 pairs ----
+  const uint32_t q4 = p.CS / 4;                 // 4-channel groups in the slab
+  const uint32_t nslots = kDwThreads / q4;      // positions processed concurrently
+  const uint32_t c4 = tid % q4;
+  const uint32_t slot = tid / q4;
+  const bool active = slot < nslots;
+  const uint32_t cg = c0 + c4 * 4;              // first global channel of this thread
+
+  uint32_t wpair[PAIRS][4];
+  int32_t bias[4];
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < PAIRS; i++) {
+      const uint2 lo = *reinterpret_cast<const uint2*>(p.wadj + (2 * i) * p.c_pad + cg);   // 4 x int16
+      uint2 hi = make_uint2(0u, 0u);
+      if (2 * i + 1 < TAPS) hi = *reinterpret_cast<const uint2*>(p.wadj + (2 * i + 1) * p.c_pad + cg);
+      wpair[i][0] = (lo.x & 0xFFFFu) | (hi.x << 16);
+      wpair[i][1] = (lo.x >> 16) | (hi.x & 0xFFFF0000u);
+      wpair[i][2] = (lo.y & 0xFFFFu) | (hi.y << 16);
+      wpair[i][3] = (lo.y >> 16) | (hi.y & 0xFFFF0000u);
+    }
+    const int4 bv = *reinterpret_cast<const int4*>(p.bias1 + cg);
+    bias[0] = bv.x; bias[1] = bv.y; bias[2] = bv.z; bias[3] = bv.w;
+  }
+
+  __syncthreads();
+  if (!active) return;
+
+  const uint32_t npos = toh * p.OW;
+  uint8_t* out_img = p.output + (static_cast<uint64_t>(n) * p.OH + oy0) * p.OW * p.out_stride + cg;
+  for (uint32_t pos = slot; pos < npos; pos += nslots) {
+    const uint32_t oyl = pos / p.OW;
+    const uint32_t ox = pos - oyl * p.OW;
+    const uint8_t* base = tile + ((oyl * p.sh) * p.IC + ox * p.sw) * p.CS + c4 * 4;
+    int32_t acc0 = bias[0], acc1 = bias[1], acc2 = bias[2], acc3 = bias[3];
+#pragma unroll
+    for (int i = 0; i < PAIRS; i++) {
+      const int t0 = 2 * i, t1 = 2 * i + 1;
+      const uint32_t in0 = *reinterpret_cast<const uint32_t*>(
+          base + (((t0 / KW) * p.dh) * p.IC + (t0 % KW) * p.dw) * p.CS);
+      uint32_t in1 = 0u;
+      if (t1 < TAPS) {
+        in1 = *reinterpret_cast<const uint32_t*>(
+            base + (((t1 / KW) * p.dh) * p.IC + (t1 % KW) * p.dw) * p.CS);
+      }
+      // v_perm_b32: result bytes {in0.c, 0, in1.c, 0} = the two taps of channel c as int16 x2
+      const uint32_t p0 = __builtin_amdgcn_perm(in1, in0, 0x0c040c00u);
+      const uint32_t p1 = __builtin_amdgcn_perm(in1, in0, 0x0c050c01u);
+      const uint32_t p2 = __builtin_amdgcn_perm(in1, in0, 0x0c060c02u);
+      const uint32_t p3 = __builtin_amdgcn_perm(in1, in0, 0x0c070c03u);
+      acc0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p0), __builtin_bit_cast(v2s, wpair[i][0]), acc0, false);
+      acc1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p1), __builtin_bit_cast(v2s, wpair[i][1]), acc1, false);
+      acc2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p2), __builtin_bit_cast(v2s, wpair[i][2]), acc2, false);
+      acc3 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p3), __builtin_bit_cast(v2s, wpair[i][3]), acc3, false);
+    }
+    const uint32_t packed = qnnp::q31_requantize_pack4(acc0, acc1, acc2, acc3, p.rq);
+    *reinterpret_cast<uint32_t*>(out_img + static_cast<uint64_t>(pos) * p.out_stride) = packed;
+  }
+}
+
+constexpr uint32_t kDwLdsBudget = 64 * 1024;   // bytes per workgroup (2 workgroups per CU)
+
+// Pick slab width / band height for kernel A. Returns false if the shape does not fit.
+bool plan_lds(DwParams& p)
+{
+  if (p.C % 4 != 0) return false;
+  p.IC = (p.OW - 1) * p.sw + (p.KW - 1) * p.dw + 1;
+  const uint32_t halo = (p.KH - 1) * p.dh + 1;
+  const uint32_t want = p.OH < 4 ? p.OH : 4;
+  uint32_t best_cs = 0, best_toh = 0;
+  // candidate slabs: divisors of C, multiples of 4 (prefer 16), at most 4*kDwThreads channels
+  for (uint32_t parts = 1; parts <= p.C / 4; parts++) {
+    if (p.C % parts != 0) continue;
+    const uint32_t cs = p.C / parts;
+    if (cs % 4 != 0 || cs / 4 > kDwThreads) continue;
+    const uint32_t row_bytes = p.IC * cs;
+    const uint32_t max_rows = kDwLdsBudget / row_bytes;
+    if (max_rows < halo) continue;
+    uint32_t toh = (max_rows - halo) / p.sh + 1;
+    if (toh > p.OH) toh = p.OH;
+    if (best_cs == 0) { best_cs = cs; best_toh = toh; }   // widest slab that fits at all
+    if (toh >= want) { best_cs = cs; best_toh = toh; break; }
+  }
+  if (best_cs == 0) return false;
+  p.CS = best_cs;
+  p.slabs = p.C / best_cs;
+  // keep the machine busy: at least ~2 workgroups per CU when the batch is small
+  uint32_t toh = best_toh;
+  while (toh > 1 && static_cast<uint64_t>(p.batch) * ((p.OH + toh - 1) / toh) * p.slabs < 512) {
+    toh = (toh + 1) / 2;
+  }
+  p.TOH = toh;
+  p.bands = (p.OH + toh - 1) / toh;
+  p.IR = (toh - 1) * p.sh + halo;
+  return true;
+}
+
+template <int KH, int KW>
+int launch_lds(const DwParams& p, bool vec16, hipStream_t stream)
+{
+  const uint32_t blocks = p.batch * p.bands * p.slabs;
+  const size_t lds_bytes = static_cast<size_t>(p.IR) * p.IC * p.CS;
+  if (vec16) {
+    hipLaunchKernelGGL((q8_dwconv_lds_kernel<KH, KW, 16>), dim3(blocks), dim3(kDwThreads), lds_bytes, stream, p);
+  } else {
+    hipLaunchKernelGGL((q8_dwconv_lds_kernel<KH, KW, 4>), dim3(blocks), dim3(kDwThreads), lds_bytes, stream, p);
+  }
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+}  // namespace
+
+extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const char** kernel_name)
+{
+  if (a == nullptr || a->batch == 0 || a->channels == 0) return QNNP_HIP_EINVAL;
+  DwParams p;
+  p.input = a->input;
+  p.output = a->output;
+  p.wadj = a->wadj;
+  p.bias1 = a->bias1;
+  p.batch = a->batch;
+  p.H = a->input_height; p.W = a->input_width;
+  p.OH = a->output_height; p.OW = a->output_width;
+  p.C = a->channels; p.c_pad = a->c_pad;
+  p.KH = a->kernel_height; p.KW = a->kernel_width;
+  p.sh = a->stride_height; p.sw = a->stride_width;
+  p.dh = a->dilation_height; p.dw = a->dilation_width;
+  p.pad_top = a->pad_top; p.pad_left = a->pad_left;
+  p.in_stride = a->input_stride; p.out_stride = a->output_stride;
+  p.izp = a->input_zero_point & 0xFFu;
+  p.CS = p.TOH = p.IR = p.IC = p.bands = p.slabs = 0;
+  p.rq = a->rq;
+
+  hipStream_t stream = reinterpret_cast<hipStream_t>(qnnp_hip_get_stream());
+  const uintptr_t in_addr = reinterpret_cast<uintptr_t>(a->input);
+  const uintptr_t out_addr = reinterpret_cast<uintptr_t>(a->output);
+
+  const bool k33 = p.KH == 3 && p.KW == 3;
+  const bool k55 = p.KH == 5 && p.KW == 5;
+  const bool aligned4 = p.in_stride % 4 == 0 && p.out_stride % 4 == 0 && in_addr % 4 == 0 && out_addr % 4 == 0;
+  bool use_lds = a->variant != 1 && (k33 || k55) && aligned4 && plan_lds(p);
+  if (a->variant == 2 && !use_lds) return QNNP_HIP_EINVAL;
+
+  if (use_lds) {
+    const bool vec16 = p.CS % 16 == 0 && p.in_stride % 16 == 0 && in_addr % 16 == 0;
+    if (kernel_name != nullptr) *kernel_name = k33 ? "q8_dwconv_lds_3x3" : "q8_dwconv_lds_5x5";
+    return k33 ? launch_lds<3, 3>(p, vec16, stream) : launch_lds<5, 5>(p, vec16, stream);
+  }
+
+  if (kernel_name != nullptr) *kernel_name = "q8_dwconv_direct";
+  const uint64_t total = static_cast<uint64_t>(p.batch) * p.OH * p.OW * p.C;
+  uint64_t blocks = (total + 255) / 256;
+  if (blocks > 256u * 16u) blocks = 256u * 16u;   // grid-stride beyond 16 workgroups per CU
+  hipLaunchKernelGGL(q8_dwconv_direct_kernel, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}

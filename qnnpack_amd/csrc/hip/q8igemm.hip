@@ -1,0 +1,446 @@
+/*
+ * q8igemm.hip -- uint8 GEMM and implicit-GEMM convolution on CDNA4 matrix cores.
+ *
+ * Replaces, as whole-operator launches, the reference's per-tile CPU microkernels
+ *   q8gemm_ukernel_4x4c2__sse2  (src/q8gemm/4x4c2-sse2.c:14-318)
+ *   q8conv_ukernel_4x4c2__sse2  (src/q8conv/4x4c2-sse2.c:14-273)
+ * and their pthreadpool tilers compute_q8gemm / compute_q8conv
+ * (src/operator-run.c:39-70, 183-217, 797-802, 837-842).
+ *
+ * Arithmetic (exact int32, bit-identical to the reference definition
+ * test/gemm-microkernel-tester.h:213-226 + qnnp_q31_requantize):
+ *   v_mfma_i32_32x32x32_i8 multiplies SIGNED int8, so both operands are
+ *   re-centred at 128 (a' = a ^ 0x80, w' = w ^ 0x80 -- the latter at pack time)
+ *   and the cross terms are restored from a per-row sum of a' and a folded
+ *   per-column bias (pack.h). This is the reference's own "XZP" algebra
+ *   (src/operator-run.c:727-743) re-centred for a signed matrix core.
+ *
+ * Kernel 1 (this file, "generic"): q8_igemm_mfma_kernel
+ *   - one workgroup = 4 waves; tile BM x BN x 64, BM = 128, BN in {32, 64, 128}
+ *   - activations: global -> VGPR -> (^0x80, row-sum) -> LDS, double buffered,
+ *     XOR-swizzled 16-B chunks so the ds_read_b128 fragment reads are conflict free
+ *   - weights: pre-packed MFMA fragments (pack.h), one coalesced 1-KiB global read
+ *     per fragment per wave straight into VGPRs (weights are L2 resident; no LDS)
+ *   - convolution gathers activation rows through the device-side int32 offset
+ *     table (indirection.c); im2col is never materialised; padding taps read the
+ *     input zero point
+ *   - fused epilogue: + bias2 + row_coeff * rowsum -> Q31 requantize -> clamp ->
+ *     4 channels packed per dword store
+ *   - any M/N/K, any pixel strides, any alignment: the activation load width VEC
+ *     (16/8/4/1 bytes) is picked per launch from the actual alignment
+ *
+ * MFMA operand roles: weights are the "A" operand (32 output channels across
+ * lanes 0-31), activations the "B" operand (32 rows across lanes 0-31), so each
+ * lane ends up with 4 CONSECUTIVE output channels of one row per accumulator
+ * quad: C/D layout col = lane & 31 (row m), reg r -> n = (r & 3) + 8*(r >> 2) +
+ * 4*(lane >> 5).
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "qnnp_hip.h"
+#include "requant.cuh"
+
+extern "C" void* qnnp_hip_get_stream(void);
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 64;                       // bytes of K per main-loop step
+constexpr uint32_t kPadK = 0x80808080u;      // raw bytes whose a' = a ^ 0x80 is zero
+
+struct IgemmParams {
+  const uint8_t* input;
+  uint8_t* output;
+  const int8_t* packed_w;
+  const int32_t* bias2;
+  const int32_t* offsets;
+  uint32_t rows;
+  uint32_t rows_per_image;
+  uint64_t image_stride;
+  uint32_t n;
+  uint32_t n_pad;
+  uint32_t kc;
+  uint32_t ks;
+  uint32_t k_total;
+  uint32_t k_pad;
+  uint32_t input_stride;
+  uint32_t output_stride;
+  int32_t row_coeff;
+  uint32_t izp_fill;       // input zero point replicated into 4 bytes
+  uint32_t store_dword;    // 1: 4-channel dword stores are aligned and in-bounds
+  qnnp_hip_requant rq;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const uint8_t* p, uint32_t (&w)[4], int j);
+
+template <>
+__device__ __forceinline__ void load_vec<16>(const uint8_t* p, uint32_t (&w)[4], int) {
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void load_vec<8>(const uint8_t* p, uint32_t (&w)[4], int j) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  w[2 * j] = v.x; w[2 * j + 1] = v.y;
+}
+template <>
+__device__ __forceinline__ void load_vec<4>(const uint8_t* p, uint32_t (&w)[4], int j) {
+  w[j] = *reinterpret_cast<const uint32_t*>(p);
+}
+template <>
+__device__ __forceinline__ void load_vec<1>(const uint8_t* p, uint32_t (&w)[4], int j) {
+  const uint32_t b = *p;
+  const int sh = (j & 3) * 8;
+  w[j >> 2] = (w[j >> 2] & ~(0xFFu << sh)) | (b << sh);
+}
+
+template <int VEC>
+__device__ __forceinline__ void fill_vec(uint32_t fill, uint32_t (&w)[4], int j) {
+  if constexpr (VEC == 16) {
+    w[0] = fill; w[1] = fill; w[2] = fill; w[3] = fill;
+  } else if constexpr (VEC == 8) {
+    w[2 * j] = fill; w[2 * j + 1] = fill;
+  } else if constexpr (VEC == 4) {
+    w[j] = fill;
+  } else {
+    const int sh = (j & 3) * 8;
+    w[j >> 2] = (w[j >> 2] & ~(0xFFu << sh)) | ((fill & 0xFFu) << sh);
+  }
+}
+
+/*
+ * WM x WN waves, each computing TM x TN MFMA tiles of 32x32.
+ */
+template <int WM, int WN, int TM, int TN, int VEC, bool IS_CONV>
+__global__ __launch_bounds__(WM * WN * 64)
+void q8_igemm_mfma_kernel(const IgemmParams p)
+{
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  constexpr int CH = (BM * (BK / 16)) / NT;  // 16-byte activation chunks staged per thread per step
+  static_assert((BM * (BK / 16)) % NT == 0, "tile/thread mismatch");
+  static_assert(CH >= 1, "tile too small");
+
+  // one LDS object only: [2][BM][BK] activation ring, then [BM] int32 row sums
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BM * BK + BM * 4];
+  int32_t* lds_rowsum = reinterpret_cast<int32_t*>(lds + 2 * BM * BK);
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63;
+  const uint32_t wave = tid >> 6;
+  const uint32_t wm = wave / WN;
+  const uint32_t wn = wave % WN;
+  const uint32_t g = blockIdx.y;
+
+  // XCD-aware bijective remap: consecutive logical tiles (which share an
+  // activation row block) land on the same XCD / L2 (hardware: block b -> XCD b % 8).
+  const uint32_t ntiles_n = (p.n_pad + BN - 1) / BN;
+  uint32_t logical;
+  {
+    const uint32_t nwg = gridDim.x;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t idx = blockIdx.x >> 3;
+    const uint32_t q = nwg >> 3, r = nwg & 7u;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const uint32_t n_tile = logical % ntiles_n;
+  const uint32_t m_tile = logical / ntiles_n;
+
+  const uint32_t ksteps = p.k_pad / BK;
+  const uint32_t kblocks = p.k_pad / 32;   // 32-deep fragment blocks per column block
+  const uint32_t nblocks = p.n_pad / 32;
+
+  // ---- per-thread activation staging assignment (fixed across K steps) ----
+  const uint8_t* a_base[CH];   // gemm: row base (+group); conv: image base (+group)
+  const int32_t* a_offs[CH];   // conv: this pixel's row of the offset table
+  bool a_valid[CH];
+  uint32_t a_lds[CH];          // swizzled byte offset inside one LDS buffer
+  uint32_t a_kchunk[CH];       // 0..3: which 16-byte chunk of the K step
+  int32_t rowsum_part[CH];
+#pragma unroll
+  for (int q = 0; q < CH; q++) {
+    const uint32_t id = q * NT + tid;
+    const uint32_t row = id >> 2;
+    const uint32_t c = id & 3u;
+    const uint32_t m = m_tile * BM + row;
+    a_valid[q] = m < p.rows;
+    a_kchunk[q] = c;
+    a_lds[q] = row * BK + ((c ^ ((row >> 2) & 3u)) << 4);
+    rowsum_part[q] = 0;
+    if constexpr (IS_CONV) {
+      const uint32_t mm = a_valid[q] ? m : 0u;
+      const uint32_t img = mm / p.rows_per_image;
+      const uint32_t pix = mm - img * p.rows_per_image;
+      a_base[q] = p.input + static_cast<uint64_t>(img) * p.image_stride + static_cast<uint64_t>(g) * p.kc;
+      a_offs[q] = p.offsets + static_cast<uint64_t>(pix) * p.ks;
+    } else {
+      const uint32_t mm = a_valid[q] ? m : 0u;
+      a_base[q] = p.input + static_cast<uint64_t>(mm) * p.input_stride + static_cast<uint64_t>(g) * p.kc;
+      a_offs[q] = nullptr;
+    }
+  }
+
+  // global -> registers for K step `kstep` (raw uint8, already filled for padding)
+  auto load_chunks = [&](uint32_t kstep, uint32_t (&regs)[CH][4]) {
+#pragma unroll
+    for (int q = 0; q < CH; q++) {
+      const uint32_t kk0 = kstep * BK + a_kchunk[q] * 16;
+      regs[q][0] = kPadK; regs[q][1] = kPadK; regs[q][2] = kPadK; regs[q][3] = kPadK;
+      uint32_t tap = 0, ch = kk0;
+      if constexpr (IS_CONV) {
+        tap = kk0 / p.kc;
+        ch = kk0 - tap * p.kc;
+      }
+#pragma unroll
+      for (int j = 0; j < 16 / VEC; j++) {
+        const uint32_t kk = kk0 + j * VEC;
+        if (a_valid[q] && kk < p.k_total) {
+          if constexpr (IS_CONV) {
+            const int32_t off = a_offs[q][tap];
+            if (off >= 0) {
+              load_vec<VEC>(a_base[q] + off + ch, regs[q], j);
+            } else {
+              fill_vec<VEC>(p.izp_fill, regs[q], j);   // padding tap: a == input zero point
+            }
+          } else {
+            load_vec<VEC>(a_base[q] + kk, regs[q], j);
+          }
+        }
+        if constexpr (IS_CONV) {
+          ch += VEC;
+          if (ch >= p.kc) { ch = 0; tap += 1; }   // VEC divides kc, so taps never straddle a vector
+        }
+      }
+    }
+  };
+
+  // registers -> LDS: recentre at 128, accumulate the row sum of a'
+  auto store_chunks = [&](uint32_t buf, const uint32_t (&regs)[CH][4]) {
+#pragma unroll
+    for (int q = 0; q < CH; q++) {
+      v4i x;
+      x.x = static_cast<int>(regs[q][0] ^ kPadK);
+      x.y = static_cast<int>(regs[q][1] ^ kPadK);
+      x.z = static_cast<int>(regs[q][2] ^ kPadK);
+      x.w = static_cast<int>(regs[q][3] ^ kPadK);
+      int32_t s = rowsum_part[q];
+      s = __builtin_amdgcn_sdot4(x.x, 0x01010101, s, false);
+      s = __builtin_amdgcn_sdot4(x.y, 0x01010101, s, false);
+      s = __builtin_amdgcn_sdot4(x.z, 0x01010101, s, false);
+      s = __builtin_amdgcn_sdot4(x.w, 0x01010101, s, false);
+      rowsum_part[q] = s;
+      *reinterpret_cast<v4i*>(lds + buf * (BM * BK) + a_lds[q]) = x;
+    }
+  };
+
+  // weight fragments: lane l reads its 16 bytes of the (column block, K block) panel
+  const uint32_t nb0 = n_tile * (BN / 32) + wn * TN;   // first 32-column block of this wave
+  const int8_t* w_lane = p.packed_w + (static_cast<uint64_t>(g) * nblocks * kblocks) * 1024 + lane * 16;
+  auto load_wfrags = [&](uint32_t kstep, v4i (&wf)[TN][2]) {
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+      const uint32_t nb = nb0 + tn;
+#pragma unroll
+      for (int ksub = 0; ksub < 2; ksub++) {
+        if (nb < nblocks) {
+          const uint32_t kb = kstep * 2 + ksub;
+          wf[tn][ksub] = *reinterpret_cast<const v4i*>(
+              w_lane + (static_cast<uint64_t>(nb) * kblocks + kb) * 1024);
+        } else {
+          wf[tn][ksub] = v4i{0, 0, 0, 0};
+        }
+      }
+    }
+  };
+
+  v16i acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0;
+
+  uint32_t a_regs[CH][4];
+  v4i w_cur[TN][2];
+  v4i w_nxt[TN][2];
+
+  load_chunks(0, a_regs);
+  load_wfrags(0, w_cur);
+
+  const uint32_t frag_row0 = wm * (TM * 32) + (lane & 31u);
+  const uint32_t frag_khalf = lane >> 5;
+
+  for (uint32_t kstep = 0; kstep < ksteps; kstep++) {
+    const uint32_t buf = kstep & 1u;
+    store_chunks(buf, a_regs);
+    __syncthreads();
+    if (kstep + 1 < ksteps) {
+      load_chunks(kstep + 1, a_regs);
+      load_wfrags(kstep + 1, w_nxt);
+    }
+    const uint8_t* a_tile = lds + buf * (BM * BK);
+#pragma unroll
+    for (int ksub = 0; ksub < 2; ksub++) {
+      v4i af[TM];
+#pragma unroll
+      for (int tm = 0; tm < TM; tm++) {
+        const uint32_t row = frag_row0 + tm * 32;
+        const uint32_t chunk = (ksub * 2 + frag_khalf) ^ ((row >> 2) & 3u);
+        af[tm] = *reinterpret_cast<const v4i*>(a_tile + row * BK + (chunk << 4));
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++)
+          acc[tm][tn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w_cur[tn][ksub], af[tm], acc[tm][tn], 0, 0, 0);
+    }
+    if (kstep + 1 < ksteps) {
+#pragma unroll
+      for (int tn = 0; tn < TN; tn++) {
+        w_cur[tn][0] = w_nxt[tn][0];
+        w_cur[tn][1] = w_nxt[tn][1];
+      }
+    }
+    // no second barrier: the next step writes the other LDS buffer, whose last
+    // readers all passed this step's barrier
+  }
+
+  // ---- row sums: the 4 threads that staged one row are adjacent lanes ----
+#pragma unroll
+  for (int q = 0; q < CH; q++) {
+    int32_t s = rowsum_part[q];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (a_kchunk[q] == 0) lds_rowsum[(q * NT + tid) >> 2] = s;
+  }
+  __syncthreads();
+
+  // ---- fused epilogue ----
+#pragma unroll
+  for (int tm = 0; tm < TM; tm++) {
+    const uint32_t row = frag_row0 + tm * 32;
+    const uint32_t m = m_tile * BM + row;
+    const int32_t rowterm = p.row_coeff * lds_rowsum[row];
+    uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride + static_cast<uint64_t>(g) * p.n;
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+      const uint32_t nb = nb0 + tn;
+      if (nb >= nblocks) continue;
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const uint32_t ncol = nb * 32 + rg * 8 + frag_khalf * 4;   // first of 4 consecutive channels
+        const int4 b = *reinterpret_cast<const int4*>(p.bias2 + static_cast<uint64_t>(g) * p.n_pad + ncol);
+        const int32_t v0 = acc[tm][tn][rg * 4 + 0] + rowterm + b.x;
+        const int32_t v1 = acc[tm][tn][rg * 4 + 1] + rowterm + b.y;
+        const int32_t v2 = acc[tm][tn][rg * 4 + 2] + rowterm + b.z;
+        const int32_t v3 = acc[tm][tn][rg * 4 + 3] + rowterm + b.w;
+        const uint32_t packed = qnnp::q31_requantize_pack4(v0, v1, v2, v3, p.rq);
+        if (m < p.rows && ncol < p.n) {
+          if (p.store_dword) {
+            *reinterpret_cast<uint32_t*>(out_row + ncol) = packed;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (ncol + j < p.n) out_row[ncol + j] = static_cast<uint8_t>(packed >> (8 * j));
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int TM, int TN, int VEC, bool IS_CONV>
+int launch_generic(const IgemmParams& p, uint32_t groups, hipStream_t stream)
+{
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  const uint32_t tiles_m = (p.rows + BM - 1) / BM;
+  const uint32_t tiles_n = (p.n_pad + BN - 1) / BN;
+  const dim3 grid(tiles_m * tiles_n, groups, 1);
+  const dim3 block(WM * WN * 64, 1, 1);
+  hipLaunchKernelGGL((q8_igemm_mfma_kernel<WM, WN, TM, TN, VEC, IS_CONV>), grid, block, 0, stream, p);
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+template <int VEC, bool IS_CONV>
+int dispatch_tile(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name)
+{
+  if (p.n_pad <= 32) {
+    *name = "q8_igemm_mfma_128x32";
+    return launch_generic<4, 1, 1, 1, VEC, IS_CONV>(p, groups, stream);
+  }
+  if (p.n_pad <= 64) {
+    *name = "q8_igemm_mfma_128x64";
+    return launch_generic<4, 1, 1, 2, VEC, IS_CONV>(p, groups, stream);
+  }
+  *name = "q8_igemm_mfma_128x128";
+  return launch_generic<2, 2, 2, 2, VEC, IS_CONV>(p, groups, stream);
+}
+
+template <bool IS_CONV>
+int dispatch_vec(const IgemmParams& p, uint32_t groups, uint32_t vec, hipStream_t stream, const char** name)
+{
+  switch (vec) {
+    case 16: return dispatch_tile<16, IS_CONV>(p, groups, stream, name);
+    case 8: return dispatch_tile<8, IS_CONV>(p, groups, stream, name);
+    case 4: return dispatch_tile<4, IS_CONV>(p, groups, stream, name);
+    default: return dispatch_tile<1, IS_CONV>(p, groups, stream, name);
+  }
+}
+
+}  // namespace
+
+extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const char** kernel_name)
+{
+  if (a == nullptr || a->rows == 0 || a->groups == 0 || a->groups > 65535u) return QNNP_HIP_EINVAL;
+  if (a->n_pad % 32 != 0 || a->k_pad % BK != 0 || a->k_pad < a->k_total) return QNNP_HIP_EINVAL;
+
+  IgemmParams p;
+  p.input = a->input;
+  p.output = a->output;
+  p.packed_w = a->packed_w;
+  p.bias2 = a->bias2;
+  p.offsets = a->offsets;
+  p.rows = a->rows;
+  p.rows_per_image = a->rows_per_image;
+  p.image_stride = a->image_stride;
+  p.n = a->n;
+  p.n_pad = a->n_pad;
+  p.kc = a->kc;
+  p.ks = a->ks;
+  p.k_total = a->k_total;
+  p.k_pad = a->k_pad;
+  p.input_stride = a->input_stride;
+  p.output_stride = a->output_stride;
+  p.row_coeff = a->row_coeff;
+  p.izp_fill = (a->input_zero_point & 0xFFu) * 0x01010101u;
+  p.rq = a->rq;
+
+  // widest activation vector the actual alignment allows (a vector never straddles a tap)
+  const uintptr_t in_addr = reinterpret_cast<uintptr_t>(a->input);
+  uint32_t vec = 1;
+  const uint32_t candidates[3] = {16u, 8u, 4u};
+  for (uint32_t v : candidates) {
+    if (a->kc % v == 0 && a->input_stride % v == 0 && in_addr % v == 0) {
+      vec = v;
+      break;
+    }
+  }
+  const uintptr_t out_addr = reinterpret_cast<uintptr_t>(a->output);
+  p.store_dword = (a->n % 4 == 0 && a->output_stride % 4 == 0 && out_addr % 4 == 0) ? 1u : 0u;
+
+  hipStream_t stream = reinterpret_cast<hipStream_t>(qnnp_hip_get_stream());
+  const char* name = nullptr;
+  const int rc = (a->offsets != nullptr) ? dispatch_vec<true>(p, a->groups, vec, stream, &name)
+                                          : dispatch_vec<false>(p, a->groups, vec, stream, &name);
+  if (kernel_name != nullptr) *kernel_name = name;
+  return rc;
+}

@@ -1,0 +1,134 @@
+/*
+ * qnnp_hip.h -- the C-ABI seam between the plain-C host code (init.c,
+ * convolution.c, fully-connected.c, operator-run.c, operator-delete.c) and the
+ * gfx950 HIP translation units. Host C never includes a HIP header: everything
+ * that crosses this seam is POD (sizes, strides, raw pointers, fixed-width ints).
+ *
+ * It replaces the reference's microkernel function-pointer table
+ * (src/qnnpack/params.h:267-378, 520-538) and the pthreadpool fan-out in
+ * src/operator-run.c:675, 797, 837: one call here = one whole-operator launch.
+ *
+ * Return convention: 0 on success, a negative QNNP_HIP_E* code otherwise.
+ */
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QNNP_HIP_OK 0
+#define QNNP_HIP_ENODEV (-1)   /* no usable gfx950 device */
+#define QNNP_HIP_ENOMEM (-2)   /* hipMalloc failed */
+#define QNNP_HIP_ELAUNCH (-3)  /* kernel launch / runtime error */
+#define QNNP_HIP_EINVAL (-4)   /* argument the kernels cannot serve */
+
+/* Fused fixed-point down-convert parameters: the scalar member of
+ * union qnnp_conv_quantization_params (src/qnnpack/params.h:128-138) minus the
+ * two zero points, which this build folds into the packed bias / row term. */
+struct qnnp_hip_requant {
+  int32_t multiplier;           /* [0x40000000, 0x7FFFFF80] */
+  int32_t remainder_mask;       /* (1 << shift) - 1 */
+  int32_t remainder_threshold;  /* remainder_mask >> 1 */
+  uint32_t shift;               /* [0, 31] */
+  int32_t output_min_less_zero_point;
+  int32_t output_max_less_zero_point;
+  int32_t output_zero_point;
+};
+
+/* ---- runtime ---------------------------------------------------------- */
+int qnnp_hip_init(int device /* <0: current/env */);
+int qnnp_hip_shutdown(void);
+int qnnp_hip_device(void);
+int qnnp_hip_device_info(char* arch, size_t arch_len, int* cus, int* clock_khz, size_t* mem_bytes);
+void qnnp_hip_set_stream(void* stream);
+void* qnnp_hip_get_stream(void);
+int qnnp_hip_stream_sync(void);
+
+void* qnnp_hip_alloc(size_t bytes);
+void qnnp_hip_free(void* p);
+int qnnp_hip_h2d(void* dst, const void* src, size_t bytes, int async);
+int qnnp_hip_d2h(void* dst, const void* src, size_t bytes, int async);
+int qnnp_hip_memset(void* dst, int value, size_t bytes);
+/* 1 = device-accessible pointer on the bound device, 0 = host memory */
+int qnnp_hip_is_device_pointer(const void* p);
+
+/* hipEvent-based timing on the library stream (for qnnp_gfx950_time_operator) */
+int qnnp_hip_timer_create(void** timer);
+int qnnp_hip_timer_start(void* timer);
+int qnnp_hip_timer_stop_ms(void* timer, float* ms);
+void qnnp_hip_timer_destroy(void* timer);
+
+/* ---- q8 GEMM / implicit-GEMM convolution (MFMA) ------------------------
+ * Replaces q8gemm_ukernel_4x4c2__sse2 (src/q8gemm/4x4c2-sse2.c:14-318) and
+ * q8conv_ukernel_4x4c2__sse2 (src/q8conv/4x4c2-sse2.c:14-273) together with
+ * their tilers compute_q8gemm / compute_q8conv (src/operator-run.c:39-70, 183-217).
+ *
+ * For each group g, row m in [0, rows) and column n in [0, n):
+ *   out[m*output_stride + g*n_ + n] = requant( bias2[g*n_pad + n]
+ *        + row_coeff * sum_k a'(m,k) + sum_k a'(m,k) * w'(g,n,k) )
+ * with a' = a - 128, w' = w - 128 (both valid int8), k flattened as
+ * tap * group_input_channels + channel, and a(m,k) read from
+ *   gemm : input[m*input_stride + g*kc + k]
+ *   conv : input[img*image_stride + offsets[pix*ks + tap] + g*kc + ch], or the
+ *          input zero point where offsets[...] < 0 (padding)   (img = m / rows_per_image).
+ */
+struct qnnp_hip_igemm_args {
+  const uint8_t* input;
+  uint8_t* output;
+  const int8_t* packed_w;     /* MFMA-fragment panels, see pack.h */
+  const int32_t* bias2;       /* [groups][n_pad] */
+  const int32_t* offsets;     /* conv: [rows_per_image][ks]; NULL for gemm */
+  uint32_t rows;              /* batch * output pixels */
+  uint32_t rows_per_image;    /* output pixels per image (gemm: rows) */
+  uint64_t image_stride;      /* bytes between consecutive input images (conv) */
+  uint32_t groups;
+  uint32_t n;                 /* group output channels */
+  uint32_t n_pad;             /* round_up(n, 32) */
+  uint32_t kc;                /* group input channels */
+  uint32_t ks;                /* taps (1 for gemm) */
+  uint32_t k_total;           /* ks * kc */
+  uint32_t k_pad;             /* round_up(k_total, 64) */
+  uint32_t input_stride;      /* bytes between pixels */
+  uint32_t output_stride;
+  int32_t row_coeff;          /* 128 - kernel_zero_point */
+  uint32_t input_zero_point;
+  struct qnnp_hip_requant rq;
+  int variant;                /* 0 auto, 1 generic, 2 big-tile LDS-DMA */
+};
+int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* args, const char** kernel_name);
+
+/* ---- q8 depthwise convolution ------------------------------------------
+ * Replaces q8dwconv_ukernel_up8x9__sse2 (src/q8dwconv/up8x9-sse2.c:14-372) and
+ * q8dwconv_ukernel_mp8x25__sse2 (src/q8dwconv/mp8x25-sse2.c:14-742) plus
+ * compute_dwconv_unipass/multiipass (src/operator-run.c:238-284).
+ *   out[c] = requant( bias1[c] + sum_taps a(tap,c) * wadj[tap][c] )
+ * wadj = w - kernel_zero_point (int16), bias1 = bias + taps*izp*kzp - izp*sum w
+ * (the reference's own folding, src/qnnpack/pack.h:146-159); padding taps read
+ * a = input_zero_point.
+ */
+struct qnnp_hip_dwconv_args {
+  const uint8_t* input;
+  uint8_t* output;
+  const int16_t* wadj;        /* [taps][c_pad], tap = ky*kw + kx */
+  const int32_t* bias1;       /* [c_pad] */
+  uint32_t batch;
+  uint32_t input_height, input_width;
+  uint32_t output_height, output_width;
+  uint32_t channels, c_pad;   /* c_pad = round_up(channels, 16) */
+  uint32_t kernel_height, kernel_width;
+  uint32_t stride_height, stride_width;
+  uint32_t dilation_height, dilation_width;
+  uint32_t pad_top, pad_left;
+  uint32_t input_stride, output_stride;
+  uint32_t input_zero_point;
+  struct qnnp_hip_requant rq;
+  int variant;                /* 0 auto, 1 generic direct, 2 LDS-tiled */
+};
+int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* args, const char** kernel_name);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,176 @@
+/*
+ * runtime.hip -- device binding, memory, stream and event plumbing behind the
+ * C-ABI seam of qnnp_hip.h. The reference has no counterpart (its runtime is
+ * cpuinfo + pthreadpool, src/init.c:244-263); this is what "initialize" means
+ * on an MI355X: bind one gfx950 device, keep one launch stream.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "qnnp_hip.h"
+
+namespace {
+
+struct Runtime {
+  bool bound = false;
+  int device = -1;
+  hipStream_t stream = nullptr;  // nullptr = default stream
+  hipDeviceProp_t props;
+};
+
+Runtime g_rt;
+
+struct Timer {
+  hipEvent_t start;
+  hipEvent_t stop;
+};
+
+inline bool ok(hipError_t e) { return e == hipSuccess; }
+
+}  // namespace
+
+extern "C" {
+
+int qnnp_hip_init(int device)
+{
+  int count = 0;
+  if (!ok(hipGetDeviceCount(&count)) || count <= 0) {
+    (void) hipGetLastError();
+    return QNNP_HIP_ENODEV;
+  }
+  if (device < 0) {
+    if (!ok(hipGetDevice(&device))) device = 0;
+  }
+  if (device >= count) return QNNP_HIP_ENODEV;
+  if (!ok(hipSetDevice(device))) return QNNP_HIP_ENODEV;
+  if (!ok(hipGetDeviceProperties(&g_rt.props, device))) return QNNP_HIP_ENODEV;
+  // Only CDNA4: the kernels use v_mfma_i32_32x32x32_i8 and are built for gfx950 alone.
+  if (std::strncmp(g_rt.props.gcnArchName, "gfx950", 6) != 0) {
+    return QNNP_HIP_ENODEV;
+  }
+  g_rt.device = device;
+  g_rt.stream = nullptr;
+  g_rt.bound = true;
+  return QNNP_HIP_OK;
+}
+
+int qnnp_hip_shutdown(void)
+{
+  g_rt.bound = false;
+  g_rt.stream = nullptr;
+  return QNNP_HIP_OK;
+}
+
+int qnnp_hip_device(void) { return g_rt.bound ? g_rt.device : -1; }
+
+int qnnp_hip_device_info(char* arch, size_t arch_len, int* cus, int* clock_khz, size_t* mem_bytes)
+{
+  if (!g_rt.bound) return QNNP_HIP_ENODEV;
+  if (arch != nullptr && arch_len > 0) {
+    std::strncpy(arch, g_rt.props.gcnArchName, arch_len - 1);
+    arch[arch_len - 1] = '\0';
+  }
+  if (cus != nullptr) *cus = g_rt.props.multiProcessorCount;
+  if (clock_khz != nullptr) *clock_khz = g_rt.props.clockRate;
+  if (mem_bytes != nullptr) *mem_bytes = g_rt.props.totalGlobalMem;
+  return QNNP_HIP_OK;
+}
+
+void qnnp_hip_set_stream(void* stream) { g_rt.stream = reinterpret_cast<hipStream_t>(stream); }
+void* qnnp_hip_get_stream(void) { return reinterpret_cast<void*>(g_rt.stream); }
+
+int qnnp_hip_stream_sync(void)
+{
+  return ok(hipStreamSynchronize(g_rt.stream)) ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+void* qnnp_hip_alloc(size_t bytes)
+{
+  if (!g_rt.bound) return nullptr;
+  void* p = nullptr;
+  if (bytes == 0) bytes = 16;
+  if (!ok(hipMalloc(&p, bytes))) {
+    (void) hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+void qnnp_hip_free(void* p)
+{
+  if (p != nullptr) (void) hipFree(p);
+}
+
+int qnnp_hip_h2d(void* dst, const void* src, size_t bytes, int async)
+{
+  if (bytes == 0) return QNNP_HIP_OK;
+  const hipError_t e = async ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_rt.stream)
+                             : hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+  return ok(e) ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+int qnnp_hip_d2h(void* dst, const void* src, size_t bytes, int async)
+{
+  if (bytes == 0) return QNNP_HIP_OK;
+  const hipError_t e = async ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_rt.stream)
+                             : hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+  return ok(e) ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+int qnnp_hip_memset(void* dst, int value, size_t bytes)
+{
+  if (bytes == 0) return QNNP_HIP_OK;
+  if (!ok(hipMemsetAsync(dst, value, bytes, g_rt.stream))) return QNNP_HIP_ELAUNCH;
+  return ok(hipStreamSynchronize(g_rt.stream)) ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+int qnnp_hip_is_device_pointer(const void* p)
+{
+  if (p == nullptr || !g_rt.bound) return 0;
+  hipPointerAttribute_t attr;
+  if (!ok(hipPointerGetAttributes(&attr, p))) {
+    (void) hipGetLastError();  // plain host memory is "invalid value" to the runtime
+    return 0;
+  }
+  return (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) ? 1 : 0;
+}
+
+int qnnp_hip_timer_create(void** timer)
+{
+  Timer* t = new (std::nothrow) Timer;
+  if (t == nullptr) return QNNP_HIP_ENOMEM;
+  if (!ok(hipEventCreate(&t->start)) || !ok(hipEventCreate(&t->stop))) {
+    delete t;
+    return QNNP_HIP_ENOMEM;
+  }
+  *timer = t;
+  return QNNP_HIP_OK;
+}
+
+int qnnp_hip_timer_start(void* timer)
+{
+  Timer* t = static_cast<Timer*>(timer);
+  return ok(hipEventRecord(t->start, g_rt.stream)) ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+int qnnp_hip_timer_stop_ms(void* timer, float* ms)
+{
+  Timer* t = static_cast<Timer*>(timer);
+  if (!ok(hipEventRecord(t->stop, g_rt.stream))) return QNNP_HIP_ELAUNCH;
+  if (!ok(hipEventSynchronize(t->stop))) return QNNP_HIP_ELAUNCH;
+  return ok(hipEventElapsedTime(ms, t->start, t->stop)) ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+void qnnp_hip_timer_destroy(void* timer)
+{
+  Timer* t = static_cast<Timer*>(timer);
+  if (t == nullptr) return;
+  (void) hipEventDestroy(t->start);
+  (void) hipEventDestroy(t->stop);
+  delete t;
+}
+
+}  // extern "C"

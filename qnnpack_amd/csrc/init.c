@@ -1,0 +1,164 @@
+/*
+ * init.c -- qnnp_initialize / qnnp_deinitialize and the gfx950 extension knobs.
+ *
+ * Replaces reference src/init.c:244-263. The reference probes the CPU with
+ * cpuinfo and fills a microkernel table once (pthread_once, :40, :251); this
+ * build probes for a gfx950 GPU through the HIP shim and binds to it once.
+ * No GPU => qnnp_status_unsupported_hardware (reference: same status when no
+ * ISA table could be filled, init.c:253-257). There is no CPU fallback.
+ */
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <qnnpack.h>
+#include <qnnpack_gfx950.h>
+
+#include "hip/qnnp_hip.h"
+#include "log.h"
+#include "operator.h"
+#include "state.h"
+
+struct qnnp_state qnnp_state = {
+  .initialized = false,
+  .requested_device = -1,
+  .async = 0,
+  .opt_gemm_kernel = 0,
+  .opt_dwconv_kernel = 0,
+};
+
+static pthread_mutex_t init_lock = PTHREAD_MUTEX_INITIALIZER;
+
+enum qnnp_status qnnp_initialize(void)
+{
+  enum qnnp_status status = qnnp_status_success;
+  pthread_mutex_lock(&init_lock);
+  if (!qnnp_state.initialized) {
+    int device = qnnp_state.requested_device;
+    if (device < 0) {
+      const char* env = getenv("QNNP_GFX950_DEVICE");
+      if (env != NULL && env[0] != '\0') device = atoi(env);
+    }
+    const int rc = qnnp_hip_init(device);
+    if (rc == QNNP_HIP_OK) {
+      qnnp_state.initialized = true;
+    } else if (rc == QNNP_HIP_ENOMEM) {
+      qnnp_log_error("qnnp_initialize: out of device memory while binding the gfx950 device");
+      status = qnnp_status_out_of_memory;
+    } else {
+      qnnp_log_error("qnnp_initialize: no usable gfx950 (MI355X) device; this build has no CPU path");
+      status = qnnp_status_unsupported_hardware;
+    }
+  }
+  pthread_mutex_unlock(&init_lock);
+  return status;
+}
+
+enum qnnp_status qnnp_deinitialize(void)
+{
+  pthread_mutex_lock(&init_lock);
+  if (qnnp_state.initialized) {
+    qnnp_hip_shutdown();
+    qnnp_state.initialized = false;
+  }
+  pthread_mutex_unlock(&init_lock);
+  return qnnp_status_success;
+}
+
+/* ---- qnnpack_gfx950.h ---- */
+
+enum qnnp_status qnnp_gfx950_set_device(int device)
+{
+  enum qnnp_status status = qnnp_status_success;
+  pthread_mutex_lock(&init_lock);
+  if (qnnp_state.initialized || device < 0) {
+    status = qnnp_status_invalid_parameter;
+  } else {
+    qnnp_state.requested_device = device;
+  }
+  pthread_mutex_unlock(&init_lock);
+  return status;
+}
+
+int qnnp_gfx950_get_device(void)
+{
+  return qnnp_state.initialized ? qnnp_hip_device() : -1;
+}
+
+enum qnnp_status qnnp_gfx950_set_stream(void* hip_stream)
+{
+  if (!qnnp_state.initialized) return qnnp_status_uninitialized;
+  qnnp_hip_set_stream(hip_stream);
+  return qnnp_status_success;
+}
+
+enum qnnp_status qnnp_gfx950_set_async(int async)
+{
+  qnnp_state.async = async != 0;
+  return qnnp_status_success;
+}
+
+enum qnnp_status qnnp_gfx950_synchronize(void)
+{
+  if (!qnnp_state.initialized) return qnnp_status_uninitialized;
+  return qnnp_hip_stream_sync() == QNNP_HIP_OK ? qnnp_status_success : qnnp_status_unsupported_hardware;
+}
+
+void* qnnp_gfx950_malloc(size_t bytes)
+{
+  if (!qnnp_state.initialized) return NULL;
+  return qnnp_hip_alloc(bytes);
+}
+
+void qnnp_gfx950_free(void* device_ptr)
+{
+  if (qnnp_state.initialized) qnnp_hip_free(device_ptr);
+}
+
+enum qnnp_status qnnp_gfx950_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes)
+{
+  if (!qnnp_state.initialized) return qnnp_status_uninitialized;
+  return qnnp_hip_h2d(dst_device, src_host, bytes, 0) == QNNP_HIP_OK ?
+      qnnp_status_success : qnnp_status_invalid_parameter;
+}
+
+enum qnnp_status qnnp_gfx950_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes)
+{
+  if (!qnnp_state.initialized) return qnnp_status_uninitialized;
+  return qnnp_hip_d2h(dst_host, src_device, bytes, 0) == QNNP_HIP_OK ?
+      qnnp_status_success : qnnp_status_invalid_parameter;
+}
+
+enum qnnp_status qnnp_gfx950_memset(void* dst_device, int value, size_t bytes)
+{
+  if (!qnnp_state.initialized) return qnnp_status_uninitialized;
+  return qnnp_hip_memset(dst_device, value, bytes) == QNNP_HIP_OK ?
+      qnnp_status_success : qnnp_status_invalid_parameter;
+}
+
+enum qnnp_status qnnp_gfx950_set_option(const char* key, int value)
+{
+  if (key == NULL) return qnnp_status_invalid_parameter;
+  if (strcmp(key, "gemm_kernel") == 0 && value >= 0 && value <= 2) {
+    qnnp_state.opt_gemm_kernel = value;
+    return qnnp_status_success;
+  }
+  if (strcmp(key, "dwconv_kernel") == 0 && value >= 0 && value <= 2) {
+    qnnp_state.opt_dwconv_kernel = value;
+    return qnnp_status_success;
+  }
+  return qnnp_status_invalid_parameter;
+}
+
+const char* qnnp_gfx950_operator_kernel(qnnp_operator_t op)
+{
+  return op == NULL ? NULL : op->kernel_name;
+}
+
+enum qnnp_status qnnp_gfx950_device_info(
+    char* arch, size_t arch_len, int* compute_units, int* clock_khz, size_t* hbm_bytes)
+{
+  if (!qnnp_state.initialized) return qnnp_status_uninitialized;
+  return qnnp_hip_device_info(arch, arch_len, compute_units, clock_khz, hbm_bytes) == QNNP_HIP_OK ?
+      qnnp_status_success : qnnp_status_unsupported_hardware;
+}

@@ -1,0 +1,27 @@
+/*
+ * operator-delete.c -- qnnp_delete_operator.
+ * Replaces reference src/operator-delete.c:15-28: frees everything the
+ * operator owns -- here device allocations (weights, folded bias, offset table,
+ * staging buffers) instead of host packed weights / indirection / zero buffers.
+ * delete(NULL) -> invalid_parameter, as in the reference (:17-19).
+ */
+#include <stdlib.h>
+
+#include <qnnpack.h>
+
+#include "hip/qnnp_hip.h"
+#include "operator.h"
+
+enum qnnp_status qnnp_delete_operator(qnnp_operator_t op)
+{
+  if (op == NULL) {
+    return qnnp_status_invalid_parameter;
+  }
+  qnnp_hip_free(op->d_weights);
+  qnnp_hip_free(op->d_bias);
+  qnnp_hip_free(op->d_offsets);
+  qnnp_hip_free(op->d_stage_in);
+  qnnp_hip_free(op->d_stage_out);
+  free(op);
+  return qnnp_status_success;
+}

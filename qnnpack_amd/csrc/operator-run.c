@@ -1,0 +1,218 @@
+/*
+ * operator-run.c -- qnnp_run_operator for the gfx950 build.
+ *
+ * Replaces the hot cases of reference src/operator-run.c:639-844. The reference
+ * switches on op->ukernel_type, builds a stack context and fans MRxNR microkernel
+ * calls out over a pthreadpool (:675 dwconv, :797 gemm, :837 conv). Here the same
+ * switch builds a POD argument block and makes ONE call through the C-ABI HIP
+ * shim per operator (hip/qnnp_hip.h): a whole-operator kernel launch on the
+ * library stream. `threadpool` is ignored.
+ *
+ * Like the reference, nothing is allocated and nothing is logged on this path
+ * (device pointers). Host pointers given to setup are staged through device
+ * scratch sized at setup.
+ */
+#include <stddef.h>
+#include <stdint.h>
+
+#include <qnnpack.h>
+#include <qnnpack_gfx950.h>
+
+#include "hip/qnnp_hip.h"
+#include "operator.h"
+#include "state.h"
+
+static enum qnnp_status status_from_hip(int rc)
+{
+  switch (rc) {
+    case QNNP_HIP_OK: return qnnp_status_success;
+    case QNNP_HIP_ENOMEM: return qnnp_status_out_of_memory;
+    case QNNP_HIP_EINVAL: return qnnp_status_unsupported_parameter;
+    default: return qnnp_status_unsupported_hardware;
+  }
+}
+
+/* Enqueue the operator's kernel on the library stream, reading `input` and
+ * writing `output` (both device pointers). */
+static int launch(struct qnnp_operator* op, const void* input, void* output)
+{
+  switch (op->ukernel_type) {
+    case qnnp_ukernel_type_dwconv:
+    {
+      /* reference operator-run.c:647-710 (context) + :238-284 (trampolines) */
+      const struct qnnp_hip_dwconv_args args = {
+        .input = (const uint8_t*) input,
+        .output = (uint8_t*) output,
+        .wadj = (const int16_t*) op->d_weights,
+        .bias1 = op->d_bias,
+        .batch = (uint32_t) op->batch_size,
+        .input_height = (uint32_t) op->input_height,
+        .input_width = (uint32_t) op->input_width,
+        .output_height = (uint32_t) op->output_height,
+        .output_width = (uint32_t) op->output_width,
+        .channels = op->groups,
+        .c_pad = op->c_pad,
+        .kernel_height = op->kernel_height,
+        .kernel_width = op->kernel_width,
+        .stride_height = op->stride_height,
+        .stride_width = op->stride_width,
+        .dilation_height = op->dilation_height,
+        .dilation_width = op->dilation_width,
+        .pad_top = op->input_padding_top,
+        .pad_left = op->input_padding_left,
+        .input_stride = (uint32_t) op->input_pixel_stride,
+        .output_stride = (uint32_t) op->output_pixel_stride,
+        .input_zero_point = op->input_zero_point,
+        .rq = op->requant,
+        .variant = op->variant,
+      };
+      return qnnp_hip_dwconv_run(&args, &op->kernel_name);
+    }
+    case qnnp_ukernel_type_gemm:
+    case qnnp_ukernel_type_conv:
+    {
+      /* reference operator-run.c:770-804 (gemm) and :805-844 (conv) */
+      const int is_conv = op->ukernel_type == qnnp_ukernel_type_conv;
+      const uint32_t output_size = (uint32_t) (op->output_height * op->output_width);
+      const uint32_t taps = is_conv ? op->kernel_height * op->kernel_width : 1;
+      const struct qnnp_hip_igemm_args args = {
+        .input = (const uint8_t*) input,
+        .output = (uint8_t*) output,
+        .packed_w = (const int8_t*) op->d_weights,
+        .bias2 = op->d_bias,
+        .offsets = is_conv ? op->d_offsets : NULL,
+        .rows = (uint32_t) op->batch_size * output_size,
+        .rows_per_image = output_size,
+        .image_stride = (uint64_t) op->input_height * op->input_width * op->input_pixel_stride,
+        .groups = op->groups,
+        .n = (uint32_t) op->group_output_channels,
+        .n_pad = op->n_pad,
+        .kc = (uint32_t) op->group_input_channels,
+        .ks = taps,
+        .k_total = taps * (uint32_t) op->group_input_channels,
+        .k_pad = op->k_pad,
+        .input_stride = (uint32_t) op->input_pixel_stride,
+        .output_stride = (uint32_t) op->output_pixel_stride,
+        .row_coeff = 128 - (int32_t) op->kernel_zero_point,
+        .input_zero_point = op->input_zero_point,
+        .rq = op->requant,
+        .variant = op->variant,
+      };
+      return qnnp_hip_igemm_run(&args, &op->kernel_name);
+    }
+    default:
+      return QNNP_HIP_EINVAL;
+  }
+}
+
+enum qnnp_status qnnp_run_operator(qnnp_operator_t op, pthreadpool_t threadpool)
+{
+  (void) threadpool;
+  if (op == NULL) {
+    return qnnp_status_invalid_parameter;
+  }
+  if (!qnnp_state.initialized) {
+    return qnnp_status_uninitialized;
+  }
+  /* reference operator-run.c:642-644: nothing to do for an empty batch */
+  if (op->batch_size == 0) {
+    return qnnp_status_success;
+  }
+  if (op->input == NULL || op->output == NULL) {
+    return qnnp_status_invalid_parameter;  /* run before setup */
+  }
+
+  const void* input = op->input;
+  void* output = op->output;
+  const int staged = !op->input_on_device || !op->output_on_device;
+
+  if (!op->input_on_device) {
+    if (qnnp_hip_h2d(op->d_stage_in, op->input, op->input_span, 1) != QNNP_HIP_OK) {
+      return qnnp_status_invalid_parameter;
+    }
+    input = op->d_stage_in;
+  }
+  if (!op->output_on_device) {
+    const size_t out_channels = (size_t) op->groups * op->group_output_channels;
+    if (op->output_pixel_stride != out_channels) {
+      /* keep the caller's bytes between pixels intact across the round trip */
+      if (qnnp_hip_h2d(op->d_stage_out, op->output, op->output_span, 1) != QNNP_HIP_OK) {
+        return qnnp_status_invalid_parameter;
+      }
+    }
+    output = op->d_stage_out;
+  }
+
+  const int rc = launch(op, input, output);
+  if (rc != QNNP_HIP_OK) {
+    return status_from_hip(rc);
+  }
+
+  if (!op->output_on_device) {
+    if (qnnp_hip_d2h(op->output, op->d_stage_out, op->output_span, 1) != QNNP_HIP_OK) {
+      return qnnp_status_invalid_parameter;
+    }
+  }
+  if (staged || !qnnp_state.async) {
+    /* reference semantics: outputs are complete when run returns */
+    return status_from_hip(qnnp_hip_stream_sync());
+  }
+  return qnnp_status_success;
+}
+
+/* ---- qnnpack_gfx950.h timing helpers ---------------------------------- */
+
+enum qnnp_status qnnp_gfx950_time_operator_rotating(
+    qnnp_operator_t op, size_t nsets, const void* const* inputs, void* const* outputs,
+    int warmup, int iters, float* avg_ms_out)
+{
+  if (op == NULL || avg_ms_out == NULL || iters <= 0 || nsets == 0 || inputs == NULL || outputs == NULL) {
+    return qnnp_status_invalid_parameter;
+  }
+  if (!qnnp_state.initialized) {
+    return qnnp_status_uninitialized;
+  }
+  if (op->batch_size == 0) {
+    *avg_ms_out = 0.0f;
+    return qnnp_status_success;
+  }
+  for (size_t s = 0; s < nsets; s++) {
+    if (!qnnp_hip_is_device_pointer(inputs[s]) || !qnnp_hip_is_device_pointer(outputs[s])) {
+      return qnnp_status_invalid_parameter;
+    }
+  }
+  void* timer = NULL;
+  if (qnnp_hip_timer_create(&timer) != QNNP_HIP_OK) {
+    return qnnp_status_out_of_memory;
+  }
+  enum qnnp_status status = qnnp_status_success;
+  size_t set = 0;
+  for (int i = 0; i < warmup && status == qnnp_status_success; i++) {
+    status = status_from_hip(launch(op, inputs[set], outputs[set]));
+    set = (set + 1) % nsets;
+  }
+  if (status == qnnp_status_success) {
+    qnnp_hip_timer_start(timer);
+    for (int i = 0; i < iters && status == qnnp_status_success; i++) {
+      status = status_from_hip(launch(op, inputs[set], outputs[set]));
+      set = (set + 1) % nsets;
+    }
+    float ms = 0.0f;
+    const int rc = qnnp_hip_timer_stop_ms(timer, &ms);
+    if (status == qnnp_status_success) status = status_from_hip(rc);
+    *avg_ms_out = ms / (float) iters;
+  }
+  qnnp_hip_timer_destroy(timer);
+  return status;
+}
+
+enum qnnp_status qnnp_gfx950_time_operator(
+    qnnp_operator_t op, int warmup, int iters, float* avg_ms_out)
+{
+  if (op == NULL) {
+    return qnnp_status_invalid_parameter;
+  }
+  const void* in = op->input;
+  void* out = op->output;
+  return qnnp_gfx950_time_operator_rotating(op, 1, &in, &out, warmup, iters, avg_ms_out);
+}

@@ -1,0 +1,79 @@
+/*
+ * operator.h -- the opaque `struct qnnp_operator` behind qnnp_operator_t.
+ *
+ * Role-equivalent to the reference's src/qnnpack/operator.h:39-102, but laid out
+ * for the gfx950 build: the host-side packed weights / pointer indirection
+ * buffer / zero buffer of the reference become device allocations (an MFMA
+ * fragment-panel weight image, an int32 offset table, folded int32 bias).
+ */
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "hip/qnnp_hip.h"
+
+/* subset of reference enum qnnp_ukernel_type (src/qnnpack/operator.h:23-37) */
+enum qnnp_ukernel_type {
+  qnnp_ukernel_type_none = 0,
+  qnnp_ukernel_type_conv,
+  qnnp_ukernel_type_dwconv,
+  qnnp_ukernel_type_gemm,
+};
+
+struct qnnp_operator {
+  /* geometry fixed at create (reference operator.h:40-57) */
+  size_t batch_size;
+  uint32_t input_padding_top;
+  uint32_t input_padding_right;
+  uint32_t input_padding_bottom;
+  uint32_t input_padding_left;
+  uint32_t kernel_height;
+  uint32_t kernel_width;
+  uint32_t stride_height;
+  uint32_t stride_width;
+  uint32_t dilation_height;
+  uint32_t dilation_width;
+  uint32_t groups;
+  size_t group_input_channels;
+  size_t group_output_channels;
+
+  /* bound at setup (reference operator.h:59-73): caller-owned, not copied */
+  size_t input_height;
+  size_t input_width;
+  size_t input_pixel_stride;
+  const void* input;
+  size_t output_height;
+  size_t output_width;
+  size_t output_pixel_stride;
+  void* output;
+
+  uint8_t input_zero_point;
+  uint8_t kernel_zero_point;
+  struct qnnp_hip_requant requant;
+  enum qnnp_ukernel_type ukernel_type;
+
+  /* ---- device-side state owned by the operator ---- */
+  void* d_weights;        /* igemm: int8 fragment panels; dwconv: int16 [taps][c_pad] */
+  int32_t* d_bias;        /* igemm: bias2 [groups][n_pad]; dwconv: bias1 [c_pad] */
+  uint32_t n_pad;         /* igemm */
+  uint32_t k_pad;         /* igemm */
+  uint32_t c_pad;         /* dwconv */
+
+  int32_t* d_offsets;     /* conv: [output pixels][taps] int32, -1 = padding */
+  size_t offsets_capacity;     /* in entries */
+  size_t offsets_in_h, offsets_in_w, offsets_in_stride;  /* geometry the table was built for */
+
+  /* host-pointer staging (only used when setup() received host memory) */
+  int input_on_device;
+  int output_on_device;
+  void* d_stage_in;
+  size_t stage_in_capacity;
+  void* d_stage_out;
+  size_t stage_out_capacity;
+  size_t input_span;      /* bytes of caller input touched by the operator */
+  size_t output_span;     /* bytes of caller output the operator may write */
+
+  int variant;            /* kernel-variant option captured at setup */
+  const char* kernel_name;
+};

@@ -1,0 +1,108 @@
+/*
+ * pack.h -- create-time weight/bias packing into the gfx950 device layouts.
+ *
+ * Role-equivalent to the reference's src/qnnpack/pack.h, whose packers interleave
+ * weights for 4x4c2 / 8x8 CPU register tiles and fold the input zero point into
+ * the bias (pack_q8gemm_w :12-49, pack_q8conv_w :51-91, pack_q8dw_w :135-167).
+ * Here the targets are (a) MFMA operand fragments for
+ * v_mfma_i32_32x32x32_i8 and (b) a tap-major int16 image for the depthwise
+ * kernels. All arithmetic is exact int32 (wraps mod 2^32 like the reference).
+ */
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+static inline uint32_t qnnp_round_up_u32(uint32_t x, uint32_t q) {
+  return (x + q - 1) / q * q;
+}
+
+/*
+ * igemm weight image.
+ *
+ * Source (one group): kernel[n][kk], kk = tap * kc + channel in [0, k_total) --
+ * exactly the reference's [oc][ky][kx][ic] tensor flattened
+ * (test/convolution-operator-tester.h:393), or [N][K] for fully connected.
+ *
+ * Destination: for group g, 32-column block nb, 32-deep K block kb, one
+ * 1024-byte MFMA fragment: lane l (0..63) owns 16 consecutive bytes
+ *     w'(n = nb*32 + (l & 31), kk = kb*32 + (l >> 5)*16 + j),  j = 0..15
+ * at byte offset ((((g*NB + nb)*KB + kb)*64 + l)*16 + j), NB = n_pad/32,
+ * KB = k_pad/32. w' = w - 128 (uint8 -> int8 by flipping the top bit);
+ * positions with n >= N or kk >= k_total hold 0 so they add nothing.
+ * A wave loads its whole fragment with one coalesced 16-B-per-lane read.
+ *
+ * bias2[g*n_pad + n] = bias + (128 - izp) * sum_kk w'(n,kk)
+ *                           + k_total * (128 - izp) * (128 - kzp)
+ * so that, with a' = a - 128,
+ *   bias + sum (a - izp)(w - kzp) = bias2 + (128 - kzp) * sum a' + sum a' w'.
+ * This is the same zero-point algebra the reference uses for its ARM "XZP"
+ * GEMM (src/operator-run.c:727-743, pack.h:204-256), re-centred at 128 because
+ * the MFMA multiplies signed int8.
+ */
+static inline size_t qnnp_igemm_packed_weights_size(uint32_t groups, uint32_t n_pad, uint32_t k_pad) {
+  return (size_t) groups * n_pad * k_pad;
+}
+
+static inline void qnnp_pack_igemm_w(
+    uint32_t groups, uint32_t n, uint32_t k_total,
+    uint32_t n_pad, uint32_t k_pad,
+    uint8_t izp, uint8_t kzp,
+    const uint8_t* kernel, const int32_t* bias,
+    int8_t* packed, int32_t* bias2)
+{
+  const uint32_t nblocks = n_pad / 32;
+  const uint32_t kblocks = k_pad / 32;
+  memset(packed, 0, qnnp_igemm_packed_weights_size(groups, n_pad, k_pad));
+  const uint32_t a_off = (uint32_t) (128 - (int32_t) izp);
+  const uint32_t w_off = (uint32_t) (128 - (int32_t) kzp);
+  for (uint32_t g = 0; g < groups; g++) {
+    for (uint32_t col = 0; col < n_pad; col++) {
+      uint32_t b2 = 0;
+      if (col < n) {
+        const uint8_t* src = kernel + ((size_t) g * n + col) * k_total;
+        const uint32_t nb = col / 32;
+        const uint32_t lane_lo = col % 32;
+        uint32_t wsum = 0;
+        for (uint32_t kk = 0; kk < k_total; kk++) {
+          const int32_t ws = (int32_t) src[kk] - 128;
+          wsum += (uint32_t) ws;
+          const uint32_t kb = kk / 32;
+          const uint32_t lane = lane_lo + 32 * ((kk % 32) / 16);
+          const size_t dst = ((((size_t) g * nblocks + nb) * kblocks + kb) * 64 + lane) * 16 + (kk % 16);
+          packed[dst] = (int8_t) ws;
+        }
+        b2 = (uint32_t) bias[(size_t) g * n + col] + a_off * wsum + k_total * a_off * w_off;
+      }
+      bias2[(size_t) g * n_pad + col] = (int32_t) b2;
+    }
+  }
+}
+
+/*
+ * depthwise image: wadj[tap][c] = w[c][ky][kx] - kzp as int16, tap = ky*kw + kx,
+ * row length c_pad (zero padded); bias1[c] = bias[c] + taps*izp*kzp - izp*sum_taps w
+ * -- the folding of pack_q8dw_w (src/qnnpack/pack.h:146,151,159), so the kernel
+ * accumulates sum a*(w - kzp) over raw uint8 activations.
+ * Source kernel layout: [c][ky][kx] (groups = c, one input/output channel each).
+ */
+static inline void qnnp_pack_dwconv_w(
+    uint32_t channels, uint32_t c_pad, uint32_t kh, uint32_t kw,
+    uint8_t izp, uint8_t kzp,
+    const uint8_t* kernel, const int32_t* bias,
+    int16_t* wadj, int32_t* bias1)
+{
+  const uint32_t taps = kh * kw;
+  memset(wadj, 0, sizeof(int16_t) * (size_t) taps * c_pad);
+  memset(bias1, 0, sizeof(int32_t) * (size_t) c_pad);
+  for (uint32_t c = 0; c < channels; c++) {
+    uint32_t wsum = 0;
+    for (uint32_t t = 0; t < taps; t++) {
+      const uint8_t w = kernel[(size_t) c * taps + t];
+      wsum += w;
+      wadj[(size_t) t * c_pad + c] = (int16_t) ((int32_t) w - (int32_t) kzp);
+    }
+    bias1[c] = (int32_t) ((uint32_t) bias[c] + taps * (uint32_t) izp * (uint32_t) kzp - (uint32_t) izp * wsum);
+  }
+}

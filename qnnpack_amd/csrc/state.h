@@ -1,0 +1,19 @@
+/*
+ * state.h -- process-wide library state. Role-equivalent to the reference's
+ * global `qnnp_params` (src/qnnpack/params.h:520-538): there it is the per-ISA
+ * microkernel table filled by init(); here it records that a gfx950 device is
+ * bound plus the extension knobs of qnnpack_gfx950.h.
+ */
+#pragma once
+
+#include <stdbool.h>
+
+struct qnnp_state {
+  bool initialized;
+  int requested_device;   /* -1: env / current */
+  int async;              /* 1: qnnp_run_operator only enqueues */
+  int opt_gemm_kernel;    /* 0 auto, 1 generic, 2 big-tile */
+  int opt_dwconv_kernel;  /* 0 auto, 1 generic, 2 LDS-tiled */
+};
+
+extern struct qnnp_state qnnp_state;
