@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the q8 conv/GEMM hot path on MI355X, one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU; RANK/LOCAL_RANK/WORLD_SIZE from env)
+
+Headline (BASELINE.json `metric`, configs[1]): int8 TOPS of q8gemm M=N=K=4096 (uint8 in, int32 MFMA
+accumulate, fused Q31 requantize, uint8 out) through qnnp_*_fully_connected_nc_q8. A "step" is one
+whole GEMM launch. ops = 2*M*N*K, the reference's accounting (bench/q8gemm.cc:108).
+At N > 1 every rank runs its own replica of the GEMM (no batch dimension to shard: "replicas only",
+DESIGN.md) -> weak scaling, value = sum over ranks.
+
+Secondary numbers travel in the same JSON line under "extra" (not separate bench lines):
+  * q8conv 3x3 56x56x64->64 batch 128 (configs[2]),
+  * the MobileNetV2 depthwise layers (configs[3]) as HBM GB/s,
+  * the 31-layer MobileNetV2 conv sweep (configs[4], bench/convolution.cc:453-536) as images/s with the
+    batch sharded across ranks (no collective), each layer timed as its own operator like the reference bench.
+
+"roofline" is for the dominant kernel of the headline workload, timed with HIP events on the launch
+stream inside this process. "cpu_baseline" times the reference's own SSE2 path (oracle/_ref, built from
+the reference sources) on this box's host cores on a bounded sample -- rank 0, N = 1 only.
+Inputs are synthetic uniform-random uint8 already resident in HBM when the timed region starts.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# chip ceilings, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_I8_TOPS = 256 * 4 * 1024 * 2 * 2.4e9 / 1e12   # 5033: 256 CU x 4 SIMD x 1024 MAC/clk x 2.4 GHz (i8 = 2x the 2.5 PF bf16 dense rate)
+PEAK_HBM_GBS = 8000.0                               # HBM3E spec; ~6300 achievable
+
+# bench/convolution.cc:453-536 (the 31 active rows): N is replaced by the per-GPU batch
+#                 H    W   KH KW S  D   G   GCin  GCout
+MOBILENETV2 = [(224, 224, 3, 3, 2, 1,   1,    3,   32),
+               (112, 112, 3, 3, 1, 1,  32,    1,    1), (112, 112, 1, 1, 1, 1, 1,  32,  16),
+               (112, 112, 1, 1, 1, 1,   1,   16,   96), (112, 112, 3, 3, 2, 1, 96,  1,   1),
+               (56, 56, 1, 1, 1, 1, 1,  96,  24), (56, 56, 1, 1, 1, 1, 1,  24, 144),
+               (56, 56, 3, 3, 1, 1, 144, 1,   1), (56, 56, 1, 1, 1, 1, 1, 144,  24),
+               (56, 56, 3, 3, 2, 1, 144, 1,   1), (28, 28, 1, 1, 1, 1, 1, 144,  32),
+               (28, 28, 1, 1, 1, 1, 1,  32, 192), (28, 28, 3, 3, 1, 1, 192, 1,   1),
+               (28, 28, 1, 1, 1, 1, 1, 192,  32), (28, 28, 3, 3, 2, 1, 192, 1,   1),
+               (14, 14, 1, 1, 1, 1, 1, 192,  64), (14, 14, 1, 1, 1, 1, 1,  64, 384),
+               (14, 14, 3, 3, 1, 1, 384, 1,   1), (14, 14, 1, 1, 1, 1, 1, 384,  64),
+               (14, 14, 1, 1, 1, 1, 1, 384,  96), (14, 14, 1, 1, 1, 1, 1,  96, 576),
+               (14, 14, 3, 3, 1, 1, 576, 1,   1), (14, 14, 1, 1, 1, 1, 1, 576,  96),
+               (14, 14, 3, 3, 2, 1, 576, 1,   1), (7, 7, 1, 1, 1, 1, 1, 576, 160),
+               (7, 7, 1, 1, 1, 1, 1, 160, 960), (7, 7, 3, 3, 1, 1, 960, 1,   1),
+               (7, 7, 1, 1, 1, 1, 1, 960, 160), (7, 7, 1, 1, 1, 1, 1, 960, 320),
+               (7, 7, 1, 1, 1, 1, 1, 320, 1280), (1, 1, 1, 1, 1, 1, 1, 1280, 1000)]
+
+
+def conv_geometry(H, W, KH, KW, S, D):
+    """Padding and output size exactly as bench/convolution.cc:37-47 computes them."""
+    eh, ew = (KH - 1) * D + 1, (KW - 1) * D + 1
+    pl, pt = ew // 2, eh // 2
+    pr, pb = ew - 1 - pl, eh - 1 - pt
+    oh = (pt + H + pb - eh) // S + 1
+    ow = (pl + W + pr - ew) // S + 1
+    return (pt, pr, pb, pl), oh, ow
+
+
+class ConvLayer:
+    """One qnnp convolution operator with device-resident synthetic tensors (rotating buffer sets)."""
+
+    def __init__(self, lib, torch, batch, H, W, KH, KW, S, D, G, GIC, GOC, seed, min_bytes_between_reuse=0):
+        self.lib = lib
+        (pt, pr, pb, pl), oh, ow = conv_geometry(H, W, KH, KW, S, D)
+        rng = np.random.default_rng(seed)
+        kernel = rng.integers(0, 256, size=(G, GOC, KH, KW, GIC), dtype=np.uint8)
+        bias = rng.integers(-10000, 10001, size=G * GOC, dtype=np.int32)
+        # quantization parameters of the reference bench (bench/convolution.cc:71-74)
+        self.op = lib.create_convolution2d_nhwc_q8(pt, pr, pb, pl, KH, KW, S, S, D, D, G, GIC, GOC,
+                                                   127, 0.5, 127, 0.5, kernel, bias, 127, 0.5, 0, 255, 0)
+        self.batch, self.H, self.W = batch, H, W
+        self.cin, self.cout = G * GIC, G * GOC
+        self.in_bytes = batch * H * W * self.cin
+        self.out_bytes = batch * oh * ow * self.cout
+        self.ops = 2 * batch * oh * ow * G * GIC * GOC * KH * KW          # bench/convolution.cc:100-104
+        nsets = 1
+        if min_bytes_between_reuse:
+            nsets = max(1, -(-min_bytes_between_reuse // (self.in_bytes + self.out_bytes)))
+            nsets = min(nsets, 64)
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(seed)
+        self.inputs = [torch.randint(0, 256, (self.in_bytes,), dtype=torch.uint8, device="cuda", generator=gen)
+                       for _ in range(nsets)]
+        self.outputs = [torch.empty(self.out_bytes, dtype=torch.uint8, device="cuda") for _ in range(nsets)]
+        lib.setup_convolution2d_nhwc_q8(self.op, batch, H, W, self.inputs[0], self.cin, self.outputs[0], self.cout)
+        lib.run_operator(self.op)       # also resolves kernel_name
+        self.kernel = lib.operator_kernel(self.op)
+
+    def time_ms(self, warmup, iters):
+        return self.lib.time_operator_rotating(self.op, self.inputs, self.outputs, warmup, iters)
+
+    def close(self):
+        self.lib.delete_operator(self.op)
+        self.inputs = self.outputs = None
+
+
+def cpu_baseline_gemm(seconds_budget=12.0):
+    """Reference SSE2 q8gemm (qnnp_fully_connected_nc_q8 of the compiled reference) on the host cores:
+    a 512-row slice of the same 4096^3 problem (same N, K, data distribution), all cores via the
+    OpenMP pthreadpool shim, repeated for ~seconds_budget."""
+    from oracle import o1, ref
+    N = K = 4096
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(0x51A0 + 2)
+    w = rng.integers(0, 256, size=(N, K), dtype=np.uint8)
+    bias = rng.integers(-10000, 10001, size=N, dtype=np.int32)
+    if ref.available():
+        lib = ref.lib()
+        M = 512
+        a = rng.integers(0, 256, size=M * K + 16, dtype=np.uint8)
+        c = np.zeros(M * N, dtype=np.uint8)
+        op = lib.create_fully_connected_nc_q8(K, N, 127, 0.5, 127, 0.5, w, bias, 127, 0.5, 0, 255)
+        lib.setup_fully_connected_nc_q8(op, M, a[8:], K, c, N)
+        pool = lib.threadpool(cores)
+        lib.run_operator(op, pool)      # warm-up
+        iters, t0 = 0, time.perf_counter()
+        while True:
+            lib.run_operator(op, pool)
+            iters += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds_budget or iters >= 50:
+                break
+        lib.destroy_threadpool(pool)
+        lib.delete_operator(op)
+        tops = 2.0 * M * N * K * iters / dt / 1e12
+        return {"value": round(tops, 5), "unit": "TOPS", "cores": cores, "kind": "reference",
+                "sample": f"reference SSE2 4x4c2 q8gemm via qnnp_fully_connected_nc_q8, M={M} rows of the "
+                          f"N=K=4096 problem x {iters} runs, {cores}-thread pthreadpool (OpenMP shim), {dt:.1f} s"}
+    M = 32
+    a = rng.integers(0, 256, size=(M, K), dtype=np.uint8)
+    o1.set_threads(cores)
+    t0 = time.perf_counter()
+    acc = o1.gemm_acc(a, w, bias, 127, 127)
+    o1.requantize_rows(acc, 0.5, 127, 0, 255)
+    dt = time.perf_counter() - t0
+    o1.set_threads(1)
+    return {"value": round(2.0 * M * N * K / dt / 1e12, 6), "unit": "TOPS", "cores": cores, "kind": "port",
+            "sample": f"scalar oracle port, M={M} rows of the N=K=4096 problem, {cores} OpenMP threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--sweep-batch", type=int, default=128, help="MobileNetV2 sweep images per GPU")
+    ap.add_argument("--no-extra", action="store_true", help="headline GEMM only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-kernel", type=int, default=0, help="0 auto, 1 generic MFMA kernel, 2 big-tile kernel")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    torch.zeros(1, device="cuda")
+
+    import qnnpack_amd
+    from qnnpack_amd.shard import job_time_ms, shard_batch
+    lib = qnnpack_amd.load()
+    lib.set_device(local_rank)
+    lib.initialize()
+    lib.set_stream(torch.cuda.current_stream().cuda_stream)
+    lib.set_option("gemm_kernel", args.gemm_kernel)
+    info = lib.device_info()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ------------------------------------------------------------------ headline: q8gemm 4096^3
+    M = N = K = 4096
+    rng = np.random.default_rng(0x51A0 + 2 + rank)
+    w = rng.integers(0, 256, size=(N, K), dtype=np.uint8)
+    bias = rng.integers(-10000, 10001, size=N, dtype=np.int32)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0x51A0 + rank)
+    a = torch.randint(0, 256, (M * K,), dtype=torch.uint8, device="cuda", generator=gen)   # random, not zeros (DVFS)
+    c = torch.empty(M * N, dtype=torch.uint8, device="cuda")
+    # zero points 127, requantization scale 0.75, clamp [1, 254]: bench/q8gemm.cc:103
+    op = lib.create_fully_connected_nc_q8(K, N, 127, 0.75, 127, 1.0, w, bias, 127, 1.0, 1, 254)
+    lib.setup_fully_connected_nc_q8(op, M, a, K, c, N)
+    lib.set_async(True)
+    for _ in range(args.warmup):
+        lib.run_operator(op)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lib.run_operator(op)
+    torch.cuda.synchronize()
+    local_ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    barrier()
+    ms_per_step = job_time_ms(local_ms, world)
+    gemm_kernel = lib.operator_kernel(op)
+    # kernel-only duration with HIP events on the launch stream (same launches, same data)
+    ev_ms = lib.time_operator(op, 3, max(args.steps, 20))
+    gemm_ops = 2.0 * M * N * K
+    value = world * gemm_ops / (ms_per_step * 1e-3) / 1e12
+    achieved = gemm_ops / (ev_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(gemm_kernel)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "mfma", "kernel": gemm_kernel, "achieved": round(achieved, 2), "peak": round(PEAK_I8_TOPS, 1),
+                "unit": "TOP/s", "frac": round(achieved / PEAK_I8_TOPS, 4), "traffic": traffic,
+                "launch_ms": round(ev_ms, 5), "algorithmic_bytes_per_launch": 3 * M * N + 4 * N}
+    lib.delete_operator(op)
+    del a, c
+
+    extra = {}
+    if not args.no_extra:
+        lib.set_async(False)
+        # ---------------------------------------------------------- configs[2]: 3x3 conv 56x56x64->64, batch 128
+        layer = ConvLayer(lib, torch, 128, 56, 56, 3, 3, 1, 1, 1, 64, 64, seed=3, min_bytes_between_reuse=320 << 20)
+        ms = layer.time_ms(3, 20)
+        extra["q8conv_3x3_56x56x64_b128"] = {
+            "kernel": layer.kernel, "ms": round(ms, 4), "tops": round(layer.ops / (ms * 1e-3) / 1e12, 2),
+            "gbs": round((layer.in_bytes + layer.out_bytes) / (ms * 1e-3) / 1e9, 1),
+            "roofline_ms": round(max(layer.ops / (PEAK_I8_TOPS * 1e12), (layer.in_bytes + layer.out_bytes) / (PEAK_HBM_GBS * 1e9)) * 1e3, 4)}
+        layer.close()
+
+        # ---------------------------------------------------------- configs[3] + [4]: MobileNetV2 sweep, batch sharded
+        total_batch = args.sweep_batch * world
+        _, my_batch = shard_batch(total_batch, world, rank)
+        sweep_ms, dw_ms, dw_bytes, act_bytes, total_ops, rows = 0.0, 0.0, 0, 0, 0.0, []
+        for i, (H, W, KH, KW, S, D, G, GIC, GOC) in enumerate(MOBILENETV2):
+            layer = ConvLayer(lib, torch, my_batch, H, W, KH, KW, S, D, G, GIC, GOC, seed=100 + i,
+                              min_bytes_between_reuse=512 << 20)
+            ms = layer.time_ms(2, 10)
+            b = layer.in_bytes + layer.out_bytes
+            sweep_ms += ms
+            act_bytes += b
+            total_ops += layer.ops
+            if G > 1:
+                dw_ms += ms
+                dw_bytes += b
+            rows.append({"layer": i + 1, "shape": [H, W, KH, S, G, GIC, GOC], "kernel": layer.kernel,
+                         "ms": round(ms, 4), "gbs": round(b / (ms * 1e-3) / 1e9, 1),
+                         "tops": round(layer.ops / (ms * 1e-3) / 1e12, 2)})
+            layer.close()
+        job_sweep_ms = job_time_ms(sweep_ms, world)
+        extra["mobilenetv2_sweep"] = {
+            "images_per_s": round(total_batch / (job_sweep_ms * 1e-3), 1), "batch_per_gpu": my_batch,
+            "ms_per_batch": round(job_sweep_ms, 4), "hbm_gbs": round(act_bytes / (sweep_ms * 1e-3) / 1e9, 1),
+            "frac_of_hbm_peak": round(act_bytes / (sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "tops": round(total_ops / (sweep_ms * 1e-3) / 1e12, 2),
+            "roofline_images_per_s_per_gpu": round(PEAK_HBM_GBS * 1e9 / (act_bytes / my_batch), 1),
+            "layers": rows}
+        extra["q8dwconv_mobilenetv2_layers"] = {
+            "hbm_gbs": round(dw_bytes / (dw_ms * 1e-3) / 1e9, 1), "ms": round(dw_ms, 4),
+            "frac_of_hbm_peak": round(dw_bytes / (dw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_gemm()
+
+    if rank == 0:
+        line = {
+            "metric": "q8gemm_int8_tops", "value": round(value, 2), "unit": "TOPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "q8gemm M=N=K=4096 uint8 (qnnp_fully_connected_nc_q8, int8 MFMA, fused Q31 requantize)"
+                                   + (" -- one replica per GPU" if world > 1 else ""),
+                       "kernel": gemm_kernel, "device": info["arch"], "compute_units": info["compute_units"],
+                       "pct_of_i8_mfma_peak": round(100.0 * value / world / PEAK_I8_TOPS, 2)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "extra": extra,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,13 @@ def load() -> Gfx950Library:
     """
     global _loaded
     if _loaded is None:
+        try:
+            # Load torch's bundled HIP runtime FIRST when torch is installed: both it and
+            # /opt/rocm's copy have SONAME libamdhip64.so.7, and two HIP runtimes in one
+            # process cannot see each other's allocations or streams.
+            import torch  # noqa: F401
+        except Exception:
+            pass
         path = library_path()
         if not os.path.exists(path):
             raise RuntimeError(

@@ -1,0 +1,19 @@
+#!/bin/bash
+# One gpurun call: GPU-tier tests, bench line, rocprofv3 kernel stats. Everything lands in gpurun_out/.
+# usage: gpurun --timeout 1500 -- bash scripts/gpu_round.sh [tag]
+TAG=${1:-r01}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+echo "== device"; rocminfo 2>/dev/null | grep -E "gfx|Compute Unit" | head -4; nproc
+echo "== pytest -m gpu"
+timeout 900 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider 2>&1 | tail -n 120 > $OUT/pytest_gpu.log
+tail -n 45 $OUT/pytest_gpu.log
+echo "== smoke"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 5 | tee $OUT/smoke.log
+echo "== bench"
+timeout 600 python bench.py --steps 30 --warmup 5 2>&1 | tail -n 3 | tee $OUT/bench.json
+echo "== rocprofv3 kernel stats (headline GEMM only)"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o gemm -- python $OLDPWD/bench.py --steps 30 --warmup 5 --no-extra --no-cpu-baseline > $OLDPWD/$OUT/prof_run.log 2>&1)
+find $OUT/prof -name "*kernel_stats*" | head -3
+for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -n 12 $f; done

@@ -1,0 +1,169 @@
+"""GPU tier: BASELINE.json's full-size configurations. The scalar oracle cannot run 137 GOP in
+seconds, so full sizes are checked by (a) the oracle on a sample of rows / images that straddles
+every tile edge, and (b) size-independent properties of the operator: outputs of a row / image do
+not depend on where it sits in the batch (permutation equivariance), checked over the WHOLE output."""
+import numpy as np
+import pytest
+
+from _cases import ConvCase, conv_tensors, output_quantization
+from _gpu import from_device, to_device
+from _runner import FILL, assert_bytes_equal
+from oracle import o1
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c2_q8gemm_4096_cubed(qnnp):
+    """configs[1]: q8gemm M=N=K=4096 through qnnp_fully_connected_nc_q8."""
+    import torch
+    M = N = K = 4096
+    rng = np.random.default_rng(0x51A0 + 2)
+    a = rng.integers(0, 256, size=(M, K), dtype=np.uint8)
+    w = rng.integers(0, 256, size=(N, K), dtype=np.uint8)
+    bias = rng.integers(-10000, 10001, size=N, dtype=np.int32)
+    izp, kzp = 127, 127
+    o1.set_threads(8)
+    sample = np.unique(np.concatenate([
+        [0, 1, 31, 32, 127, 128, 255, 256, 257, 2047, 2048, 4094, 4095], rng.integers(0, M, size=40)]))
+    acc = o1.gemm_acc(np.ascontiguousarray(a[sample]), w, bias, izp, kzp)
+    oscale, ozp = output_quantization(acc)
+    expected = o1.requantize_rows(acc, np.float32(1.0) / oscale, ozp, 0, 255)
+    o1.set_threads(1)
+
+    op = qnnp.create_fully_connected_nc_q8(K, N, izp, 1.0, kzp, 1.0, w, bias, ozp, float(oscale), 0, 255)
+    try:
+        d_a = to_device(a.reshape(-1))
+        d_c = to_device(np.full(M * N, FILL, np.uint8))
+        qnnp.setup_fully_connected_nc_q8(op, M, d_a, K, d_c, N)
+        qnnp.run_operator(op)
+        c = from_device(d_c).reshape(M, N)
+        assert_bytes_equal(c[sample].reshape(-1), expected.reshape(-1), "4096^3 sampled rows vs oracle")
+        assert c.min() < 64 and c.max() > 192, "outputs should span the uint8 range"
+        # permutation equivariance over the full output: reversing the rows of A reverses the rows of C
+        d_a2 = torch.flip(d_a.view(M, K), dims=[0]).contiguous().view(-1)
+        d_c2 = to_device(np.full(M * N, FILL, np.uint8))
+        qnnp.setup_fully_connected_nc_q8(op, M, d_a2, K, d_c2, N)
+        qnnp.run_operator(op)
+        c2 = from_device(d_c2).reshape(M, N)
+        assert np.array_equal(c2[::-1], c), "row permutation equivariance violated at 4096^3"
+    finally:
+        qnnp.delete_operator(op)
+
+
+def test_c3_q8conv_3x3_56x56x64_batch128(qnnp):
+    """configs[2]: 3x3 s1 pad1 conv via the device-side offset table, 56x56x64 -> 64, batch 128."""
+    import torch
+    case = ConvCase("c3_fullsize", (56, 56), (3, 3), (1, 1, 1, 1), gic=64, goc=64, batch=128)
+    inp, kernel, bias = conv_tensors(case)
+    img = 56 * 56 * 64
+    sample = [0, 1, 63, 127]
+    o1.set_threads(8)
+    shape = o1.conv_shape(len(sample), 56, 56, case.padding, (3, 3), (1, 1), (1, 1), 1, 64, 64, 64)
+    sub = np.concatenate([inp[i * img:(i + 1) * img] for i in sample])
+    acc = o1.conv2d_acc(shape, sub, kernel, bias, case.izp, case.kzp)
+    oscale, ozp = output_quantization(acc)
+    expected = o1.requantize_rows(acc.reshape(-1, 64), np.float32(1.0) / oscale, ozp, 0, 255).reshape(len(sample), -1)
+    o1.set_threads(1)
+
+    op = qnnp.create_convolution2d_nhwc_q8(1, 1, 1, 1, 3, 3, 1, 1, 1, 1, 1, 64, 64, case.izp, 1.0, case.kzp, 1.0,
+                                           kernel, bias, ozp, float(oscale), 0, 255, 0)
+    try:
+        d_in = to_device(inp)
+        d_out = to_device(np.full(128 * img, FILL, np.uint8))
+        qnnp.setup_convolution2d_nhwc_q8(op, 128, 56, 56, d_in, 64, d_out, 64)
+        qnnp.run_operator(op)
+        assert qnnp.operator_kernel(op).startswith("q8_igemm")
+        out = from_device(d_out).reshape(128, img)
+        for j, i in enumerate(sample):
+            assert_bytes_equal(out[i], expected[j], f"C3 image {i} vs oracle")
+        # image-permutation equivariance over all 128 images
+        d_in2 = torch.flip(d_in.view(128, img), dims=[0]).contiguous().view(-1)
+        d_out2 = to_device(np.full(128 * img, FILL, np.uint8))
+        qnnp.setup_convolution2d_nhwc_q8(op, 128, 56, 56, d_in2, 64, d_out2, 64)
+        qnnp.run_operator(op)
+        out2 = from_device(d_out2).reshape(128, img)
+        assert np.array_equal(out2[::-1], out), "image permutation equivariance violated"
+    finally:
+        qnnp.delete_operator(op)
+
+
+# configs[3]: every MobileNetV2 depthwise layer (bench/convolution.cc:461-518): (H, stride, C)
+MOBILENETV2_DW = [(112, 1, 32), (112, 2, 96), (56, 1, 144), (56, 2, 144), (28, 1, 192), (28, 2, 192),
+                  (14, 1, 384), (14, 1, 576), (14, 2, 576), (7, 1, 960)]
+
+
+@pytest.mark.parametrize("h,s,c", MOBILENETV2_DW, ids=lambda v: str(v))
+def test_c4_mobilenetv2_depthwise_layers(qnnp, h, s, c):
+    batch = 8
+    case = ConvCase(f"c4_dw_{h}_{s}_{c}", (h, h), (3, 3), (1, 1, 1, 1), subsampling=(s, s), groups=c, batch=batch)
+    inp, kernel, bias = conv_tensors(case)
+    o1.set_threads(8)
+    shape = o1.conv_shape(batch, h, h, case.padding, (3, 3), (s, s), (1, 1), c, 1, 1, c)
+    acc = o1.conv2d_acc(shape, inp, kernel, bias, case.izp, case.kzp)
+    oscale, ozp = output_quantization(acc)
+    expected = o1.requantize_rows(acc.reshape(-1, c), np.float32(1.0) / oscale, ozp, 0, 255).reshape(-1)
+    o1.set_threads(1)
+    op = qnnp.create_convolution2d_nhwc_q8(1, 1, 1, 1, 3, 3, s, s, 1, 1, c, 1, 1, case.izp, 1.0, case.kzp, 1.0,
+                                           kernel, bias, ozp, float(oscale), 0, 255, 0)
+    try:
+        d_in = to_device(inp)
+        d_out = to_device(np.full(expected.size, FILL, np.uint8))
+        qnnp.setup_convolution2d_nhwc_q8(op, batch, h, h, d_in, c, d_out, c)
+        qnnp.run_operator(op)
+        kname = qnnp.operator_kernel(op)
+        assert kname == "q8_dwconv_lds_3x3", kname       # the LDS-tiled kernel must take every MobileNetV2 layer
+        assert_bytes_equal(from_device(d_out), expected, f"C4 depthwise {h}x{h} s{s} C{c} vs oracle")
+    finally:
+        qnnp.delete_operator(op)
+
+
+# configs[4] building blocks: every pointwise / first-layer shape of the MobileNetV2 sweep at batch 4
+MOBILENETV2_GEMM = [(112, 32, 16), (112, 16, 96), (56, 96, 24), (56, 24, 144), (56, 144, 24), (28, 144, 32),
+                    (28, 32, 192), (28, 192, 32), (14, 192, 64), (14, 64, 384), (14, 384, 64), (14, 384, 96),
+                    (14, 96, 576), (14, 576, 96), (7, 576, 160), (7, 160, 960), (7, 960, 160), (7, 960, 320),
+                    (7, 320, 1280), (1, 1280, 1000)]
+
+
+@pytest.mark.parametrize("h,cin,cout", MOBILENETV2_GEMM, ids=lambda v: str(v))
+def test_c5_mobilenetv2_pointwise_layers(qnnp, h, cin, cout):
+    batch = 4 if h > 14 else 16
+    case = ConvCase(f"c5_pw_{h}_{cin}_{cout}", (h, h), gic=cin, goc=cout, batch=batch)
+    inp, kernel, bias = conv_tensors(case)
+    o1.set_threads(8)
+    a = inp.reshape(batch * h * h, cin)
+    acc = o1.gemm_acc(a, kernel.reshape(cout, cin), bias, case.izp, case.kzp)
+    oscale, ozp = output_quantization(acc)
+    expected = o1.requantize_rows(acc, np.float32(1.0) / oscale, ozp, 0, 255).reshape(-1)
+    o1.set_threads(1)
+    op = qnnp.create_convolution2d_nhwc_q8(0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, cin, cout, case.izp, 1.0, case.kzp, 1.0,
+                                           kernel, bias, ozp, float(oscale), 0, 255, 0)
+    try:
+        d_in, d_out = to_device(inp), to_device(np.full(expected.size, FILL, np.uint8))
+        qnnp.setup_convolution2d_nhwc_q8(op, batch, h, h, d_in, cin, d_out, cout)
+        qnnp.run_operator(op)
+        assert_bytes_equal(from_device(d_out), expected,
+                           f"C5 pointwise {h}x{h} {cin}->{cout} vs oracle kernel={qnnp.operator_kernel(op)}")
+    finally:
+        qnnp.delete_operator(op)
+
+
+def test_c5_mobilenetv2_first_layer(qnnp):
+    """3x3 s2 3->32 on 224x224 (bench/convolution.cc:457), padding as the bench computes it (:42-47)."""
+    batch = 2
+    case = ConvCase("c5_first", (224, 224), (3, 3), (1, 1, 1, 1), subsampling=(2, 2), gic=3, goc=32, batch=batch)
+    inp, kernel, bias = conv_tensors(case)
+    o1.set_threads(8)
+    shape = o1.conv_shape(batch, 224, 224, case.padding, (3, 3), (2, 2), (1, 1), 1, 3, 32, 3)
+    acc = o1.conv2d_acc(shape, inp, kernel, bias, case.izp, case.kzp)
+    oscale, ozp = output_quantization(acc)
+    expected = o1.requantize_rows(acc.reshape(-1, 32), np.float32(1.0) / oscale, ozp, 0, 255).reshape(-1)
+    o1.set_threads(1)
+    op = qnnp.create_convolution2d_nhwc_q8(1, 1, 1, 1, 3, 3, 2, 2, 1, 1, 1, 3, 32, case.izp, 1.0, case.kzp, 1.0,
+                                           kernel, bias, ozp, float(oscale), 0, 255, 0)
+    try:
+        d_in, d_out = to_device(inp), to_device(np.full(expected.size, FILL, np.uint8))
+        qnnp.setup_convolution2d_nhwc_q8(op, batch, 224, 224, d_in, 3, d_out, 32)
+        qnnp.run_operator(op)
+        assert_bytes_equal(from_device(d_out), expected, "C5 first layer vs oracle")
+    finally:
+        qnnp.delete_operator(op)

@@ -1,0 +1,82 @@
+"""CPU tier: the create/setup-time host logic of the product library (weight packing into MFMA
+fragment panels with folded zero points, the device offset table, Q31 parameter builder) is
+replayed through a numpy model of the device kernels' index arithmetic and must reproduce the
+oracle byte for byte. No GPU and no compute entry point of the library is used here."""
+import numpy as np
+import pytest
+
+import _emulate as em
+from _cases import CONV_CASES, EXTRA_CONV_CASES, EXTRA_FC_CASES, FC_CASES, conv_tensors, fc_tensors, strided_view
+from _runner import assert_bytes_equal, conv_expected, fc_expected
+from oracle import o1
+
+SMALL_CONV = [c for c in CONV_CASES + EXTRA_CONV_CASES
+              if c.batch > 0 and c.batch * c.input_size[0] * c.input_size[1] * c.groups * c.gic <= 30000]
+SMALL_FC = [c for c in FC_CASES + EXTRA_FC_CASES if c.batch > 0 and c.batch * c.input_channels <= 40000]
+
+
+@pytest.fixture(scope="module")
+def hooks(product):
+    return em.bind_debug_hooks(product)
+
+
+def test_requant_params_match_oracle(hooks):
+    for scale in [2.0 ** -32, 2.0 ** -20, 0.0031, 1 / 255.0, 0.5, 0.75, float.fromhex("0x1.FFFFFEp-1")]:
+        for zp, qmin, qmax in [(0, 0, 255), (127, 0, 255), (255, 10, 200), (5, 128, 255)]:
+            rq = em.host_requant(hooks, scale, zp, qmin, qmax)
+            p = o1.q31_params(scale, zp, qmin, qmax)
+            assert (rq.multiplier, rq.remainder_mask, rq.remainder_threshold, rq.shift,
+                    rq.output_min_less_zero_point, rq.output_max_less_zero_point, rq.output_zero_point) == \
+                   (p.multiplier, p.remainder_mask, p.remainder_threshold, p.shift,
+                    p.min_less_zero_point, p.max_less_zero_point, p.zero_point)
+
+
+def test_numpy_requant_model_matches_oracle(hooks):
+    rng = np.random.default_rng(3)
+    acc = rng.integers(-2**31, 2**31, size=20000).astype(np.int32)
+    for scale in [2.0 ** -32, 0.003, 0.5, 0.9999]:
+        rq = em.host_requant(hooks, scale, 77, 3, 250)
+        assert np.array_equal(em.q31_requantize_np(acc, rq), o1.q31_requantize(acc, scale, 77, 3, 250))
+
+
+@pytest.mark.parametrize("case", SMALL_FC, ids=lambda c: c.name)
+def test_fully_connected_host_images(hooks, case):
+    inp, kernel, bias = fc_tensors(case)
+    expected, (oscale, ozp) = fc_expected(case, inp, kernel, bias)
+    rq = em.host_requant(hooks, np.float32(1.0) / oscale, ozp, case.qmin, case.qmax)
+    a = strided_view(inp, case.batch, case.input_channels, case.in_stride)
+    out = em.emulate_igemm(hooks, 1, case.output_channels, case.input_channels, 1, case.izp, case.kzp,
+                           kernel, bias, lambda g: a, case.batch, rq, case.out_stride)
+    assert_bytes_equal(out, expected, f"host images replay vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("case", SMALL_CONV, ids=lambda c: c.name)
+def test_convolution_host_images(hooks, case):
+    inp, kernel, bias = conv_tensors(case)
+    expected, (oscale, ozp), (oh, ow) = conv_expected(case, inp, kernel, bias)
+    rq = em.host_requant(hooks, np.float32(1.0) / oscale, ozp, case.qmin, case.qmax)
+    depthwise = case.gic == 1 and case.goc == 1 and case.groups > 1
+    if depthwise:
+        out = em.emulate_dwconv(hooks, case, inp, kernel, bias, rq, oh, ow)
+    else:
+        offsets = em.host_offsets(hooks, case, oh, ow)
+        taps = case.kernel_size[0] * case.kernel_size[1]
+        rows = case.batch * oh * ow
+        out = em.emulate_igemm(
+            hooks, case.groups, case.goc, case.gic, taps, case.izp, case.kzp,
+            kernel.reshape(case.groups * case.goc, taps * case.gic), bias,
+            lambda g: em.gather_conv_rows(case, inp, offsets, g, oh, ow), rows, rq, case.out_stride)
+    assert_bytes_equal(out, expected, f"host images replay vs oracle [{case.name}]")
+
+
+def test_offset_table_semantics(hooks):
+    # src/indirection.c:56-60 index arithmetic: 3x3, pad 1, stride 2 on a 5x4 image with pixel stride 7
+    from _cases import ConvCase
+    case = ConvCase("t", (5, 4), (3, 3), (1, 1, 1, 1), subsampling=(2, 2), gic=7, goc=1)
+    table = em.host_offsets(hooks, case, 3, 2)
+    assert table.shape == (6, 9)
+    # output (0,0): taps with ky=0 or kx=0 fall in the padding
+    assert table[0].tolist() == [-1, -1, -1, -1, 0, 7, -1, 28, 35]
+    # output (2,1): oy*2-1 = 3, ox*2-1 = 1 -> rows 3,4,(5 out), cols 1,2,3
+    assert table[5].tolist() == [(3 * 4 + 1) * 7, (3 * 4 + 2) * 7, (3 * 4 + 3) * 7,
+                                 (4 * 4 + 1) * 7, (4 * 4 + 2) * 7, (4 * 4 + 3) * 7, -1, -1, -1]

@@ -1,0 +1,60 @@
+"""CPU tier, world_size 2 over gloo: the multi-GPU path is batch sharding with no data-path
+collective. Checks that the per-rank slices partition the batch and that
+the whole-job time is the max over ranks, exactly as bench.py uses them."""
+import os
+import socket
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_batch_partitions():
+    from qnnpack_amd.shard import shard_batch
+    for total in [0, 1, 7, 128, 1024, 1025]:
+        for world in [1, 2, 3, 4, 8]:
+            slices = [shard_batch(total, world, r) for r in range(world)]
+            assert slices[0][0] == 0
+            for (s0, c0), (s1, _) in zip(slices, slices[1:]):
+                assert s0 + c0 == s1
+            assert slices[-1][0] + slices[-1][1] == total
+            counts = [c for _, c in slices]
+            assert max(counts) - min(counts) <= 1
+    with pytest.raises(ValueError):
+        shard_batch(8, 2, 2)
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from qnnpack_amd.shard import job_time_ms, shard_batch
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    start, count = shard_batch(total, world, rank)
+    dist.barrier()
+    local_ms = 10.0 + 5.0 * rank          # rank 1 is the slow one
+    job_ms = job_time_ms(local_ms, world)
+    q.put((rank, start, count, job_ms))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_job_over_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, total = 2, 129
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, c0, t0), (r1, s1, c1, t1) = results
+    assert (s0, c0, s1, c1) == (0, 65, 65, 64)
+    assert t0 == t1 == 15.0                    # max over ranks, seen by every rank
