@@ -14,6 +14,6 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 5 
 echo "== bench"
 timeout 600 python bench.py --steps 30 --warmup 5 2>&1 | tail -n 3 | tee $OUT/bench.json
 echo "== rocprofv3 kernel stats (headline GEMM only)"
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o gemm -- python $OLDPWD/bench.py --steps 30 --warmup 5 --no-extra --no-cpu-baseline > $OLDPWD/$OUT/prof_run.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o gemm -- python $OLDPWD/bench.py --steps 30 --warmup 5 --no-extra --no-cpu-baseline > $OLDPWD/$OUT/prof_run.log 2>&1)
 find $OUT/prof -name "*kernel_stats*" | head -3
 for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -n 12 $f; done
