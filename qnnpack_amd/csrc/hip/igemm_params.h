@@ -1,0 +1,43 @@
+/*
+ * igemm_params.h -- kernel-argument block shared by the MFMA GEMM / implicit-GEMM kernels
+ * (q8igemm.hip: generic kernel + dispatch; q8gemm256.hip: 256x256 LDS-DMA kernel).
+ */
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "qnnp_hip.h"
+
+namespace qnnp {
+
+struct IgemmParams {
+  const uint8_t* input;
+  uint8_t* output;
+  const int8_t* packed_w;
+  const int32_t* bias2;
+  const int32_t* offsets;
+  uint32_t rows;
+  uint32_t rows_per_image;
+  uint64_t image_stride;
+  uint32_t n;
+  uint32_t n_pad;
+  uint32_t kc;
+  uint32_t ks;
+  uint32_t k_total;
+  uint32_t k_pad;
+  uint32_t input_stride;
+  uint32_t output_stride;
+  int32_t row_coeff;
+  uint32_t izp_fill;       // input zero point replicated into 4 bytes
+  uint32_t store_dword;    // 1: 4-channel dword stores are aligned and in-bounds
+  const uint8_t* fill_table; // [256][16]: entry v = 16 bytes of value v (LDS-DMA padding sources)
+  qnnp_hip_requant rq;
+};
+
+/* q8gemm256.hip */
+bool gemm256_supported(const IgemmParams& p, uint32_t vec);
+int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name);
+
+}  // namespace qnnp

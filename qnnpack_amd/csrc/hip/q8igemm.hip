@@ -39,12 +39,14 @@
 
 #include <stdint.h>
 
+#include "igemm_params.h"
 #include "qnnp_hip.h"
 #include "requant.cuh"
 
-extern "C" void* qnnp_hip_get_stream(void);
 
 namespace {
+
+using qnnp::IgemmParams;
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -52,28 +54,6 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int BK = 64;                       // bytes of K per main-loop step
 constexpr uint32_t kPadK = 0x80808080u;      // raw bytes whose a' = a ^ 0x80 is zero
 
-struct IgemmParams {
-  const uint8_t* input;
-  uint8_t* output;
-  const int8_t* packed_w;
-  const int32_t* bias2;
-  const int32_t* offsets;
-  uint32_t rows;
-  uint32_t rows_per_image;
-  uint64_t image_stride;
-  uint32_t n;
-  uint32_t n_pad;
-  uint32_t kc;
-  uint32_t ks;
-  uint32_t k_total;
-  uint32_t k_pad;
-  uint32_t input_stride;
-  uint32_t output_stride;
-  int32_t row_coeff;
-  uint32_t izp_fill;       // input zero point replicated into 4 bytes
-  uint32_t store_dword;    // 1: 4-channel dword stores are aligned and in-bounds
-  qnnp_hip_requant rq;
-};
 
 template <int VEC>
 __device__ __forceinline__ void load_vec(const uint8_t* p, uint32_t (&w)[4], int j);
@@ -423,6 +403,7 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   p.row_coeff = a->row_coeff;
   p.izp_fill = (a->input_zero_point & 0xFFu) * 0x01010101u;
   p.rq = a->rq;
+  p.fill_table = qnnp_hip_fill_table();
 
   // widest activation vector the actual alignment allows (a vector never straddles a tap)
   const uintptr_t in_addr = reinterpret_cast<uintptr_t>(a->input);
@@ -439,8 +420,17 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
 
   hipStream_t stream = reinterpret_cast<hipStream_t>(qnnp_hip_get_stream());
   const char* name = nullptr;
-  const int rc = (a->offsets != nullptr) ? dispatch_vec<true>(p, a->groups, vec, stream, &name)
-                                          : dispatch_vec<false>(p, a->groups, vec, stream, &name);
+  // Large MFMA-bound problems take the 256x256 LDS-DMA kernel; everything else the generic one.
+  const bool big_ok = qnnp::gemm256_supported(p, vec);
+  const bool big_auto = a->n >= 256 && a->k_total >= 512 && a->rows >= 2048;
+  if (a->variant == 2 && !big_ok) return QNNP_HIP_EINVAL;
+  int rc;
+  if (big_ok && (a->variant == 2 || (a->variant == 0 && big_auto))) {
+    rc = qnnp::gemm256_launch(p, a->groups, stream, &name);
+  } else {
+    rc = (a->offsets != nullptr) ? dispatch_vec<true>(p, a->groups, vec, stream, &name)
+                                 : dispatch_vec<false>(p, a->groups, vec, stream, &name);
+  }
   if (kernel_name != nullptr) *kernel_name = name;
   return rc;
 }

@@ -46,6 +46,8 @@ int qnnp_hip_device_info(char* arch, size_t arch_len, int* cus, int* clock_khz, 
 void qnnp_hip_set_stream(void* stream);
 void* qnnp_hip_get_stream(void);
 int qnnp_hip_stream_sync(void);
+/* device table [256][16]: entry v = sixteen bytes of value v (constant LDS-DMA sources) */
+const uint8_t* qnnp_hip_fill_table(void);
 
 void* qnnp_hip_alloc(size_t bytes);
 void qnnp_hip_free(void* p);

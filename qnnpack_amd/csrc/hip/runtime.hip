@@ -6,6 +6,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -19,6 +20,7 @@ struct Runtime {
   int device = -1;
   hipStream_t stream = nullptr;  // nullptr = default stream
   hipDeviceProp_t props;
+  uint8_t* fill_table = nullptr;  // [256][16]: entry v = sixteen bytes of value v (LDS-DMA padding sources)
 };
 
 Runtime g_rt;
@@ -53,12 +55,24 @@ int qnnp_hip_init(int device)
   }
   g_rt.device = device;
   g_rt.stream = nullptr;
+  if (g_rt.fill_table == nullptr) {
+    uint8_t host[256 * 16];
+    for (int v = 0; v < 256; v++) std::memset(host + v * 16, v, 16);
+    if (!ok(hipMalloc(reinterpret_cast<void**>(&g_rt.fill_table), sizeof(host)))) return QNNP_HIP_ENOMEM;
+    if (!ok(hipMemcpy(g_rt.fill_table, host, sizeof(host), hipMemcpyHostToDevice))) return QNNP_HIP_ENOMEM;
+  }
   g_rt.bound = true;
   return QNNP_HIP_OK;
 }
 
+const uint8_t* qnnp_hip_fill_table(void) { return g_rt.fill_table; }
+
 int qnnp_hip_shutdown(void)
 {
+  if (g_rt.fill_table != nullptr) {
+    (void) hipFree(g_rt.fill_table);
+    g_rt.fill_table = nullptr;
+  }
   g_rt.bound = false;
   g_rt.stream = nullptr;
   return QNNP_HIP_OK;

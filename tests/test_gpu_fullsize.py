@@ -36,6 +36,7 @@ def test_c2_q8gemm_4096_cubed(qnnp):
         d_c = to_device(np.full(M * N, FILL, np.uint8))
         qnnp.setup_fully_connected_nc_q8(op, M, d_a, K, d_c, N)
         qnnp.run_operator(op)
+        assert qnnp.operator_kernel(op) == "q8_gemm_mfma_256x256", qnnp.operator_kernel(op)
         c = from_device(d_c).reshape(M, N)
         assert_bytes_equal(c[sample].reshape(-1), expected.reshape(-1), "4096^3 sampled rows vs oracle")
         assert c.min() < 64 and c.max() > 192, "outputs should span the uint8 range"

@@ -1,0 +1,84 @@
+"""GPU tier: the 256x256 LDS-DMA MFMA kernel (qnnpack_amd/csrc/hip/q8gemm256.hip), forced with the
+"gemm_kernel" = 2 option, against the scalar oracle -- tile-edge sweeps in M, N and K, grouped and
+convolution (offset-table) forms, zero-point variants. The auto-selected path for BASELINE configs[1]
+(4096^3) is this kernel; tests/test_gpu_fullsize.py asserts that."""
+import numpy as np
+import pytest
+
+from _cases import ConvCase, FcCase
+from _gpu import from_device, to_device
+from _runner import assert_bytes_equal, conv_expected, conv_run, fc_expected, fc_run
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def big(qnnp):
+    qnnp.set_option("gemm_kernel", 2)
+    yield qnnp
+    qnnp.set_option("gemm_kernel", 0)
+
+
+def _fc(big, case):
+    expected, quant = fc_expected(case)
+    out, kname = fc_run(big, case, quant, to_device=to_device, from_device=from_device)
+    assert kname == "q8_gemm_mfma_256x256", kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("m", [1, 31, 255, 256, 257, 300, 511, 512, 1000])
+def test_m_edges(big, m):
+    _fc(big, FcCase(f"b_m{m}", m, 256, 256))
+
+
+@pytest.mark.parametrize("n", [1, 4, 31, 32, 33, 100, 255, 256, 257, 300, 512, 520])
+def test_n_edges(big, n):
+    _fc(big, FcCase(f"b_n{n}", 130, 128, n))
+
+
+@pytest.mark.parametrize("k", [16, 32, 48, 64, 80, 112, 128, 144, 256, 272, 384, 1024])
+def test_k_edges(big, k):
+    _fc(big, FcCase(f"b_k{k}", 270, k, 260))
+
+
+@pytest.mark.parametrize("kw", [dict(izp=0, kzp=0), dict(izp=255, kzp=255), dict(izp=128, kzp=128),
+                                dict(izp=3, kzp=250), dict(qmin=128), dict(qmax=128)],
+                         ids=lambda d: "_".join(f"{k}{v}" for k, v in d.items()))
+def test_quantization_variants(big, kw):
+    _fc(big, FcCase("b_q_" + "_".join(f"{k}{v}" for k, v in kw.items()), 300, 192, 288, **kw))
+
+
+def test_strided_rows(big):
+    _fc(big, FcCase("b_strided", 300, 128, 260, input_stride=160, output_stride=264))
+
+
+def test_unaligned_output_uses_byte_stores(big):
+    _fc(big, FcCase("b_out_unaligned", 260, 128, 258, output_stride=259))
+
+
+@pytest.mark.parametrize("case", [
+    ConvCase("b_conv3x3_c64", (12, 10), (3, 3), (1, 1, 1, 1), gic=64, goc=64, batch=3),
+    ConvCase("b_conv3x3_c16_s2", (15, 17), (3, 3), (1, 1, 1, 1), subsampling=(2, 2), gic=16, goc=48, batch=2),
+    ConvCase("b_conv3x3_c48_d2", (13, 14), (3, 3), (2, 2, 2, 2), dilation=(2, 2), gic=48, goc=40),
+    ConvCase("b_conv5x5_c32", (11, 12), (5, 5), (2, 2, 2, 2), gic=32, goc=300),
+    ConvCase("b_grouped_conv3x3", (10, 11), (3, 3), (1, 1, 1, 1), groups=3, gic=16, goc=24, batch=2),
+    ConvCase("b_grouped_1x1", (9, 9), groups=2, gic=32, goc=40, batch=4),
+    ConvCase("b_conv3x3_strided_pixels", (9, 9), (3, 3), (1, 1, 1, 1), gic=32, goc=36, input_pixel_stride=48,
+             output_pixel_stride=40),
+    ConvCase("b_conv1x3_pad", (8, 19), (1, 3), (0, 1, 0, 1), gic=80, goc=33),
+], ids=lambda c: c.name)
+def test_convolution_forms(big, case):
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(big, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    want = "q8_gemm_mfma_256x256_conv" if case.kernel_size != (1, 1) else "q8_gemm_mfma_256x256"
+    assert kname == want, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+def test_unsupported_alignment_is_reported_not_silently_rerouted(big):
+    """Forcing the big kernel on a shape it cannot take (K % 16 != 0) must fail loudly."""
+    from qnnpack_amd import QnnpackError
+    case = FcCase("b_bad", 64, 23, 19)
+    _, quant = fc_expected(case)
+    with pytest.raises(QnnpackError):
+        fc_run(big, case, quant, to_device=to_device, from_device=from_device)
