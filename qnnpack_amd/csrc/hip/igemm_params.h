@@ -31,7 +31,7 @@ struct IgemmParams {
   uint32_t output_stride;
   int32_t row_coeff;
   uint32_t izp_fill;       // input zero point replicated into 4 bytes
-  uint32_t store_dword;    // 1: 4-channel dword stores are aligned and in-bounds
+  uint32_t store_mode;     // 2: 16-byte stores, 1: dword stores, 0: byte stores (igemm_epilogue.cuh)
   const uint8_t* fill_table; // [256][16]: entry v = 16 bytes of value v (LDS-DMA padding sources)
   qnnp_hip_requant rq;
 };

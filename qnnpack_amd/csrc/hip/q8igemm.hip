@@ -39,6 +39,7 @@
 
 #include <stdint.h>
 
+#include "igemm_epilogue.cuh"
 #include "igemm_params.h"
 #include "qnnp_hip.h"
 #include "requant.cuh"
@@ -292,6 +293,19 @@ void q8_igemm_mfma_kernel(const IgemmParams p)
     // readers all passed this step's barrier
   }
 
+  // ---- bias for this lane's 4-channel groups (issued before the barrier so the latency hides) ----
+  int4 bias4[TN][4];
+#pragma unroll
+  for (int tn = 0; tn < TN; tn++) {
+    uint32_t nb = nb0 + tn;
+    if (nb >= nblocks) nb = nblocks - 1;       // clamped blocks are never stored
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const uint32_t ncol = nb * 32 + rg * 8 + frag_khalf * 4;
+      bias4[tn][rg] = *reinterpret_cast<const int4*>(p.bias2 + static_cast<uint64_t>(g) * p.n_pad + ncol);
+    }
+  }
+
   // ---- row sums: the 4 threads that staged one row are adjacent lanes ----
 #pragma unroll
   for (int q = 0; q < CH; q++) {
@@ -302,7 +316,7 @@ void q8_igemm_mfma_kernel(const IgemmParams p)
   }
   __syncthreads();
 
-  // ---- fused epilogue ----
+  // ---- fused epilogue (igemm_epilogue.cuh) ----
 #pragma unroll
   for (int tm = 0; tm < TM; tm++) {
     const uint32_t row = frag_row0 + tm * 32;
@@ -312,27 +326,8 @@ void q8_igemm_mfma_kernel(const IgemmParams p)
 #pragma unroll
     for (int tn = 0; tn < TN; tn++) {
       const uint32_t nb = nb0 + tn;
-      if (nb >= nblocks) continue;
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const uint32_t ncol = nb * 32 + rg * 8 + frag_khalf * 4;   // first of 4 consecutive channels
-        const int4 b = *reinterpret_cast<const int4*>(p.bias2 + static_cast<uint64_t>(g) * p.n_pad + ncol);
-        const int32_t v0 = acc[tm][tn][rg * 4 + 0] + rowterm + b.x;
-        const int32_t v1 = acc[tm][tn][rg * 4 + 1] + rowterm + b.y;
-        const int32_t v2 = acc[tm][tn][rg * 4 + 2] + rowterm + b.z;
-        const int32_t v3 = acc[tm][tn][rg * 4 + 3] + rowterm + b.w;
-        const uint32_t packed = qnnp::q31_requantize_pack4(v0, v1, v2, v3, p.rq);
-        if (m < p.rows && ncol < p.n) {
-          if (p.store_dword) {
-            *reinterpret_cast<uint32_t*>(out_row + ncol) = packed;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              if (ncol + j < p.n) out_row[ncol + j] = static_cast<uint8_t>(packed >> (8 * j));
-            }
-          }
-        }
-      }
+      if (nb >= nblocks) continue;       // wave-uniform
+      qnnp::igemm_store_tile(acc[tm][tn], bias4[tn], rowterm, out_row, nb * 32, frag_khalf, m < p.rows, p);
     }
   }
 }
@@ -416,7 +411,12 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
     }
   }
   const uintptr_t out_addr = reinterpret_cast<uintptr_t>(a->output);
-  p.store_dword = (a->n % 4 == 0 && a->output_stride % 4 == 0 && out_addr % 4 == 0) ? 1u : 0u;
+  p.store_mode = 0;
+  if (a->n % 16 == 0 && a->output_stride % 16 == 0 && out_addr % 16 == 0) {
+    p.store_mode = 2;
+  } else if (a->n % 4 == 0 && a->output_stride % 4 == 0 && out_addr % 4 == 0) {
+    p.store_mode = 1;
+  }
 
   hipStream_t stream = reinterpret_cast<hipStream_t>(qnnp_hip_get_stream());
   const char* name = nullptr;
