@@ -16,6 +16,7 @@
 #include "operator.h"
 #include "pack.h"
 #include "requantization.h"
+#include "hip/requant_math.h"
 
 void qnnp_debug_pack_igemm_w(
     uint32_t groups, uint32_t n, uint32_t k_total, uint32_t n_pad, uint32_t k_pad,
@@ -64,4 +65,18 @@ void qnnp_debug_compute_requant(
     float scale, uint8_t zero_point, uint8_t qmin, uint8_t qmax, struct qnnp_hip_requant* out)
 {
   *out = qnnp_compute_requant(scale, zero_point, qmin, qmax);
+}
+
+/* the device requantization arithmetic (hip/requant_math.h) evaluated on the host: scale, clamp, add zero point */
+void qnnp_debug_requant_fast(
+    size_t count, const int32_t* acc, float scale, uint8_t zero_point, uint8_t qmin, uint8_t qmax, uint8_t* out)
+{
+  const struct qnnp_hip_requant rq = qnnp_compute_requant(scale, zero_point, qmin, qmax);
+  const struct qnnp_requant_fast f = qnnp_requant_fast_init(rq.multiplier, rq.shift);
+  for (size_t i = 0; i < count; i++) {
+    int32_t y = qnnp_requant_scale(acc[i], f);
+    if (y < rq.output_min_less_zero_point) y = rq.output_min_less_zero_point;
+    if (y > rq.output_max_less_zero_point) y = rq.output_max_less_zero_point;
+    out[i] = (uint8_t) (y + rq.output_zero_point);
+  }
 }

@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "qnnp_hip.h"
+#include "requant.cuh"
 
 namespace qnnp {
 
@@ -33,7 +34,7 @@ struct IgemmParams {
   uint32_t izp_fill;       // input zero point replicated into 4 bytes
   uint32_t store_mode;     // 2: 16-byte stores, 1: dword stores, 0: byte stores (igemm_epilogue.cuh)
   const uint8_t* fill_table; // [256][16]: entry v = 16 bytes of value v (LDS-DMA padding sources)
-  qnnp_hip_requant rq;
+  RequantDev rq;
 };
 
 /* q8gemm256.hip */

@@ -63,7 +63,7 @@ struct DwParams {
   uint32_t IR, IC;    // staged input rows / columns per band
   uint32_t bands;     // ceil(OH / TOH)
   uint32_t slabs;     // C / CS
-  qnnp_hip_requant rq;
+  qnnp::RequantDev rq;
 };
 
 // --------------------------------------------------------------------------
@@ -286,7 +286,7 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
   p.in_stride = a->input_stride; p.out_stride = a->output_stride;
   p.izp = a->input_zero_point & 0xFFu;
   p.CS = p.TOH = p.IR = p.IC = p.bands = p.slabs = 0;
-  p.rq = a->rq;
+  p.rq = qnnp::make_requant_dev(a->rq);
 
   hipStream_t stream = reinterpret_cast<hipStream_t>(qnnp_hip_get_stream());
   const uintptr_t in_addr = reinterpret_cast<uintptr_t>(a->input);

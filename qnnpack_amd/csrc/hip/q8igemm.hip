@@ -397,7 +397,7 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   p.output_stride = a->output_stride;
   p.row_coeff = a->row_coeff;
   p.izp_fill = (a->input_zero_point & 0xFFu) * 0x01010101u;
-  p.rq = a->rq;
+  p.rq = qnnp::make_requant_dev(a->rq);
   p.fill_table = qnnp_hip_fill_table();
 
   // widest activation vector the actual alignment allows (a vector never straddles a tap)

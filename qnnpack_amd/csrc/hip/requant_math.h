@@ -1,0 +1,69 @@
+/*
+ * requant_math.h -- the Q31 fixed-point down-convert as plain integer arithmetic,
+ * written once and compiled both for the device (requant.cuh) and for the host
+ * (debug-hooks.c, so the CPU test tier can check it against the oracle over
+ * hundreds of millions of accumulators without a GPU).
+ *
+ * Normative definition (reference src/qnnpack/requantization.h:464-480):
+ *     P   = (int64) n * M + 2^30                       M in [2^30, 2^31)
+ *     q   = (int32) (P >> 31)
+ *     rem = (q & (2^s - 1)) - (n < 0)
+ *     y   = (q >> s) + (rem > ((2^s - 1) >> 1))
+ *     out = min(max(y, qmin - zp), qmax - zp) + zp
+ *
+ * Equivalent single-shift form used here (derivation in DESIGN.md "Requantization"):
+ *   s == 0 :  y = q                                    (mask 0, threshold 0: nothing to add)
+ *   s >= 1 :  (rem > thr)  <=>  (q mod 2^s) >= 2^(s-1) + (n < 0), hence
+ *             y = floor((q + 2^(s-1) - (n<0)) / 2^s)
+ *               = floor((n*M + 2^30 + 2^(30+s) - (n<0)*2^31) / 2^(31+s))
+ *             and with n = u - (n<0)*2^31, u = n & 0x7FFFFFFF:
+ *               n*M - (n<0)*2^31 = n*(M+1) - u
+ *             so y = high32( n*(M+1) + (2^30 + 2^(30+s) - u) ) >> (s-1)      [arithmetic]
+ *   No intermediate overflows: |n*(M+1)| < 2^62, 2^(30+s) <= 2^61.
+ * One 32x32+64 multiply-add, no remainder/threshold compare chain.
+ */
+#pragma once
+
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#define QNNP_HD __host__ __device__ __forceinline__
+#else
+#define QNNP_HD static inline
+#endif
+
+/* per-operator constants derived from (multiplier, shift) */
+struct qnnp_requant_fast {
+  int32_t multiplier_plus_1;   /* M + 1 (used when shift >= 1) */
+  int32_t multiplier;          /* M */
+  uint32_t addend_lo;          /* low / high word of 2^30 + 2^(30+s)   (shift >= 1) */
+  uint32_t addend_hi;
+  uint32_t shift;              /* s */
+};
+
+QNNP_HD struct qnnp_requant_fast qnnp_requant_fast_init(int32_t multiplier, uint32_t shift)
+{
+  struct qnnp_requant_fast f;
+  f.multiplier = multiplier;
+  f.multiplier_plus_1 = multiplier + 1;          /* <= 0x7FFFFF81, no overflow */
+  const uint64_t addend = (UINT64_C(1) << 30) + (shift >= 1 ? (UINT64_C(1) << (30 + shift)) : 0);
+  f.addend_lo = (uint32_t) addend;
+  f.addend_hi = (uint32_t) (addend >> 32);
+  f.shift = shift;
+  return f;
+}
+
+/* y = requantized value BEFORE clamping and zero-point addition */
+QNNP_HD int32_t qnnp_requant_scale(int32_t n, const struct qnnp_requant_fast f)
+{
+  if (f.shift == 0) {
+    const int64_t p = (int64_t) n * (int64_t) f.multiplier + INT64_C(0x40000000);
+    return (int32_t) (uint32_t) ((uint64_t) p >> 31);
+  }
+  const uint32_t u = (uint32_t) n & UINT32_C(0x7FFFFFFF);
+  const uint64_t addend = (((uint64_t) f.addend_hi << 32) | f.addend_lo) - (uint64_t) u;
+  const int64_t t = (int64_t) n * (int64_t) f.multiplier_plus_1 + (int64_t) addend;
+  const int32_t hi = (int32_t) (uint32_t) ((uint64_t) t >> 32);
+  const uint32_t sh = f.shift - 1;
+  return hi >= 0 ? (int32_t) ((uint32_t) hi >> sh) : (int32_t) ~(~(uint32_t) hi >> sh);
+}

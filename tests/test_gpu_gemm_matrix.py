@@ -77,3 +77,29 @@ def test_large_accumulators_wrap_like_int32(qnnp):
     expected = o1.requantize_rows(acc, scale, zp, 0, 255).reshape(-1)
     out, _ = fc_run(qnnp, case, (np.float32(1.0) / scale, zp), inp, kernel, bias, to_device, from_device)
     assert_bytes_equal(out, expected, "gfx950 vs oracle [wrapping accumulators]")
+
+
+@pytest.mark.parametrize("scale_hex,zp", [("0x1.FFFFFEp-1", 255), ("0x1.FFFFFEp-1", 0), ("0x1.0p-1", 128), ("0x1.8p-1", 3)])
+def test_extreme_accumulators_at_scale_near_one(qnnp, scale_hex, zp):
+    """|acc| close to 2^31 with requantization scale in [0.5, 1): the scaled value itself is ~+-2^31, so the
+    zero-point add must not wrap before the clamp (the [0,255] path saturates to int16 first)."""
+    from _cases import fc_tensors, strided_view
+    from oracle import o1
+    case = FcCase("g_extreme_" + scale_hex + str(zp), 70, 64, 48)
+    inp, kernel, bias = fc_tensors(case)
+    bias = bias.copy()
+    bias[0::3] = 2**31 - 1 - 3000000
+    bias[1::3] = -2**31 + 3000000
+    a = strided_view(inp, case.batch, case.input_channels, case.in_stride)
+    acc = o1.gemm_acc(a, kernel, bias, case.izp, case.kzp)
+    scale = np.float32(float.fromhex(scale_hex))
+    expected = o1.requantize_rows(acc, scale, zp, 0, 255).reshape(-1)
+    # choose (input, kernel, output) scales whose float32 quotient is exactly `scale`
+    op = qnnp.create_fully_connected_nc_q8(64, 48, case.izp, float(scale), case.kzp, 1.0, kernel, bias, zp, 1.0, 0, 255)
+    try:
+        d_in, d_out = to_device(inp), to_device(np.full(expected.size, 0xA5, np.uint8))
+        qnnp.setup_fully_connected_nc_q8(op, case.batch, d_in, 64, d_out, 48)
+        qnnp.run_operator(op)
+        assert_bytes_equal(from_device(d_out), expected, "extreme accumulators")
+    finally:
+        qnnp.delete_operator(op)

@@ -80,3 +80,27 @@ def test_offset_table_semantics(hooks):
     # output (2,1): oy*2-1 = 3, ox*2-1 = 1 -> rows 3,4,(5 out), cols 1,2,3
     assert table[5].tolist() == [(3 * 4 + 1) * 7, (3 * 4 + 2) * 7, (3 * 4 + 3) * 7,
                                  (4 * 4 + 1) * 7, (4 * 4 + 2) * 7, (4 * 4 + 3) * 7, -1, -1, -1]
+
+
+def test_device_requantization_arithmetic_matches_oracle(product):
+    """hip/requant_math.h (the single-shift form the kernels evaluate) compiled for the host."""
+    import ctypes
+    L = product.lib
+    L.qnnp_debug_requant_fast.restype = None
+    L.qnnp_debug_requant_fast.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_float, ctypes.c_uint8,
+                                          ctypes.c_uint8, ctypes.c_uint8, ctypes.c_void_p]
+    rng = np.random.default_rng(11)
+    acc = rng.integers(-2**31, 2**31, size=1 << 20).astype(np.int32)
+    acc[:8] = [-2**31, 2**31 - 1, 0, -1, 1, -2**30, 2**30, -2**31 + 1]
+    # exact ties of the second rounding for a few shifts
+    ties = []
+    for s in range(1, 12):
+        for k in range(-20, 21):
+            ties += [(k << s) + (1 << (s - 1)) + d for d in (-1, 0, 1)]
+    acc[8:8 + len(ties)] = np.array(ties, dtype=np.int64).astype(np.int32)
+    for scale in [2.0 ** -32, 2.0 ** -31, 2.0 ** -12, 2.0 ** -5, 0.0031, 1 / 255.0, 0.25, 0.49999997, 0.5, 0.75,
+                  float.fromhex("0x1.FFFFFEp-1")]:
+        for zp, qmin, qmax in [(0, 0, 255), (127, 0, 255), (255, 0, 255), (100, 128, 255), (100, 0, 128), (7, 5, 9)]:
+            out = np.empty(acc.size, np.uint8)
+            L.qnnp_debug_requant_fast(acc.size, acc.ctypes.data, np.float32(scale), zp, qmin, qmax, out.ctypes.data)
+            assert np.array_equal(out, o1.q31_requantize(acc, scale, zp, qmin, qmax)), (scale, zp, qmin, qmax)
