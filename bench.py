@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="headline GEMM only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-kernel", type=int, default=0, help="0 auto, 1 generic MFMA kernel, 2 big-tile kernel")
+    ap.add_argument("--layer", type=int, default=0,
+                    help="measurement aid: time only MobileNetV2 sweep layer N (1-based) and print a short JSON line")
     args = ap.parse_args()
 
     import torch
@@ -187,6 +189,18 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
+
+    if args.layer:
+        H, W, KH, KW, S, D, G, GIC, GOC = MOBILENETV2[args.layer - 1]
+        layer = ConvLayer(lib, torch, args.sweep_batch, H, W, KH, KW, S, D, G, GIC, GOC, seed=100 + args.layer,
+                          min_bytes_between_reuse=512 << 20)
+        ms = layer.time_ms(args.warmup, args.steps)
+        b = layer.in_bytes + layer.out_bytes
+        print(json.dumps({"layer": args.layer, "shape": [H, W, KH, S, G, GIC, GOC], "kernel": layer.kernel,
+                          "ms": round(ms, 5), "gbs": round(b / (ms * 1e-3) / 1e9, 1), "bytes": b,
+                          "tops": round(layer.ops / (ms * 1e-3) / 1e12, 2)}), flush=True)
+        layer.close()
+        return
 
     # ------------------------------------------------------------------ headline: q8gemm 4096^3
     M = N = K = 4096
