@@ -29,7 +29,7 @@ namespace qnnp {
 
 typedef int epi_v16i __attribute__((ext_vector_type(16)));
 
-template <bool NO_REQUANT = false>
+template <bool SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false>
 __device__ __forceinline__ void igemm_store_tile(
     const epi_v16i& acc, const int4 (&bias)[4], int32_t rowterm,
     uint8_t* out_row,        /* output + m*stride + g*n */
@@ -48,7 +48,7 @@ __device__ __forceinline__ void igemm_store_tile(
     if constexpr (NO_REQUANT) {
       pk[rg] = static_cast<uint32_t>(v0 ^ v1 ^ v2 ^ v3);   // measurement-only ablation
     } else {
-      pk[rg] = q31_requantize_pack4(v0, v1, v2, v3, p.rq);
+      pk[rg] = q31_requantize_pack4<SHIFT0, FULL_RANGE>(v0, v1, v2, v3, p.rq);
     }
   }
   if (p.store_mode == 2) {
@@ -76,6 +76,56 @@ __device__ __forceinline__ void igemm_store_tile(
         }
       }
     }
+  }
+}
+
+/*
+ * Staged variant for store_mode 2: instead of storing its 16 bytes straight to global memory (one
+ * instruction then touches 32 different rows, 32 bytes each -- the L2 sees a stream of 32-byte partial
+ * line writes), the lane drops them into a row-major LDS image of the workgroup's output tile; after a
+ * barrier igemm_copy_out() streams the image out with consecutive lanes on consecutive 16-byte chunks
+ * of a row, so full 128-byte lines (whole rows, for dense NHWC outputs) leave in one request.
+ * `pitch` = tile width in bytes + 16 keeps the 8-lane ds_write_b128 groups on distinct banks.
+ */
+template <bool SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false>
+__device__ __forceinline__ void igemm_stage_tile(
+    const epi_v16i& acc, const int4 (&bias)[4], int32_t rowterm,
+    uint8_t* lds_row,        /* LDS image + tile_row * pitch */
+    uint32_t col0,           /* first channel of this 32-channel tile inside the workgroup tile */
+    uint32_t khalf, const IgemmParams& p)
+{
+  uint32_t pk[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) {
+    const int32_t v0 = acc[rg * 4 + 0] + rowterm + bias[rg].x;
+    const int32_t v1 = acc[rg * 4 + 1] + rowterm + bias[rg].y;
+    const int32_t v2 = acc[rg * 4 + 2] + rowterm + bias[rg].z;
+    const int32_t v3 = acc[rg * 4 + 3] + rowterm + bias[rg].w;
+    if constexpr (NO_REQUANT) {
+      pk[rg] = static_cast<uint32_t>(v0 ^ v1 ^ v2 ^ v3);
+    } else {
+      pk[rg] = q31_requantize_pack4<SHIFT0, FULL_RANGE>(v0, v1, v2, v3, p.rq);
+    }
+  }
+  const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+  const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+  *reinterpret_cast<uint4*>(lds_row + col0 + khalf * 16) = make_uint4(s02[0], s02[1], s13[0], s13[1]);
+}
+
+/* Stream a staged [rows_valid][n_valid] uint8 tile (LDS, row pitch `pitch`) to global memory. */
+template <int NT>
+__device__ __forceinline__ void igemm_copy_out(
+    const uint8_t* lds_tile, uint32_t pitch, uint32_t rows_valid, uint32_t n_valid,
+    uint8_t* out_tile,       /* output + m0*stride + g*n + n0 */
+    uint32_t out_stride, uint32_t tid)
+{
+  const uint32_t cpr = n_valid >> 4;                 // 16-byte chunks per row
+  const uint32_t total = rows_valid * cpr;
+  for (uint32_t idx = tid; idx < total; idx += NT) {
+    const uint32_t r = idx / cpr;
+    const uint32_t cc = idx - r * cpr;
+    const uint4 v = *reinterpret_cast<const uint4*>(lds_tile + r * pitch + cc * 16);
+    *reinterpret_cast<uint4*>(out_tile + static_cast<uint64_t>(r) * out_stride + cc * 16) = v;
   }
 }
 

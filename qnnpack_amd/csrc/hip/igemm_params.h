@@ -33,6 +33,7 @@ struct IgemmParams {
   int32_t row_coeff;
   uint32_t izp_fill;       // input zero point replicated into 4 bytes
   uint32_t store_mode;     // 2: 16-byte stores, 1: dword stores, 0: byte stores (igemm_epilogue.cuh)
+  uint32_t cu_count;       // compute units of the bound device (persistent-grid sizing)
   const uint8_t* fill_table; // [256][16]: entry v = 16 bytes of value v (LDS-DMA padding sources)
   RequantDev rq;
 };

@@ -185,34 +185,38 @@ void q8_dwconv_lds_kernel(const DwParams p)
 
   const uint32_t npos = toh * p.OW;
   uint8_t* out_img = p.output + (static_cast<uint64_t>(n) * p.OH + oy0) * p.OW * p.out_stride + cg;
-  for (uint32_t pos = slot; pos < npos; pos += nslots) {
-    const uint32_t oyl = pos / p.OW;
-    const uint32_t ox = pos - oyl * p.OW;
-    const uint8_t* base = tile + ((oyl * p.sh) * p.IC + ox * p.sw) * p.CS + c4 * 4;
-    int32_t acc0 = bias[0], acc1 = bias[1], acc2 = bias[2], acc3 = bias[3];
+  // the requantization flavour (shift == 0? clamp == [0,255]?) is chosen once, outside the position loop
+  qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
+    for (uint32_t pos = slot; pos < npos; pos += nslots) {
+      const uint32_t oyl = pos / p.OW;
+      const uint32_t ox = pos - oyl * p.OW;
+      const uint8_t* base = tile + ((oyl * p.sh) * p.IC + ox * p.sw) * p.CS + c4 * 4;
+      int32_t acc0 = bias[0], acc1 = bias[1], acc2 = bias[2], acc3 = bias[3];
 #pragma unroll
-    for (int i = 0; i < PAIRS; i++) {
-      const int t0 = 2 * i, t1 = 2 * i + 1;
-      const uint32_t in0 = *reinterpret_cast<const uint32_t*>(
-          base + (((t0 / KW) * p.dh) * p.IC + (t0 % KW) * p.dw) * p.CS);
-      uint32_t in1 = 0u;
-      if (t1 < TAPS) {
-        in1 = *reinterpret_cast<const uint32_t*>(
-            base + (((t1 / KW) * p.dh) * p.IC + (t1 % KW) * p.dw) * p.CS);
+      for (int i = 0; i < PAIRS; i++) {
+        const int t0 = 2 * i, t1 = 2 * i + 1;
+        const uint32_t in0 = *reinterpret_cast<const uint32_t*>(
+            base + (((t0 / KW) * p.dh) * p.IC + (t0 % KW) * p.dw) * p.CS);
+        uint32_t in1 = 0u;
+        if (t1 < TAPS) {
+          in1 = *reinterpret_cast<const uint32_t*>(
+              base + (((t1 / KW) * p.dh) * p.IC + (t1 % KW) * p.dw) * p.CS);
+        }
+        // v_perm_b32: result bytes {in0.c, 0, in1.c, 0} = the two taps of channel c as int16 x2
+        const uint32_t p0 = __builtin_amdgcn_perm(in1, in0, 0x0c040c00u);
+        const uint32_t p1 = __builtin_amdgcn_perm(in1, in0, 0x0c050c01u);
+        const uint32_t p2 = __builtin_amdgcn_perm(in1, in0, 0x0c060c02u);
+        const uint32_t p3 = __builtin_amdgcn_perm(in1, in0, 0x0c070c03u);
+        acc0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p0), __builtin_bit_cast(v2s, wpair[i][0]), acc0, false);
+        acc1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p1), __builtin_bit_cast(v2s, wpair[i][1]), acc1, false);
+        acc2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p2), __builtin_bit_cast(v2s, wpair[i][2]), acc2, false);
+        acc3 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p3), __builtin_bit_cast(v2s, wpair[i][3]), acc3, false);
       }
-      // v_perm_b32: result bytes {in0.c, 0, in1.c, 0} = the two taps of channel c as int16 x2
-      const uint32_t p0 = __builtin_amdgcn_perm(in1, in0, 0x0c040c00u);
-      const uint32_t p1 = __builtin_amdgcn_perm(in1, in0, 0x0c050c01u);
-      const uint32_t p2 = __builtin_amdgcn_perm(in1, in0, 0x0c060c02u);
-      const uint32_t p3 = __builtin_amdgcn_perm(in1, in0, 0x0c070c03u);
-      acc0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p0), __builtin_bit_cast(v2s, wpair[i][0]), acc0, false);
-      acc1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p1), __builtin_bit_cast(v2s, wpair[i][1]), acc1, false);
-      acc2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p2), __builtin_bit_cast(v2s, wpair[i][2]), acc2, false);
-      acc3 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p3), __builtin_bit_cast(v2s, wpair[i][3]), acc3, false);
+      const uint32_t packed = qnnp::q31_requantize_pack4<decltype(shift0)::value, decltype(full)::value>(
+          acc0, acc1, acc2, acc3, p.rq);
+      *reinterpret_cast<uint32_t*>(out_img + static_cast<uint64_t>(pos) * p.out_stride) = packed;
     }
-    const uint32_t packed = qnnp::q31_requantize_pack4(acc0, acc1, acc2, acc3, p.rq);
-    *reinterpret_cast<uint32_t*>(out_img + static_cast<uint64_t>(pos) * p.out_stride) = packed;
-  }
+  });
 }
 
 constexpr uint32_t kDwLdsBudget = 64 * 1024;   // bytes per workgroup (2 workgroups per CU)

@@ -426,20 +426,23 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
   }
   __syncthreads();
 
-  // ---- fused epilogue (igemm_epilogue.cuh) ----
+  // ---- fused epilogue (igemm_epilogue.cuh); the requantization flavour is chosen once ----
+  requant_dispatch(p.rq, [&](auto shift0, auto full) {
 #pragma unroll
-  for (int tm = 0; tm < kTM; tm++) {
-    const uint32_t row = frag_row0 + tm * 32;
-    const uint32_t m = m_tile * kBM + row;
-    const int32_t rowterm = p.row_coeff * (lds_rowsum[row] + lds_rowsum[kBM + row]);
-    uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride + static_cast<uint64_t>(g) * p.n;
+    for (int tm = 0; tm < kTM; tm++) {
+      const uint32_t row = frag_row0 + tm * 32;
+      const uint32_t m = m_tile * kBM + row;
+      const int32_t rowterm = p.row_coeff * (lds_rowsum[row] + lds_rowsum[kBM + row]);
+      uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride + static_cast<uint64_t>(g) * p.n;
 #pragma unroll
-    for (int tn = 0; tn < kTN; tn++) {
-      const uint32_t nb = nb0 + wn * kTN + tn;
-      if (nb >= nblocks) continue;       // wave-uniform
-      igemm_store_tile<(ABL & 1) != 0>(acc[tm][tn], bias4[tn], rowterm, out_row, nb * 32, frag_khalf, m < p.rows, p);
+      for (int tn = 0; tn < kTN; tn++) {
+        const uint32_t nb = nb0 + wn * kTN + tn;
+        if (nb >= nblocks) continue;       // wave-uniform
+        igemm_store_tile<decltype(shift0)::value, decltype(full)::value, (ABL & 1) != 0>(
+            acc[tm][tn], bias4[tn], rowterm, out_row, nb * 32, frag_khalf, m < p.rows, p);
+      }
     }
-  }
+  });
 }
 
 }  // namespace

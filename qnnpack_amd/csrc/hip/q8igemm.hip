@@ -95,10 +95,13 @@ __device__ __forceinline__ void fill_vec(uint32_t fill, uint32_t (&w)[4], int j)
 }
 
 /*
- * WM x WN waves, each computing TM x TN MFMA tiles of 32x32.
+ * WM x WN waves, each computing TM x TN MFMA tiles of 32x32. PERSISTENT over row tiles: a workgroup
+ * keeps one channel tile and walks row tiles m = cta_m, cta_m + ctas_m, ...; the activation loads of the
+ * next row tile are issued before the epilogue of the current one, so the (latency-bound) global reads
+ * overlap the (VALU-bound) requantization instead of alternating with it.
  */
 template <int WM, int WN, int TM, int TN, int VEC, bool IS_CONV>
-__global__ __launch_bounds__(WM * WN * 64)
+__global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 4) ? 2 : 3)
 void q8_igemm_mfma_kernel(const IgemmParams p)
 {
   constexpr int NT = WM * WN * 64;
@@ -108,9 +111,13 @@ void q8_igemm_mfma_kernel(const IgemmParams p)
   static_assert((BM * (BK / 16)) % NT == 0, "tile/thread mismatch");
   static_assert(CH >= 1, "tile too small");
 
-  // one LDS object only: [2][BM][BK] activation ring, then [BM] int32 row sums
-  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BM * BK + BM * 4];
-  int32_t* lds_rowsum = reinterpret_cast<int32_t*>(lds + 2 * BM * BK);
+  // one LDS object only: [2][BM][BK] activation ring | [BM][BN+16] staged output tile | [BM] int32 row sums
+  constexpr int OUT_PITCH = BN + 16;
+  constexpr int RING_BYTES = 2 * BM * BK;
+  constexpr int OUT_BYTES = BM * OUT_PITCH;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[RING_BYTES + OUT_BYTES + BM * 4];
+  uint8_t* lds_out = lds + RING_BYTES;
+  int32_t* lds_rowsum = reinterpret_cast<int32_t*>(lds + RING_BYTES + OUT_BYTES);
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
@@ -119,9 +126,10 @@ void q8_igemm_mfma_kernel(const IgemmParams p)
   const uint32_t wn = wave % WN;
   const uint32_t g = blockIdx.y;
 
-  // XCD-aware bijective remap: consecutive logical tiles (which share an
-  // activation row block) land on the same XCD / L2 (hardware: block b -> XCD b % 8).
-  const uint32_t ntiles_n = (p.n_pad + BN - 1) / BN;
+  // XCD-aware bijective remap: consecutive logical ids (which share activation row tiles) land on the
+  // same XCD / L2 (hardware: block b -> XCD b % 8).
+  const uint32_t tiles_n = (p.n_pad + BN - 1) / BN;
+  const uint32_t tiles_m = (p.rows + BM - 1) / BM;
   uint32_t logical;
   {
     const uint32_t nwg = gridDim.x;
@@ -130,45 +138,51 @@ void q8_igemm_mfma_kernel(const IgemmParams p)
     const uint32_t q = nwg >> 3, r = nwg & 7u;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const uint32_t n_tile = logical % ntiles_n;
-  const uint32_t m_tile = logical / ntiles_n;
+  const uint32_t n_tile = logical % tiles_n;
+  const uint32_t cta_m = logical / tiles_n;
+  const uint32_t ctas_m = gridDim.x / tiles_n;
 
   const uint32_t ksteps = p.k_pad / BK;
   const uint32_t kblocks = p.k_pad / 32;   // 32-deep fragment blocks per column block
   const uint32_t nblocks = p.n_pad / 32;
 
-  // ---- per-thread activation staging assignment (fixed across K steps) ----
-  const uint8_t* a_base[CH];   // gemm: row base (+group); conv: image base (+group)
-  const int32_t* a_offs[CH];   // conv: this pixel's row of the offset table
-  bool a_valid[CH];
+  // ---- per-thread activation staging assignment: chunk slots are fixed, rows change per row tile ----
+  struct RowCtx {
+    const uint8_t* base[CH];   // gemm: row base (+group); conv: image base (+group)
+    const int32_t* offs[CH];   // conv: this pixel's row of the offset table
+    bool valid[CH];
+  };
   uint32_t a_lds[CH];          // swizzled byte offset inside one LDS buffer
   uint32_t a_kchunk[CH];       // 0..3: which 16-byte chunk of the K step
-  int32_t rowsum_part[CH];
 #pragma unroll
   for (int q = 0; q < CH; q++) {
     const uint32_t id = q * NT + tid;
     const uint32_t row = id >> 2;
     const uint32_t c = id & 3u;
-    const uint32_t m = m_tile * BM + row;
-    a_valid[q] = m < p.rows;
     a_kchunk[q] = c;
     a_lds[q] = row * BK + ((c ^ ((row >> 2) & 3u)) << 4);
-    rowsum_part[q] = 0;
-    if constexpr (IS_CONV) {
-      const uint32_t mm = a_valid[q] ? m : 0u;
-      const uint32_t img = mm / p.rows_per_image;
-      const uint32_t pix = mm - img * p.rows_per_image;
-      a_base[q] = p.input + static_cast<uint64_t>(img) * p.image_stride + static_cast<uint64_t>(g) * p.kc;
-      a_offs[q] = p.offsets + static_cast<uint64_t>(pix) * p.ks;
-    } else {
-      const uint32_t mm = a_valid[q] ? m : 0u;
-      a_base[q] = p.input + static_cast<uint64_t>(mm) * p.input_stride + static_cast<uint64_t>(g) * p.kc;
-      a_offs[q] = nullptr;
-    }
   }
+  auto make_ctx = [&](uint32_t m_tile, RowCtx& ctx) {
+#pragma unroll
+    for (int q = 0; q < CH; q++) {
+      const uint32_t row = (q * NT + tid) >> 2;
+      const uint32_t m = m_tile * BM + row;
+      ctx.valid[q] = m_tile < tiles_m && m < p.rows;
+      const uint32_t mm = ctx.valid[q] ? m : 0u;
+      if constexpr (IS_CONV) {
+        const uint32_t img = mm / p.rows_per_image;
+        const uint32_t pix = mm - img * p.rows_per_image;
+        ctx.base[q] = p.input + static_cast<uint64_t>(img) * p.image_stride + static_cast<uint64_t>(g) * p.kc;
+        ctx.offs[q] = p.offsets + static_cast<uint64_t>(pix) * p.ks;
+      } else {
+        ctx.base[q] = p.input + static_cast<uint64_t>(mm) * p.input_stride + static_cast<uint64_t>(g) * p.kc;
+        ctx.offs[q] = nullptr;
+      }
+    }
+  };
 
   // global -> registers for K step `kstep` (raw uint8, already filled for padding)
-  auto load_chunks = [&](uint32_t kstep, uint32_t (&regs)[CH][4]) {
+  auto load_chunks = [&](const RowCtx& ctx, uint32_t kstep, uint32_t (&regs)[CH][4]) {
 #pragma unroll
     for (int q = 0; q < CH; q++) {
       const uint32_t kk0 = kstep * BK + a_kchunk[q] * 16;
@@ -181,16 +195,16 @@ void q8_igemm_mfma_kernel(const IgemmParams p)
 #pragma unroll
       for (int j = 0; j < 16 / VEC; j++) {
         const uint32_t kk = kk0 + j * VEC;
-        if (a_valid[q] && kk < p.k_total) {
+        if (ctx.valid[q] && kk < p.k_total) {
           if constexpr (IS_CONV) {
-            const int32_t off = a_offs[q][tap];
+            const int32_t off = ctx.offs[q][tap];
             if (off >= 0) {
-              load_vec<VEC>(a_base[q] + off + ch, regs[q], j);
+              load_vec<VEC>(ctx.base[q] + off + ch, regs[q], j);
             } else {
               fill_vec<VEC>(p.izp_fill, regs[q], j);   // padding tap: a == input zero point
             }
           } else {
-            load_vec<VEC>(a_base[q] + kk, regs[q], j);
+            load_vec<VEC>(ctx.base[q] + kk, regs[q], j);
           }
         }
         if constexpr (IS_CONV) {
@@ -201,6 +215,7 @@ void q8_igemm_mfma_kernel(const IgemmParams p)
     }
   };
 
+  int32_t rowsum_part[CH];
   // registers -> LDS: recentre at 128, accumulate the row sum of a'
   auto store_chunks = [&](uint32_t buf, const uint32_t (&regs)[CH][4]) {
 #pragma unroll
@@ -240,94 +255,137 @@ void q8_igemm_mfma_kernel(const IgemmParams p)
     }
   };
 
-  v16i acc[TM][TN];
-#pragma unroll
-  for (int tm = 0; tm < TM; tm++)
-#pragma unroll
-    for (int tn = 0; tn < TN; tn++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0;
+  const uint32_t frag_row0 = wm * (TM * 32) + (lane & 31u);
+  const uint32_t frag_khalf = lane >> 5;
 
+  RowCtx ctx, ctx_next;
   uint32_t a_regs[CH][4];
   v4i w_cur[TN][2];
   v4i w_nxt[TN][2];
 
-  load_chunks(0, a_regs);
+  make_ctx(cta_m, ctx);
+  load_chunks(ctx, 0, a_regs);
   load_wfrags(0, w_cur);
+  uint32_t step = 0;                           // global K-step counter: LDS ring slot = step & 1
 
-  const uint32_t frag_row0 = wm * (TM * 32) + (lane & 31u);
-  const uint32_t frag_khalf = lane >> 5;
+  for (uint32_t m_tile = cta_m; m_tile < tiles_m; m_tile += ctas_m) {
+    v16i acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+      for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0;
+#pragma unroll
+    for (int q = 0; q < CH; q++) rowsum_part[q] = 0;
 
-  for (uint32_t kstep = 0; kstep < ksteps; kstep++) {
-    const uint32_t buf = kstep & 1u;
-    store_chunks(buf, a_regs);
-    __syncthreads();
-    if (kstep + 1 < ksteps) {
-      load_chunks(kstep + 1, a_regs);
-      load_wfrags(kstep + 1, w_nxt);
-    }
-    const uint8_t* a_tile = lds + buf * (BM * BK);
-#pragma unroll
-    for (int ksub = 0; ksub < 2; ksub++) {
-      v4i af[TM];
-#pragma unroll
-      for (int tm = 0; tm < TM; tm++) {
-        const uint32_t row = frag_row0 + tm * 32;
-        const uint32_t chunk = (ksub * 2 + frag_khalf) ^ ((row >> 2) & 3u);
-        af[tm] = *reinterpret_cast<const v4i*>(a_tile + row * BK + (chunk << 4));
+    for (uint32_t kstep = 0; kstep < ksteps; kstep++, step++) {
+      const uint32_t buf = step & 1u;
+      store_chunks(buf, a_regs);
+      __syncthreads();
+      if (kstep + 1 < ksteps) {
+        load_chunks(ctx, kstep + 1, a_regs);
+        load_wfrags(kstep + 1, w_nxt);
+      } else {
+        // last K step of this row tile: fetch the first step of the NEXT row tile now, so its latency
+        // hides under this tile's MFMAs and epilogue
+        make_ctx(m_tile + ctas_m, ctx_next);
+        load_chunks(ctx_next, 0, a_regs);
+        if (ksteps > 1) load_wfrags(0, w_nxt);
       }
+      const uint8_t* a_tile = lds + buf * (BM * BK);
 #pragma unroll
-      for (int tm = 0; tm < TM; tm++)
+      for (int ksub = 0; ksub < 2; ksub++) {
+        v4i af[TM];
 #pragma unroll
-        for (int tn = 0; tn < TN; tn++)
-          acc[tm][tn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w_cur[tn][ksub], af[tm], acc[tm][tn], 0, 0, 0);
-    }
-    if (kstep + 1 < ksteps) {
+        for (int tm = 0; tm < TM; tm++) {
+          const uint32_t row = frag_row0 + tm * 32;
+          const uint32_t chunk = (ksub * 2 + frag_khalf) ^ ((row >> 2) & 3u);
+          af[tm] = *reinterpret_cast<const v4i*>(a_tile + row * BK + (chunk << 4));
+        }
 #pragma unroll
-      for (int tn = 0; tn < TN; tn++) {
-        w_cur[tn][0] = w_nxt[tn][0];
-        w_cur[tn][1] = w_nxt[tn][1];
+        for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+          for (int tn = 0; tn < TN; tn++)
+            acc[tm][tn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w_cur[tn][ksub], af[tm], acc[tm][tn], 0, 0, 0);
       }
+      if (ksteps > 1) {
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++) {
+          w_cur[tn][0] = w_nxt[tn][0];
+          w_cur[tn][1] = w_nxt[tn][1];
+        }
+      }
+      // no second barrier: the next step writes the other ring slot, whose last readers all passed
+      // this step's barrier
     }
-    // no second barrier: the next step writes the other LDS buffer, whose last
-    // readers all passed this step's barrier
-  }
+    ctx = ctx_next;
 
-  // ---- bias for this lane's 4-channel groups (issued before the barrier so the latency hides) ----
-  int4 bias4[TN][4];
-#pragma unroll
-  for (int tn = 0; tn < TN; tn++) {
-    uint32_t nb = nb0 + tn;
-    if (nb >= nblocks) nb = nblocks - 1;       // clamped blocks are never stored
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) {
-      const uint32_t ncol = nb * 32 + rg * 8 + frag_khalf * 4;
-      bias4[tn][rg] = *reinterpret_cast<const int4*>(p.bias2 + static_cast<uint64_t>(g) * p.n_pad + ncol);
-    }
-  }
-
-  // ---- row sums: the 4 threads that staged one row are adjacent lanes ----
-#pragma unroll
-  for (int q = 0; q < CH; q++) {
-    int32_t s = rowsum_part[q];
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    if (a_kchunk[q] == 0) lds_rowsum[(q * NT + tid) >> 2] = s;
-  }
-  __syncthreads();
-
-  // ---- fused epilogue (igemm_epilogue.cuh) ----
-#pragma unroll
-  for (int tm = 0; tm < TM; tm++) {
-    const uint32_t row = frag_row0 + tm * 32;
-    const uint32_t m = m_tile * BM + row;
-    const int32_t rowterm = p.row_coeff * lds_rowsum[row];
-    uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride + static_cast<uint64_t>(g) * p.n;
+    // bias of this lane's 4-channel groups (issued before the barrier so the latency hides; L1/L2 resident)
+    int4 bias4[TN][4];
 #pragma unroll
     for (int tn = 0; tn < TN; tn++) {
-      const uint32_t nb = nb0 + tn;
-      if (nb >= nblocks) continue;       // wave-uniform
-      qnnp::igemm_store_tile(acc[tm][tn], bias4[tn], rowterm, out_row, nb * 32, frag_khalf, m < p.rows, p);
+      uint32_t nb = nb0 + tn;
+      if (nb >= nblocks) nb = nblocks - 1;       // clamped blocks are never stored
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const uint32_t ncol = nb * 32 + rg * 8 + frag_khalf * 4;
+        bias4[tn][rg] = *reinterpret_cast<const int4*>(p.bias2 + static_cast<uint64_t>(g) * p.n_pad + ncol);
+      }
+    }
+
+    // ---- row sums: the 4 threads that staged one row are adjacent lanes ----
+#pragma unroll
+    for (int q = 0; q < CH; q++) {
+      int32_t s = rowsum_part[q];
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      if (a_kchunk[q] == 0) lds_rowsum[(q * NT + tid) >> 2] = s;
+    }
+    __syncthreads();
+
+    // ---- fused epilogue (igemm_epilogue.cuh); the requantization flavour is chosen once per tile ----
+    if (p.store_mode == 2) {
+      // staged: requantized tile -> LDS (row-major image of the output) -> line-sized coalesced stores
+      qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) {
+          const uint32_t row = frag_row0 + tm * 32;
+          const int32_t rowterm = p.row_coeff * lds_rowsum[row];
+#pragma unroll
+          for (int tn = 0; tn < TN; tn++) {
+            if (nb0 + tn >= nblocks) continue;       // wave-uniform
+            qnnp::igemm_stage_tile<decltype(shift0)::value, decltype(full)::value>(
+                acc[tm][tn], bias4[tn], rowterm, lds_out + row * OUT_PITCH, (wn * TN + tn) * 32, frag_khalf, p);
+          }
+        }
+      });
+      __syncthreads();
+      const uint32_t m0 = m_tile * BM;
+      const uint32_t n0 = n_tile * BN;
+      const uint32_t rows_valid = min(static_cast<uint32_t>(BM), p.rows - m0);
+      const uint32_t n_valid = min(static_cast<uint32_t>(BN), p.n - n0);
+      qnnp::igemm_copy_out<NT>(
+          lds_out, OUT_PITCH, rows_valid, n_valid,
+          p.output + static_cast<uint64_t>(m0) * p.output_stride + static_cast<uint64_t>(g) * p.n + n0,
+          p.output_stride, tid);
+    } else {
+      qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) {
+          const uint32_t row = frag_row0 + tm * 32;
+          const uint32_t m = m_tile * BM + row;
+          const int32_t rowterm = p.row_coeff * lds_rowsum[row];
+          uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride + static_cast<uint64_t>(g) * p.n;
+#pragma unroll
+          for (int tn = 0; tn < TN; tn++) {
+            const uint32_t nb = nb0 + tn;
+            if (nb >= nblocks) continue;       // wave-uniform
+            qnnp::igemm_store_tile<decltype(shift0)::value, decltype(full)::value>(
+                acc[tm][tn], bias4[tn], rowterm, out_row, nb * 32, frag_khalf, m < p.rows, p);
+          }
+        }
+      });
     }
   }
 }
@@ -339,7 +397,23 @@ int launch_generic(const IgemmParams& p, uint32_t groups, hipStream_t stream)
   constexpr int BN = WN * TN * 32;
   const uint32_t tiles_m = (p.rows + BM - 1) / BM;
   const uint32_t tiles_n = (p.n_pad + BN - 1) / BN;
-  const dim3 grid(tiles_m * tiles_n, groups, 1);
+  // persistent over row tiles: exactly as many workgroups as are co-resident on the chip, each walking
+  // tiles_m / ctas_m row tiles
+  static int blocks_per_cu = 0;       // per instantiation; benign race (same value)
+  if (blocks_per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &nb, q8_igemm_mfma_kernel<WM, WN, TM, TN, VEC, IS_CONV>, WM * WN * 64, 0) != hipSuccess || nb < 1) {
+      (void) hipGetLastError();
+      nb = 2;
+    }
+    blocks_per_cu = nb;
+  }
+  const uint32_t target = p.cu_count * static_cast<uint32_t>(blocks_per_cu);
+  uint32_t ctas_m = target / (tiles_n * groups);
+  if (ctas_m < 1) ctas_m = 1;
+  if (ctas_m > tiles_m) ctas_m = tiles_m;
+  const dim3 grid(ctas_m * tiles_n, groups, 1);
   const dim3 block(WM * WN * 64, 1, 1);
   hipLaunchKernelGGL((q8_igemm_mfma_kernel<WM, WN, TM, TN, VEC, IS_CONV>), grid, block, 0, stream, p);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
@@ -399,6 +473,10 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   p.izp_fill = (a->input_zero_point & 0xFFu) * 0x01010101u;
   p.rq = qnnp::make_requant_dev(a->rq);
   p.fill_table = qnnp_hip_fill_table();
+  {
+    int cus = 0;
+    p.cu_count = (qnnp_hip_device_info(nullptr, 0, &cus, nullptr, nullptr) == QNNP_HIP_OK && cus > 0) ? static_cast<uint32_t>(cus) : 256u;
+  }
 
   // widest activation vector the actual alignment allows (a vector never straddles a tap)
   const uintptr_t in_addr = reinterpret_cast<uintptr_t>(a->input);

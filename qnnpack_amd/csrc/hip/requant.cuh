@@ -24,6 +24,8 @@
 
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "qnnp_hip.h"
 #include "requant_math.h"
 
@@ -58,28 +60,54 @@ __device__ __forceinline__ int32_t q31_requantize(int32_t n, const RequantDev& r
   return y + rq.zp;  // in [0, 255]
 }
 
-/* four results packed little-endian into one dword (channel c at byte c) */
+/*
+ * Four results packed little-endian into one dword (channel c at byte c).
+ * SHIFT0 / FULL_RANGE are the two per-operator facts that change the instruction sequence; kernels
+ * branch on them ONCE (requant_dispatch) instead of once per element.
+ */
+template <bool SHIFT0, bool FULL_RANGE>
 __device__ __forceinline__ uint32_t q31_requantize_pack4(
     int32_t n0, int32_t n1, int32_t n2, int32_t n3, const RequantDev& rq)
 {
-  if (rq.full_range) {
+  int32_t y0, y1, y2, y3;
+  if constexpr (SHIFT0) {
+    y0 = qnnp_requant_scale_s0(n0, rq.f); y1 = qnnp_requant_scale_s0(n1, rq.f);
+    y2 = qnnp_requant_scale_s0(n2, rq.f); y3 = qnnp_requant_scale_s0(n3, rq.f);
+  } else {
+    y0 = qnnp_requant_scale_sn(n0, rq.f); y1 = qnnp_requant_scale_sn(n1, rq.f);
+    y2 = qnnp_requant_scale_sn(n2, rq.f); y3 = qnnp_requant_scale_sn(n3, rq.f);
+  }
+  if constexpr (FULL_RANGE) {
     // clamp to [0, 255] == saturation, two values per instruction:
     //   i32 -> i16 (signed saturation) -> + zero point (saturating packed add) -> u8 (unsigned saturation).
     // Saturating BEFORE the zero-point add keeps y + zp from wrapping for |y| near 2^31, and cannot
     // change the result: a saturated +-32767 still lands outside [0, 255] on the correct side.
-    const auto p01 = __builtin_amdgcn_cvt_pk_i16(qnnp_requant_scale(n0, rq.f), qnnp_requant_scale(n1, rq.f));
-    const auto p23 = __builtin_amdgcn_cvt_pk_i16(qnnp_requant_scale(n2, rq.f), qnnp_requant_scale(n3, rq.f));
+    const auto p01 = __builtin_amdgcn_cvt_pk_i16(y0, y1);
+    const auto p23 = __builtin_amdgcn_cvt_pk_i16(y2, y3);
     const uint32_t zp2 = static_cast<uint32_t>(rq.zp) * 0x00010001u;
     uint32_t lo, hi;
     asm("v_pk_add_i16 %0, %1, %2 clamp\n\tv_sat_pk_u8_i16 %0, %0" : "=&v"(lo) : "v"(p01), "s"(zp2));
     asm("v_pk_add_i16 %0, %1, %2 clamp\n\tv_sat_pk_u8_i16 %0, %0" : "=&v"(hi) : "v"(p23), "s"(zp2));
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);   // {lo.b0, lo.b1, hi.b0, hi.b1}
+  } else {
+    y0 = min(max(y0, rq.min_less_zp), rq.max_less_zp) + rq.zp;
+    y1 = min(max(y1, rq.min_less_zp), rq.max_less_zp) + rq.zp;
+    y2 = min(max(y2, rq.min_less_zp), rq.max_less_zp) + rq.zp;
+    y3 = min(max(y3, rq.min_less_zp), rq.max_less_zp) + rq.zp;
+    return static_cast<uint32_t>(y0) | (static_cast<uint32_t>(y1) << 8) | (static_cast<uint32_t>(y2) << 16) |
+           (static_cast<uint32_t>(y3) << 24);
   }
-  const uint32_t b0 = static_cast<uint32_t>(q31_requantize(n0, rq));
-  const uint32_t b1 = static_cast<uint32_t>(q31_requantize(n1, rq));
-  const uint32_t b2 = static_cast<uint32_t>(q31_requantize(n2, rq));
-  const uint32_t b3 = static_cast<uint32_t>(q31_requantize(n3, rq));
-  return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+}
+
+/* Calls f(shift0_tag, full_range_tag) with the compile-time tags matching `rq` (one uniform branch tree). */
+template <typename F>
+__device__ __forceinline__ void requant_dispatch(const RequantDev& rq, F&& f)
+{
+  if (rq.f.shift == 0) {
+    if (rq.full_range) f(std::true_type{}, std::true_type{}); else f(std::true_type{}, std::false_type{});
+  } else {
+    if (rq.full_range) f(std::false_type{}, std::true_type{}); else f(std::false_type{}, std::false_type{});
+  }
 }
 
 }  // namespace qnnp

@@ -53,17 +53,27 @@ QNNP_HD struct qnnp_requant_fast qnnp_requant_fast_init(int32_t multiplier, uint
   return f;
 }
 
-/* y = requantized value BEFORE clamping and zero-point addition */
-QNNP_HD int32_t qnnp_requant_scale(int32_t n, const struct qnnp_requant_fast f)
+/* arithmetic shift right of a signed value (gcc, clang and hipcc all implement >> on signed as arithmetic) */
+QNNP_HD int32_t qnnp_asr32(int32_t x, uint32_t n) { return x >> n; }
+
+/* y = requantized value BEFORE clamping and zero-point addition; shift == 0 form */
+QNNP_HD int32_t qnnp_requant_scale_s0(int32_t n, const struct qnnp_requant_fast f)
 {
-  if (f.shift == 0) {
-    const int64_t p = (int64_t) n * (int64_t) f.multiplier + INT64_C(0x40000000);
-    return (int32_t) (uint32_t) ((uint64_t) p >> 31);
-  }
+  const int64_t p = (int64_t) n * (int64_t) f.multiplier + INT64_C(0x40000000);
+  return (int32_t) (uint32_t) ((uint64_t) p >> 31);
+}
+
+/* shift >= 1 form */
+QNNP_HD int32_t qnnp_requant_scale_sn(int32_t n, const struct qnnp_requant_fast f)
+{
   const uint32_t u = (uint32_t) n & UINT32_C(0x7FFFFFFF);
   const uint64_t addend = (((uint64_t) f.addend_hi << 32) | f.addend_lo) - (uint64_t) u;
   const int64_t t = (int64_t) n * (int64_t) f.multiplier_plus_1 + (int64_t) addend;
   const int32_t hi = (int32_t) (uint32_t) ((uint64_t) t >> 32);
-  const uint32_t sh = f.shift - 1;
-  return hi >= 0 ? (int32_t) ((uint32_t) hi >> sh) : (int32_t) ~(~(uint32_t) hi >> sh);
+  return qnnp_asr32(hi, f.shift - 1);
+}
+
+QNNP_HD int32_t qnnp_requant_scale(int32_t n, const struct qnnp_requant_fast f)
+{
+  return f.shift == 0 ? qnnp_requant_scale_s0(n, f) : qnnp_requant_scale_sn(n, f);
 }
