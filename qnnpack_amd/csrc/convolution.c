@@ -186,7 +186,10 @@ enum qnnp_status qnnp_create_convolution2d_nhwc_q8(
       goto error;
     }
   } else {
-    const uint32_t k_total = (uint32_t) (kernel_size * group_input_channels);
+    /* 3-channel inputs (first layers): one unaligned 4-byte fetch per tap, see pack.h "channel slots" */
+    const uint32_t kc_slot = (ukernel_type == qnnp_ukernel_type_conv && groups == 1 && group_input_channels == 3) ?
+        4u : (uint32_t) group_input_channels;
+    const uint32_t k_total = (uint32_t) (kernel_size * kc_slot);
     const uint32_t n_pad = qnnp_round_up_u32((uint32_t) group_output_channels, 32);
     const uint32_t k_pad = qnnp_round_up_u32(k_total, 64);
     const size_t w_bytes = qnnp_igemm_packed_weights_size(groups, n_pad, k_pad);
@@ -197,10 +200,12 @@ enum qnnp_status qnnp_create_convolution2d_nhwc_q8(
       qnnp_log_error("failed to allocate %zu bytes for packed weights", w_bytes + b_bytes);
       goto error;
     }
-    qnnp_pack_igemm_w(groups, (uint32_t) group_output_channels, k_total, n_pad, k_pad,
+    qnnp_pack_igemm_w_slots(groups, (uint32_t) group_output_channels, (uint32_t) kernel_size,
+        (uint32_t) group_input_channels, kc_slot, n_pad, k_pad,
         input_zero_point, kernel_zero_point, kernel, bias, (int8_t*) host_weights, host_bias);
     op->n_pad = n_pad;
     op->k_pad = k_pad;
+    op->kc_slot = kc_slot;
     op->d_weights = qnnp_hip_alloc(w_bytes);
     op->d_bias = (int32_t*) qnnp_hip_alloc(b_bytes);
     if (op->d_weights == NULL || op->d_bias == NULL ||

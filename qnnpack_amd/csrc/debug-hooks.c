@@ -80,3 +80,11 @@ void qnnp_debug_requant_fast(
     out[i] = (uint8_t) (y + rq.output_zero_point);
   }
 }
+
+void qnnp_debug_pack_igemm_w_slots(
+    uint32_t groups, uint32_t n, uint32_t ks, uint32_t kc, uint32_t kc_slot, uint32_t n_pad, uint32_t k_pad,
+    uint8_t izp, uint8_t kzp, const uint8_t* kernel, const int32_t* bias,
+    int8_t* packed, int32_t* bias2)
+{
+  qnnp_pack_igemm_w_slots(groups, n, ks, kc, kc_slot, n_pad, k_pad, izp, kzp, kernel, bias, packed, bias2);
+}

@@ -114,6 +114,7 @@ enum qnnp_status qnnp_create_fully_connected_nc_q8(
       input_zero_point, kernel_zero_point, kernel, bias, host_weights, host_bias);
   op->n_pad = n_pad;
   op->k_pad = k_pad;
+  op->kc_slot = (uint32_t) input_channels;
   op->d_weights = qnnp_hip_alloc(w_bytes);
   op->d_bias = (int32_t*) qnnp_hip_alloc(b_bytes);
   if (op->d_weights == NULL || op->d_bias == NULL ||

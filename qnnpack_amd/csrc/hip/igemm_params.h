@@ -24,7 +24,8 @@ struct IgemmParams {
   uint64_t image_stride;
   uint32_t n;
   uint32_t n_pad;
-  uint32_t kc;
+  uint32_t kc;             // K positions per tap as the kernel sees them (= kc_slot)
+  const uint8_t* input_end; // one past the last readable input byte (pad3 mode bound)
   uint32_t ks;
   uint32_t k_total;
   uint32_t k_pad;

@@ -54,6 +54,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 64;                       // bytes of K per main-loop step
 constexpr uint32_t kPadK = 0x80808080u;      // raw bytes whose a' = a ^ 0x80 is zero
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
 
 template <int VEC>
@@ -100,7 +101,7 @@ __device__ __forceinline__ void fill_vec(uint32_t fill, uint32_t (&w)[4], int j)
  * next row tile are issued before the epilogue of the current one, so the (latency-bound) global reads
  * overlap the (VALU-bound) requantization instead of alternating with it.
  */
-template <int WM, int WN, int TM, int TN, int VEC, bool IS_CONV>
+template <int WM, int WN, int TM, int TN, int VEC, bool IS_CONV, bool PAD3 = false>
 __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 4) ? 2 : 3)
 void q8_igemm_mfma_kernel(const IgemmParams p)
 {
@@ -199,7 +200,21 @@ void q8_igemm_mfma_kernel(const IgemmParams p)
           if constexpr (IS_CONV) {
             const int32_t off = ctx.offs[q][tap];
             if (off >= 0) {
-              load_vec<VEC>(ctx.base[q] + off + ch, regs[q], j);
+              if constexpr (PAD3) {
+                // 3-channel pixel: one unaligned dword (the 4th byte belongs to the next pixel and is
+                // replaced by K padding); the very last pixel of the tensor is fetched bytewise
+                const uint8_t* src = ctx.base[q] + off;
+                uint32_t v;
+                if (src + 4 <= p.input_end) {
+                  v = *reinterpret_cast<const u32_unaligned*>(src);
+                } else {
+                  v = static_cast<uint32_t>(src[0]) | (static_cast<uint32_t>(src[1]) << 8) |
+                      (static_cast<uint32_t>(src[2]) << 16);
+                }
+                regs[q][j] = (v & 0x00FFFFFFu) | 0x80000000u;
+              } else {
+                load_vec<VEC>(ctx.base[q] + off + ch, regs[q], j);
+              }
             } else {
               fill_vec<VEC>(p.izp_fill, regs[q], j);   // padding tap: a == input zero point
             }
@@ -390,7 +405,7 @@ void q8_igemm_mfma_kernel(const IgemmParams p)
   }
 }
 
-template <int WM, int WN, int TM, int TN, int VEC, bool IS_CONV>
+template <int WM, int WN, int TM, int TN, int VEC, bool IS_CONV, bool PAD3 = false>
 int launch_generic(const IgemmParams& p, uint32_t groups, hipStream_t stream)
 {
   constexpr int BM = WM * TM * 32;
@@ -403,7 +418,7 @@ int launch_generic(const IgemmParams& p, uint32_t groups, hipStream_t stream)
   if (blocks_per_cu == 0) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &nb, q8_igemm_mfma_kernel<WM, WN, TM, TN, VEC, IS_CONV>, WM * WN * 64, 0) != hipSuccess || nb < 1) {
+            &nb, q8_igemm_mfma_kernel<WM, WN, TM, TN, VEC, IS_CONV, PAD3>, WM * WN * 64, 0) != hipSuccess || nb < 1) {
       (void) hipGetLastError();
       nb = 2;
     }
@@ -415,23 +430,23 @@ int launch_generic(const IgemmParams& p, uint32_t groups, hipStream_t stream)
   if (ctas_m > tiles_m) ctas_m = tiles_m;
   const dim3 grid(ctas_m * tiles_n, groups, 1);
   const dim3 block(WM * WN * 64, 1, 1);
-  hipLaunchKernelGGL((q8_igemm_mfma_kernel<WM, WN, TM, TN, VEC, IS_CONV>), grid, block, 0, stream, p);
+  hipLaunchKernelGGL((q8_igemm_mfma_kernel<WM, WN, TM, TN, VEC, IS_CONV, PAD3>), grid, block, 0, stream, p);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
-template <int VEC, bool IS_CONV>
+template <int VEC, bool IS_CONV, bool PAD3 = false>
 int dispatch_tile(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name)
 {
   if (p.n_pad <= 32) {
-    *name = "q8_igemm_mfma_128x32";
-    return launch_generic<4, 1, 1, 1, VEC, IS_CONV>(p, groups, stream);
+    *name = PAD3 ? "q8_igemm_mfma_128x32_c3" : "q8_igemm_mfma_128x32";
+    return launch_generic<4, 1, 1, 1, VEC, IS_CONV, PAD3>(p, groups, stream);
   }
   if (p.n_pad <= 64) {
-    *name = "q8_igemm_mfma_128x64";
-    return launch_generic<4, 1, 1, 2, VEC, IS_CONV>(p, groups, stream);
+    *name = PAD3 ? "q8_igemm_mfma_128x64_c3" : "q8_igemm_mfma_128x64";
+    return launch_generic<4, 1, 1, 2, VEC, IS_CONV, PAD3>(p, groups, stream);
   }
-  *name = "q8_igemm_mfma_128x128";
-  return launch_generic<2, 2, 2, 2, VEC, IS_CONV>(p, groups, stream);
+  *name = PAD3 ? "q8_igemm_mfma_128x128_c3" : "q8_igemm_mfma_128x128";
+  return launch_generic<2, 2, 2, 2, VEC, IS_CONV, PAD3>(p, groups, stream);
 }
 
 template <bool IS_CONV>
@@ -463,14 +478,19 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   p.image_stride = a->image_stride;
   p.n = a->n;
   p.n_pad = a->n_pad;
-  p.kc = a->kc;
+  p.kc = a->kc_slot;
+  p.input_end = a->input + a->input_bytes;
   p.ks = a->ks;
   p.k_total = a->k_total;
   p.k_pad = a->k_pad;
   p.input_stride = a->input_stride;
   p.output_stride = a->output_stride;
   p.row_coeff = a->row_coeff;
-  p.izp_fill = (a->input_zero_point & 0xFFu) * 0x01010101u;
+  const bool pad3 = a->offsets != nullptr && a->kc == 3 && a->kc_slot == 4 && a->groups == 1;
+  if (a->kc_slot != a->kc && !pad3) return QNNP_HIP_EINVAL;
+  // padding taps read the input zero point; in 3-channel slot mode the slot's 4th byte is K padding (a' = 0)
+  p.izp_fill = pad3 ? ((a->input_zero_point & 0xFFu) * 0x00010101u) | 0x80000000u
+                    : (a->input_zero_point & 0xFFu) * 0x01010101u;
   p.rq = qnnp::make_requant_dev(a->rq);
   p.fill_table = qnnp_hip_fill_table();
   {
@@ -488,6 +508,7 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
       break;
     }
   }
+  if (pad3) vec = 4;   // one (unaligned) dword per tap
   const uintptr_t out_addr = reinterpret_cast<uintptr_t>(a->output);
   p.store_mode = 0;
   if (a->n % 16 == 0 && a->output_stride % 16 == 0 && out_addr % 16 == 0) {
@@ -499,15 +520,19 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   hipStream_t stream = reinterpret_cast<hipStream_t>(qnnp_hip_get_stream());
   const char* name = nullptr;
   // Large MFMA-bound problems take the 256x256 LDS-DMA kernel; everything else the generic one.
-  const bool big_ok = qnnp::gemm256_supported(p, vec);
+  const bool big_ok = !pad3 && qnnp::gemm256_supported(p, vec);
   const bool big_auto = a->n >= 256 && a->k_total >= 512 && a->rows >= 2048;
   if (a->variant == 2 && !big_ok) return QNNP_HIP_EINVAL;
   int rc;
   if (big_ok && (a->variant == 2 || (a->variant == 0 && big_auto))) {
     rc = qnnp::gemm256_launch(p, a->groups, stream, &name);
   } else {
-    rc = (a->offsets != nullptr) ? dispatch_vec<true>(p, a->groups, vec, stream, &name)
-                                 : dispatch_vec<false>(p, a->groups, vec, stream, &name);
+    if (pad3) {
+      rc = dispatch_tile<4, true, true>(p, a->groups, stream, &name);
+    } else {
+      rc = (a->offsets != nullptr) ? dispatch_vec<true>(p, a->groups, vec, stream, &name)
+                                   : dispatch_vec<false>(p, a->groups, vec, stream, &name);
+    }
   }
   if (kernel_name != nullptr) *kernel_name = name;
   return rc;

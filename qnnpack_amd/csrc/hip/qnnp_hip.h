@@ -90,8 +90,10 @@ struct qnnp_hip_igemm_args {
   uint32_t n;                 /* group output channels */
   uint32_t n_pad;             /* round_up(n, 32) */
   uint32_t kc;                /* group input channels */
+  uint32_t kc_slot;           /* K positions per tap: kc, or 4 when kc == 3 (one unaligned dword fetch per tap) */
+  uint64_t input_bytes;       /* extent of the input tensor from `input` (bounds the 4-byte fetches of kc == 3) */
   uint32_t ks;                /* taps (1 for gemm) */
-  uint32_t k_total;           /* ks * kc */
+  uint32_t k_total;           /* ks * kc_slot */
   uint32_t k_pad;             /* round_up(k_total, 64) */
   uint32_t input_stride;      /* bytes between pixels */
   uint32_t output_stride;

@@ -88,8 +88,10 @@ static int launch(struct qnnp_operator* op, const void* input, void* output)
         .n = (uint32_t) op->group_output_channels,
         .n_pad = op->n_pad,
         .kc = (uint32_t) op->group_input_channels,
+        .kc_slot = op->kc_slot,
+        .input_bytes = op->input_span,
         .ks = taps,
-        .k_total = taps * (uint32_t) op->group_input_channels,
+        .k_total = taps * op->kc_slot,
         .k_pad = op->k_pad,
         .input_stride = (uint32_t) op->input_pixel_stride,
         .output_stride = (uint32_t) op->output_pixel_stride,

@@ -58,6 +58,7 @@ struct qnnp_operator {
   int32_t* d_bias;        /* igemm: bias2 [groups][n_pad]; dwconv: bias1 [c_pad] */
   uint32_t n_pad;         /* igemm */
   uint32_t k_pad;         /* igemm */
+  uint32_t kc_slot;       /* igemm: K positions per tap (group_input_channels, or 4 for 3-channel inputs) */
   uint32_t c_pad;         /* dwconv */
 
   int32_t* d_offsets;     /* conv: [output pixels][taps] int32, -1 = padding */

@@ -45,6 +45,49 @@ static inline size_t qnnp_igemm_packed_weights_size(uint32_t groups, uint32_t n_
   return (size_t) groups * n_pad * k_pad;
 }
 
+/*
+ * Channel slots: a tap normally occupies `kc` consecutive K positions. For 3-channel inputs (first
+ * layers) the device kernel fetches each tap with ONE unaligned 4-byte load, so a tap occupies a
+ * 4-wide slot whose last position is K padding (w' = 0 here, a' forced to 0 in the kernel):
+ * packed K index = tap * kc_slot + channel, k_total (real) = ks * kc.
+ */
+static inline void qnnp_pack_igemm_w_slots(
+    uint32_t groups, uint32_t n, uint32_t ks, uint32_t kc, uint32_t kc_slot,
+    uint32_t n_pad, uint32_t k_pad,
+    uint8_t izp, uint8_t kzp,
+    const uint8_t* kernel, const int32_t* bias,
+    int8_t* packed, int32_t* bias2)
+{
+  const uint32_t k_total = ks * kc;
+  const uint32_t nblocks = n_pad / 32;
+  const uint32_t kblocks = k_pad / 32;
+  memset(packed, 0, qnnp_igemm_packed_weights_size(groups, n_pad, k_pad));
+  const uint32_t a_off = (uint32_t) (128 - (int32_t) izp);
+  const uint32_t w_off = (uint32_t) (128 - (int32_t) kzp);
+  for (uint32_t g = 0; g < groups; g++) {
+    for (uint32_t col = 0; col < n_pad; col++) {
+      uint32_t b2 = 0;
+      if (col < n) {
+        const uint8_t* src = kernel + ((size_t) g * n + col) * k_total;
+        const uint32_t nb = col / 32;
+        const uint32_t lane_lo = col % 32;
+        uint32_t wsum = 0;
+        for (uint32_t kk = 0; kk < k_total; kk++) {
+          const int32_t ws = (int32_t) src[kk] - 128;
+          wsum += (uint32_t) ws;
+          const uint32_t kp = (kk / kc) * kc_slot + (kk % kc);   /* packed K position */
+          const uint32_t kb = kp / 32;
+          const uint32_t lane = lane_lo + 32 * ((kp % 32) / 16);
+          const size_t dst = ((((size_t) g * nblocks + nb) * kblocks + kb) * 64 + lane) * 16 + (kp % 16);
+          packed[dst] = (int8_t) ws;
+        }
+        b2 = (uint32_t) bias[(size_t) g * n + col] + a_off * wsum + k_total * a_off * w_off;
+      }
+      bias2[(size_t) g * n_pad + col] = (int32_t) b2;
+    }
+  }
+}
+
 static inline void qnnp_pack_igemm_w(
     uint32_t groups, uint32_t n, uint32_t k_total,
     uint32_t n_pad, uint32_t k_pad,

@@ -116,6 +116,10 @@ EXTRA_CONV_CASES = [
     ConvCase("x_3x3_c64_vec16", (12, 10), (3, 3), _pad(1, 1), gic=64, goc=64, batch=2),
     ConvCase("x_3x3_c16_s2", (15, 17), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=16, goc=48),
     ConvCase("x_3x3_c3_first_layer", (32, 32), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=32, batch=2),
+    ConvCase("x_3x3_c3_s1_pad", (13, 11), (3, 3), _pad(1, 1), gic=3, goc=24, batch=2),
+    ConvCase("x_3x3_c3_pixel_stride5", (9, 10), (3, 3), _pad(1, 1), gic=3, goc=40, input_pixel_stride=5),
+    ConvCase("x_5x5_c3_s2_zp", (17, 15), (5, 5), _pad(2, 2), subsampling=(2, 2), gic=3, goc=16, izp=9, kzp=200),
+    ConvCase("x_1x1_c3_s2", (9, 9), (1, 1), subsampling=(2, 2), gic=3, goc=33),
     ConvCase("x_3x3_c8_vec8", (9, 9), (3, 3), _pad(1, 1), gic=8, goc=20),
     ConvCase("x_5x5_c4", (11, 12), (5, 5), _pad(2, 2), gic=4, goc=12),
     ConvCase("x_7x7_dw_c12", (13, 13), (7, 7), _pad(3, 3), groups=12),

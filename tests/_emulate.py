@@ -24,6 +24,8 @@ def bind_debug_hooks(lib):
     L = lib.lib
     L.qnnp_debug_pack_igemm_w.restype = None
     L.qnnp_debug_pack_igemm_w.argtypes = [c_uint32] * 5 + [c_uint8, c_uint8, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.qnnp_debug_pack_igemm_w_slots.restype = None
+    L.qnnp_debug_pack_igemm_w_slots.argtypes = [c_uint32] * 7 + [c_uint8, c_uint8, c_void_p, c_void_p, c_void_p, c_void_p]
     L.qnnp_debug_pack_dwconv_w.restype = None
     L.qnnp_debug_pack_dwconv_w.argtypes = [c_uint32] * 4 + [c_uint8, c_uint8, c_void_p, c_void_p, c_void_p, c_void_p]
     L.qnnp_debug_conv2d_offsets.restype = None
@@ -68,6 +70,38 @@ def host_pack_igemm(L, groups, n, k_total, izp, kzp, kernel, bias):
     L.qnnp_debug_pack_igemm_w(groups, n, k_total, n_pad, k_pad, izp, kzp, kernel.ctypes.data, bias.ctypes.data,
                               packed.ctypes.data, bias2.ctypes.data)
     return packed, bias2, n_pad, k_pad
+
+
+def host_pack_igemm_slots(L, groups, n, ks, kc, kc_slot, izp, kzp, kernel, bias):
+    """pack.h "channel slots": a tap occupies kc_slot K positions (4 for 3-channel inputs)."""
+    n_pad, k_pad = round_up(n, 32), round_up(ks * kc_slot, 64)
+    kernel = np.ascontiguousarray(kernel, dtype=np.uint8)
+    bias = np.ascontiguousarray(bias, dtype=np.int32)
+    packed = np.empty(groups * n_pad * k_pad, dtype=np.int8)
+    bias2 = np.empty(groups * n_pad, dtype=np.int32)
+    L.qnnp_debug_pack_igemm_w_slots(groups, n, ks, kc, kc_slot, n_pad, k_pad, izp, kzp, kernel.ctypes.data,
+                                    bias.ctypes.data, packed.ctypes.data, bias2.ctypes.data)
+    return packed, bias2, n_pad, k_pad
+
+
+def emulate_igemm_c3(L, n, ks, izp, kzp, kernel, bias, a_rows, rows, rq, out_stride, fill=0xA5):
+    """3-channel slot mode of q8igemm.hip: each tap is fetched as one dword whose 4th byte is replaced by
+    K padding (raw 0x80 -> a' = 0); padding taps read {izp, izp, izp, 0x80}. a_rows: uint8 [rows, ks*3]."""
+    packed, bias2, n_pad, k_pad = host_pack_igemm_slots(L, 1, n, ks, 3, 4, izp, kzp, kernel, bias)
+    w = unpack_fragments(packed, 1, n_pad, k_pad)[0]
+    a4 = np.full((rows, ks, 4), 0x80, dtype=np.int64)
+    a4[:, :, :3] = a_rows.reshape(rows, ks, 3)
+    a4 = a4.reshape(rows, ks * 4)
+    a_s = (a4 ^ 0x80) - 256 * ((a4 ^ 0x80) >= 128)
+    a_pad = np.zeros((rows, k_pad), dtype=np.int64)
+    a_pad[:, :ks * 4] = a_s
+    rowsum = a_pad.sum(axis=1)
+    acc = wrap32(a_pad @ w.T + (128 - kzp) * rowsum[:, None] + bias2[None, :].astype(np.int64))
+    q = q31_requantize_np(acc[:, :n], rq)
+    out = np.full((rows - 1) * out_stride + n, fill, dtype=np.uint8)
+    for r in range(rows):
+        out[r * out_stride: r * out_stride + n] = q[r]
+    return out
 
 
 def unpack_fragments(packed, groups, n_pad, k_pad) -> np.ndarray:

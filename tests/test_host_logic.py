@@ -58,6 +58,15 @@ def test_convolution_host_images(hooks, case):
     depthwise = case.gic == 1 and case.goc == 1 and case.groups > 1
     if depthwise:
         out = em.emulate_dwconv(hooks, case, inp, kernel, bias, rq, oh, ow)
+    elif case.groups == 1 and case.gic == 3 and not (
+            case.kernel_size == (1, 1) and case.subsampling == (1, 1) and case.padding == (0, 0, 0, 0)):
+        # 3-channel slot mode (first layers): one dword fetch per tap, 4-wide K slots
+        offsets = em.host_offsets(hooks, case, oh, ow)
+        taps = case.kernel_size[0] * case.kernel_size[1]
+        rows = case.batch * oh * ow
+        a_rows = em.gather_conv_rows(case, inp, offsets, 0, oh, ow)
+        out = em.emulate_igemm_c3(hooks, case.goc, taps, case.izp, case.kzp,
+                                  kernel.reshape(case.goc, taps * 3), bias, a_rows, rows, rq, case.out_stride)
     else:
         offsets = em.host_offsets(hooks, case, oh, ow)
         taps = case.kernel_size[0] * case.kernel_size[1]
