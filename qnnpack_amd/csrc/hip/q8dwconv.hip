@@ -21,7 +21,8 @@
  * Kernel A  q8_dwconv_lds_kernel<KH, KW, VECL>   (3x3 and 5x5, C % 4 == 0)
  *   workgroup = one image x a band of output rows x all output columns x a channel
  *   slab. The input band (with halo, padding materialised as the zero point) is
- *   staged into LDS with 16-byte (or 4-byte) coalesced loads along C; each thread
+ *   staged into LDS with 16-byte (or 4-byte) coalesced loads along C, laid out
+ *   [row][4-channel group][column] so an output's taps are immediate offsets apart; each thread
  *   owns one 4-channel group (its tap weights live in registers as int16 pairs)
  *   and walks output positions, reading dwords from LDS, pairing taps with
  *   v_perm_b32 and accumulating two taps per v_dot2_i32_i16; one coalesced dword
@@ -34,6 +35,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "qnnp_hip.h"
 #include "requant.cuh"
@@ -61,6 +63,7 @@ struct DwParams {
   uint32_t CS;        // channels per slab (multiple of 4, divides C)
   uint32_t TOH;       // output rows per band
   uint32_t IR, IC;    // staged input rows / columns per band
+  uint32_t PP;        // LDS dwords per (row, 4-channel group) line: IC padded for bank spread
   uint32_t bands;     // ceil(OH / TOH)
   uint32_t slabs;     // C / CS
   qnnp::RequantDev rq;
@@ -102,13 +105,19 @@ void q8_dwconv_direct_kernel(const DwParams p)
 // --------------------------------------------------------------------------
 constexpr int kDwThreads = 512;
 
-template <int KH, int KW, int VECL>
+/*
+ * LDS image of the staged band: [input row][4-channel group][column] dwords, i.e. for one row and one
+ * 4-channel group the columns are consecutive dwords. The KW taps of an output are then 4*dw bytes apart
+ * (immediate ds_read offsets when dw == 1) and only one address per kernel row is computed.
+ * `p.PP` = dwords per (row, group) line, padded so that consecutive groups start on spread-out banks.
+ */
+template <int KH, int KW, int VECL, bool DW1>
 __global__ __launch_bounds__(kDwThreads)
 void q8_dwconv_lds_kernel(const DwParams p)
 {
   constexpr int TAPS = KH * KW;
   constexpr int PAIRS = (TAPS + 1) / 2;
-  extern __shared__ __attribute__((aligned(16))) uint8_t tile[];   // [IR][IC][CS]
+  extern __shared__ __attribute__((aligned(16))) uint8_t tile[];   // [IR][CS/4][PP] dwords
 
   const uint32_t tid = threadIdx.x;
   // block -> (image, band, slab); slab fastest so that the blocks sharing input
@@ -121,8 +130,11 @@ void q8_dwconv_lds_kernel(const DwParams p)
   const uint32_t oy0 = band * p.TOH;
   const uint32_t toh = min(p.TOH, p.OH - oy0);
   const uint32_t ir = (toh - 1) * p.sh + (KH - 1) * p.dh + 1;   // rows actually needed
+  const uint32_t q4 = p.CS / 4;                 // 4-channel groups in the slab
+  const uint32_t line_bytes = p.PP * 4;         // one (row, group) line
+  const uint32_t row_bytes = q4 * line_bytes;
 
-  // ---- stage the input band: coalesced VECL-byte vectors along C ----
+  // ---- stage the input band: coalesced VECL-byte vectors along C, scattered into the group planes ----
   {
     const uint32_t vpp = p.CS / VECL;                 // vectors per pixel
     const uint32_t nvec = ir * p.IC * vpp;
@@ -130,33 +142,50 @@ void q8_dwconv_lds_kernel(const DwParams p)
     const int32_t ix_base = -static_cast<int32_t>(p.pad_left);
     const uint8_t* img = p.input + static_cast<uint64_t>(n) * p.H * p.W * p.in_stride + c0;
     const uint32_t fill = p.izp * 0x01010101u;
+    // incremental (vector-in-pixel, column, row) walk: no divisions in the loop
+    uint32_t cv = tid % vpp;
+    uint32_t px = tid / vpp;
+    uint32_t ixl = px % p.IC;
+    uint32_t iyl = px / p.IC;
+    const uint32_t d_cv = kDwThreads % vpp;
+    const uint32_t d_px = kDwThreads / vpp;
+    const uint32_t d_ix = d_px % p.IC;
+    const uint32_t d_iy = d_px / p.IC;
     for (uint32_t v = tid; v < nvec; v += kDwThreads) {
-      const uint32_t cv = v % vpp;
-      const uint32_t px = v / vpp;
-      const uint32_t ixl = px % p.IC;
-      const uint32_t iyl = px / p.IC;
       const int32_t iy = iy_base + static_cast<int32_t>(iyl);
       const int32_t ix = ix_base + static_cast<int32_t>(ixl);
       const bool inb = iy >= 0 && iy < static_cast<int32_t>(p.H) && ix >= 0 && ix < static_cast<int32_t>(p.W);
-      uint8_t* dst = tile + (iyl * p.IC + ixl) * p.CS + cv * VECL;
-      const uint8_t* src = img;   // only dereferenced in bounds
-      if (inb) {
-        src += (static_cast<uint64_t>(static_cast<uint32_t>(iy)) * p.W + static_cast<uint32_t>(ix)) * p.in_stride + cv * VECL;
-      }
+      uint8_t* dst = tile + iyl * row_bytes + (cv * (VECL / 4)) * line_bytes + ixl * 4;
       if constexpr (VECL == 16) {
         uint4 val = make_uint4(fill, fill, fill, fill);
-        if (inb) val = *reinterpret_cast<const uint4*>(src);
-        *reinterpret_cast<uint4*>(dst) = val;
+        if (inb) {
+          val = *reinterpret_cast<const uint4*>(
+              img + (static_cast<uint64_t>(static_cast<uint32_t>(iy)) * p.W + static_cast<uint32_t>(ix)) * p.in_stride + cv * 16);
+        }
+        *reinterpret_cast<uint32_t*>(dst) = val.x;
+        *reinterpret_cast<uint32_t*>(dst + line_bytes) = val.y;
+        *reinterpret_cast<uint32_t*>(dst + 2 * line_bytes) = val.z;
+        *reinterpret_cast<uint32_t*>(dst + 3 * line_bytes) = val.w;
       } else {
         uint32_t val = fill;
-        if (inb) val = *reinterpret_cast<const uint32_t*>(src);
+        if (inb) {
+          val = *reinterpret_cast<const uint32_t*>(
+              img + (static_cast<uint64_t>(static_cast<uint32_t>(iy)) * p.W + static_cast<uint32_t>(ix)) * p.in_stride + cv * 4);
+        }
         *reinterpret_cast<uint32_t*>(dst) = val;
       }
+      // advance by kDwThreads vectors
+      cv += d_cv;
+      uint32_t carry = 0;
+      if (cv >= vpp) { cv -= vpp; carry = 1; }
+      ixl += d_ix + carry;
+      iyl += d_iy;
+      if (ixl >= p.IC) { ixl -= p.IC; iyl += 1; }
+      if (ixl >= p.IC) { ixl -= p.IC; iyl += 1; }
     }
   }
 
   // ---- per-thread channel group: weights as (tap 2i, tap 2i+1) int16 pairs ----
-  const uint32_t q4 = p.CS / 4;                 // 4-channel groups in the slab
   const uint32_t nslots = kDwThreads / q4;      // positions processed concurrently
   const uint32_t c4 = tid % q4;
   const uint32_t slot = tid / q4;
@@ -184,24 +213,38 @@ void q8_dwconv_lds_kernel(const DwParams p)
   if (!active) return;
 
   const uint32_t npos = toh * p.OW;
-  uint8_t* out_img = p.output + (static_cast<uint64_t>(n) * p.OH + oy0) * p.OW * p.out_stride + cg;
+  uint8_t* out_ptr = p.output + (static_cast<uint64_t>(n) * p.OH + oy0) * p.OW * p.out_stride + cg +
+                     static_cast<uint64_t>(slot) * p.out_stride;
+  const uint64_t out_step = static_cast<uint64_t>(nslots) * p.out_stride;
+  // incremental (row, column) walk over this thread's positions slot, slot + nslots, ...
+  uint32_t ox = slot % p.OW;
+  uint32_t oyl = slot / p.OW;
+  const uint32_t d_ox = nslots % p.OW;
+  const uint32_t d_oy = nslots / p.OW;
+  const uint32_t tap_row_bytes = p.dh * row_bytes;
+  const uint32_t tap_col_bytes = p.dw * 4;
   // the requantization flavour (shift == 0? clamp == [0,255]?) is chosen once, outside the position loop
   qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
     for (uint32_t pos = slot; pos < npos; pos += nslots) {
-      const uint32_t oyl = pos / p.OW;
-      const uint32_t ox = pos - oyl * p.OW;
-      const uint8_t* base = tile + ((oyl * p.sh) * p.IC + ox * p.sw) * p.CS + c4 * 4;
+      const uint8_t* base = tile + (oyl * p.sh) * row_bytes + c4 * line_bytes + (ox * p.sw) * 4;
+      uint32_t in[TAPS];
+#pragma unroll
+      for (int ky = 0; ky < KH; ky++) {
+        const uint8_t* row = base + ky * tap_row_bytes;
+#pragma unroll
+        for (int kx = 0; kx < KW; kx++) {
+          if constexpr (DW1) {
+            in[ky * KW + kx] = *reinterpret_cast<const uint32_t*>(row + kx * 4);          // immediate offset
+          } else {
+            in[ky * KW + kx] = *reinterpret_cast<const uint32_t*>(row + kx * tap_col_bytes);
+          }
+        }
+      }
       int32_t acc0 = bias[0], acc1 = bias[1], acc2 = bias[2], acc3 = bias[3];
 #pragma unroll
       for (int i = 0; i < PAIRS; i++) {
-        const int t0 = 2 * i, t1 = 2 * i + 1;
-        const uint32_t in0 = *reinterpret_cast<const uint32_t*>(
-            base + (((t0 / KW) * p.dh) * p.IC + (t0 % KW) * p.dw) * p.CS);
-        uint32_t in1 = 0u;
-        if (t1 < TAPS) {
-          in1 = *reinterpret_cast<const uint32_t*>(
-              base + (((t1 / KW) * p.dh) * p.IC + (t1 % KW) * p.dw) * p.CS);
-        }
+        const uint32_t in0 = in[2 * i];
+        const uint32_t in1 = (2 * i + 1 < TAPS) ? in[2 * i + 1] : 0u;
         // v_perm_b32: result bytes {in0.c, 0, in1.c, 0} = the two taps of channel c as int16 x2
         const uint32_t p0 = __builtin_amdgcn_perm(in1, in0, 0x0c040c00u);
         const uint32_t p1 = __builtin_amdgcn_perm(in1, in0, 0x0c050c01u);
@@ -214,40 +257,51 @@ void q8_dwconv_lds_kernel(const DwParams p)
       }
       const uint32_t packed = qnnp::q31_requantize_pack4<decltype(shift0)::value, decltype(full)::value>(
           acc0, acc1, acc2, acc3, p.rq);
-      *reinterpret_cast<uint32_t*>(out_img + static_cast<uint64_t>(pos) * p.out_stride) = packed;
+      *reinterpret_cast<uint32_t*>(out_ptr) = packed;
+      out_ptr += out_step;
+      ox += d_ox;
+      oyl += d_oy;
+      if (ox >= p.OW) { ox -= p.OW; oyl += 1; }
     }
   });
 }
 
-constexpr uint32_t kDwLdsBudget = 64 * 1024;   // bytes per workgroup (2 workgroups per CU)
+constexpr uint32_t kDwLdsBudgetDefault = 32 * 1024;   // bytes per workgroup (4 workgroups per CU)
 
 // Pick slab width / band height for kernel A. Returns false if the shape does not fit.
-bool plan_lds(DwParams& p)
+bool plan_lds(DwParams& p, uint32_t budget)
 {
   if (p.C % 4 != 0) return false;
   p.IC = (p.OW - 1) * p.sw + (p.KW - 1) * p.dw + 1;
   const uint32_t halo = (p.KH - 1) * p.dh + 1;
   const uint32_t want = p.OH < 4 ? p.OH : 4;
-  uint32_t best_cs = 0, best_toh = 0;
+  uint32_t best_cs = 0, best_toh = 0, best_pp = 0;
   // candidate slabs: divisors of C, multiples of 4 (prefer 16), at most 4*kDwThreads channels
   for (uint32_t parts = 1; parts <= p.C / 4; parts++) {
     if (p.C % parts != 0) continue;
     const uint32_t cs = p.C / parts;
     if (cs % 4 != 0 || cs / 4 > kDwThreads) continue;
-    const uint32_t row_bytes = p.IC * cs;
-    const uint32_t max_rows = kDwLdsBudget / row_bytes;
+    const uint32_t q4 = cs / 4;
+    // line pitch (dwords): >= IC, and == spread (mod 32) so that the q4 group lines of a row start on
+    // different banks: spread = 32/q4 for few groups, 1 (odd) for many
+    const uint32_t spread = q4 >= 32 ? 1u : (32u + q4 - 1) / q4;
+    uint32_t pp = p.IC;
+    while (pp % 32 != spread % 32) pp++;
+    const uint32_t row_bytes = q4 * pp * 4;
+    const uint32_t max_rows = budget / row_bytes;
     if (max_rows < halo) continue;
     uint32_t toh = (max_rows - halo) / p.sh + 1;
     if (toh > p.OH) toh = p.OH;
-    if (best_cs == 0) { best_cs = cs; best_toh = toh; }   // widest slab that fits at all
-    if (toh >= want) { best_cs = cs; best_toh = toh; break; }
+    if (best_cs == 0) { best_cs = cs; best_toh = toh; best_pp = pp; }   // widest slab that fits at all
+    if (toh >= want) { best_cs = cs; best_toh = toh; best_pp = pp; break; }
   }
   if (best_cs == 0) return false;
   p.CS = best_cs;
+  p.PP = best_pp;
   p.slabs = p.C / best_cs;
-  // keep the machine busy: at least ~2 workgroups per CU when the batch is small
+  // keep the machine busy: at least ~4 workgroups per CU when the batch is small
   uint32_t toh = best_toh;
-  while (toh > 1 && static_cast<uint64_t>(p.batch) * ((p.OH + toh - 1) / toh) * p.slabs < 512) {
+  while (toh > 1 && static_cast<uint64_t>(p.batch) * ((p.OH + toh - 1) / toh) * p.slabs < 1024) {
     toh = (toh + 1) / 2;
   }
   p.TOH = toh;
@@ -260,12 +314,16 @@ template <int KH, int KW>
 int launch_lds(const DwParams& p, bool vec16, hipStream_t stream)
 {
   const uint32_t blocks = p.batch * p.bands * p.slabs;
-  const size_t lds_bytes = static_cast<size_t>(p.IR) * p.IC * p.CS;
+  const size_t lds_bytes = static_cast<size_t>(p.IR) * (p.CS / 4) * p.PP * 4;
+  const bool dw1 = p.dw == 1;
+#define QNNP_DW_LAUNCH(V, D) \
+  hipLaunchKernelGGL((q8_dwconv_lds_kernel<KH, KW, V, D>), dim3(blocks), dim3(kDwThreads), lds_bytes, stream, p)
   if (vec16) {
-    hipLaunchKernelGGL((q8_dwconv_lds_kernel<KH, KW, 16>), dim3(blocks), dim3(kDwThreads), lds_bytes, stream, p);
+    if (dw1) QNNP_DW_LAUNCH(16, true); else QNNP_DW_LAUNCH(16, false);
   } else {
-    hipLaunchKernelGGL((q8_dwconv_lds_kernel<KH, KW, 4>), dim3(blocks), dim3(kDwThreads), lds_bytes, stream, p);
+    if (dw1) QNNP_DW_LAUNCH(4, true); else QNNP_DW_LAUNCH(4, false);
   }
+#undef QNNP_DW_LAUNCH
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
@@ -289,7 +347,7 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
   p.pad_top = a->pad_top; p.pad_left = a->pad_left;
   p.in_stride = a->input_stride; p.out_stride = a->output_stride;
   p.izp = a->input_zero_point & 0xFFu;
-  p.CS = p.TOH = p.IR = p.IC = p.bands = p.slabs = 0;
+  p.CS = p.TOH = p.IR = p.IC = p.PP = p.bands = p.slabs = 0;
   p.rq = qnnp::make_requant_dev(a->rq);
 
   hipStream_t stream = reinterpret_cast<hipStream_t>(qnnp_hip_get_stream());
@@ -299,7 +357,12 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
   const bool k33 = p.KH == 3 && p.KW == 3;
   const bool k55 = p.KH == 5 && p.KW == 5;
   const bool aligned4 = p.in_stride % 4 == 0 && p.out_stride % 4 == 0 && in_addr % 4 == 0 && out_addr % 4 == 0;
-  bool use_lds = a->variant != 1 && (k33 || k55) && aligned4 && plan_lds(p);
+  uint32_t budget = kDwLdsBudgetDefault;
+  if (const char* env = getenv("QNNP_GFX950_DW_LDS_KB")) {   // tuning knob (measurement only)
+    const int kb = atoi(env);
+    if (kb >= 4 && kb <= 64) budget = static_cast<uint32_t>(kb) * 1024u;
+  }
+  bool use_lds = a->variant != 1 && (k33 || k55) && aligned4 && plan_lds(p, budget);
   if (a->variant == 2 && !use_lds) return QNNP_HIP_EINVAL;
 
   if (use_lds) {
