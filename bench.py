@@ -191,7 +191,8 @@ def main():
             dist.barrier()
 
     if args.layer:
-        H, W, KH, KW, S, D, G, GIC, GOC = MOBILENETV2[args.layer - 1]
+        # layer 99 = BASELINE configs[2]: 3x3 s1 conv 56x56x64 -> 64
+        H, W, KH, KW, S, D, G, GIC, GOC = (56, 56, 3, 3, 1, 1, 1, 64, 64) if args.layer == 99 else MOBILENETV2[args.layer - 1]
         layer = ConvLayer(lib, torch, args.sweep_batch, H, W, KH, KW, S, D, G, GIC, GOC, seed=100 + args.layer,
                           min_bytes_between_reuse=512 << 20)
         ms = layer.time_ms(args.warmup, args.steps)

@@ -61,7 +61,8 @@ enum qnnp_status qnnp_gfx950_time_operator_rotating(
     int warmup, int iters, float* avg_ms_out);
 
 /* Kernel-variant control for A/B measurement and tests. Keys:
- *   "gemm_kernel":   0 = auto, 1 = generic MFMA implicit-GEMM kernel, 2 = 256x256 LDS-DMA MFMA kernel
+ *   "gemm_kernel":   0 = auto, 1 = generic MFMA implicit-GEMM kernel, 2 = 256x256 LDS-DMA MFMA kernel,
+ *                    3 = LDS-tiled direct-convolution MFMA kernel (convolutions only)
  *   "dwconv_kernel": 0 = auto, 1 = generic direct kernel, 2 = LDS-tiled kernel
  * Unknown key -> invalid_parameter. Applies to operators set up afterwards. */
 enum qnnp_status qnnp_gfx950_set_option(const char* key, int value);

@@ -39,6 +39,17 @@ struct IgemmParams {
   RequantDev rq;
 };
 
+/* convolution geometry for the LDS-tiled direct-convolution kernel */
+struct ConvGeom {
+  uint32_t H, W, OH, OW;
+  uint32_t KH, KW, sh, sw, dh, dw;
+  uint32_t pad_top, pad_left;
+};
+
+/* q8convlds.hip */
+bool convlds_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32_t vec);
+int convlds_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipStream_t stream, const char** name);
+
 /* q8gemm256.hip */
 bool gemm256_supported(const IgemmParams& p, uint32_t vec);
 int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name);

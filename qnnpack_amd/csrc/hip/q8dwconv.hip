@@ -135,7 +135,10 @@ void q8_dwconv_lds_kernel(const DwParams p)
   const uint32_t row_bytes = q4 * line_bytes;
 
   // ---- stage the input band: coalesced VECL-byte vectors along C, scattered into the group planes ----
+  // Batches of kStageBatch vectors per thread: every global load of a batch is issued before the first
+  // LDS write, so a thread keeps several loads in flight (a load -> write -> load loop is latency-bound).
   {
+    constexpr int kStageBatch = (VECL == 16) ? 4 : 8;
     const uint32_t vpp = p.CS / VECL;                 // vectors per pixel
     const uint32_t nvec = ir * p.IC * vpp;
     const int32_t iy_base = static_cast<int32_t>(oy0 * p.sh) - static_cast<int32_t>(p.pad_top);
@@ -151,37 +154,49 @@ void q8_dwconv_lds_kernel(const DwParams p)
     const uint32_t d_px = kDwThreads / vpp;
     const uint32_t d_ix = d_px % p.IC;
     const uint32_t d_iy = d_px / p.IC;
-    for (uint32_t v = tid; v < nvec; v += kDwThreads) {
-      const int32_t iy = iy_base + static_cast<int32_t>(iyl);
-      const int32_t ix = ix_base + static_cast<int32_t>(ixl);
-      const bool inb = iy >= 0 && iy < static_cast<int32_t>(p.H) && ix >= 0 && ix < static_cast<int32_t>(p.W);
-      uint8_t* dst = tile + iyl * row_bytes + (cv * (VECL / 4)) * line_bytes + ixl * 4;
-      if constexpr (VECL == 16) {
-        uint4 val = make_uint4(fill, fill, fill, fill);
-        if (inb) {
-          val = *reinterpret_cast<const uint4*>(
-              img + (static_cast<uint64_t>(static_cast<uint32_t>(iy)) * p.W + static_cast<uint32_t>(ix)) * p.in_stride + cv * 16);
+    for (uint32_t v0 = tid; v0 < nvec; v0 += kDwThreads * kStageBatch) {
+      uint32_t dst[kStageBatch];
+      bool live[kStageBatch];
+      uint4 val16[VECL == 16 ? kStageBatch : 1];
+      uint32_t val4[VECL == 16 ? 1 : kStageBatch];
+#pragma unroll
+      for (int u = 0; u < kStageBatch; u++) {
+        live[u] = v0 + u * kDwThreads < nvec;
+        const int32_t iy = iy_base + static_cast<int32_t>(iyl);
+        const int32_t ix = ix_base + static_cast<int32_t>(ixl);
+        const bool inb = live[u] && iy >= 0 && iy < static_cast<int32_t>(p.H) && ix >= 0 && ix < static_cast<int32_t>(p.W);
+        dst[u] = iyl * row_bytes + (cv * (VECL / 4)) * line_bytes + ixl * 4;
+        const uint8_t* src =
+            img + (static_cast<uint64_t>(static_cast<uint32_t>(iy)) * p.W + static_cast<uint32_t>(ix)) * p.in_stride + cv * VECL;
+        if constexpr (VECL == 16) {
+          val16[u] = make_uint4(fill, fill, fill, fill);
+          if (inb) val16[u] = *reinterpret_cast<const uint4*>(src);
+        } else {
+          val4[u] = fill;
+          if (inb) val4[u] = *reinterpret_cast<const uint32_t*>(src);
         }
-        *reinterpret_cast<uint32_t*>(dst) = val.x;
-        *reinterpret_cast<uint32_t*>(dst + line_bytes) = val.y;
-        *reinterpret_cast<uint32_t*>(dst + 2 * line_bytes) = val.z;
-        *reinterpret_cast<uint32_t*>(dst + 3 * line_bytes) = val.w;
-      } else {
-        uint32_t val = fill;
-        if (inb) {
-          val = *reinterpret_cast<const uint32_t*>(
-              img + (static_cast<uint64_t>(static_cast<uint32_t>(iy)) * p.W + static_cast<uint32_t>(ix)) * p.in_stride + cv * 4);
-        }
-        *reinterpret_cast<uint32_t*>(dst) = val;
+        // advance by kDwThreads vectors
+        cv += d_cv;
+        uint32_t carry = 0;
+        if (cv >= vpp) { cv -= vpp; carry = 1; }
+        ixl += d_ix + carry;
+        iyl += d_iy;
+        if (ixl >= p.IC) { ixl -= p.IC; iyl += 1; }
       }
-      // advance by kDwThreads vectors
-      cv += d_cv;
-      uint32_t carry = 0;
-      if (cv >= vpp) { cv -= vpp; carry = 1; }
-      ixl += d_ix + carry;
-      iyl += d_iy;
-      if (ixl >= p.IC) { ixl -= p.IC; iyl += 1; }
-      if (ixl >= p.IC) { ixl -= p.IC; iyl += 1; }
+#pragma unroll
+      for (int u = 0; u < kStageBatch; u++) {
+        if (live[u]) {
+          uint8_t* d = tile + dst[u];
+          if constexpr (VECL == 16) {
+            *reinterpret_cast<uint32_t*>(d) = val16[u].x;
+            *reinterpret_cast<uint32_t*>(d + line_bytes) = val16[u].y;
+            *reinterpret_cast<uint32_t*>(d + 2 * line_bytes) = val16[u].z;
+            *reinterpret_cast<uint32_t*>(d + 3 * line_bytes) = val16[u].w;
+          } else {
+            *reinterpret_cast<uint32_t*>(d) = val4[u];
+          }
+        }
+      }
     }
   }
 

@@ -519,6 +519,19 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
 
   hipStream_t stream = reinterpret_cast<hipStream_t>(qnnp_hip_get_stream());
   const char* name = nullptr;
+  // Dense convolutions with power-of-two channel counts: LDS-tiled direct convolution (input read once).
+  qnnp::ConvGeom geom;
+  geom.H = a->input_height; geom.W = a->input_width; geom.OH = a->output_height; geom.OW = a->output_width;
+  geom.KH = a->kernel_height; geom.KW = a->kernel_width; geom.sh = a->stride_height; geom.sw = a->stride_width;
+  geom.dh = a->dilation_height; geom.dw = a->dilation_width; geom.pad_top = a->pad_top; geom.pad_left = a->pad_left;
+  const bool lds_ok = a->offsets != nullptr && !pad3 && a->rows_per_image > 0 &&
+      a->output_stride % 16 == 0 && qnnp::convlds_supported(p, geom, a->groups, vec);
+  if (a->variant == 3 && !lds_ok) return QNNP_HIP_EINVAL;
+  if (lds_ok && (a->variant == 3 || (a->variant == 0 && a->kernel_height * a->kernel_width > 1))) {
+    const int rc_lds = qnnp::convlds_launch(p, geom, a->rows / a->rows_per_image, stream, &name);
+    if (kernel_name != nullptr) *kernel_name = name;
+    return rc_lds;
+  }
   // Large MFMA-bound problems take the 256x256 LDS-DMA kernel; everything else the generic one.
   const bool big_ok = !pad3 && qnnp::gemm256_supported(p, vec);
   const bool big_auto = a->n >= 256 && a->k_total >= 512 && a->rows >= 2048;

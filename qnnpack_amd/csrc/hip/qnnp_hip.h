@@ -100,7 +100,11 @@ struct qnnp_hip_igemm_args {
   int32_t row_coeff;          /* 128 - kernel_zero_point */
   uint32_t input_zero_point;
   struct qnnp_hip_requant rq;
-  int variant;                /* 0 auto, 1 generic, 2 big-tile LDS-DMA */
+  int variant;                /* 0 auto, 1 generic, 2 big-tile LDS-DMA, 3 LDS-tiled direct convolution */
+  /* convolution geometry (conv only; lets the LDS-tiled kernel address the input directly) */
+  uint32_t input_height, input_width, output_height, output_width;
+  uint32_t kernel_height, kernel_width, stride_height, stride_width, dilation_height, dilation_width;
+  uint32_t pad_top, pad_left;
 };
 int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* args, const char** kernel_name);
 

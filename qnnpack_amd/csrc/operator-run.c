@@ -99,6 +99,18 @@ static int launch(struct qnnp_operator* op, const void* input, void* output)
         .input_zero_point = op->input_zero_point,
         .rq = op->requant,
         .variant = op->variant,
+        .input_height = (uint32_t) op->input_height,
+        .input_width = (uint32_t) op->input_width,
+        .output_height = (uint32_t) op->output_height,
+        .output_width = (uint32_t) op->output_width,
+        .kernel_height = op->kernel_height,
+        .kernel_width = op->kernel_width,
+        .stride_height = op->stride_height,
+        .stride_width = op->stride_width,
+        .dilation_height = op->dilation_height,
+        .dilation_width = op->dilation_width,
+        .pad_top = op->input_padding_top,
+        .pad_left = op->input_padding_left,
       };
       return qnnp_hip_igemm_run(&args, &op->kernel_name);
     }
