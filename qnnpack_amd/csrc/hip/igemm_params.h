@@ -13,6 +13,17 @@
 
 namespace qnnp {
 
+// cycle stamp of lane 0 / wave 0 into trace[(block * items + item) * 8 + slot]; compiled out of the product
+#ifdef QNNP_ENABLE_ABLATION
+#define QNNP_TRACE(p, block, item, slot)                                                        \
+  do {                                                                                           \
+    if ((p).trace != nullptr && threadIdx.x == 0 && (item) < 4)                                  \
+      (p).trace[((block) * 4 + (item)) * 8 + (slot)] = __builtin_readcyclecounter();            \
+  } while (0)
+#else
+#define QNNP_TRACE(p, block, item, slot) do { } while (0)
+#endif
+
 struct IgemmParams {
   const uint8_t* input;
   uint8_t* output;
@@ -35,6 +46,7 @@ struct IgemmParams {
   uint32_t izp_fill;       // input zero point replicated into 4 bytes
   uint32_t store_mode;     // 2: 16-byte stores, 1: dword stores, 0: byte stores (igemm_epilogue.cuh)
   uint32_t cu_count;       // compute units of the bound device (persistent-grid sizing)
+  unsigned long long* trace;  // measurement builds only (QNNP_ENABLE_ABLATION + env QNNP_GFX950_TRACE): cycle stamps
   const uint8_t* fill_table; // [256][16]: entry v = 16 bytes of value v (LDS-DMA padding sources)
   RequantDev rq;
 };

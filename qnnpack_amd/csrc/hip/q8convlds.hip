@@ -87,7 +87,9 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
   }
 
   // persistent: work item = (image, 256-position block); items of one image are consecutive
-  for (uint32_t item = blockIdx.x; item < total_items; item += gridDim.x) {
+  uint32_t item_no = 0;
+  for (uint32_t item = blockIdx.x; item < total_items; item += gridDim.x, item_no++) {
+  QNNP_TRACE(p, blockIdx.x, item_no, 0);
   const uint32_t img = item / blocks_per_image;
   const uint32_t blk = item - img * blocks_per_image;
   const uint32_t p0 = blk * kPosPerBlock;
@@ -146,6 +148,7 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
     }
   }
 
+  QNNP_TRACE(p, blockIdx.x, item_no, 1);
   // ---- this lane's two output positions ----
   const uint32_t khalf = lane >> 5;
   uint32_t pos[2], qbase[2];
@@ -178,6 +181,7 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
   int32_t rs[2] = {0, 0};
 
   __syncthreads();
+  QNNP_TRACE(p, blockIdx.x, item_no, 2);
 
   const uint32_t kblocks = p.k_pad / 32;
   const uint32_t cblocks = cin >> 5;
@@ -222,6 +226,7 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
     }
   }
 
+  QNNP_TRACE(p, blockIdx.x, item_no, 3);
   // ---- fused epilogue ----
   requant_dispatch(p.rq, [&](auto shift0, auto full) {
 #pragma unroll
@@ -237,7 +242,9 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
       }
     }
   });
+  QNNP_TRACE(p, blockIdx.x, item_no, 4);
   __syncthreads();    // every wave is done with this band before the next item overwrites it
+  QNNP_TRACE(p, blockIdx.x, item_no, 5);
   }
 }
 

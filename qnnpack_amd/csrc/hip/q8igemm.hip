@@ -493,6 +493,10 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
                     : (a->input_zero_point & 0xFFu) * 0x01010101u;
   p.rq = qnnp::make_requant_dev(a->rq);
   p.fill_table = qnnp_hip_fill_table();
+  p.trace = nullptr;
+#ifdef QNNP_ENABLE_ABLATION
+  p.trace = static_cast<unsigned long long*>(qnnp_hip_trace_buffer());
+#endif
   {
     int cus = 0;
     p.cu_count = (qnnp_hip_device_info(nullptr, 0, &cus, nullptr, nullptr) == QNNP_HIP_OK && cus > 0) ? static_cast<uint32_t>(cus) : 256u;

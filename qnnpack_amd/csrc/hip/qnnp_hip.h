@@ -48,6 +48,9 @@ void* qnnp_hip_get_stream(void);
 int qnnp_hip_stream_sync(void);
 /* device table [256][16]: entry v = sixteen bytes of value v (constant LDS-DMA sources) */
 const uint8_t* qnnp_hip_fill_table(void);
+/* measurement builds: device buffer for in-kernel cycle stamps (NULL unless env QNNP_GFX950_TRACE is set) and its dump */
+void* qnnp_hip_trace_buffer(void);
+int qnnp_hip_trace_dump(unsigned long long* host, size_t count);
 
 void* qnnp_hip_alloc(size_t bytes);
 void qnnp_hip_free(void* p);

@@ -8,6 +8,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -66,6 +67,24 @@ int qnnp_hip_init(int device)
 }
 
 const uint8_t* qnnp_hip_fill_table(void) { return g_rt.fill_table; }
+
+static unsigned long long* g_trace = nullptr;
+static const size_t kTraceWords = 4096 * 4 * 8;
+void* qnnp_hip_trace_buffer(void)
+{
+  if (g_trace == nullptr && getenv("QNNP_GFX950_TRACE") != nullptr) {
+    if (hipMalloc(reinterpret_cast<void**>(&g_trace), kTraceWords * 8) != hipSuccess) g_trace = nullptr;
+    else (void) hipMemset(g_trace, 0, kTraceWords * 8);
+  }
+  return g_trace;
+}
+int qnnp_hip_trace_dump(unsigned long long* host, size_t count)
+{
+  if (g_trace == nullptr) return QNNP_HIP_EINVAL;
+  if (count > kTraceWords) count = kTraceWords;
+  (void) hipDeviceSynchronize();
+  return hipMemcpy(host, g_trace, count * 8, hipMemcpyDeviceToHost) == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
 
 int qnnp_hip_shutdown(void)
 {
