@@ -20,8 +20,22 @@ namespace qnnp {
     if ((p).trace != nullptr && threadIdx.x == 0 && (item) < 4)                                  \
       (p).trace[((block) * 4 + (item)) * 8 + (slot)] = __builtin_readcyclecounter();            \
   } while (0)
+/* same, but the constant 100 MHz counter (s_memrealtime): calibrates the shader clock of a traced run */
+#define QNNP_TRACE_WALL(p, block, item, slot)                                                   \
+  do {                                                                                           \
+    if ((p).trace != nullptr && threadIdx.x == 0 && (item) < 4)                                  \
+      (p).trace[((block) * 4 + (item)) * 8 + (slot)] = wall_clock64();                           \
+  } while (0)
+/* per-wave stamp: lane 0 of the wave whose index is `item` */
+#define QNNP_TRACE_WAVE(p, block, item, slot)                                                   \
+  do {                                                                                           \
+    if ((p).trace != nullptr && (threadIdx.x & 63u) == 0 && (item) < 4)                          \
+      (p).trace[((block) * 4 + (item)) * 8 + (slot)] = __builtin_readcyclecounter();            \
+  } while (0)
 #else
+#define QNNP_TRACE_WAVE(p, block, item, slot) do { } while (0)
 #define QNNP_TRACE(p, block, item, slot) do { } while (0)
+#define QNNP_TRACE_WALL(p, block, item, slot) do { } while (0)
 #endif
 
 struct IgemmParams {
@@ -64,6 +78,6 @@ int convlds_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipS
 
 /* q8gemm256.hip */
 bool gemm256_supported(const IgemmParams& p, uint32_t vec);
-int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name);
+int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, bool waves4);
 
 }  // namespace qnnp

@@ -7,28 +7,32 @@
  * src/q8conv/4x4c2-sse2.c:14-273) for shapes big enough to be MFMA-bound, i.e.
  * BASELINE.json configs[1] (q8gemm M=N=K=4096).
  *
- * Structure (per workgroup, 8 waves as 4 (rows) x 2 (channels), 64 x 128 outputs per wave):
- *   - K advances 128 bytes per tile; two LDS stages of {activations 256x128 B,
- *     weights 256x128 B} = 128 KiB, filled with global_load_lds (16 B per lane, no
- *     VGPR round trip), one barrier per K tile, the next tile's DMA in flight while
- *     the current one is multiplied.
- *   - activations keep the caller's row-major image in full 128-byte lines; the
- *     16-byte chunk index is XOR-swizzled with (row >> 1) & 7 -- applied to the DMA
- *     SOURCE address and to the ds_read_b128 address (the LDS-DMA destination is
- *     lane-linear by construction), so fragment reads are bank-conflict free.
- *   - weights arrive already as MFMA fragments (pack.h), copied verbatim: fragment
- *     reads are linear.
- *   - uint8 -> int8 re-centring of activations is one v_xor per fragment dword after
- *     the LDS read; the per-row sum of a' needed for the kernel-zero-point term is
- *     taken with v_dot4 on those same registers, each of the 2 channel-waves doing
- *     one half of K (the wave-specific rotation of the K sub-step order makes that
- *     branch-free), combined through LDS at the end. Fragment reads of sub-step j+1
- *     are issued before the MFMAs of sub-step j.
- *   - convolution: each lane's DMA source comes from the device offset table
- *     (table entries for tile t+1 are fetched while tile t is multiplied); padding
- *     taps and K padding read constant 16-byte lines of the fill table.
- *   - epilogue fused in registers: + bias2 + row term -> Q31 requantize -> clamp ->
- *     4 channels per dword.
+ * Structure (per workgroup: one 256 x 256 output tile; 8 waves as 4 (rows) x 2 (channels), 64 x 128
+ * outputs per wave -- or, A/B flavour, 4 waves as 2 x 2 with 128 x 128 per wave):
+ *   - K advances 64 bytes per tile; a ring of four LDS stages of {activations 256x64 B, weights
+ *     256x64 B} = 128 KiB, filled with global_load_lds (16 B per lane, no VGPR round trip). One raw
+ *     s_barrier per K tile behind a counted s_waitcnt vmcnt, so up to three tiles stay in flight;
+ *     the DMA of tile kt+4 goes into the slot of tile kt from that tile's mid-point barrier on.
+ *   - activations keep the caller's row-major image; the 16-byte chunk index is XOR-swizzled with
+ *     (row >> 2) & 3 -- applied to the DMA SOURCE address and to the ds_read_b128 address (the
+ *     LDS-DMA destination is lane-linear by construction), so fragment reads are conflict free.
+ *   - weights arrive already as MFMA fragments (pack.h), copied verbatim: fragment reads are linear.
+ *   - uint8 -> int8 re-centring of activations is one v_xor per fragment dword after the LDS read;
+ *     the per-row sum needed for the kernel-zero-point term is taken over the RAW bytes with
+ *     v_sad_u8 (v_dot4c costs ~7 cycles beside MFMAs, v_sad_u8 ~0.5), each of the 2 channel-waves
+ *     doing one half of K (the wave-specific rotation of the K sub-step order makes that
+ *     branch-free), combined through LDS at the end.
+ *   - two software-pipelined phases per tile, instruction order pinned with sched_barrier (see the
+ *     comment at `iteration`).
+ *   - convolution: each lane's DMA source comes from the device offset table; padding taps and
+ *     K padding read constant 16-byte lines of the fill table.
+ *   - epilogue fused in registers: + bias2 + row term -> Q31 requantize -> clamp -> 4 channels
+ *     per dword.
+ *
+ * What bounds it on MI355X (measured, DESIGN.md "GEMM headroom"): under this kernel the chip clocks at
+ * 1.3-1.5 GHz (power management; a bare random-operand MFMA loop holds 1.78 GHz = 3.5 POP/s, the
+ * vendor int8 GEMM of hipBLASLt reaches 2.0-2.1 POP/s on the same problem), and the L2 -> LDS
+ * stream alone accounts for 15-20 % of the clock.
  *
  * Requirements (checked by gemm256_supported): 16-byte aligned activations with
  * group_input_channels % 16 == 0 and pixel stride % 16 == 0.
@@ -58,32 +62,44 @@ constexpr int kStages = 4;                     // LDS ring: tile t+3 is being fe
 constexpr int kATile = kBM * kBK;              // 16 KiB
 constexpr int kWTile = kBN * kBK;              // 16 KiB
 constexpr int kStage = kATile + kWTile;        // 32 KiB
-constexpr int kThreads = 512;
 constexpr uint32_t kFlip = 0x80808080u;
 
+#ifndef QNNP_DMA_AUX
+#define QNNP_DMA_AUX 0
+#endif
 __device__ __forceinline__ void dma16(const uint8_t* src, uint8_t* lds_wave_base)
 {
   // 16 bytes per lane, LDS destination = wave-uniform base + lane * 16
   __builtin_amdgcn_global_load_lds(
       (const __attribute__((address_space(1))) void*) src,
-      (__attribute__((address_space(3))) void*) lds_wave_base, 16, 0, 0);
+      (__attribute__((address_space(3))) void*) lds_wave_base, 16, 0, QNNP_DMA_AUX);
 }
 
-constexpr int kWM = 4;                         // waves along rows
-constexpr int kWN = 2;                         // waves along channels
-constexpr int kTM = kBM / (kWM * 32);          // 2 MFMA tiles of 32 rows per wave
-constexpr int kTN = kBN / (kWN * 32);          // 4 MFMA tiles of 32 channels per wave
-static_assert(kWM * kWN * 64 == kThreads, "wave layout");
+constexpr int kWN = 2;                         // waves along channels (each 128 channels = 4 MFMA tiles)
+constexpr int kTN = kBN / (kWN * 32);
 static_assert(kWN == 2 && kBK == 64, "row-sum split: each channel-wave owns one of the two K sub-steps");
 
 // ABL: measurement-only ablation mask (builds with -DQNNP_ENABLE_ABLATION, env QNNP_GFX950_ABLATE);
 // 0 in the product. 1 = no requantization in the epilogue, 2 = no recentring / row sums,
 // 4 = no MFMA, 8 = no LDS-DMA after the prologue, 16 = no fragment reads after the first tile,
 // 32 = no per-tile wait + barrier.
-template <bool IS_CONV, int ABL = 0>
-__global__ __launch_bounds__(kThreads, 2)
+// WM = waves along rows: 4 -> 8 waves (two per SIMD), 64 x 128 outputs per wave, 12 fragment reads per 16 MFMAs;
+//                        2 -> 4 waves (one per SIMD, the whole register file), 128 x 128 outputs per wave,
+//                             16 fragment reads per 32 MFMAs.
+template <bool IS_CONV, int WM, int ABL = 0>
+__global__ __launch_bounds__(WM * kWN * 64, WM == 4 ? 2 : 1)
 void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 {
+  constexpr int kWM = WM;
+  constexpr int kThreads = WM * kWN * 64;
+  constexpr int kTM = kBM / (kWM * 32);          // MFMA tiles of 32 rows per wave
+  constexpr int kAChunks = (kBM * 4) / kThreads; // 16-byte activation chunks per thread per tile
+  constexpr int kWFrags = 16 / (kWM * kWN);      // 1 KiB weight fragments per wave per tile
+  constexpr int kDma = kAChunks + kWFrags;       // LDS-DMA instructions per thread per tile
+  constexpr int kMma = kTM * kTN;                // MFMAs per K sub-step
+  constexpr int kParts = 2 * kTM;                // recentring parts per fragment set
+  static_assert(kMma - kDma >= kParts, "phase 2 schedule needs one MFMA per recentring part after the DMA pieces");
+
   // single LDS object: ring of {A, W} tiles, then kWN x 256 partial row sums
   __shared__ __attribute__((aligned(16))) uint8_t lds[kStages * kStage + kWN * kBM * 4];
   int32_t* lds_rowsum = reinterpret_cast<int32_t*>(lds + kStages * kStage);
@@ -91,7 +107,7 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t wm = wave / kWN;      // 0..3: 64-row quarter
+  const uint32_t wm = wave / kWN;      // row slice of this wave
   const uint32_t wn = wave % kWN;      // 0..1: 128-channel half
   const uint32_t g = blockIdx.y;
 
@@ -99,6 +115,8 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
   // logical ids, and walk logical ids in bands of 4 row-tiles (channel-tile fastest inside a band)
   // so the ~32 co-resident tiles of an XCD form a compact patch that shares row panels and weight
   // panels in that XCD's L2.
+  QNNP_TRACE(p, blockIdx.x, 0, 0);
+  QNNP_TRACE_WALL(p, blockIdx.x, 3, 0);
   const uint32_t tiles_m = (p.rows + kBM - 1) / kBM;
   const uint32_t tiles_n = (p.n_pad + kBN - 1) / kBN;
   uint32_t m_tile, n_tile;
@@ -124,14 +142,14 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
   const uint8_t* pad_zp = p.fill_table + (p.izp_fill & 0xFFu) * 16;      // a == input zero point
   const uint8_t* pad_w = p.fill_table;                                   // w' == 0
 
-  // ---- activation DMA assignment: 2 chunks per thread, LDS linear index L = i*512 + tid ----
+  // ---- activation DMA assignment: kAChunks chunks per thread, LDS linear index L = i*kThreads + tid ----
   // LDS image of an activation tile: [256 rows][4 chunks of 16 B], chunk slot s of row r holds logical
   // chunk s ^ ((r >> 2) & 3): conflict-free ds_read_b128 fragment reads (4 rows share a 256-byte bank row).
-  const uint8_t* a_row[2];      // gemm: row base (+ group); conv: image base (+ group)
-  const int32_t* a_offs[2];     // conv: offset-table row of this pixel
-  uint32_t a_chunk[2];          // logical 16-byte chunk (0..3) this lane fetches for its slot
+  const uint8_t* a_row[kAChunks];   // gemm: row base (+ group); conv: image base (+ group)
+  const int32_t* a_offs[kAChunks];  // conv: offset-table row of this pixel
+  uint32_t a_chunk[kAChunks];       // logical 16-byte chunk (0..3) this lane fetches for its slot
 #pragma unroll
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < kAChunks; i++) {
     const uint32_t L = i * kThreads + tid;
     const uint32_t r = L >> 2;
     const uint32_t s = L & 3u;
@@ -149,17 +167,28 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
     }
   }
 
-  // ---- weight DMA assignment: 16 fragments of 1 KiB per tile, 2 per wave ----
+  // ---- weight DMA assignment: 16 fragments of 1 KiB per tile, kWFrags per wave ----
   const uint32_t nb0 = n_tile * (kBN / 32);
   const uint8_t* w_group = reinterpret_cast<const uint8_t*>(p.packed_w) +
       static_cast<uint64_t>(g) * nblocks * kblocks * 1024 + lane * 16;
 
-  // One K tile = exactly 4 LDS-DMA instructions per thread (the vmcnt arithmetic depends on it):
-  // pieces 0,1 = activation chunks, pieces 2,3 = weight fragments.
+  const uint8_t* w_src0[kWFrags];   // source of this wave's fragment i in K tile 0 ...
+  uint32_t w_kstep[kWFrags];        // ... and its advance per K tile (0 when the block is N padding)
+#pragma unroll
+  for (int i = 0; i < kWFrags; i++) {
+    const uint32_t F = i * (kWM * kWN) + wave;
+    const uint32_t nb = nb0 + (F >> 1);
+    const bool valid = nb < nblocks;
+    w_src0[i] = valid ? w_group + (static_cast<uint64_t>(nb) * kblocks + (F & 1u)) * 1024 : pad_w;
+    w_kstep[i] = valid ? 2048u : 0u;
+  }
+
+  // One K tile = exactly kDma LDS-DMA instructions per thread (the vmcnt arithmetic depends on it):
+  // pieces 0..kAChunks-1 = activation chunks, the rest = weight fragments.
   auto stage_piece = [&](uint32_t kt, int piece) {
     uint8_t* a_dst = lds + (kt % kStages) * kStage;
     uint8_t* w_dst = a_dst + kATile;
-    if (piece < 2) {
+    if (piece < kAChunks) {
       const int i = piece;
       const uint32_t kk = kt * kBK + a_chunk[i] * 16;
       const uint8_t* src;
@@ -176,17 +205,15 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
       }
       dma16(src, a_dst + (i * kThreads + wave * 64) * 16);
     } else {
-      const int i = piece - 2;
-      const uint32_t F = i * 8 + wave;             // fragment slot: (32-channel block, 32-deep K block)
-      const uint32_t nb = nb0 + (F >> 1);
-      const uint32_t kb = kt * 2 + (F & 1u);
-      const uint8_t* src = nb < nblocks ? w_group + (static_cast<uint64_t>(nb) * kblocks + kb) * 1024 : pad_w;
+      const int i = piece - kAChunks;
+      const uint32_t F = i * (kWM * kWN) + wave;   // fragment slot: (32-channel block, 32-deep K block)
+      const uint8_t* src = w_src0[i] + static_cast<uint64_t>(kt) * w_kstep[i];   // branch-free: step 0 on the zero chunk
       dma16(src, w_dst + F * 1024);
     }
   };
   auto stage = [&](uint32_t kt) {
 #pragma unroll
-    for (int piece = 0; piece < 4; piece++) stage_piece(kt, piece);
+    for (int piece = 0; piece < kDma; piece++) stage_piece(kt, piece);
   };
 
   v16i acc[kTM][kTN];
@@ -196,7 +223,7 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
     for (int tn = 0; tn < kTN; tn++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0;
-  int32_t rs[kTM];
+  uint32_t rs[kTM];
 #pragma unroll
   for (int tm = 0; tm < kTM; tm++) rs[tm] = 0;
 
@@ -216,14 +243,15 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
     v4i a[kTM];
     v4i w[kTN];
   };
-  auto read_frags = [&](const uint8_t* st, uint32_t ksub, Frags& f) {
-#pragma unroll
-    for (int tn = 0; tn < kTN; tn++) {
-      f.w[tn] = *reinterpret_cast<const v4i*>(st + w_fbase + (tn * 2 + ksub) * 1024);
-    }
+  // activation fragments first: they are recentred (VALU) before the weight fragments are needed
+  auto read_frags = [&](const uint8_t* st, uint32_t ksub, Frags& f) __attribute__((always_inline)) {
 #pragma unroll
     for (int tm = 0; tm < kTM; tm++) {
       f.a[tm] = *reinterpret_cast<const v4i*>(st + (a_fbase[tm] ^ (ksub << 5)));
+    }
+#pragma unroll
+    for (int tn = 0; tn < kTN; tn++) {
+      f.w[tn] = *reinterpret_cast<const v4i*>(st + w_fbase + (tn * 2 + ksub) * 1024);
     }
   };
   auto flip = [&](Frags& f) {
@@ -235,18 +263,22 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
       f.a[tm].w ^= static_cast<int>(kFlip);
     }
   };
+  // Row sums are taken over the RAW uint8 bytes (before recentring) with v_sad_u8 -- |a - 0| summed over the
+  // 4 bytes of a dword plus an accumulator, one plain VALU op; v_dot4c beside MFMAs costs ~7 cycles each on
+  // the matrix pipe (tools/ubench_gap.hip). sum(a') = sum(a) - 128 * k_pad is applied once in the epilogue
+  // (K padding is staged as a = 0x80, i.e. a' = 0, so it is covered by the same constant).
   auto rowsum = [&](const Frags& f) {
 #pragma unroll
     for (int tm = 0; tm < kTM; tm++) {
-      int32_t s = rs[tm];
-      s = __builtin_amdgcn_sdot4(f.a[tm].x, 0x01010101, s, false);
-      s = __builtin_amdgcn_sdot4(f.a[tm].y, 0x01010101, s, false);
-      s = __builtin_amdgcn_sdot4(f.a[tm].z, 0x01010101, s, false);
-      s = __builtin_amdgcn_sdot4(f.a[tm].w, 0x01010101, s, false);
+      uint32_t s = rs[tm];
+      s = __builtin_amdgcn_sad_u8(f.a[tm].x, 0u, s);
+      s = __builtin_amdgcn_sad_u8(f.a[tm].y, 0u, s);
+      s = __builtin_amdgcn_sad_u8(f.a[tm].z, 0u, s);
+      s = __builtin_amdgcn_sad_u8(f.a[tm].w, 0u, s);
       rs[tm] = s;
     }
   };
-  auto mma = [&](const Frags& f, int i) {       // i = 0..7 -> (tm, tn)
+  auto mma = [&](const Frags& f, int i) {       // i = 0..kMma-1 -> (tm, tn)
     const int tm = i / kTN, tn = i % kTN;
     acc[tm][tn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[tn], f.a[tm], acc[tm][tn], 0, 0, 0);
   };
@@ -270,25 +302,27 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
   auto settle_w = [&](Frags& f) {
     asm volatile("" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3]));
   };
-  auto rowsum_part = [&](const Frags& f, int h) {
+  auto rowsum_part = [&](const Frags& f, int h) {     // on the RAW bytes: call BEFORE flip_part(f, h)
     const int tm = h >> 1;
     if (h & 1) {
-      rs[tm] = __builtin_amdgcn_sdot4(f.a[tm].z, 0x01010101, rs[tm], false);
-      rs[tm] = __builtin_amdgcn_sdot4(f.a[tm].w, 0x01010101, rs[tm], false);
+      rs[tm] = __builtin_amdgcn_sad_u8(f.a[tm].z, 0u, rs[tm]);
+      rs[tm] = __builtin_amdgcn_sad_u8(f.a[tm].w, 0u, rs[tm]);
     } else {
-      rs[tm] = __builtin_amdgcn_sdot4(f.a[tm].x, 0x01010101, rs[tm], false);
-      rs[tm] = __builtin_amdgcn_sdot4(f.a[tm].y, 0x01010101, rs[tm], false);
+      rs[tm] = __builtin_amdgcn_sad_u8(f.a[tm].x, 0u, rs[tm]);
+      rs[tm] = __builtin_amdgcn_sad_u8(f.a[tm].y, 0u, rs[tm]);
     }
   };
 #define QNNP_PIN() __builtin_amdgcn_sched_barrier(0)
 
   // Counted wait: tile `kt` has landed when at most the LDS-DMA groups of the tiles issued after it
-  // (4 instructions each, completing in issue order) are still outstanding.
+  // (kDma instructions each, completing in issue order) are still outstanding.
   auto wait_tile = [&](uint32_t later_tiles_in_flight) {
     if (later_tiles_in_flight >= 2) {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if constexpr (kDma == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     } else if (later_tiles_in_flight == 1) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if constexpr (kDma == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -309,140 +343,213 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
   Frags fa, fb;
   read_frags(lds, s_first, fa);
   if (!(ABL & 2)) {
-    flip(fa);
     rowsum(fa);
+    flip(fa);
   }
   settle_w(fa);
+  QNNP_TRACE(p, blockIdx.x, 0, 1);
 
   /*
-   * Software pipeline, two phases per K tile, every phase = 8 MFMAs whose shadow hides the other work:
-   *   phase 1: multiply fa = (tile kt, first sub-step)  | read fb = (tile kt, second sub-step), recentre fb
-   *   -- counted vmcnt + raw barrier: tile kt+1 resident, ring slot of tile kt-1 free --
-   *   phase 2: multiply fb                               | read fa = (tile kt+1, first sub-step), recentre +
-   *                                                        row-sum fa, issue the LDS-DMA of tile kt+3
+   * Software pipeline: two phases per K tile (one per 32-deep K sub-step), every phase = kMma MFMAs on one
+   * fragment set while the other set is read from LDS and recentred:
+   *   phase 1: multiply fa = (tile kt, first sub-step)  | read + recentre fb = (tile kt, second sub-step)
+   *   -- counted vmcnt + raw barrier: tile kt+1 resident, ring slot of tile kt free for the DMA --
+   *   phase 2: multiply fb                               | read + recentre + row-sum fa = (tile kt+1, first sub-step)
    * A __syncthreads() would drain the DMA queue (vmcnt(0)); the raw barrier keeps two tiles in flight.
+   * Details that matter (each measured, tools/ubench_gap.hip and the ablation build):
+   *  - the LDS-DMA of a tile is spread over BOTH phases (half the pieces each, one piece every few
+   *    MFMAs) instead of one burst in which all waves of the CU queue on the texture-address path;
+   *  - the ring is used to its full depth: slot kt%4 is free from the mid-tile barrier of tile kt on, so
+   *    phase 2 of tile kt already fetches tile kt+4 (first half) and phase 1 of tile kt+1 the second half;
+   *  - activation fragments are read first and recentred in the shadow of the LAST MFMAs of a phase, so
+   *    the LDS wait sits a whole phase after the reads were issued.
+   * P1F: phase 1 issues the second half of tile kt+3; MORE: tile kt+1 exists; P2F: tile kt+4 exists.
    */
-  // MORE: a tile kt+1 exists; FETCH: a tile kt+3 exists (compile-time so that the steady-state loop body
-  // is one straight-line block: the wait-count pass is conservative at every control-flow join).
-  auto iteration = [&](auto more_c, auto fetch_c, uint32_t kt, uint32_t later_in_flight) {
+  constexpr int kHalf = kDma / 2;                 // LDS-DMA pieces per phase
+  constexpr int kDmaGap = kMma / kHalf;           // one piece every kDmaGap MFMAs
+  constexpr int kFlipMma = kParts / 2;            // the last kFlipMma MFMAs of a phase carry 2 recentring parts each
+  auto iteration = [&](auto p1f_c, auto more_c, auto p2f_c, uint32_t kt) __attribute__((always_inline)) {
+    constexpr bool P1F = decltype(p1f_c)::value;
     constexpr bool MORE = decltype(more_c)::value;
-    constexpr bool FETCH = decltype(fetch_c)::value;
+    constexpr bool P2F = decltype(p2f_c)::value;
     const uint8_t* st = lds + (kt % kStages) * kStage;
 
-    // ---- phase 1: the order below is pinned (sched_barrier) so the reads, the recentring and the
-    //      MFMAs interleave the way the pipeline needs instead of the way the scheduler clusters them
     QNNP_PIN();
     if (!(ABL & 16)) read_frags(st, s_second, fb);
     QNNP_PIN();
-    if (!(ABL & 4)) { mma(fa, 0); mma(fa, 1); mma(fa, 2); mma(fa, 3); }
-    QNNP_PIN();
 #pragma unroll
-    for (int h = 0; h < 4; h++) {
-      if (!(ABL & 2)) flip_part(fb, h);
+    for (int i = 0; i < kMma; i++) {
+      if (!(ABL & 4)) mma(fa, i);
       QNNP_PIN();
-      if (!(ABL & 4)) mma(fa, 4 + h);
-      QNNP_PIN();
+      if constexpr (P1F) {
+        if (i % kDmaGap == 0 && !(ABL & 8)) stage_piece(kt + 3, kHalf + i / kDmaGap);
+        QNNP_PIN();
+      }
+      if (i >= kMma - kFlipMma) {
+        const int h = (i - (kMma - kFlipMma)) * 2;
+        if (!(ABL & 2)) {
+          flip_part(fb, h);
+          flip_part(fb, h + 1);
+        }
+        QNNP_PIN();
+      }
     }
     if (!(ABL & 16)) settle_w(fb);
     QNNP_PIN();
+#ifdef QNNP_ENABLE_ABLATION
+    constexpr bool kStamp = P1F && MORE && P2F;
+    const bool stamp = kStamp && (kt == 20 || kt == 21);
+    if (stamp) QNNP_TRACE_WAVE(p, 1024 + blockIdx.x, wave, (kt - 20) * 4 + 0);
+    QNNP_PIN();
+#endif
 
-    if constexpr (MORE && !(ABL & 32)) {
-      if constexpr (FETCH) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile kt+1 resident; tile kt+2 still flies
+    if constexpr (MORE) {
+      // tile kt+1 must be resident; issued after it so far: tiles kt+2 .. min(kt+3, ktiles-1), complete
+      if constexpr (P1F || P2F) {
+        if constexpr (kDma == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#ifdef QNNP_ENABLE_ABLATION
+        QNNP_PIN();
+        if (stamp) QNNP_TRACE_WAVE(p, 1024 + blockIdx.x, wave, (kt - 20) * 4 + 1);
+        QNNP_PIN();
+#endif
       } else {
-        wait_tile(later_in_flight);
+        const uint32_t last = min(kt + 3, ktiles - 1);
+        wait_tile(last - (kt + 1));
       }
       __builtin_amdgcn_s_barrier();
     }
     QNNP_PIN();
+#ifdef QNNP_ENABLE_ABLATION
+    if (stamp) QNNP_TRACE_WAVE(p, 1024 + blockIdx.x, wave, (kt - 20) * 4 + 2);
+    QNNP_PIN();
+#endif
 
-    // ---- phase 2 ----
     if constexpr (MORE) {
       if (!(ABL & 16)) read_frags(lds + ((kt + 1) % kStages) * kStage, s_first, fa);
     }
     QNNP_PIN();
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < kMma; i++) {
       if (!(ABL & 4)) mma(fb, i);
       QNNP_PIN();
-      if constexpr (FETCH) {
-        if (!(ABL & 8)) stage_piece(kt + kStages - 1, i);
+      if constexpr (P2F) {
+        if (i % kDmaGap == 0 && !(ABL & 8)) stage_piece(kt + 4, i / kDmaGap);
+        QNNP_PIN();
       }
-      QNNP_PIN();
-    }
-#pragma unroll
-    for (int h = 0; h < 4; h++) {
-      if (!(ABL & 4)) mma(fb, 4 + h);
-      QNNP_PIN();
       if constexpr (MORE) {
-        if (!(ABL & 2)) {
-          flip_part(fa, h);
-          rowsum_part(fa, h);
+        if (i >= kMma - kFlipMma) {
+          const int h = (i - (kMma - kFlipMma)) * 2;
+          if (!(ABL & 2)) {
+            rowsum_part(fa, h);
+            flip_part(fa, h);
+            rowsum_part(fa, h + 1);
+            flip_part(fa, h + 1);
+          }
+          QNNP_PIN();
         }
       }
-      QNNP_PIN();
     }
-    if constexpr (MORE) {
-      if (!(ABL & 16)) settle_w(fa);
-    }
+    if constexpr (MORE) { if (!(ABL & 16)) settle_w(fa); }
     QNNP_PIN();
-    if (ABL & 4) {
-      asm volatile("" :: "v"(fa.a[0]), "v"(fa.a[1]), "v"(fa.w[0]), "v"(fa.w[1]), "v"(fa.w[2]), "v"(fa.w[3]));
-      asm volatile("" :: "v"(fb.a[0]), "v"(fb.a[1]), "v"(fb.w[0]), "v"(fb.w[1]), "v"(fb.w[2]), "v"(fb.w[3]));
-    }
+#ifdef QNNP_ENABLE_ABLATION
+    if (stamp) QNNP_TRACE_WAVE(p, 1024 + blockIdx.x, wave, (kt - 20) * 4 + 3);
+    QNNP_PIN();
+#endif
   };
 
+  // (the prologue above staged tiles 0..2; tile 3 completes the ring)
+  if (ktiles > 3) stage(3);
   uint32_t kt = 0;
-  for (; kt + kStages - 1 < ktiles; kt++) {                 // steady state
-    iteration(std::true_type{}, std::true_type{}, kt, 1u);
+  if (ktiles > 4) {
+    iteration(std::false_type{}, std::true_type{}, std::true_type{}, 0u);
+    for (kt = 1; kt + 4 < ktiles; kt++) {                 // steady state
+      iteration(std::true_type{}, std::true_type{}, std::true_type{}, kt);
+    }
+    iteration(std::true_type{}, std::true_type{}, std::false_type{}, kt);   // kt == ktiles - 4
+    kt++;
   }
-  for (; kt + 1 < ktiles; kt++) {                            // drain: no tile left to fetch
-    iteration(std::true_type{}, std::false_type{}, kt, min(1u, ktiles - 2 - kt));
+  for (; kt + 1 < ktiles; kt++) {                          // drain: nothing left to fetch
+    iteration(std::false_type{}, std::true_type{}, std::false_type{}, kt);
   }
-  if (kt < ktiles) {
-    iteration(std::false_type{}, std::false_type{}, kt, 0u);  // last tile
-  }
+  iteration(std::false_type{}, std::false_type{}, std::false_type{}, kt);   // last tile
 #undef QNNP_PIN
 
-  // ---- bias for this lane's 4-channel groups (issued before the barrier so the latency hides) ----
-  int4 bias4[kTN][4];
-#pragma unroll
-  for (int tn = 0; tn < kTN; tn++) {
+  QNNP_TRACE(p, blockIdx.x, 0, 2);
+  // ---- bias for this lane's 4-channel groups (issued before the barrier so the latency hides);
+  //      the 4-wave flavour has no registers to hold all of it and loads one 32-channel block at a time ----
+  constexpr int kBiasSets = kWM == 4 ? kTN : 1;
+  int4 bias4[kBiasSets][4];
+  auto load_bias = [&](int tn, int4 (&dst)[4]) __attribute__((always_inline)) {
     uint32_t nb = nb0 + wn * kTN + tn;
     if (nb >= nblocks) nb = nblocks - 1;       // clamped blocks are never stored
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) {
       const uint32_t ncol = nb * 32 + rg * 8 + frag_khalf * 4;
-      bias4[tn][rg] = *reinterpret_cast<const int4*>(p.bias2 + static_cast<uint64_t>(g) * p.n_pad + ncol);
+      dst[rg] = *reinterpret_cast<const int4*>(p.bias2 + static_cast<uint64_t>(g) * p.n_pad + ncol);
     }
+  };
+  if constexpr (kWM == 4) {
+#pragma unroll
+    for (int tn = 0; tn < kTN; tn++) load_bias(tn, bias4[tn]);
+  } else {
+    load_bias(0, bias4[0]);
   }
 
   // ---- combine the row sums: 2 K halves (lane, lane+32) then the 2 channel-waves ----
 #pragma unroll
   for (int tm = 0; tm < kTM; tm++) {
-    int32_t s = rs[tm];
+    uint32_t s = rs[tm];
     s += __shfl_xor(s, 32);
-    if (lane < 32) lds_rowsum[wn * kBM + wm * (kTM * 32) + tm * 32 + lane] = s;
+    if (lane < 32) lds_rowsum[wn * kBM + wm * (kTM * 32) + tm * 32 + lane] = static_cast<int32_t>(s);
   }
   __syncthreads();
+  QNNP_TRACE(p, blockIdx.x, 0, 3);
 
   // ---- fused epilogue (igemm_epilogue.cuh); the requantization flavour is chosen once ----
+  const uint32_t raw_to_centred = 128u * p.k_pad;      // sum(a') = sum(a) - 128 * k_pad
   requant_dispatch(p.rq, [&](auto shift0, auto full) {
+    if constexpr (kWM == 4) {
 #pragma unroll
-    for (int tm = 0; tm < kTM; tm++) {
-      const uint32_t row = frag_row0 + tm * 32;
-      const uint32_t m = m_tile * kBM + row;
-      const int32_t rowterm = p.row_coeff * (lds_rowsum[row] + lds_rowsum[kBM + row]);
-      uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride + static_cast<uint64_t>(g) * p.n;
+      for (int tm = 0; tm < kTM; tm++) {
+        const uint32_t row = frag_row0 + tm * 32;
+        const uint32_t m = m_tile * kBM + row;
+        const int32_t rowterm = p.row_coeff *
+            static_cast<int32_t>(static_cast<uint32_t>(lds_rowsum[row]) + static_cast<uint32_t>(lds_rowsum[kBM + row]) - raw_to_centred);
+        uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride + static_cast<uint64_t>(g) * p.n;
+#pragma unroll
+        for (int tn = 0; tn < kTN; tn++) {
+          const uint32_t nb = nb0 + wn * kTN + tn;
+          if (nb >= nblocks) continue;       // wave-uniform
+          igemm_store_tile<decltype(shift0)::value, decltype(full)::value, (ABL & 1) != 0>(
+              acc[tm][tn], bias4[tn], rowterm, out_row, nb * 32, frag_khalf, m < p.rows, p);
+        }
+      }
+    } else {
+      int32_t rowterm[kTM];
+#pragma unroll
+      for (int tm = 0; tm < kTM; tm++) {
+        const uint32_t row = frag_row0 + tm * 32;
+        rowterm[tm] = p.row_coeff *
+            static_cast<int32_t>(static_cast<uint32_t>(lds_rowsum[row]) + static_cast<uint32_t>(lds_rowsum[kBM + row]) - raw_to_centred);
+      }
 #pragma unroll
       for (int tn = 0; tn < kTN; tn++) {
         const uint32_t nb = nb0 + wn * kTN + tn;
-        if (nb >= nblocks) continue;       // wave-uniform
-        igemm_store_tile<decltype(shift0)::value, decltype(full)::value, (ABL & 1) != 0>(
-            acc[tm][tn], bias4[tn], rowterm, out_row, nb * 32, frag_khalf, m < p.rows, p);
+        if (tn > 0) load_bias(tn, bias4[0]);
+        if (nb >= nblocks) continue;         // wave-uniform
+#pragma unroll
+        for (int tm = 0; tm < kTM; tm++) {
+          const uint32_t m = m_tile * kBM + frag_row0 + tm * 32;
+          uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride + static_cast<uint64_t>(g) * p.n;
+          igemm_store_tile<decltype(shift0)::value, decltype(full)::value, (ABL & 1) != 0>(
+              acc[tm][tn], bias4[0], rowterm[tm], out_row, nb * 32, frag_khalf, m < p.rows, p);
+        }
       }
     }
   });
+  QNNP_TRACE(p, blockIdx.x, 0, 4);
+  QNNP_TRACE_WALL(p, blockIdx.x, 3, 1);
 }
 
 }  // namespace
@@ -452,37 +559,44 @@ bool gemm256_supported(const IgemmParams& p, uint32_t vec)
   return vec == 16 && p.fill_table != nullptr && p.rows >= 1 && p.k_total % 16 == 0;
 }
 
-int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name)
+template <bool IS_CONV, int WM>
+static int launch256(const IgemmParams& p, const dim3& grid, hipStream_t stream)
+{
+  hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<IS_CONV, WM>), grid, dim3(WM * kWN * 64), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+/* waves4 = false: 8 waves (two per SIMD), 64 x 128 outputs per wave -- the default;
+ * waves4 = true:  4 waves (one per SIMD, the whole register file), 128 x 128 per wave: a third less LDS read
+ *                 traffic and a higher sustained clock, but every issue stall is exposed (A/B flavour). */
+int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, bool waves4)
 {
   const uint32_t tiles_m = (p.rows + kBM - 1) / kBM;
   const uint32_t tiles_n = (p.n_pad + kBN - 1) / kBN;
   const dim3 grid(tiles_m * tiles_n, groups, 1);
-  const dim3 block(kThreads, 1, 1);
+  const bool conv = p.offsets != nullptr;
 #ifdef QNNP_ENABLE_ABLATION
-  if (p.offsets == nullptr) {
+  if (!conv) {
     const char* env = getenv("QNNP_GFX950_ABLATE");
     const int abl = env != nullptr ? atoi(env) : 0;
-    *name = "q8_gemm_mfma_256x256";
+    *name = waves4 ? "q8_gemm_mfma_256x256_w4" : "q8_gemm_mfma_256x256";
+#define QNNP_ABL_CASE(V) case V: if (waves4) hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 2, V>), grid, dim3(256), 0, stream, p); \
+        else hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 4, V>), grid, dim3(512), 0, stream, p); \
+        return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
     switch (abl) {
       case 0: break;
-#define QNNP_ABL_CASE(V) case V: hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, V>), grid, block, 0, stream, p); \
-        return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
-      QNNP_ABL_CASE(1) QNNP_ABL_CASE(2) QNNP_ABL_CASE(3) QNNP_ABL_CASE(4) QNNP_ABL_CASE(8) QNNP_ABL_CASE(11)
-      QNNP_ABL_CASE(12) QNNP_ABL_CASE(15) QNNP_ABL_CASE(27) QNNP_ABL_CASE(31) QNNP_ABL_CASE(7)
-      QNNP_ABL_CASE(59) QNNP_ABL_CASE(63) QNNP_ABL_CASE(43) QNNP_ABL_CASE(35)
-#undef QNNP_ABL_CASE
+      QNNP_ABL_CASE(1) QNNP_ABL_CASE(2) QNNP_ABL_CASE(4) QNNP_ABL_CASE(8) QNNP_ABL_CASE(16) QNNP_ABL_CASE(24) QNNP_ABL_CASE(26)
       default: break;
     }
+#undef QNNP_ABL_CASE
   }
 #endif
-  if (p.offsets != nullptr) {
-    *name = "q8_gemm_mfma_256x256_conv";
-    hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<true>), grid, block, 0, stream, p);
-  } else {
-    *name = "q8_gemm_mfma_256x256";
-    hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false>), grid, block, 0, stream, p);
+  if (conv) {
+    *name = waves4 ? "q8_gemm_mfma_256x256_w4_conv" : "q8_gemm_mfma_256x256_conv";
+    return waves4 ? launch256<true, 2>(p, grid, stream) : launch256<true, 4>(p, grid, stream);
   }
-  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+  *name = waves4 ? "q8_gemm_mfma_256x256_w4" : "q8_gemm_mfma_256x256";
+  return waves4 ? launch256<false, 2>(p, grid, stream) : launch256<false, 4>(p, grid, stream);
 }
 
 }  // namespace qnnp

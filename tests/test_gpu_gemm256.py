@@ -12,9 +12,14 @@ from _runner import assert_bytes_equal, conv_expected, conv_run, fc_expected, fc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def big(qnnp):
-    qnnp.set_option("gemm_kernel", 2)
+# gemm_kernel option -> kernel-name suffix (8-wave default / 4-wave A/B flavour)
+_SUFFIX = {2: "", 4: "_w4"}
+
+
+@pytest.fixture(params=[2, 4], ids=["w8", "w4"])
+def big(qnnp, request):
+    qnnp.set_option("gemm_kernel", request.param)
+    qnnp._flavour = _SUFFIX[request.param]
     yield qnnp
     qnnp.set_option("gemm_kernel", 0)
 
@@ -22,7 +27,7 @@ def big(qnnp):
 def _fc(big, case):
     expected, quant = fc_expected(case)
     out, kname = fc_run(big, case, quant, to_device=to_device, from_device=from_device)
-    assert kname == "q8_gemm_mfma_256x256", kname
+    assert kname == "q8_gemm_mfma_256x256" + big._flavour, kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 
 
@@ -70,7 +75,7 @@ def test_unaligned_output_uses_byte_stores(big):
 def test_convolution_forms(big, case):
     expected, quant, out_hw = conv_expected(case)
     out, kname = conv_run(big, case, quant, out_hw, to_device=to_device, from_device=from_device)
-    want = "q8_gemm_mfma_256x256_conv" if case.kernel_size != (1, 1) else "q8_gemm_mfma_256x256"
+    want = "q8_gemm_mfma_256x256" + big._flavour + ("_conv" if case.kernel_size != (1, 1) else "")
     assert kname == want, kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 
