@@ -76,6 +76,10 @@ struct ConvGeom {
 bool convlds_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32_t vec);
 int convlds_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipStream_t stream, const char** name);
 
+/* q8pwconv.hip */
+bool pwstream_supported(const IgemmParams& p, uint32_t groups, uint32_t vec);
+int pwstream_launch(const IgemmParams& p, uint32_t vec, hipStream_t stream, const char** name);
+
 /* q8gemm256.hip */
 bool gemm256_supported(const IgemmParams& p, uint32_t vec);
 int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, bool waves4);

@@ -536,6 +536,14 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
     if (kernel_name != nullptr) *kernel_name = name;
     return rc_lds;
   }
+  // Short-K pointwise / fully-connected layers over many rows: barrier-free streaming kernel.
+  const bool pw_ok = !pad3 && qnnp::pwstream_supported(p, a->groups, vec);
+  if (a->variant == 5 && !pw_ok) return QNNP_HIP_EINVAL;
+  if (pw_ok && (a->variant == 5 || (a->variant == 0 && a->rows >= 2048))) {
+    const int rc_pw = qnnp::pwstream_launch(p, vec, stream, &name);
+    if (kernel_name != nullptr) *kernel_name = name;
+    return rc_pw;
+  }
   // Large MFMA-bound problems take the 256x256 LDS-DMA kernel; everything else the generic one.
   const bool big_ok = !pad3 && qnnp::gemm256_supported(p, vec);
   const bool big_auto = a->n >= 256 && a->k_total >= 512 && a->rows >= 2048;

@@ -1,0 +1,229 @@
+/*
+ * q8pwconv.hip -- streaming MFMA kernel for pointwise (1x1, stride 1) convolutions and
+ * fully-connected layers with a SHORT reduction (K <= 256) over MANY rows: the
+ * MobileNet-style expand / project layers. Same arithmetic as q8igemm.hip (which see);
+ * replaces the same reference path: qnnp_ukernel_type_gemm -> q8gemm 4x4c2 / 8x8
+ * (src/operator-run.c:770-804, src/q8gemm/4x4c2-sse2.c:14-318).
+ *
+ * Why a separate kernel: these layers move 10-100x more bytes than they multiply
+ * (K = 16..192 against N = 16..576), so they are bound by HBM and by the VALU work
+ * of the requantization, not by the matrix cores. The tiled kernels stage
+ * activations through LDS behind workgroup barriers, which serialises
+ * load -> barrier -> multiply -> barrier -> requantize -> store per tile. Here
+ *   - the whole weight matrix (<= 64 KiB of MFMA fragments) and the folded bias are
+ *     copied into LDS ONCE per (persistent) workgroup;
+ *   - each WAVE then walks 32-row blocks on its own, no barrier in the loop: a
+ *     lane loads its 16 bytes of the activation row straight from global memory in
+ *     MFMA B-operand layout (lane l = row l%32, K half l/32), the loads of the next
+ *     block being in flight while the current one is multiplied and requantized;
+ *   - per 32-channel block: K/32 MFMAs against fragments read from LDS, the fused
+ *     Q31 epilogue of igemm_epilogue.cuh, one 16-byte store per lane.
+ * Rows are independent, so there is no exchange between waves at all.
+ *
+ * Zero-point algebra as in pack.h; row sums over the RAW bytes with v_sad_u8 (K
+ * padding is loaded as 0x80 = a' of 0 from the fill table, so
+ * sum(a') = sum(a) - 128 * 32 * KB).
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "igemm_epilogue.cuh"
+#include "igemm_params.h"
+#include "requant.cuh"
+
+namespace qnnp {
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int kWaves = 4;
+constexpr int kThreads = kWaves * 64;
+constexpr uint32_t kFlip = 0x80808080u;
+constexpr uint32_t kMaxLds = 64 * 1024;     // weights + bias: two workgroups per CU
+
+/* KB = 32-deep K blocks (k_total <= 32 * KB); VEC = bytes per activation load (16, or 8 when rows are
+ * only 8-byte aligned, e.g. 24 channels) */
+template <int KB, int VEC>
+__global__ __launch_bounds__(kThreads, (KB <= 5) ? 4 : 2)
+void q8_pw_stream_mfma_kernel(const IgemmParams p)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
+  const uint32_t row_in_block = lane & 31u;
+  const uint32_t khalf = lane >> 5;
+
+  const uint32_t nblocks = p.n_pad / 32;
+  const uint32_t kblocks = p.k_pad / 32;          // fragment blocks per channel block in the packed image
+
+  // ---- once per workgroup: weight fragments (only the KB non-empty K blocks) and bias2 into LDS ----
+  // LDS image: [nb][kb < KB] fragments of 1 KiB, then n_pad int32 of bias2
+  {
+    const uint32_t frags = nblocks * KB;
+    for (uint32_t f = wave; f < frags; f += kWaves) {
+      const uint32_t nb = f / KB;
+      const uint32_t kb = f - nb * KB;
+      const v4i v = *reinterpret_cast<const v4i*>(
+          p.packed_w + (static_cast<uint64_t>(nb) * kblocks + kb) * 1024 + lane * 16);
+      *reinterpret_cast<v4i*>(lds + f * 1024 + lane * 16) = v;
+    }
+    int32_t* lds_bias = reinterpret_cast<int32_t*>(lds + frags * 1024);
+    for (uint32_t i = tid; i < p.n_pad; i += kThreads) lds_bias[i] = p.bias2[i];
+  }
+  __syncthreads();
+  const uint8_t* lds_w = lds + lane * 16;
+  const int4* lds_bias4 = reinterpret_cast<const int4*>(lds + nblocks * KB * 1024);
+
+  // ---- which of this lane's 16-byte K pieces exist (only the last block can be short) ----
+  const uint8_t* pad16 = p.fill_table + 0x80 * 16;        // 16 bytes of a' == 0
+  const uint32_t k_last = (KB - 1) * 32 + khalf * 16;     // first K position of the lane's last piece
+  // VEC 16: the piece is whole or absent. VEC 8: each 8-byte half is whole or absent.
+  const bool last_lo_ok = k_last < p.k_total;
+  const bool last_hi_ok = k_last + 8 < p.k_total;
+
+  const uint32_t units = (p.rows + 31u) / 32u;
+  const uint32_t unit_stride = gridDim.x * kWaves;
+
+  auto load_rows = [&](uint32_t unit, v4i (&a)[KB]) __attribute__((always_inline)) {
+    uint32_t m = unit * 32u + row_in_block;
+    if (m >= p.rows) m = p.rows - 1;                      // clamped rows are never stored
+    const uint8_t* row = p.input + static_cast<uint64_t>(m) * p.input_stride + khalf * 16;
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+      const uint8_t* src = row + kb * 32;
+      if constexpr (VEC == 16) {
+        if (kb == KB - 1) src = last_lo_ok ? src : pad16;
+        a[kb] = *reinterpret_cast<const v4i*>(src);
+      } else {
+        const uint8_t* lo = src;
+        const uint8_t* hi = src + 8;
+        if (kb == KB - 1) {
+          lo = last_lo_ok ? lo : pad16;
+          hi = last_hi_ok ? hi : pad16;
+        }
+        const int2 vlo = *reinterpret_cast<const int2*>(lo);
+        const int2 vhi = *reinterpret_cast<const int2*>(hi);
+        a[kb] = v4i{vlo.x, vlo.y, vhi.x, vhi.y};
+      }
+    }
+  };
+
+  const uint32_t raw_to_centred = 128u * 32u * KB;
+
+  uint32_t unit = blockIdx.x * kWaves + wave;
+  v4i a_next[KB];
+  if (unit < units) load_rows(unit, a_next);
+
+  requant_dispatch(p.rq, [&](auto shift0, auto full) {
+    for (; unit < units; unit += unit_stride) {
+      v4i a[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; kb++) a[kb] = a_next[kb];
+      if (unit + unit_stride < units) load_rows(unit + unit_stride, a_next);
+
+      // row sum over the raw bytes, then recentre at 128
+      uint32_t rs = 0;
+#pragma unroll
+      for (int kb = 0; kb < KB; kb++) {
+        rs = __builtin_amdgcn_sad_u8(a[kb].x, 0u, rs);
+        rs = __builtin_amdgcn_sad_u8(a[kb].y, 0u, rs);
+        rs = __builtin_amdgcn_sad_u8(a[kb].z, 0u, rs);
+        rs = __builtin_amdgcn_sad_u8(a[kb].w, 0u, rs);
+        a[kb].x ^= static_cast<int>(kFlip);
+        a[kb].y ^= static_cast<int>(kFlip);
+        a[kb].z ^= static_cast<int>(kFlip);
+        a[kb].w ^= static_cast<int>(kFlip);
+      }
+      rs += __shfl_xor(rs, 32);                           // the other K half of the same row
+      const int32_t rowterm = p.row_coeff * static_cast<int32_t>(rs - raw_to_centred);
+
+      const uint32_t m = unit * 32u + row_in_block;
+      uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride;
+      const bool row_ok = m < p.rows;
+
+      for (uint32_t nb = 0; nb < nblocks; nb++) {
+        v16i acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0;
+        const uint8_t* wf = lds_w + nb * (KB * 1024);
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) {
+          const v4i w = *reinterpret_cast<const v4i*>(wf + kb * 1024);
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a[kb], acc, 0, 0, 0);
+        }
+        int4 bias4[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[nb * 8 + rg * 2 + khalf];
+        igemm_store_tile<decltype(shift0)::value, decltype(full)::value>(
+            acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p);
+      }
+    }
+  });
+}
+
+template <int KB, int VEC>
+int launch_pw(const IgemmParams& p, uint32_t lds_bytes, hipStream_t stream)
+{
+  static int blocks_per_cu = 0;       // per instantiation; benign race (same value)
+  auto kernel = q8_pw_stream_mfma_kernel<KB, VEC>;
+  if (blocks_per_cu == 0) {
+    (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    blocks_per_cu = (KB <= 5) ? 4 : 2;
+  }
+  // LDS bounds the residency: kMaxLds -> 2 per CU, half of that -> 4
+  uint32_t per_cu = static_cast<uint32_t>(blocks_per_cu);
+  const uint32_t by_lds = lds_bytes > 0 ? (160u * 1024u) / lds_bytes : per_cu;
+  if (by_lds < per_cu) per_cu = by_lds > 0 ? by_lds : 1u;
+  const uint32_t units = (p.rows + 31u) / 32u;
+  uint32_t grid = p.cu_count * per_cu;
+  const uint32_t needed = (units + kWaves - 1) / kWaves;
+  if (grid > needed) grid = needed;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds_bytes, stream, p);
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+template <int VEC>
+int dispatch_kb(const IgemmParams& p, uint32_t kb, uint32_t lds_bytes, hipStream_t stream)
+{
+  switch (kb) {
+    case 1: return launch_pw<1, VEC>(p, lds_bytes, stream);
+    case 2: return launch_pw<2, VEC>(p, lds_bytes, stream);
+    case 3: return launch_pw<3, VEC>(p, lds_bytes, stream);
+    case 4: return launch_pw<4, VEC>(p, lds_bytes, stream);
+    case 5: return launch_pw<5, VEC>(p, lds_bytes, stream);
+    case 6: return launch_pw<6, VEC>(p, lds_bytes, stream);
+    case 7: return launch_pw<7, VEC>(p, lds_bytes, stream);
+    default: return launch_pw<8, VEC>(p, lds_bytes, stream);
+  }
+}
+
+uint32_t pw_lds_bytes(const IgemmParams& p)
+{
+  const uint32_t kb = (p.k_total + 31u) / 32u;
+  return (p.n_pad / 32u) * kb * 1024u + p.n_pad * 4u;
+}
+
+}  // namespace
+
+/* pointwise / fully-connected form only (no offset table), one group, K <= 256, weights + bias <= 64 KiB */
+bool pwstream_supported(const IgemmParams& p, uint32_t groups, uint32_t vec)
+{
+  if (p.offsets != nullptr || groups != 1 || (vec != 16 && vec != 8)) return false;
+  if (p.fill_table == nullptr || p.rows == 0 || p.k_total == 0 || p.k_total > 256u) return false;
+  if (p.k_total % vec != 0) return false;
+  return pw_lds_bytes(p) <= kMaxLds;
+}
+
+int pwstream_launch(const IgemmParams& p, uint32_t vec, hipStream_t stream, const char** name)
+{
+  const uint32_t kb = (p.k_total + 31u) / 32u;
+  const uint32_t lds_bytes = pw_lds_bytes(p);
+  *name = "q8_pw_stream_mfma";
+  return vec == 16 ? dispatch_kb<16>(p, kb, lds_bytes, stream) : dispatch_kb<8>(p, kb, lds_bytes, stream);
+}
+
+}  // namespace qnnp

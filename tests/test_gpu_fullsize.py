@@ -142,6 +142,9 @@ def test_c5_mobilenetv2_pointwise_layers(qnnp, h, cin, cout):
         d_in, d_out = to_device(inp), to_device(np.full(expected.size, FILL, np.uint8))
         qnnp.setup_convolution2d_nhwc_q8(op, batch, h, h, d_in, cin, d_out, cout)
         qnnp.run_operator(op)
+        if cin <= 256 and h >= 14 and cin * cout <= 60000:
+            # short-K layers over many rows: the barrier-free streaming kernel must be the one that ran
+            assert qnnp.operator_kernel(op) == "q8_pw_stream_mfma", qnnp.operator_kernel(op)
         assert_bytes_equal(from_device(d_out), expected,
                            f"C5 pointwise {h}x{h} {cin}->{cout} vs oracle kernel={qnnp.operator_kernel(op)}")
     finally:

@@ -1,0 +1,100 @@
+"""GPU tier: the barrier-free streaming kernel for short-K pointwise / fully-connected layers
+(qnnpack_amd/csrc/hip/q8pwconv.hip), forced with "gemm_kernel" = 5, against the scalar oracle: row-block
+edges, every K-block count and both load widths (16- and 8-byte aligned rows), channel-count edges and the
+three store modes, strides, zero-point / clamp variants, and the 1x1 convolution form. MobileNetV2's
+pointwise layers (BASELINE configs[3]) take this kernel automatically; test_gpu_fullsize.py asserts that."""
+import numpy as np
+import pytest
+
+from _cases import ConvCase, FcCase
+from _gpu import from_device, to_device
+from _runner import assert_bytes_equal, conv_expected, conv_run, fc_expected, fc_run
+
+pytestmark = pytest.mark.gpu
+
+KERNEL = "q8_pw_stream_mfma"
+
+
+@pytest.fixture()
+def pw(qnnp):
+    qnnp.set_option("gemm_kernel", 5)
+    yield qnnp
+    qnnp.set_option("gemm_kernel", 0)
+
+
+def _fc(pw, case):
+    expected, quant = fc_expected(case)
+    out, kname = fc_run(pw, case, quant, to_device=to_device, from_device=from_device)
+    assert kname == KERNEL, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("m", [1, 2, 31, 32, 33, 63, 64, 65, 100, 1000, 4097])
+def test_row_edges(pw, m):
+    _fc(pw, FcCase(f"pw_m{m}", m, 32, 48))
+
+
+@pytest.mark.parametrize("k", [16, 32, 48, 64, 80, 96, 112, 128, 144, 160, 176, 192, 208, 224, 240, 256])
+def test_k_blocks_16_byte_rows(pw, k):
+    _fc(pw, FcCase(f"pw_k{k}", 131, k, 40))
+
+
+@pytest.mark.parametrize("k", [8, 24, 40, 56, 72, 104, 136, 200, 248])
+def test_k_blocks_8_byte_rows(pw, k):
+    _fc(pw, FcCase(f"pw_k{k}", 77, k, 36))
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 15, 16, 17, 31, 32, 33, 48, 96, 100, 144, 255, 256, 576])
+def test_channel_edges_and_store_modes(pw, n):
+    _fc(pw, FcCase(f"pw_n{n}", 70, 32, n))
+
+
+@pytest.mark.parametrize("kw", [dict(izp=0, kzp=0), dict(izp=255, kzp=255), dict(izp=128, kzp=128),
+                                dict(izp=3, kzp=250), dict(qmin=128), dict(qmax=128)],
+                         ids=lambda d: "_".join(f"{k}{v}" for k, v in d.items()))
+def test_quantization_variants(pw, kw):
+    _fc(pw, FcCase("pw_q_" + "_".join(f"{k}{v}" for k, v in kw.items()), 90, 48, 52, **kw))
+
+
+def test_strided_rows(pw):
+    _fc(pw, FcCase("pw_strided", 130, 48, 80, input_stride=64, output_stride=96))
+
+
+def test_strided_rows_8_byte(pw):
+    _fc(pw, FcCase("pw_strided8", 130, 24, 20, input_stride=40, output_stride=28))
+
+
+def test_unaligned_output_uses_byte_stores(pw):
+    _fc(pw, FcCase("pw_out_unaligned", 67, 32, 18, output_stride=19))
+
+
+@pytest.mark.parametrize("case", [
+    ConvCase("pw_1x1_16_96", (28, 30), gic=16, goc=96, batch=3),
+    ConvCase("pw_1x1_24_144", (14, 14), gic=24, goc=144, batch=2),
+    ConvCase("pw_1x1_144_24", (13, 11), gic=144, goc=24, batch=2),
+    ConvCase("pw_1x1_strided_pixels", (9, 9), gic=32, goc=36, input_pixel_stride=48, output_pixel_stride=40),
+], ids=lambda c: c.name)
+def test_pointwise_convolution(pw, case):
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(pw, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == KERNEL, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("case", [FcCase("pw_bad_k", 64, 260, 16),       # K > 256
+                                  FcCase("pw_bad_align", 64, 20, 16),    # rows only 4-byte aligned
+                                  FcCase("pw_bad_lds", 64, 256, 512)],   # weights exceed the LDS budget
+                         ids=lambda c: c.name)
+def test_unsupported_shapes_are_reported_not_silently_rerouted(pw, case):
+    from qnnpack_amd import QnnpackError
+    _, quant = fc_expected(case)
+    with pytest.raises(QnnpackError):
+        fc_run(pw, case, quant, to_device=to_device, from_device=from_device)
+
+
+def test_auto_selection_takes_it_for_many_rows(qnnp):
+    case = FcCase("pw_auto", 4096, 32, 64)
+    expected, quant = fc_expected(case)
+    out, kname = fc_run(qnnp, case, quant, to_device=to_device, from_device=from_device)
+    assert kname == KERNEL, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
