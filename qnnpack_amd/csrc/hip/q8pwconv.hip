@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "igemm_epilogue.cuh"
 #include "igemm_params.h"
@@ -63,16 +64,24 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
   // ---- once per workgroup: weight fragments (only the KB non-empty K blocks) and bias2 into LDS ----
   // LDS image: [nb][kb < KB] fragments of 1 KiB, then n_pad int32 of bias2
   {
+    // LDS-DMA (no VGPR round trip, all of a wave's fragments in flight at once)
     const uint32_t frags = nblocks * KB;
     for (uint32_t f = wave; f < frags; f += kWaves) {
       const uint32_t nb = f / KB;
       const uint32_t kb = f - nb * KB;
-      const v4i v = *reinterpret_cast<const v4i*>(
-          p.packed_w + (static_cast<uint64_t>(nb) * kblocks + kb) * 1024 + lane * 16);
-      *reinterpret_cast<v4i*>(lds + f * 1024 + lane * 16) = v;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*) (p.packed_w + (static_cast<uint64_t>(nb) * kblocks + kb) * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*) (lds + f * 1024), 16, 0, 0);
     }
-    int32_t* lds_bias = reinterpret_cast<int32_t*>(lds + frags * 1024);
-    for (uint32_t i = tid; i < p.n_pad; i += kThreads) lds_bias[i] = p.bias2[i];
+    uint8_t* lds_bias = lds + frags * 1024;
+    const uint32_t bias_chunks = p.n_pad / 4;             // 16-byte pieces; n_pad is a multiple of 32
+    for (uint32_t c0 = wave * 64; c0 < bias_chunks; c0 += kThreads) {
+      const uint32_t c = min(c0 + lane, bias_chunks - 1); // the tail lanes repeat the last piece (same bytes)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(p.bias2) + c * 16),
+          (__attribute__((address_space(3))) void*) (lds_bias + c0 * 16), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
   const uint8_t* lds_w = lds + lane * 16;
@@ -143,23 +152,49 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
 
       const uint32_t m = unit * 32u + row_in_block;
       uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride;
-      const bool row_ok = m < p.rows;
+      bool row_ok = m < p.rows;
+#ifdef QNNP_ENABLE_ABLATION
+      if (p.izp_fill & 1u) row_ok = false;                // measurement: no stores
+#endif
 
-      for (uint32_t nb = 0; nb < nblocks; nb++) {
-        v16i acc;
+      // accumulators start at bias + row term (the MFMA adds into them): two VALU adds per value saved
+      int4 bias4[4];
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0;
+      for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[rg * 2 + khalf];
+      auto multiply = [&](uint32_t nb, v16i& acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          acc[rg * 4 + 0] = bias4[rg].x + rowterm;
+          acc[rg * 4 + 1] = bias4[rg].y + rowterm;
+          acc[rg * 4 + 2] = bias4[rg].z + rowterm;
+          acc[rg * 4 + 3] = bias4[rg].w + rowterm;
+        }
+        if (nb + 1 < nblocks) {
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[(nb + 1) * 8 + rg * 2 + khalf];
+        }
         const uint8_t* wf = lds_w + nb * (KB * 1024);
 #pragma unroll
         for (int kb = 0; kb < KB; kb++) {
           const v4i w = *reinterpret_cast<const v4i*>(wf + kb * 1024);
           acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a[kb], acc, 0, 0, 0);
         }
-        int4 bias4[4];
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[nb * 8 + rg * 2 + khalf];
-        igemm_store_tile<decltype(shift0)::value, decltype(full)::value>(
-            acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p);
+      };
+
+      // direct 16-byte stores (32 rows x 32 bytes per instruction). Staging four blocks through LDS to store
+      // whole 128-byte lines was measured: 5 % faster on the widest-output layer, 15-30 % slower on the rest.
+      for (uint32_t nb = 0; nb < nblocks; nb++) {
+        v16i acc;
+#ifdef QNNP_ENABLE_ABLATION
+        if (p.izp_fill & 2u) {                            // measurement: stores only (no multiply, no requantization)
+          const uint32_t c = nb * 32 + khalf * 16;
+          if (row_ok && c < p.n) *reinterpret_cast<uint4*>(out_row + c) = make_uint4(a[0].x, a[0].y, a[0].z, a[0].w);
+          continue;
+        }
+#endif
+        multiply(nb, acc);
+        igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, true>(
+            acc, bias4, 0, out_row, nb * 32, khalf, row_ok, p);
       }
     }
   });
@@ -179,10 +214,20 @@ int launch_pw(const IgemmParams& p, uint32_t lds_bytes, hipStream_t stream)
   const uint32_t by_lds = lds_bytes > 0 ? (160u * 1024u) / lds_bytes : per_cu;
   if (by_lds < per_cu) per_cu = by_lds > 0 ? by_lds : 1u;
   const uint32_t units = (p.rows + 31u) / 32u;
+#ifdef QNNP_ENABLE_ABLATION
+  if (const char* env = getenv("QNNP_PW_BLOCKS")) per_cu = static_cast<uint32_t>(atoi(env));
+#endif
   uint32_t grid = p.cu_count * per_cu;
   const uint32_t needed = (units + kWaves - 1) / kWaves;
   if (grid > needed) grid = needed;
+#ifdef QNNP_ENABLE_ABLATION
+  IgemmParams pa = p;
+  pa.izp_fill = 0;
+  if (const char* env = getenv("QNNP_PW_ABL")) pa.izp_fill = static_cast<uint32_t>(atoi(env));
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds_bytes, stream, pa);
+#else
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds_bytes, stream, p);
+#endif
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
@@ -204,7 +249,8 @@ int dispatch_kb(const IgemmParams& p, uint32_t kb, uint32_t lds_bytes, hipStream
 uint32_t pw_lds_bytes(const IgemmParams& p)
 {
   const uint32_t kb = (p.k_total + 31u) / 32u;
-  return (p.n_pad / 32u) * kb * 1024u + p.n_pad * 4u;
+  // the bias region is rounded up to whole 1 KiB LDS-DMA rows (a wave-instruction always writes 64 x 16 B)
+  return (p.n_pad / 32u) * kb * 1024u + ((p.n_pad * 4u + 1023u) & ~1023u);
 }
 
 }  // namespace
