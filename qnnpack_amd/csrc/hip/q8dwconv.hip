@@ -66,8 +66,19 @@ struct DwParams {
   uint32_t PP;        // LDS dwords per (row, 4-channel group) line: IC padded for bank spread
   uint32_t bands;     // ceil(OH / TOH)
   uint32_t slabs;     // C / CS
+  unsigned long long* trace;   // measurement builds only (QNNP_ENABLE_ABLATION + env QNNP_GFX950_TRACE)
   qnnp::RequantDev rq;
 };
+
+#ifdef QNNP_ENABLE_ABLATION
+#define QNNP_DW_TRACE(p, slot)                                                                      \
+  do {                                                                                              \
+    if ((p).trace != nullptr && threadIdx.x == 0 && blockIdx.x < 4096)                              \
+      (p).trace[(blockIdx.x * 4) * 8 + (slot)] = __builtin_readcyclecounter();                     \
+  } while (0)
+#else
+#define QNNP_DW_TRACE(p, slot) do { } while (0)
+#endif
 
 // --------------------------------------------------------------------------
 // Kernel B: generic direct
@@ -120,9 +131,19 @@ void q8_dwconv_lds_kernel(const DwParams p)
   extern __shared__ __attribute__((aligned(16))) uint8_t tile[];   // [IR][CS/4][PP] dwords
 
   const uint32_t tid = threadIdx.x;
+  QNNP_DW_TRACE(p, 0);
   // block -> (image, band, slab); slab fastest so that the blocks sharing input
   // cache lines (same pixels, neighbouring channel slabs) are dispatched together
-  uint32_t b = blockIdx.x;
+  // XCD-aware bijective remap (hardware: block b -> XCD b % 8): consecutive logical ids -- the channel slabs
+  // of one band, which read the same cache lines -- land on the same XCD / L2
+  uint32_t b;
+  {
+    const uint32_t nwg = gridDim.x;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t idx = blockIdx.x >> 3;
+    const uint32_t q = nwg >> 3, r = nwg & 7u;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
   const uint32_t slab = b % p.slabs; b /= p.slabs;
   const uint32_t band = b % p.bands;
   const uint32_t n = b / p.bands;
@@ -224,7 +245,9 @@ void q8_dwconv_lds_kernel(const DwParams p)
     bias[0] = bv.x; bias[1] = bv.y; bias[2] = bv.z; bias[3] = bv.w;
   }
 
+  QNNP_DW_TRACE(p, 1);
   __syncthreads();
+  QNNP_DW_TRACE(p, 2);
   if (!active) return;
 
   const uint32_t npos = toh * p.OW;
@@ -279,6 +302,9 @@ void q8_dwconv_lds_kernel(const DwParams p)
       if (ox >= p.OW) { ox -= p.OW; oyl += 1; }
     }
   });
+  QNNP_DW_TRACE(p, 3);
+  QNNP_DW_TRACE(p, 4);
+  QNNP_DW_TRACE(p, 5);
 }
 
 constexpr uint32_t kDwLdsBudgetDefault = 32 * 1024;   // bytes per workgroup (4 workgroups per CU)
@@ -296,6 +322,7 @@ bool plan_lds(DwParams& p, uint32_t budget)
     if (p.C % parts != 0) continue;
     const uint32_t cs = p.C / parts;
     if (cs % 4 != 0 || cs / 4 > kDwThreads) continue;
+    if (p.C % 16 == 0 && cs % 16 != 0) continue;      // keep 16-byte staging loads when the tensor allows them
     const uint32_t q4 = cs / 4;
     // line pitch (dwords): >= IC, and == spread (mod 32) so that the q4 group lines of a row start on
     // different banks: spread = 32/q4 for few groups, 1 (odd) for many
@@ -364,6 +391,10 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
   p.izp = a->input_zero_point & 0xFFu;
   p.CS = p.TOH = p.IR = p.IC = p.PP = p.bands = p.slabs = 0;
   p.rq = qnnp::make_requant_dev(a->rq);
+  p.trace = nullptr;
+#ifdef QNNP_ENABLE_ABLATION
+  p.trace = static_cast<unsigned long long*>(qnnp_hip_trace_buffer());
+#endif
 
   hipStream_t stream = reinterpret_cast<hipStream_t>(qnnp_hip_get_stream());
   const uintptr_t in_addr = reinterpret_cast<uintptr_t>(a->input);

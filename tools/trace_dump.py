@@ -52,7 +52,7 @@ lib.lib.qnnp_hip_trace_dump.restype = ctypes.c_int
 lib.lib.qnnp_hip_trace_dump.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 rc = lib.lib.qnnp_hip_trace_dump(buf.ctypes.data, n)
 t = buf.reshape(4096, 4, 8).astype(np.int64)
-print("kernel", layer.kernel, "rc", rc)
+print("kernel", layer.kernel, "rc", rc, "event ms", lib.time_operator(layer.op, 2, 10))
 for item in range(4):
     rows = t[:, item, :]
     ok = rows[:, 0] > 0
