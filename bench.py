@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="headline GEMM only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-kernel", type=int, default=0, help="0 auto, 1 generic MFMA kernel, 2 big-tile kernel")
+    ap.add_argument("--dw-kernel", type=int, default=0,
+                    help="measurement aid: 0 auto, 1 direct, 2 LDS-tiled, 3 register sliding window (depthwise layers)")
     ap.add_argument("--layer", type=int, default=0,
                     help="measurement aid: time only MobileNetV2 sweep layer N (1-based) and print a short JSON line")
     args = ap.parse_args()
@@ -184,6 +186,7 @@ def main():
     lib.initialize()
     lib.set_stream(torch.cuda.current_stream().cuda_stream)
     lib.set_option("gemm_kernel", args.gemm_kernel)
+    lib.set_option("dwconv_kernel", args.dw_kernel)
     info = lib.device_info()
 
     def barrier():

@@ -66,6 +66,7 @@ struct DwParams {
   uint32_t PP;        // LDS dwords per (row, 4-channel group) line: IC padded for bank spread
   uint32_t bands;     // ceil(OH / TOH)
   uint32_t slabs;     // C / CS
+  uint32_t cu_count;  // compute units of the bound device
   unsigned long long* trace;   // measurement builds only (QNNP_ENABLE_ABLATION + env QNNP_GFX950_TRACE)
   qnnp::RequantDev rq;
 };
@@ -307,7 +308,199 @@ void q8_dwconv_lds_kernel(const DwParams p)
   QNNP_DW_TRACE(p, 5);
 }
 
-constexpr uint32_t kDwLdsBudgetDefault = 32 * 1024;   // bytes per workgroup (4 workgroups per CU)
+// --------------------------------------------------------------------------
+// Kernel C: register sliding window, 3x3, dilation 1, stride 1 or 2, C % 4 == 0
+// --------------------------------------------------------------------------
+/*
+ * No LDS, no barrier: a thread owns one 4-channel group of one output row segment and slides a 3x3 window
+ * of input dwords (4 channels each) along it in registers -- per output only the SW new window columns are
+ * loaded (3 or 6 dwords, coalesced along C across the lanes: consecutive lanes = consecutive channel
+ * groups, then consecutive output rows, so the three kernel rows of neighbouring lanes hit the same lines
+ * in L1). The vertical reuse (an input row feeds up to three output rows) is left to L1/L2.
+ * Why: the LDS kernel spends ~70 % of a workgroup's life staging its band behind a barrier (in-kernel cycle
+ * stamps); here loads, the VALU tap arithmetic and the requantization of different waves overlap freely at
+ * 8+ waves per SIMD.
+ * Padding: rows / columns outside the image are clamped to a valid address and replaced by the input zero
+ * point after the load (checked path, taken only by waves that touch a border).
+ */
+constexpr int kRowThreads = 256;
+
+template <int SW>
+__global__ __launch_bounds__(kRowThreads)
+void q8_dwconv_row3x3_kernel(const DwParams p)
+{
+  constexpr int PAIRS = 5;
+  QNNP_DW_TRACE(p, 0);
+  const uint32_t q4 = p.C / 4;
+  const uint32_t t = blockIdx.x * kRowThreads + threadIdx.x;       // host checked: fits 32 bits
+  const uint32_t c4 = t % q4;
+  uint32_t r = t / q4;
+  const uint32_t oy = r % p.OH; r /= p.OH;
+  const uint32_t seg = r % p.slabs;                                 // `slabs` = column segments per row here
+  const uint32_t n = r / p.slabs;
+  const bool live = n < p.batch;
+  const uint32_t nn = live ? n : 0u;
+  const uint32_t cg = c4 * 4;
+
+  // tap weights as (tap 2i, tap 2i+1) int16 pairs, bias
+  uint32_t wpair[PAIRS][4];
+  int32_t bias[4];
+#pragma unroll
+  for (int i = 0; i < PAIRS; i++) {
+    const uint2 lo = *reinterpret_cast<const uint2*>(p.wadj + (2 * i) * p.c_pad + cg);   // 4 x int16
+    uint2 hi = make_uint2(0u, 0u);
+    if (2 * i + 1 < 9) hi = *reinterpret_cast<const uint2*>(p.wadj + (2 * i + 1) * p.c_pad + cg);
+    wpair[i][0] = (lo.x & 0xFFFFu) | (hi.x << 16);
+    wpair[i][1] = (lo.x >> 16) | (hi.x & 0xFFFF0000u);
+    wpair[i][2] = (lo.y & 0xFFFFu) | (hi.y << 16);
+    wpair[i][3] = (lo.y >> 16) | (hi.y & 0xFFFF0000u);
+  }
+  {
+    const int4 bv = *reinterpret_cast<const int4*>(p.bias1 + cg);
+    bias[0] = bv.x; bias[1] = bv.y; bias[2] = bv.z; bias[3] = bv.w;
+  }
+
+  const uint32_t fill = p.izp * 0x01010101u;
+  // the three input rows of this output row: 32-bit byte offsets from p.input (host checked < 4 GiB)
+  uint32_t voff[3];
+  bool row_ok[3];
+  bool rows_need_check = false;
+#pragma unroll
+  for (int ky = 0; ky < 3; ky++) {
+    const int32_t iy = static_cast<int32_t>(oy * p.sh) - static_cast<int32_t>(p.pad_top) + ky;
+    row_ok[ky] = iy >= 0 && iy < static_cast<int32_t>(p.H);
+    rows_need_check |= !row_ok[ky];
+    const uint32_t iyc = row_ok[ky] ? static_cast<uint32_t>(iy) : 0u;
+    voff[ky] = ((nn * p.H + iyc) * p.W) * p.in_stride + cg;
+  }
+  const bool wave_rows_check = __builtin_amdgcn_ballot_w64(rows_need_check) != 0;
+
+  const uint32_t ox0 = seg * p.TOH;                                  // `TOH` = outputs per column segment here
+  const uint32_t ox1 = live ? min(p.OW, ox0 + p.TOH) : ox0;
+  uint8_t* out_ptr = p.output + (static_cast<uint64_t>(nn * p.OH + oy) * p.OW + ox0) * p.out_stride + cg;
+
+  // one window column (three kernel rows) at input column ix
+  auto load_col = [&](int32_t ix, uint32_t (&col)[3], bool check) __attribute__((always_inline)) {
+    if (check) {
+      const bool col_ok = ix >= 0 && ix < static_cast<int32_t>(p.W);
+      const uint32_t coff = (col_ok ? static_cast<uint32_t>(ix) : 0u) * p.in_stride;
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(p.input + (voff[ky] + coff));
+        col[ky] = (col_ok && row_ok[ky]) ? v : fill;
+      }
+    } else {
+      const uint32_t coff = static_cast<uint32_t>(ix) * p.in_stride;
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++) {
+        col[ky] = *reinterpret_cast<const uint32_t*>(p.input + (voff[ky] + coff));
+      }
+    }
+  };
+
+  qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
+    // window columns kx = 0, 1, 2 of the current output plus the SW columns the NEXT output adds: those are
+    // loaded one step ahead, so a load has a whole step of VALU work (and the other waves) to land
+    uint32_t w0[3], w1[3], w2[3], n0[3], n1[3];
+    int32_t ix = static_cast<int32_t>(ox0 * SW) - static_cast<int32_t>(p.pad_left);   // leftmost window column
+    QNNP_DW_TRACE(p, 1);
+    load_col(ix, w0, true);
+    load_col(ix + 1, w1, true);
+    load_col(ix + 2, w2, true);
+#ifdef QNNP_ENABLE_ABLATION
+    if (p.trace != nullptr) { asm volatile("" :: "v"(w0[0]), "v"(w1[1]), "v"(w2[2])); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+    QNNP_DW_TRACE(p, 2);
+#pragma unroll 4
+    for (uint32_t ox = ox0; ox < ox1; ox++) {
+      // next step's new columns; a wave takes the checked path if any of its lanes touches a border
+      const int32_t nx = ix + 3;
+      const bool lane_check = nx + (SW - 1) >= static_cast<int32_t>(p.W);
+      const bool check = wave_rows_check || lane_check;     // (no ballot here: it would block the unrolling)
+      if (ox + 1 < ox1) {
+        if (check) {
+          load_col(nx, n0, true);
+          if (SW == 2) load_col(nx + 1, n1, true);
+        } else {
+          load_col(nx, n0, false);
+          if (SW == 2) load_col(nx + 1, n1, false);
+        }
+      }
+      const uint32_t in[9] = {w0[0], w1[0], w2[0], w0[1], w1[1], w2[1], w0[2], w1[2], w2[2]};
+      int32_t acc0 = bias[0], acc1 = bias[1], acc2 = bias[2], acc3 = bias[3];
+#pragma unroll
+      for (int i = 0; i < PAIRS; i++) {
+        const uint32_t in0 = in[2 * i];
+        const uint32_t in1 = (2 * i + 1 < 9) ? in[2 * i + 1] : 0u;
+        // v_perm_b32: result bytes {in0.c, 0, in1.c, 0} = the two taps of channel c as int16 x2
+        const uint32_t p0 = __builtin_amdgcn_perm(in1, in0, 0x0c040c00u);
+        const uint32_t p1 = __builtin_amdgcn_perm(in1, in0, 0x0c050c01u);
+        const uint32_t p2 = __builtin_amdgcn_perm(in1, in0, 0x0c060c02u);
+        const uint32_t p3 = __builtin_amdgcn_perm(in1, in0, 0x0c070c03u);
+        acc0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p0), __builtin_bit_cast(v2s, wpair[i][0]), acc0, false);
+        acc1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p1), __builtin_bit_cast(v2s, wpair[i][1]), acc1, false);
+        acc2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p2), __builtin_bit_cast(v2s, wpair[i][2]), acc2, false);
+        acc3 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p3), __builtin_bit_cast(v2s, wpair[i][3]), acc3, false);
+      }
+      const uint32_t packed = qnnp::q31_requantize_pack4<decltype(shift0)::value, decltype(full)::value>(
+          acc0, acc1, acc2, acc3, p.rq);
+      *reinterpret_cast<uint32_t*>(out_ptr) = packed;
+      out_ptr += p.out_stride;
+      // slide the window by SW columns (register renaming once the loop is unrolled)
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++) {
+        if (SW == 1) { w0[ky] = w1[ky]; w1[ky] = w2[ky]; w2[ky] = n0[ky]; }
+        else { w0[ky] = w2[ky]; w1[ky] = n0[ky]; w2[ky] = n1[ky]; }
+      }
+      ix += SW;
+    }
+    QNNP_DW_TRACE(p, 3);
+    QNNP_DW_TRACE(p, 4);
+    QNNP_DW_TRACE(p, 5);
+  });
+}
+
+// geometry of kernel C: `slabs` = column segments per output row, `TOH` = outputs per segment
+bool plan_row(DwParams& p)
+{
+  if (p.C % 4 != 0 || p.KH != 3 || p.KW != 3 || p.dh != 1 || p.dw != 1) return false;
+  if (p.sh != p.sw || (p.sw != 1 && p.sw != 2)) return false;
+  if (p.pad_left > 2 || p.pad_top > 2) return false;
+  // 32-bit input offsets
+  const uint64_t in_bytes = static_cast<uint64_t>(p.batch) * p.H * p.W * p.in_stride;
+  if (in_bytes >= (UINT64_C(1) << 32)) return false;
+  // Column segments: enough threads for `waves` waves per SIMD over the whole chip (oversubscribing the 7
+  // resident ones measured faster than exactly one resident round), but segments of at least 8 outputs
+  // (each re-loads two halo columns and pays the start-up latency again).
+  uint32_t waves = 8;
+#ifdef QNNP_ENABLE_ABLATION
+  if (const char* env = getenv("QNNP_DW_ROW_WAVES")) waves = static_cast<uint32_t>(atoi(env));
+#endif
+  const uint64_t base_threads = static_cast<uint64_t>(p.batch) * p.OH * (p.C / 4);
+  const uint64_t target = static_cast<uint64_t>(p.cu_count) * 4u * waves * 64u;
+  uint32_t segs = static_cast<uint32_t>((target + base_threads - 1) / base_threads);
+  const uint32_t max_segs = p.OW >= 8 ? p.OW / 8 : 1u;
+  if (segs > max_segs) segs = max_segs;
+  if (segs < 1) segs = 1;
+  p.TOH = (p.OW + segs - 1) / segs;
+  p.slabs = (p.OW + p.TOH - 1) / p.TOH;
+  return true;
+}
+
+int launch_row(const DwParams& p, hipStream_t stream)
+{
+  const uint64_t threads = static_cast<uint64_t>(p.batch) * p.slabs * p.OH * (p.C / 4);
+  const uint64_t blocks = (threads + kRowThreads - 1) / kRowThreads;
+  if (blocks * kRowThreads > 0xFFFFFFFFull) return QNNP_HIP_EINVAL;
+  if (p.sw == 1) {
+    hipLaunchKernelGGL(q8_dwconv_row3x3_kernel<1>, dim3(static_cast<uint32_t>(blocks)), dim3(kRowThreads), 0, stream, p);
+  } else {
+    hipLaunchKernelGGL(q8_dwconv_row3x3_kernel<2>, dim3(static_cast<uint32_t>(blocks)), dim3(kRowThreads), 0, stream, p);
+  }
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+constexpr uint32_t kDwLdsBudgetDefault = 48 * 1024;   // bytes per workgroup (3 workgroups per CU)
 
 // Pick slab width / band height for kernel A. Returns false if the shape does not fit.
 bool plan_lds(DwParams& p, uint32_t budget)
@@ -395,6 +588,10 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
 #ifdef QNNP_ENABLE_ABLATION
   p.trace = static_cast<unsigned long long*>(qnnp_hip_trace_buffer());
 #endif
+  {
+    int cus = 0;
+    p.cu_count = (qnnp_hip_device_info(nullptr, 0, &cus, nullptr, nullptr) == QNNP_HIP_OK && cus > 0) ? static_cast<uint32_t>(cus) : 256u;
+  }
 
   hipStream_t stream = reinterpret_cast<hipStream_t>(qnnp_hip_get_stream());
   const uintptr_t in_addr = reinterpret_cast<uintptr_t>(a->input);
@@ -408,8 +605,16 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
     const int kb = atoi(env);
     if (kb >= 4 && kb <= 64) budget = static_cast<uint32_t>(kb) * 1024u;
   }
-  bool use_lds = a->variant != 1 && (k33 || k55) && aligned4 && plan_lds(p, budget);
+  // Order of preference (same-box A/B over the MobileNetV2 layers: the LDS-tiled and the sliding-window
+  // kernel are within +-10 % of each other, LDS ahead on the small late layers): LDS-tiled, then the
+  // register sliding window (3x3 shapes whose band does not fit the LDS budget), then the direct kernel.
+  bool use_lds = a->variant != 1 && a->variant != 3 && (k33 || k55) && aligned4 && plan_lds(p, budget);
   if (a->variant == 2 && !use_lds) return QNNP_HIP_EINVAL;
+  if (!use_lds && (a->variant == 0 || a->variant == 3) && k33 && aligned4 && plan_row(p)) {
+    if (kernel_name != nullptr) *kernel_name = "q8_dwconv_row_3x3";
+    return launch_row(p, stream);
+  }
+  if (a->variant == 3) return QNNP_HIP_EINVAL;
 
   if (use_lds) {
     const bool vec16 = p.CS % 16 == 0 && p.in_stride % 16 == 0 && in_addr % 16 == 0;

@@ -136,7 +136,7 @@ struct qnnp_hip_dwconv_args {
   uint32_t input_stride, output_stride;
   uint32_t input_zero_point;
   struct qnnp_hip_requant rq;
-  int variant;                /* 0 auto, 1 generic direct, 2 LDS-tiled */
+  int variant;                /* 0 auto, 1 generic direct, 2 LDS-tiled, 3 register sliding window (3x3) */
 };
 int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* args, const char** kernel_name);
 

@@ -13,6 +13,6 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"][:50]
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
 for k in acc:
-    if "qnnp" in k:
+    if "qnnp" in k or "q8_" in k:
         print(k, {c: round(v / cnt[(k, c)]) for c, v in acc[k].items()})
 PY
