@@ -185,6 +185,31 @@ enum qnnp_status qnnp_create_convolution2d_nhwc_q8(
       qnnp_log_error("failed to place %zu bytes of packed depthwise weights on the device", w_bytes + b_bytes);
       goto error;
     }
+    /* second image: int8 weight parts + folded bias for the matrix-core depthwise kernel */
+    {
+      const uint32_t c_pad32 = qnnp_round_up_u32(groups, 32);
+      const size_t x_bytes = (size_t) 3 * kernel_size * c_pad32;
+      const size_t bm_bytes = sizeof(int32_t) * c_pad32;
+      int8_t* host_x = (int8_t*) malloc(x_bytes);
+      int32_t* host_bm = (int32_t*) malloc(bm_bytes);
+      int ok = host_x != NULL && host_bm != NULL;
+      if (ok) {
+        op->dwm_parts = qnnp_pack_dwconv_mfma(groups, c_pad32, kernel_height, kernel_width,
+            input_zero_point, kernel_zero_point, kernel, bias, host_x, host_bm);
+        op->c_pad32 = c_pad32;
+        op->d_dwm_x = qnnp_hip_alloc(x_bytes);
+        op->d_dwm_bias = (int32_t*) qnnp_hip_alloc(bm_bytes);
+        ok = op->d_dwm_x != NULL && op->d_dwm_bias != NULL &&
+            qnnp_hip_h2d(op->d_dwm_x, host_x, x_bytes, 0) == QNNP_HIP_OK &&
+            qnnp_hip_h2d(op->d_dwm_bias, host_bm, bm_bytes, 0) == QNNP_HIP_OK;
+      }
+      free(host_x);
+      free(host_bm);
+      if (!ok) {
+        qnnp_log_error("failed to place %zu bytes of depthwise weight parts on the device", x_bytes + bm_bytes);
+        goto error;
+      }
+    }
   } else {
     /* 3-channel inputs (first layers): one unaligned 4-byte fetch per tap, see pack.h "channel slots" */
     const uint32_t kc_slot = (ukernel_type == qnnp_ukernel_type_conv && groups == 1 && group_input_channels == 3) ?

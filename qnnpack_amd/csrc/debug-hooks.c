@@ -34,6 +34,14 @@ void qnnp_debug_pack_dwconv_w(
   qnnp_pack_dwconv_w(channels, c_pad, kh, kw, izp, kzp, kernel, bias, wadj, bias1);
 }
 
+uint32_t qnnp_debug_pack_dwconv_mfma(
+    uint32_t channels, uint32_t c_pad32, uint32_t kh, uint32_t kw,
+    uint8_t izp, uint8_t kzp, const uint8_t* kernel, const int32_t* bias,
+    int8_t* xparts, int32_t* biasm)
+{
+  return qnnp_pack_dwconv_mfma(channels, c_pad32, kh, kw, izp, kzp, kernel, bias, xparts, biasm);
+}
+
 void qnnp_debug_conv2d_offsets(
     size_t input_height, size_t input_width, size_t input_pixel_stride,
     size_t output_height, size_t output_width,

@@ -37,6 +37,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "igemm_epilogue.cuh"
+#include "igemm_params.h"
 #include "qnnp_hip.h"
 #include "requant.cuh"
 
@@ -67,6 +69,11 @@ struct DwParams {
   uint32_t bands;     // ceil(OH / TOH)
   uint32_t slabs;     // C / CS
   uint32_t cu_count;  // compute units of the bound device
+  // matrix-core kernel
+  const int8_t* dwm_x;
+  const int32_t* dwm_bias;
+  uint32_t dwm_parts, c_pad32;
+  uint32_t store_mode;   // as igemm_epilogue.cuh: 2 = 16-byte stores, 1 = dword stores, 0 = byte stores
   unsigned long long* trace;   // measurement builds only (QNNP_ENABLE_ABLATION + env QNNP_GFX950_TRACE)
   qnnp::RequantDev rq;
 };
@@ -500,6 +507,172 @@ int launch_row(const DwParams& p, hipStream_t stream)
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
+// --------------------------------------------------------------------------
+// Kernel D: matrix cores, any kernel size / stride / dilation, C % 16 == 0
+// --------------------------------------------------------------------------
+/*
+ * The VALU formulations above spend ~23 instructions per output (PMC: the kernel is 60-70 % VALU-busy and
+ * still 3x off the HBM floor) -- ten of them to unpack bytes and multiply-accumulate the nine taps -- while
+ * the matrix cores idle. Here the tap arithmetic goes to v_mfma_i32_32x32x32_i8 with a DIAGONAL weight
+ * operand: for a tile of 32 output pixels x 32 channels and one tap,
+ *     acc[c][m] += sum_k Wd[c][k] * A[k][m],   Wd[c][k] = x_tap[c] if k == c else 0,  A[k][m] = a'(pixel m, channel k)
+ * 31/32 of the multiplies are by zero, but one instruction retires 1024 useful MACs, and the activation
+ * operand is exactly a coalesced NHWC load: lane l = pixel l % 32, 16 consecutive channels (l / 32).
+ * This is not a reshaping of the problem into a GEMM -- data movement is unchanged (each input byte is
+ * still fetched once per tap through L1, outputs stored once); only the multiply unit changes.
+ * x = w - kzp needs 9 bits: it is split into int8 parts (pack.h qnnp_pack_dwconv_mfma), one MFMA per tap
+ * and part. a' = a ^ 0x80; padding taps read a = izp. The accumulator starts at the folded bias.
+ * A workgroup keeps one 32-channel block (its diagonal operands live in LDS) and its four waves walk tiles
+ * of 32 consecutive output pixels of the flattened (image, row, column) index space.
+ */
+constexpr int kMfThreads = 256;
+typedef int dw_v4i __attribute__((ext_vector_type(4)));
+typedef int dw_v16i __attribute__((ext_vector_type(16)));
+
+template <int KH, int KW, int PARTS>
+__global__ __launch_bounds__(kMfThreads, 4)
+void q8_dwconv_mfma_kernel(const DwParams p)
+{
+  constexpr int TAPS = KH * KW;
+  __shared__ __attribute__((aligned(16))) uint8_t lds_w[TAPS * PARTS * 1024];
+  __shared__ __attribute__((aligned(16))) int32_t lds_bias[32];
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
+  const uint32_t m = lane & 31u;                 // pixel of the tile (operand B column / accumulator column)
+  const uint32_t khalf = lane >> 5;              // 16-channel half of the block
+  const uint32_t cblocks = p.c_pad32 / 32;
+  const uint32_t cb = blockIdx.x % cblocks;      // this workgroup's channel block
+  const uint32_t walker = blockIdx.x / cblocks;
+  const uint32_t walkers = gridDim.x / cblocks;
+
+  // ---- diagonal weight operands into LDS: lane (n = l % 32, k half = l / 32) holds bytes k = 16*half + j,
+  //      non-zero only at k == n ----
+  for (uint32_t f = wave; f < static_cast<uint32_t>(TAPS * PARTS); f += kMfThreads / 64) {
+    const uint32_t t = f / PARTS;
+    const uint32_t part = f - t * PARTS;
+    const uint32_t x = static_cast<uint8_t>(p.dwm_x[(static_cast<size_t>(part) * TAPS + t) * p.c_pad32 + cb * 32 + m]);
+    const bool mine = (m >> 4) == khalf;
+    const uint32_t val = mine ? x << ((m & 3u) * 8u) : 0u;
+    const uint32_t dw = (m & 15u) >> 2;
+    dw_v4i v;
+    v.x = static_cast<int>(dw == 0 ? val : 0u);
+    v.y = static_cast<int>(dw == 1 ? val : 0u);
+    v.z = static_cast<int>(dw == 2 ? val : 0u);
+    v.w = static_cast<int>(dw == 3 ? val : 0u);
+    *reinterpret_cast<dw_v4i*>(lds_w + f * 1024 + lane * 16) = v;
+  }
+  if (tid < 32) lds_bias[tid] = p.dwm_bias[cb * 32 + tid];
+  __syncthreads();
+
+  const uint32_t ohw = p.OH * p.OW;
+  const uint32_t total = p.batch * ohw;                             // flattened output pixels (host checked < 2^32)
+  const uint32_t tiles = (total + 31u) / 32u;
+  const uint32_t fill = p.izp * 0x01010101u;
+  const uint32_t c_first = cb * 32 + khalf * 16;                    // first channel of this lane's 16
+  const bool chan_ok = c_first < p.C;                               // C % 16 == 0: all sixteen or none
+  const uint8_t* in_c = p.input + (chan_ok ? c_first : 0u);
+
+  qnnp::IgemmParams ep;                                             // only what the shared epilogue reads
+  ep.n = p.C;
+  ep.store_mode = p.store_mode;
+  ep.rq = p.rq;
+
+  qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
+    // each workgroup owns a CONTIGUOUS run of tiles (its waves interleave inside it): the three input rows of
+    // a tile are then re-used from L1 / the same L2 by the tiles one output row further on (PMC: with a
+    // strided assignment the fabric read 2.8x the input)
+    const uint32_t per_walker = (tiles + walkers - 1) / walkers;
+    const uint32_t tile_end = min(tiles, (walker + 1) * per_walker);
+    for (uint32_t tile = walker * per_walker + wave; tile < tile_end; tile += kMfThreads / 64) {
+      const uint32_t gp = tile * 32u + m;
+      const bool valid = gp < total;
+      const uint32_t gpc = valid ? gp : total - 1;
+      const uint32_t n = gpc / ohw;
+      const uint32_t rem = gpc - n * ohw;
+      const uint32_t oy = rem / p.OW;
+      const uint32_t ox = rem - oy * p.OW;
+      const uint32_t img_off = n * p.H * p.W;                       // in pixels (host checked: bytes < 2^32)
+      const int32_t iy0 = static_cast<int32_t>(oy * p.sh) - static_cast<int32_t>(p.pad_top);
+      const int32_t ix0 = static_cast<int32_t>(ox * p.sw) - static_cast<int32_t>(p.pad_left);
+
+      // all tap operands first (independent loads in flight together), then the multiplies
+      dw_v4i a[TAPS];
+      bool ok[TAPS];
+#pragma unroll
+      for (int ky = 0; ky < KH; ky++) {
+        const int32_t iy = iy0 + ky * static_cast<int32_t>(p.dh);
+        const bool row_ok = valid && chan_ok && iy >= 0 && iy < static_cast<int32_t>(p.H);
+#pragma unroll
+        for (int kx = 0; kx < KW; kx++) {
+          const int32_t ix = ix0 + kx * static_cast<int32_t>(p.dw);
+          const bool o = row_ok && ix >= 0 && ix < static_cast<int32_t>(p.W);
+          const uint32_t pix = o ? img_off + static_cast<uint32_t>(iy) * p.W + static_cast<uint32_t>(ix) : 0u;
+          ok[ky * KW + kx] = o;
+          a[ky * KW + kx] = *reinterpret_cast<const dw_v4i*>(in_c + static_cast<uint64_t>(pix) * p.in_stride);
+        }
+      }
+      // the diagonal operands are re-read from LDS for every tile ON PURPOSE: left to itself the compiler
+      // hoists the 18 loop-invariant reads (72 VGPRs) out of the tile loop and spills
+      uint32_t w_off = lane * 16;
+      asm volatile("" : "+v"(w_off));
+      dw_v16i acc;
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int4 b = *reinterpret_cast<const int4*>(&lds_bias[rg * 8 + khalf * 4]);
+        acc[rg * 4 + 0] = b.x; acc[rg * 4 + 1] = b.y; acc[rg * 4 + 2] = b.z; acc[rg * 4 + 3] = b.w;
+      }
+#pragma unroll
+      for (int t = 0; t < TAPS; t++) {
+        dw_v4i v = a[t];
+        v.x = static_cast<int>((ok[t] ? static_cast<uint32_t>(v.x) : fill) ^ 0x80808080u);
+        v.y = static_cast<int>((ok[t] ? static_cast<uint32_t>(v.y) : fill) ^ 0x80808080u);
+        v.z = static_cast<int>((ok[t] ? static_cast<uint32_t>(v.z) : fill) ^ 0x80808080u);
+        v.w = static_cast<int>((ok[t] ? static_cast<uint32_t>(v.w) : fill) ^ 0x80808080u);
+#pragma unroll
+        for (int part = 0; part < PARTS; part++) {
+          const dw_v4i w = *reinterpret_cast<const dw_v4i*>(lds_w + (t * PARTS + part) * 1024 + w_off);
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, v, acc, 0, 0, 0);
+        }
+      }
+      uint8_t* out_row = p.output + static_cast<uint64_t>(gp) * p.out_stride;
+      const int4 unused[4] = {};
+      qnnp::igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, true>(
+          acc, unused, 0, out_row, cb * 32, khalf, valid, ep);
+    }
+  });
+}
+
+bool plan_mfma(const DwParams& p, const struct qnnp_hip_dwconv_args* a)
+{
+  if (a->dwm_x == nullptr || a->dwm_bias == nullptr || a->dwm_parts < 1 || a->dwm_parts > 3) return false;
+  if (!((p.KH == 3 && p.KW == 3) || (p.KH == 5 && p.KW == 5))) return false;
+  if (p.C % 16 != 0 || p.in_stride % 16 != 0 || reinterpret_cast<uintptr_t>(p.input) % 16 != 0) return false;
+  const uint64_t in_bytes = static_cast<uint64_t>(p.batch) * p.H * p.W * p.in_stride;
+  const uint64_t out_px = static_cast<uint64_t>(p.batch) * p.OH * p.OW;
+  return in_bytes < (UINT64_C(1) << 32) && out_px < (UINT64_C(1) << 31);
+}
+
+template <int KH, int KW>
+int launch_mfma(const DwParams& p, hipStream_t stream)
+{
+  const uint32_t cblocks = p.c_pad32 / 32;
+  const uint64_t tiles = (static_cast<uint64_t>(p.batch) * p.OH * p.OW + 31) / 32;
+  // persistent: up to 8 workgroups per CU (LDS: 9 or 18 KiB each), a multiple of the channel blocks
+  uint64_t walkers = (static_cast<uint64_t>(p.cu_count) * 8u + cblocks - 1) / cblocks;
+  const uint64_t max_walkers = (tiles + 3) / 4;
+  if (walkers > max_walkers) walkers = max_walkers;
+  if (walkers < 1) walkers = 1;
+  const dim3 grid(static_cast<uint32_t>(walkers * cblocks));
+  switch (p.dwm_parts) {
+    case 1: hipLaunchKernelGGL((q8_dwconv_mfma_kernel<KH, KW, 1>), grid, dim3(kMfThreads), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((q8_dwconv_mfma_kernel<KH, KW, 2>), grid, dim3(kMfThreads), 0, stream, p); break;
+    default: hipLaunchKernelGGL((q8_dwconv_mfma_kernel<KH, KW, 3>), grid, dim3(kMfThreads), 0, stream, p); break;
+  }
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
 constexpr uint32_t kDwLdsBudgetDefault = 48 * 1024;   // bytes per workgroup (3 workgroups per CU)
 
 // Pick slab width / band height for kernel A. Returns false if the shape does not fit.
@@ -604,6 +777,15 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
   if (const char* env = getenv("QNNP_GFX950_DW_LDS_KB")) {   // tuning knob (measurement only)
     const int kb = atoi(env);
     if (kb >= 4 && kb <= 64) budget = static_cast<uint32_t>(kb) * 1024u;
+  }
+  p.dwm_x = a->dwm_x; p.dwm_bias = a->dwm_bias; p.dwm_parts = a->dwm_parts; p.c_pad32 = a->c_pad32;
+  p.store_mode = 0;
+  if (p.C % 16 == 0 && p.out_stride % 16 == 0 && out_addr % 16 == 0) p.store_mode = 2;
+  else if (p.C % 4 == 0 && p.out_stride % 4 == 0 && out_addr % 4 == 0) p.store_mode = 1;
+  if (a->variant == 4) {
+    if (!plan_mfma(p, a)) return QNNP_HIP_EINVAL;
+    if (kernel_name != nullptr) *kernel_name = k33 ? "q8_dwconv_mfma_3x3" : "q8_dwconv_mfma_5x5";
+    return k33 ? launch_mfma<3, 3>(p, stream) : launch_mfma<5, 5>(p, stream);
   }
   // Order of preference (same-box A/B over the MobileNetV2 layers: the LDS-tiled and the sliding-window
   // kernel are within +-10 % of each other, LDS ahead on the small late layers): LDS-tiled, then the

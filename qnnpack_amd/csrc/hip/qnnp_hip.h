@@ -125,6 +125,10 @@ struct qnnp_hip_dwconv_args {
   uint8_t* output;
   const int16_t* wadj;        /* [taps][c_pad], tap = ky*kw + kx */
   const int32_t* bias1;       /* [c_pad] */
+  const int8_t* dwm_x;        /* [3][taps][c_pad32] int8 weight parts for the MFMA kernel (pack.h) */
+  const int32_t* dwm_bias;    /* [c_pad32] */
+  uint32_t dwm_parts;         /* 1..3 parts in use */
+  uint32_t c_pad32;
   uint32_t batch;
   uint32_t input_height, input_width;
   uint32_t output_height, output_width;
@@ -136,7 +140,7 @@ struct qnnp_hip_dwconv_args {
   uint32_t input_stride, output_stride;
   uint32_t input_zero_point;
   struct qnnp_hip_requant rq;
-  int variant;                /* 0 auto, 1 generic direct, 2 LDS-tiled, 3 register sliding window (3x3) */
+  int variant;                /* 0 auto, 1 generic direct, 2 LDS-tiled, 3 register sliding window (3x3), 4 matrix-core */
 };
 int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* args, const char** kernel_name);
 

@@ -143,7 +143,7 @@ enum qnnp_status qnnp_gfx950_set_option(const char* key, int value)
     qnnp_state.opt_gemm_kernel = value;
     return qnnp_status_success;
   }
-  if (strcmp(key, "dwconv_kernel") == 0 && value >= 0 && value <= 3) {
+  if (strcmp(key, "dwconv_kernel") == 0 && value >= 0 && value <= 4) {
     qnnp_state.opt_dwconv_kernel = value;
     return qnnp_status_success;
   }

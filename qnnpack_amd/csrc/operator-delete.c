@@ -19,6 +19,8 @@ enum qnnp_status qnnp_delete_operator(qnnp_operator_t op)
   }
   qnnp_hip_free(op->d_weights);
   qnnp_hip_free(op->d_bias);
+  qnnp_hip_free(op->d_dwm_x);
+  qnnp_hip_free(op->d_dwm_bias);
   qnnp_hip_free(op->d_offsets);
   qnnp_hip_free(op->d_stage_in);
   qnnp_hip_free(op->d_stage_out);

@@ -45,6 +45,10 @@ static int launch(struct qnnp_operator* op, const void* input, void* output)
         .output = (uint8_t*) output,
         .wadj = (const int16_t*) op->d_weights,
         .bias1 = op->d_bias,
+        .dwm_x = (const int8_t*) op->d_dwm_x,
+        .dwm_bias = op->d_dwm_bias,
+        .dwm_parts = op->dwm_parts,
+        .c_pad32 = op->c_pad32,
         .batch = (uint32_t) op->batch_size,
         .input_height = (uint32_t) op->input_height,
         .input_width = (uint32_t) op->input_width,

@@ -60,6 +60,10 @@ struct qnnp_operator {
   uint32_t k_pad;         /* igemm */
   uint32_t kc_slot;       /* igemm: K positions per tap (group_input_channels, or 4 for 3-channel inputs) */
   uint32_t c_pad;         /* dwconv */
+  void* d_dwm_x;          /* dwconv, MFMA kernel: int8 [3][taps][c_pad32] weight parts (pack.h) */
+  int32_t* d_dwm_bias;    /* dwconv, MFMA kernel: int32 [c_pad32] */
+  uint32_t dwm_parts;     /* 1..3 */
+  uint32_t c_pad32;
 
   int32_t* d_offsets;     /* conv: [output pixels][taps] int32, -1 = padding */
   size_t offsets_capacity;     /* in entries */

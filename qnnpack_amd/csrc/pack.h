@@ -149,3 +149,44 @@ static inline void qnnp_pack_dwconv_w(
     bias1[c] = (int32_t) ((uint32_t) bias[c] + taps * (uint32_t) izp * (uint32_t) kzp - (uint32_t) izp * wsum);
   }
 }
+
+/*
+ * depthwise image for the MFMA kernel (q8dwconv.hip, kernel D): the signed tap weights
+ *     x[t][c] = w[c][t] - kzp   in [-255, 255]
+ * do not fit int8, so they are split into up to three int8 parts x = x0 + x1 + x2
+ * (x0 = clamp(x, -128, 127), x1 = clamp(x - x0, -128, 127), x2 = the rest; x2 != 0 only for x = 255),
+ * stored as xparts[part][tap][c_pad32]; the kernel multiplies a' = a - 128 (uint8 -> int8 by flipping
+ * the top bit) by each part on the matrix cores (one diagonal 32x32 operand per tap and part) and
+ *     biasm[c] = bias[c] + (128 - izp) * sum_t x[t][c]
+ * makes  biasm + sum_t a'_t * x_t  ==  bias + sum_t (a_t - izp) * (w_t - kzp)   (padding taps read a = izp).
+ * Returns the number of parts actually needed (1 when every x fits int8, e.g. kzp == 128).
+ * Source kernel layout: [c][ky][kx], as qnnp_pack_dwconv_w.
+ */
+static inline uint32_t qnnp_pack_dwconv_mfma(
+    uint32_t channels, uint32_t c_pad32, uint32_t kh, uint32_t kw,
+    uint8_t izp, uint8_t kzp,
+    const uint8_t* kernel, const int32_t* bias,
+    int8_t* xparts /* [3][taps][c_pad32] */, int32_t* biasm /* [c_pad32] */)
+{
+  const uint32_t taps = kh * kw;
+  memset(xparts, 0, (size_t) 3 * taps * c_pad32);
+  memset(biasm, 0, sizeof(int32_t) * (size_t) c_pad32);
+  uint32_t parts = 1;
+  for (uint32_t c = 0; c < channels; c++) {
+    int32_t xsum = 0;
+    for (uint32_t t = 0; t < taps; t++) {
+      int32_t x = (int32_t) kernel[(size_t) c * taps + t] - (int32_t) kzp;
+      xsum += x;
+      for (uint32_t part = 0; part < 3; part++) {
+        int32_t piece = x;
+        if (piece > 127) piece = 127;
+        if (piece < -128) piece = -128;
+        xparts[((size_t) part * taps + t) * c_pad32 + c] = (int8_t) piece;
+        x -= piece;
+        if (piece != 0 && part + 1 > parts) parts = part + 1;
+      }
+    }
+    biasm[c] = (int32_t) ((uint32_t) bias[c] + (uint32_t) (128 - (int32_t) izp) * (uint32_t) xsum);
+  }
+  return parts;
+}

@@ -113,3 +113,34 @@ def test_device_requantization_arithmetic_matches_oracle(product):
             out = np.empty(acc.size, np.uint8)
             L.qnnp_debug_requant_fast(acc.size, acc.ctypes.data, np.float32(scale), zp, qmin, qmax, out.ctypes.data)
             assert np.array_equal(out, o1.q31_requantize(acc, scale, zp, qmin, qmax)), (scale, zp, qmin, qmax)
+
+
+@pytest.mark.parametrize("izp,kzp", [(127, 127), (0, 255), (255, 0), (3, 128), (128, 1)])
+def test_depthwise_matrix_core_weight_parts(product, izp, kzp):
+    """qnnp_pack_dwconv_mfma (pack.h): int8 parts sum to w - kzp, the part count is minimal, and the folded bias
+    makes  biasm + sum_t (a_t - 128) * x_t  ==  bias + sum_t (a_t - izp) * (w_t - kzp)  for every activation."""
+    import ctypes
+    L = product.lib if hasattr(product, "lib") else product
+    fn = L.qnnp_debug_pack_dwconv_mfma
+    fn.restype = ctypes.c_uint32
+    fn.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint8, ctypes.c_uint8,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    rng = np.random.default_rng(izp * 256 + kzp)
+    C, KH, KW = 40, 3, 3
+    taps, c_pad32 = KH * KW, 64
+    kernel = rng.integers(0, 256, size=(C, taps), dtype=np.uint8)
+    kernel[0, :3] = [0, 255, 128]                       # the extremes of x = w - kzp
+    bias = rng.integers(-2**31, 2**31, size=C).astype(np.int32)
+    xparts = np.full((3, taps, c_pad32), 99, np.int8)
+    biasm = np.full(c_pad32, 99, np.int32)
+    parts = fn(C, c_pad32, KH, KW, izp, kzp, kernel.ctypes.data, bias.ctypes.data, xparts.ctypes.data, biasm.ctypes.data)
+    x = kernel.astype(np.int64).T - kzp                 # [taps][C]
+    assert np.array_equal(xparts[:, :, :C].astype(np.int64).sum(axis=0), x)
+    assert not xparts[:, :, C:].any() and not biasm[C:].any(), "padding channels must multiply to zero"
+    need = 1 if x.min() >= -128 and x.max() <= 127 else (3 if x.max() == 255 else 2)
+    assert parts == need, (parts, need)
+    assert not xparts[parts:].any()
+    a = rng.integers(0, 256, size=(taps, C)).astype(np.int64)
+    lhs = (biasm[:C].astype(np.int64) + ((a - 128) * x).sum(axis=0)) & 0xFFFFFFFF
+    rhs = (bias.astype(np.int64) + ((a - izp) * x).sum(axis=0)) & 0xFFFFFFFF
+    assert np.array_equal(lhs, rhs)
