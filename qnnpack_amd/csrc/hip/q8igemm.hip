@@ -544,6 +544,18 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
     if (kernel_name != nullptr) *kernel_name = name;
     return rc_pw;
   }
+  // Small problems with a long reduction (late MobileNet layers, classifier heads): one wave per 32x32 block,
+  // operands from L2 -- the tiled kernels would launch fewer workgroups than there are CUs.
+  const bool gw_ok = !pad3 && qnnp::pwstream_gw_supported(p, a->groups, vec);
+  if (a->variant == 6 && !gw_ok) return QNNP_HIP_EINVAL;
+  // (selected when the 128-row x 128-channel tiling of the generic kernel would not even give ~1.5 workgroups
+  //  per CU; MobileNetV2 layer 30 -- 490 tiles -- measured faster on the tiled kernel, layers 19-29 on this one)
+  const uint64_t generic_tiles = static_cast<uint64_t>((a->rows + 127u) / 128u) * ((a->n_pad + 127u) / 128u);
+  if (gw_ok && (a->variant == 6 || (a->variant == 0 && generic_tiles <= 400u))) {
+    const int rc_gw = qnnp::pwstream_gw_launch(p, stream, &name);
+    if (kernel_name != nullptr) *kernel_name = name;
+    return rc_gw;
+  }
   // Large MFMA-bound problems take the 256x256 LDS-DMA kernel; everything else the generic one.
   const bool big_ok = !pad3 && qnnp::gemm256_supported(p, vec);
   const bool big_auto = a->n >= 256 && a->k_total >= 512 && a->rows >= 2048;

@@ -200,6 +200,84 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
   });
 }
 
+/*
+ * Second flavour for pointwise / fully-connected layers whose weights do NOT fit LDS (K up to ~1000 over few
+ * rows: the late MobileNet layers, classifier heads): one WAVE = one 32-row x 32-channel output block, both
+ * MFMA operands straight from global memory / L2 (activations: 16 B per lane in B-operand layout; weights: one
+ * coalesced 1 KiB fragment), four K blocks of loads in flight ahead of the multiplies, no LDS, no barrier.
+ * The tiled kernels launch 49-196 workgroups for these shapes on a 256-CU chip; here every 32x32 block is its
+ * own wave (980-7840 waves). Operand traffic is L2-resident by construction (the whole problem is a few MB).
+ */
+constexpr int kGwUnroll = 4;
+
+__global__ __launch_bounds__(kThreads, 4)
+void q8_pw_stream_gw_kernel(const IgemmParams p)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t row_in_block = lane & 31u;
+  const uint32_t khalf = lane >> 5;
+  const uint32_t nblocks = p.n_pad / 32;
+  const uint32_t kblocks = p.k_pad / 32;
+  const uint32_t units = ((p.rows + 31u) / 32u) * nblocks;
+  const uint32_t unit = blockIdx.x * kWaves + wave;        // channel block fastest: neighbours share the rows
+  if (unit >= units) return;
+  const uint32_t rb = unit / nblocks;
+  const uint32_t nb = unit - rb * nblocks;
+
+  uint32_t m = rb * 32u + row_in_block;
+  const bool row_ok = m < p.rows;
+  if (!row_ok) m = p.rows - 1;
+  const uint8_t* row = p.input + static_cast<uint64_t>(m) * p.input_stride + khalf * 16;
+  const uint8_t* pad16 = p.fill_table + 0x80 * 16;          // 16 bytes of a' == 0
+  const int8_t* wf = p.packed_w + static_cast<uint64_t>(nb) * kblocks * 1024 + lane * 16;
+  const uint32_t kbt = (p.k_total + 31u) / 32u;
+
+  int4 bias4[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) {
+    bias4[rg] = *reinterpret_cast<const int4*>(p.bias2 + nb * 32 + rg * 8 + khalf * 4);
+  }
+
+  v16i acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0;
+  uint32_t rs = 0;
+  for (uint32_t kb0 = 0; kb0 < kbt; kb0 += kGwUnroll) {
+    v4i a[kGwUnroll], w[kGwUnroll];
+#pragma unroll
+    for (int u = 0; u < kGwUnroll; u++) {
+      const uint32_t kb = kb0 + u;
+      const bool have = kb < kbt && kb * 32 + khalf * 16 < p.k_total;     // k_total % 16 == 0: whole piece or none
+      const uint8_t* src = have ? row + kb * 32 : pad16;
+      a[u] = *reinterpret_cast<const v4i*>(src);
+      const uint32_t kbc = kb < kbt ? kb : kbt - 1;                        // (clamped fragments meet a' == 0)
+      w[u] = *reinterpret_cast<const v4i*>(wf + static_cast<uint64_t>(kbc) * 1024);
+    }
+#pragma unroll
+    for (int u = 0; u < kGwUnroll; u++) {
+      rs = __builtin_amdgcn_sad_u8(a[u].x, 0u, rs);
+      rs = __builtin_amdgcn_sad_u8(a[u].y, 0u, rs);
+      rs = __builtin_amdgcn_sad_u8(a[u].z, 0u, rs);
+      rs = __builtin_amdgcn_sad_u8(a[u].w, 0u, rs);
+      a[u].x ^= static_cast<int>(kFlip);
+      a[u].y ^= static_cast<int>(kFlip);
+      a[u].z ^= static_cast<int>(kFlip);
+      a[u].w ^= static_cast<int>(kFlip);
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[u], a[u], acc, 0, 0, 0);
+    }
+  }
+  rs += __shfl_xor(rs, 32);                                   // the other K half of the same row
+  // every piece a lane read is either data or 0x80 padding: kGwUnroll-rounded blocks, 16 bytes each
+  const uint32_t pieces = ((kbt + kGwUnroll - 1) / kGwUnroll) * kGwUnroll * 2;
+  const int32_t rowterm = p.row_coeff * static_cast<int32_t>(rs - 128u * 16u * pieces);
+  uint8_t* out_row = p.output + static_cast<uint64_t>(rb * 32u + row_in_block) * p.output_stride;
+  requant_dispatch(p.rq, [&](auto shift0, auto full) {
+    igemm_store_tile<decltype(shift0)::value, decltype(full)::value>(
+        acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p);
+  });
+}
+
 template <int KB, int VEC>
 int launch_pw(const IgemmParams& p, uint32_t lds_bytes, hipStream_t stream)
 {
@@ -262,6 +340,23 @@ bool pwstream_supported(const IgemmParams& p, uint32_t groups, uint32_t vec)
   if (p.fill_table == nullptr || p.rows == 0 || p.k_total == 0 || p.k_total > 256u) return false;
   if (p.k_total % vec != 0) return false;
   return pw_lds_bytes(p) <= kMaxLds;
+}
+
+/* global-weights flavour: pointwise / fully-connected form, one group, 16-byte aligned rows, any K and N */
+bool pwstream_gw_supported(const IgemmParams& p, uint32_t groups, uint32_t vec)
+{
+  if (p.offsets != nullptr || groups != 1 || vec != 16) return false;
+  if (p.fill_table == nullptr || p.rows == 0 || p.k_total == 0 || p.k_total % 16 != 0) return false;
+  const uint64_t units = static_cast<uint64_t>((p.rows + 31u) / 32u) * (p.n_pad / 32u);
+  return units < (UINT64_C(1) << 31);
+}
+
+int pwstream_gw_launch(const IgemmParams& p, hipStream_t stream, const char** name)
+{
+  const uint32_t units = ((p.rows + 31u) / 32u) * (p.n_pad / 32u);
+  *name = "q8_pw_stream_gw_mfma";
+  hipLaunchKernelGGL(q8_pw_stream_gw_kernel, dim3((units + kWaves - 1) / kWaves), dim3(kThreads), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
 int pwstream_launch(const IgemmParams& p, uint32_t vec, hipStream_t stream, const char** name)

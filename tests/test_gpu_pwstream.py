@@ -98,3 +98,62 @@ def test_auto_selection_takes_it_for_many_rows(qnnp):
     out, kname = fc_run(qnnp, case, quant, to_device=to_device, from_device=from_device)
     assert kname == KERNEL, kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+# ---- the global-operand flavour ("gemm_kernel" = 6): one wave per 32x32 block, any K ----
+GW_KERNEL = "q8_pw_stream_gw_mfma"
+
+
+@pytest.fixture()
+def gw(qnnp):
+    qnnp.set_option("gemm_kernel", 6)
+    yield qnnp
+    qnnp.set_option("gemm_kernel", 0)
+
+
+def _fc_gw(gw, case):
+    expected, quant = fc_expected(case)
+    out, kname = fc_run(gw, case, quant, to_device=to_device, from_device=from_device)
+    assert kname == GW_KERNEL, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("m", [1, 31, 32, 33, 100, 1000])
+def test_gw_row_edges(gw, m):
+    _fc_gw(gw, FcCase(f"gw_m{m}", m, 384, 48))
+
+
+@pytest.mark.parametrize("k", [16, 32, 48, 112, 128, 144, 256, 272, 384, 576, 960, 1280])
+def test_gw_k_blocks_and_unroll_tails(gw, k):
+    _fc_gw(gw, FcCase(f"gw_k{k}", 70, k, 40))
+
+
+@pytest.mark.parametrize("n", [1, 4, 16, 31, 33, 96, 160, 1000])
+def test_gw_channel_edges_and_store_modes(gw, n):
+    _fc_gw(gw, FcCase(f"gw_n{n}", 50, 320, n))
+
+
+@pytest.mark.parametrize("kw", [dict(izp=0, kzp=0), dict(izp=255, kzp=255), dict(izp=3, kzp=250), dict(qmin=128)],
+                         ids=lambda d: "_".join(f"{k}{v}" for k, v in d.items()))
+def test_gw_quantization_variants(gw, kw):
+    _fc_gw(gw, FcCase("gw_q_" + "_".join(f"{k}{v}" for k, v in kw.items()), 90, 400, 52, **kw))
+
+
+def test_gw_strided_rows(gw):
+    _fc_gw(gw, FcCase("gw_strided", 130, 304, 80, input_stride=320, output_stride=96))
+
+
+def test_gw_pointwise_convolution(gw):
+    case = ConvCase("gw_1x1_960_160", (7, 7), gic=960, goc=160, batch=4)
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(gw, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == GW_KERNEL, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+def test_gw_unsupported_alignment_is_reported(gw):
+    from qnnpack_amd import QnnpackError
+    case = FcCase("gw_bad_align", 64, 24, 16)         # rows only 8-byte aligned
+    _, quant = fc_expected(case)
+    with pytest.raises(QnnpackError):
+        fc_run(gw, case, quant, to_device=to_device, from_device=from_device)
