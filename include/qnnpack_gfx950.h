@@ -65,7 +65,8 @@ enum qnnp_status qnnp_gfx950_time_operator_rotating(
  *                    3 = LDS-tiled direct-convolution MFMA kernel (convolutions only),
  *                    4 = the 256x256 kernel in its 4-wave flavour (one wave per SIMD, 128x128 per wave),
  *                    5 = barrier-free streaming kernel for short-K pointwise / fully-connected layers,
- *                    6 = its global-operand flavour (one wave per 32x32 block; small problems with long K)
+ *                    6 = its global-operand flavour (one wave per 32x32 block; small problems with long K),
+ *                    7 = its 3-channel-image convolution flavour (first layers; in-register tap gather)
  *   "dwconv_kernel": 0 = auto, 1 = generic direct kernel, 2 = LDS-tiled kernel, 3 = register sliding-window kernel (3x3),
  *                    4 = matrix-core kernel (diagonal MFMA operands; 3x3 / 5x5, channels % 16 == 0)
  * Unknown key -> invalid_parameter. Applies to operators set up afterwards. */

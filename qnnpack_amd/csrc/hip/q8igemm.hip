@@ -536,6 +536,14 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
     if (kernel_name != nullptr) *kernel_name = name;
     return rc_lds;
   }
+  // 3-channel images (first layers): barrier-free streaming kernel with an in-register tap gather.
+  const bool c3_ok = pad3 && qnnp::convstream_c3_supported(p, a->groups);
+  if (a->variant == 7 && !c3_ok) return QNNP_HIP_EINVAL;
+  if (c3_ok && (a->variant == 7 || (a->variant == 0 && a->rows >= 2048))) {
+    const int rc_c3 = qnnp::convstream_c3_launch(p, stream, &name);
+    if (kernel_name != nullptr) *kernel_name = name;
+    return rc_c3;
+  }
   // Short-K pointwise / fully-connected layers over many rows: barrier-free streaming kernel.
   const bool pw_ok = !pad3 && qnnp::pwstream_supported(p, a->groups, vec);
   if (a->variant == 5 && !pw_ok) return QNNP_HIP_EINVAL;

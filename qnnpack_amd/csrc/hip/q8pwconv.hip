@@ -278,6 +278,145 @@ void q8_pw_stream_gw_kernel(const IgemmParams p)
   });
 }
 
+/*
+ * Third flavour: convolutions over 3-channel images (network first layers, e.g. 3x3 stride 2, 3 -> 32). The
+ * reduction is tiny (taps x 4-byte slots <= 64 bytes, pack.h "channel slots"), so the same barrier-free
+ * scheme applies with an in-register gather: a lane fetches the (at most 8) taps of its K half with one
+ * unaligned dword each -- addresses from the operator's offset table, padding taps and the slot's 4th byte
+ * replaced in registers -- and multiplies against the LDS-resident weights. One wave = 32 consecutive
+ * output pixels of the flattened (image, row, column) space.
+ */
+typedef uint32_t __attribute__((aligned(1))) pw_u32_unaligned;
+
+__global__ __launch_bounds__(kThreads, 4)
+void q8_conv_stream_c3_kernel(const IgemmParams p)
+{
+  constexpr int KB = 2;                                    // k_pad == 64: up to 16 taps of 4-byte slots
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
+  const uint32_t row_in_block = lane & 31u;
+  const uint32_t khalf = lane >> 5;
+  const uint32_t nblocks = p.n_pad / 32;
+  const uint32_t kblocks = p.k_pad / 32;
+  {
+    const uint32_t frags = nblocks * KB;
+    for (uint32_t f = wave; f < frags; f += kWaves) {
+      const uint32_t nb = f / KB;
+      const uint32_t kb = f - nb * KB;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*) (p.packed_w + (static_cast<uint64_t>(nb) * kblocks + kb) * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*) (lds + f * 1024), 16, 0, 0);
+    }
+    uint8_t* lds_bias = lds + frags * 1024;
+    const uint32_t bias_chunks = p.n_pad / 4;
+    for (uint32_t c0 = wave * 64; c0 < bias_chunks; c0 += kThreads) {
+      const uint32_t c = min(c0 + lane, bias_chunks - 1);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(p.bias2) + c * 16),
+          (__attribute__((address_space(3))) void*) (lds_bias + c0 * 16), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  const uint8_t* lds_w = lds + lane * 16;
+  const int4* lds_bias4 = reinterpret_cast<const int4*>(lds + nblocks * KB * 1024);
+
+  const uint32_t units = (p.rows + 31u) / 32u;
+  const uint32_t unit_stride = gridDim.x * kWaves;
+  const uint32_t fillpix = p.izp_fill;                     // {izp, izp, izp, 0x80}: padding tap, 4th byte = K padding
+  const uint32_t raw_to_centred = 128u * 32u * KB;
+
+  // gather the lane's taps (kb*8 + khalf*4 + j, j = 0..3) of output pixel m
+  auto load_taps = [&](uint32_t unit, v4i (&a)[KB]) __attribute__((always_inline)) {
+    uint32_t m = unit * 32u + row_in_block;
+    if (m >= p.rows) m = p.rows - 1;                       // clamped rows are never stored
+    const uint32_t img = m / p.rows_per_image;
+    const uint32_t pix = m - img * p.rows_per_image;
+    const uint8_t* base = p.input + static_cast<uint64_t>(img) * p.image_stride;
+    const int32_t* offs = p.offsets + static_cast<uint64_t>(pix) * p.ks;
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+      uint32_t v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t t = kb * 8 + khalf * 4 + j;
+        const bool tap = t < p.ks;
+        const int32_t off = offs[tap ? t : 0u];
+        const bool inside = tap && off >= 0;
+        const uint8_t* src = base + (inside ? off : 0);
+        uint32_t x;
+        if (src + 4 <= p.input_end) {
+          x = *reinterpret_cast<const pw_u32_unaligned*>(src);
+        } else {                                           // the very last pixel of the tensor: bytewise
+          x = static_cast<uint32_t>(src[0]) | (static_cast<uint32_t>(src[1]) << 8) | (static_cast<uint32_t>(src[2]) << 16);
+        }
+        x = (x & 0x00FFFFFFu) | 0x80000000u;               // the slot's 4th byte is K padding: a' == 0
+        v[j] = tap ? (inside ? x : fillpix) : 0x80808080u;
+      }
+      a[kb] = v4i{static_cast<int>(v[0]), static_cast<int>(v[1]), static_cast<int>(v[2]), static_cast<int>(v[3])};
+    }
+  };
+
+  uint32_t unit = blockIdx.x * kWaves + wave;
+  v4i a_next[KB];
+  if (unit < units) load_taps(unit, a_next);
+
+  requant_dispatch(p.rq, [&](auto shift0, auto full) {
+    for (; unit < units; unit += unit_stride) {
+      v4i a[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; kb++) a[kb] = a_next[kb];
+      if (unit + unit_stride < units) load_taps(unit + unit_stride, a_next);
+
+      uint32_t rs = 0;
+#pragma unroll
+      for (int kb = 0; kb < KB; kb++) {
+        rs = __builtin_amdgcn_sad_u8(a[kb].x, 0u, rs);
+        rs = __builtin_amdgcn_sad_u8(a[kb].y, 0u, rs);
+        rs = __builtin_amdgcn_sad_u8(a[kb].z, 0u, rs);
+        rs = __builtin_amdgcn_sad_u8(a[kb].w, 0u, rs);
+        a[kb].x ^= static_cast<int>(kFlip);
+        a[kb].y ^= static_cast<int>(kFlip);
+        a[kb].z ^= static_cast<int>(kFlip);
+        a[kb].w ^= static_cast<int>(kFlip);
+      }
+      rs += __shfl_xor(rs, 32);
+      const int32_t rowterm = p.row_coeff * static_cast<int32_t>(rs - raw_to_centred);
+
+      const uint32_t m = unit * 32u + row_in_block;
+      uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride;
+      const bool row_ok = m < p.rows;
+      int4 bias4[4];
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[rg * 2 + khalf];
+      for (uint32_t nb = 0; nb < nblocks; nb++) {
+        v16i acc;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          acc[rg * 4 + 0] = bias4[rg].x + rowterm;
+          acc[rg * 4 + 1] = bias4[rg].y + rowterm;
+          acc[rg * 4 + 2] = bias4[rg].z + rowterm;
+          acc[rg * 4 + 3] = bias4[rg].w + rowterm;
+        }
+        if (nb + 1 < nblocks) {
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[(nb + 1) * 8 + rg * 2 + khalf];
+        }
+        const uint8_t* wf = lds_w + nb * (KB * 1024);
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) {
+          const v4i w = *reinterpret_cast<const v4i*>(wf + kb * 1024);
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a[kb], acc, 0, 0, 0);
+        }
+        igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, true>(
+            acc, bias4, 0, out_row, nb * 32, khalf, row_ok, p);
+      }
+    }
+  });
+}
+
 template <int KB, int VEC>
 int launch_pw(const IgemmParams& p, uint32_t lds_bytes, hipStream_t stream)
 {
@@ -340,6 +479,32 @@ bool pwstream_supported(const IgemmParams& p, uint32_t groups, uint32_t vec)
   if (p.fill_table == nullptr || p.rows == 0 || p.k_total == 0 || p.k_total > 256u) return false;
   if (p.k_total % vec != 0) return false;
   return pw_lds_bytes(p) <= kMaxLds;
+}
+
+/* 3-channel-image flavour: offset-table convolution in 4-byte tap slots, at most 16 taps, one group */
+bool convstream_c3_supported(const IgemmParams& p, uint32_t groups)
+{
+  if (p.offsets == nullptr || groups != 1 || p.kc != 4 || p.ks == 0 || p.ks > 16 || p.k_pad != 64) return false;
+  if (p.rows == 0 || p.rows_per_image == 0) return false;
+  return (p.n_pad / 32u) * 2u * 1024u + ((p.n_pad * 4u + 1023u) & ~1023u) <= kMaxLds;
+}
+
+int convstream_c3_launch(const IgemmParams& p, hipStream_t stream, const char** name)
+{
+  const uint32_t lds_bytes = (p.n_pad / 32u) * 2u * 1024u + ((p.n_pad * 4u + 1023u) & ~1023u);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void) hipFuncSetAttribute(reinterpret_cast<const void*>(q8_conv_stream_c3_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    attr_set = true;
+  }
+  const uint32_t units = (p.rows + 31u) / 32u;
+  uint32_t grid = p.cu_count * 4u;
+  const uint32_t needed = (units + kWaves - 1) / kWaves;
+  if (grid > needed) grid = needed;
+  *name = "q8_conv_stream_c3_mfma";
+  hipLaunchKernelGGL(q8_conv_stream_c3_kernel, dim3(grid), dim3(kThreads), lds_bytes, stream, p);
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
 /* global-weights flavour: pointwise / fully-connected form, one group, 16-byte aligned rows, any K and N */
