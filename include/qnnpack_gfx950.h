@@ -47,9 +47,10 @@ enum qnnp_status qnnp_gfx950_memcpy_h2d(void* dst_device, const void* src_host, 
 enum qnnp_status qnnp_gfx950_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes);
 enum qnnp_status qnnp_gfx950_memset(void* dst_device, int value, size_t bytes);
 
-/* Time `iters` back-to-back qnnp_run_operator launches of one operator with
- * hipEvents recorded on the library's stream, after `warmup` untimed launches.
- * Writes the AVERAGE milliseconds per launch. Device pointers only. */
+/* Time `iters` back-to-back qnnp_run_operator launches of one operator with hipEvents, after `warmup`
+ * untimed launches; writes the AVERAGE milliseconds per launch. Device pointers only. By default the
+ * launches are recorded into a hipGraph and its replay is timed (option "timing_graph"), so the figure is
+ * kernel time -- what rocprofv3 reports per kernel -- not the host's per-launch dispatch gap. */
 enum qnnp_status qnnp_gfx950_time_operator(
     qnnp_operator_t op, int warmup, int iters, float* avg_ms_out);
 
@@ -60,6 +61,20 @@ enum qnnp_status qnnp_gfx950_time_operator_rotating(
     qnnp_operator_t op, size_t nsets, const void* const* inputs, void* const* outputs,
     int warmup, int iters, float* avg_ms_out);
 
+/* hipGraph capture: between begin and end, qnnp_run_operator only RECORDS its launch (device pointers only; a
+ * host-pointer operator returns invalid_parameter). The graph replays the whole sequence -- e.g. every layer of
+ * a network -- as one submission: no per-launch dispatch gap, which on MI355X is as long as the small layers
+ * themselves. Replays run on the stream given to qnnp_gfx950_set_stream at capture time (a private stream
+ * stands in for the default stream, which cannot be captured): synchronous unless qnnp_gfx950_set_async(1),
+ * then qnnp_gfx950_graph_synchronize. Operators and their buffers must outlive the graph.
+ * qnnp_gfx950_graph_time: average milliseconds per replay, hipEvents on the replay stream. */
+enum qnnp_status qnnp_gfx950_graph_begin(void);
+enum qnnp_status qnnp_gfx950_graph_end(void** graph_out);
+enum qnnp_status qnnp_gfx950_graph_launch(void* graph);
+enum qnnp_status qnnp_gfx950_graph_synchronize(void* graph);
+enum qnnp_status qnnp_gfx950_graph_time(void* graph, int warmup, int iters, float* avg_ms_out);
+void qnnp_gfx950_graph_destroy(void* graph);
+
 /* Kernel-variant control for A/B measurement and tests. Keys:
  *   "gemm_kernel":   0 = auto, 1 = generic MFMA implicit-GEMM kernel, 2 = 256x256 LDS-DMA MFMA kernel,
  *                    3 = LDS-tiled direct-convolution MFMA kernel (convolutions only),
@@ -69,7 +84,9 @@ enum qnnp_status qnnp_gfx950_time_operator_rotating(
  *                    7 = its 3-channel-image convolution flavour (first layers; in-register tap gather)
  *   "dwconv_kernel": 0 = auto, 1 = generic direct kernel, 2 = LDS-tiled kernel, 3 = register sliding-window kernel (3x3),
  *                    4 = matrix-core kernel (diagonal MFMA operands; 3x3 / 5x5, channels % 16 == 0)
- * Unknown key -> invalid_parameter. Applies to operators set up afterwards. */
+ *   "timing_graph":  1 (default) = qnnp_gfx950_time_operator* time a hipGraph replay of the launches (kernel
+ *                    time without per-launch dispatch gaps); 0 = a plain back-to-back launch loop
+ * Unknown key -> invalid_parameter. Kernel choices apply to operators set up afterwards. */
 enum qnnp_status qnnp_gfx950_set_option(const char* key, int value);
 
 /* Name of the HIP kernel the operator's last setup selected (static string), or

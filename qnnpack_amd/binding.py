@@ -198,6 +198,18 @@ class Gfx950Library(QnnpackLibrary):
         L.qnnp_gfx950_time_operator_rotating.restype = c_int
         L.qnnp_gfx950_time_operator_rotating.argtypes = [
             c_void_p, c_size_t, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, POINTER(c_float)]
+        L.qnnp_gfx950_graph_begin.restype = c_int
+        L.qnnp_gfx950_graph_begin.argtypes = []
+        L.qnnp_gfx950_graph_end.restype = c_int
+        L.qnnp_gfx950_graph_end.argtypes = [POINTER(c_void_p)]
+        L.qnnp_gfx950_graph_launch.restype = c_int
+        L.qnnp_gfx950_graph_launch.argtypes = [c_void_p]
+        L.qnnp_gfx950_graph_synchronize.restype = c_int
+        L.qnnp_gfx950_graph_synchronize.argtypes = [c_void_p]
+        L.qnnp_gfx950_graph_time.restype = c_int
+        L.qnnp_gfx950_graph_time.argtypes = [c_void_p, c_int, c_int, POINTER(c_float)]
+        L.qnnp_gfx950_graph_destroy.restype = None
+        L.qnnp_gfx950_graph_destroy.argtypes = [c_void_p]
         L.qnnp_gfx950_set_option.restype = c_int
         L.qnnp_gfx950_set_option.argtypes = [c_char_p, c_int]
         L.qnnp_gfx950_operator_kernel.restype = c_char_p
@@ -260,6 +272,29 @@ class Gfx950Library(QnnpackLibrary):
         self._check("qnnp_gfx950_time_operator_rotating",
                     self.lib.qnnp_gfx950_time_operator_rotating(op, n, ins, outs, warmup, iters, ctypes.byref(ms)))
         return float(ms.value)
+
+    # ---- hipGraph capture of operator launches (qnnpack_gfx950.h) ----
+    def graph_begin(self) -> None:
+        self._check("qnnp_gfx950_graph_begin", self.lib.qnnp_gfx950_graph_begin())
+
+    def graph_end(self) -> int:
+        g = c_void_p()
+        self._check("qnnp_gfx950_graph_end", self.lib.qnnp_gfx950_graph_end(ctypes.byref(g)))
+        return g.value
+
+    def graph_launch(self, graph: int) -> None:
+        self._check("qnnp_gfx950_graph_launch", self.lib.qnnp_gfx950_graph_launch(graph))
+
+    def graph_synchronize(self, graph: int) -> None:
+        self._check("qnnp_gfx950_graph_synchronize", self.lib.qnnp_gfx950_graph_synchronize(graph))
+
+    def graph_time(self, graph: int, warmup: int, iters: int) -> float:
+        ms = c_float(0.0)
+        self._check("qnnp_gfx950_graph_time", self.lib.qnnp_gfx950_graph_time(graph, warmup, iters, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def graph_destroy(self, graph: int) -> None:
+        self.lib.qnnp_gfx950_graph_destroy(graph)
 
     def set_option(self, key: str, value: int) -> None:
         self._check("qnnp_gfx950_set_option", self.lib.qnnp_gfx950_set_option(key.encode(), value))

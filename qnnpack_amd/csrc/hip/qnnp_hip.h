@@ -66,6 +66,16 @@ int qnnp_hip_timer_start(void* timer);
 int qnnp_hip_timer_stop_ms(void* timer, float* ms);
 void qnnp_hip_timer_destroy(void* timer);
 
+/* hipGraph capture of operator launches on the library stream (a private stream stands in for the default
+ * stream, which cannot be captured); replay = one submission, no per-launch gaps */
+int qnnp_hip_graph_capturing(void);
+int qnnp_hip_graph_begin(void);
+int qnnp_hip_graph_end(void** graph);
+int qnnp_hip_graph_launch(void* graph);
+int qnnp_hip_graph_time(void* graph, int warmup, int iters, float* avg_ms);
+int qnnp_hip_graph_sync(void* graph);
+void qnnp_hip_graph_destroy(void* graph);
+
 /* ---- q8 GEMM / implicit-GEMM convolution (MFMA) ------------------------
  * Replaces q8gemm_ukernel_4x4c2__sse2 (src/q8gemm/4x4c2-sse2.c:14-318) and
  * q8conv_ukernel_4x4c2__sse2 (src/q8conv/4x4c2-sse2.c:14-273) together with

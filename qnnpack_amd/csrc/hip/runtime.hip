@@ -22,6 +22,10 @@ struct Runtime {
   hipStream_t stream = nullptr;  // nullptr = default stream
   hipDeviceProp_t props;
   uint8_t* fill_table = nullptr;  // [256][16]: entry v = sixteen bytes of value v (LDS-DMA padding sources)
+  // hipGraph capture of a sequence of operator launches (qnnp_hip_graph_*)
+  bool capturing = false;
+  hipStream_t saved_stream = nullptr;    // the library stream while a capture redirects launches
+  hipStream_t private_stream = nullptr;  // capture / replay stream when the library stream is the default stream
 };
 
 Runtime g_rt;
@@ -195,6 +199,109 @@ int qnnp_hip_timer_stop_ms(void* timer, float* ms)
   if (!ok(hipEventRecord(t->stop, g_rt.stream))) return QNNP_HIP_ELAUNCH;
   if (!ok(hipEventSynchronize(t->stop))) return QNNP_HIP_ELAUNCH;
   return ok(hipEventElapsedTime(ms, t->start, t->stop)) ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+/* ---- hipGraph capture: a run of operator launches replayed as ONE submission (no per-launch gaps) ---- */
+
+int qnnp_hip_graph_capturing(void) { return g_rt.capturing ? 1 : 0; }
+
+int qnnp_hip_graph_begin(void)
+{
+  if (!g_rt.bound || g_rt.capturing) return QNNP_HIP_EINVAL;
+  hipStream_t s = g_rt.stream;
+  if (s == nullptr) {                    // the legacy default stream cannot be captured
+    if (g_rt.private_stream == nullptr && !ok(hipStreamCreateWithFlags(&g_rt.private_stream, hipStreamNonBlocking))) {
+      return QNNP_HIP_ENOMEM;
+    }
+    if (!ok(hipDeviceSynchronize())) return QNNP_HIP_ELAUNCH;   // order after everything already enqueued
+    s = g_rt.private_stream;
+  }
+  if (!ok(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) {
+    (void) hipGetLastError();
+    return QNNP_HIP_ELAUNCH;
+  }
+  g_rt.saved_stream = g_rt.stream;
+  g_rt.stream = s;
+  g_rt.capturing = true;
+  return QNNP_HIP_OK;
+}
+
+struct Graph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  hipStream_t stream;                    // replay stream (the one it was captured on)
+};
+
+int qnnp_hip_graph_end(void** out)
+{
+  if (!g_rt.capturing || out == nullptr) return QNNP_HIP_EINVAL;
+  hipStream_t s = g_rt.stream;
+  g_rt.stream = g_rt.saved_stream;
+  g_rt.capturing = false;
+  hipGraph_t graph = nullptr;
+  if (!ok(hipStreamEndCapture(s, &graph)) || graph == nullptr) {
+    (void) hipGetLastError();
+    return QNNP_HIP_ELAUNCH;
+  }
+  hipGraphExec_t exec = nullptr;
+  if (!ok(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0))) {
+    (void) hipGetLastError();
+    (void) hipGraphDestroy(graph);
+    return QNNP_HIP_ENOMEM;
+  }
+  Graph* g = new (std::nothrow) Graph{graph, exec, s};
+  if (g == nullptr) {
+    (void) hipGraphExecDestroy(exec);
+    (void) hipGraphDestroy(graph);
+    return QNNP_HIP_ENOMEM;
+  }
+  *out = g;
+  return QNNP_HIP_OK;
+}
+
+int qnnp_hip_graph_launch(void* graph)
+{
+  Graph* g = static_cast<Graph*>(graph);
+  if (g == nullptr) return QNNP_HIP_EINVAL;
+  return ok(hipGraphLaunch(g->exec, g->stream)) ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+/* average milliseconds of one replay over `iters` replays after `warmup` untimed ones (events on the replay stream) */
+int qnnp_hip_graph_time(void* graph, int warmup, int iters, float* avg_ms)
+{
+  Graph* g = static_cast<Graph*>(graph);
+  if (g == nullptr || iters <= 0 || avg_ms == nullptr) return QNNP_HIP_EINVAL;
+  hipEvent_t e0, e1;
+  if (!ok(hipEventCreate(&e0))) return QNNP_HIP_ENOMEM;
+  if (!ok(hipEventCreate(&e1))) { (void) hipEventDestroy(e0); return QNNP_HIP_ENOMEM; }
+  bool good = true;
+  for (int i = 0; i < warmup && good; i++) good = ok(hipGraphLaunch(g->exec, g->stream));
+  good = good && ok(hipEventRecord(e0, g->stream));
+  for (int i = 0; i < iters && good; i++) good = ok(hipGraphLaunch(g->exec, g->stream));
+  good = good && ok(hipEventRecord(e1, g->stream)) && ok(hipEventSynchronize(e1));
+  float ms = 0.0f;
+  good = good && ok(hipEventElapsedTime(&ms, e0, e1));
+  (void) hipEventDestroy(e0);
+  (void) hipEventDestroy(e1);
+  if (!good) { (void) hipGetLastError(); return QNNP_HIP_ELAUNCH; }
+  *avg_ms = ms / static_cast<float>(iters);
+  return QNNP_HIP_OK;
+}
+
+int qnnp_hip_graph_sync(void* graph)
+{
+  Graph* g = static_cast<Graph*>(graph);
+  if (g == nullptr) return QNNP_HIP_EINVAL;
+  return ok(hipStreamSynchronize(g->stream)) ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+void qnnp_hip_graph_destroy(void* graph)
+{
+  Graph* g = static_cast<Graph*>(graph);
+  if (g == nullptr) return;
+  (void) hipGraphExecDestroy(g->exec);
+  (void) hipGraphDestroy(g->graph);
+  delete g;
 }
 
 void qnnp_hip_timer_destroy(void* timer)

@@ -25,6 +25,7 @@ struct qnnp_state qnnp_state = {
   .async = 0,
   .opt_gemm_kernel = 0,
   .opt_dwconv_kernel = 0,
+  .opt_timing_graph = 1,
 };
 
 static pthread_mutex_t init_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -141,6 +142,10 @@ enum qnnp_status qnnp_gfx950_set_option(const char* key, int value)
   if (key == NULL) return qnnp_status_invalid_parameter;
   if (strcmp(key, "gemm_kernel") == 0 && value >= 0 && value <= 7) {
     qnnp_state.opt_gemm_kernel = value;
+    return qnnp_status_success;
+  }
+  if (strcmp(key, "timing_graph") == 0 && (value == 0 || value == 1)) {
+    qnnp_state.opt_timing_graph = value;
     return qnnp_status_success;
   }
   if (strcmp(key, "dwconv_kernel") == 0 && value >= 0 && value <= 4) {

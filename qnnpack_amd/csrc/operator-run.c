@@ -143,6 +143,10 @@ enum qnnp_status qnnp_run_operator(qnnp_operator_t op, pthreadpool_t threadpool)
   const void* input = op->input;
   void* output = op->output;
   const int staged = !op->input_on_device || !op->output_on_device;
+  const int capturing = qnnp_hip_graph_capturing();
+  if (capturing && staged) {
+    return qnnp_status_invalid_parameter;  /* a graph can only hold device-pointer launches */
+  }
 
   if (!op->input_on_device) {
     if (qnnp_hip_h2d(op->d_stage_in, op->input, op->input_span, 1) != QNNP_HIP_OK) {
@@ -171,6 +175,9 @@ enum qnnp_status qnnp_run_operator(qnnp_operator_t op, pthreadpool_t threadpool)
       return qnnp_status_invalid_parameter;
     }
   }
+  if (capturing) {
+    return qnnp_status_success;            /* recorded into the graph; nothing has run yet */
+  }
   if (staged || !qnnp_state.async) {
     /* reference semantics: outputs are complete when run returns */
     return status_from_hip(qnnp_hip_stream_sync());
@@ -197,6 +204,31 @@ enum qnnp_status qnnp_gfx950_time_operator_rotating(
   for (size_t s = 0; s < nsets; s++) {
     if (!qnnp_hip_is_device_pointer(inputs[s]) || !qnnp_hip_is_device_pointer(outputs[s])) {
       return qnnp_status_invalid_parameter;
+    }
+  }
+  /* Preferred: record the `iters` launches into a hipGraph and time its replay -- one submission, so the
+   * figure is kernel time, not the host's per-launch dispatch gap (5-8 us, as large as the small layers).
+   * Falls back to a plain launch loop if the capture is refused. */
+  if (qnnp_state.opt_timing_graph && !qnnp_hip_graph_capturing() && qnnp_hip_graph_begin() == QNNP_HIP_OK) {
+    int rc = QNNP_HIP_OK;
+    size_t gset = 0;
+    for (int i = 0; i < iters && rc == QNNP_HIP_OK; i++) {
+      rc = launch(op, inputs[gset], outputs[gset]);
+      gset = (gset + 1) % nsets;
+    }
+    void* graph = NULL;
+    const int rc_end = qnnp_hip_graph_end(&graph);
+    if (rc == QNNP_HIP_OK && rc_end == QNNP_HIP_OK) {
+      float ms = 0.0f;
+      const int reps = warmup > 0 ? 1 : 0;
+      rc = qnnp_hip_graph_time(graph, reps, 1, &ms);
+      qnnp_hip_graph_destroy(graph);
+      if (rc == QNNP_HIP_OK) {
+        *avg_ms_out = ms / (float) iters;
+        return qnnp_status_success;
+      }
+    } else if (rc_end == QNNP_HIP_OK) {
+      qnnp_hip_graph_destroy(graph);
     }
   }
   void* timer = NULL;
@@ -233,4 +265,44 @@ enum qnnp_status qnnp_gfx950_time_operator(
   const void* in = op->input;
   void* out = op->output;
   return qnnp_gfx950_time_operator_rotating(op, 1, &in, &out, warmup, iters, avg_ms_out);
+}
+
+/* ---- qnnpack_gfx950.h graph capture ------------------------------------ */
+
+enum qnnp_status qnnp_gfx950_graph_begin(void)
+{
+  if (!qnnp_state.initialized) return qnnp_status_uninitialized;
+  return status_from_hip(qnnp_hip_graph_begin());
+}
+
+enum qnnp_status qnnp_gfx950_graph_end(void** graph_out)
+{
+  if (graph_out == NULL) return qnnp_status_invalid_parameter;
+  if (!qnnp_state.initialized) return qnnp_status_uninitialized;
+  return status_from_hip(qnnp_hip_graph_end(graph_out));
+}
+
+enum qnnp_status qnnp_gfx950_graph_launch(void* graph)
+{
+  if (graph == NULL) return qnnp_status_invalid_parameter;
+  const int rc = qnnp_hip_graph_launch(graph);
+  if (rc != QNNP_HIP_OK) return status_from_hip(rc);
+  return qnnp_state.async ? qnnp_status_success : status_from_hip(qnnp_hip_graph_sync(graph));
+}
+
+enum qnnp_status qnnp_gfx950_graph_time(void* graph, int warmup, int iters, float* avg_ms_out)
+{
+  if (graph == NULL || avg_ms_out == NULL || iters <= 0) return qnnp_status_invalid_parameter;
+  return status_from_hip(qnnp_hip_graph_time(graph, warmup, iters, avg_ms_out));
+}
+
+enum qnnp_status qnnp_gfx950_graph_synchronize(void* graph)
+{
+  if (graph == NULL) return qnnp_status_invalid_parameter;
+  return status_from_hip(qnnp_hip_graph_sync(graph));
+}
+
+void qnnp_gfx950_graph_destroy(void* graph)
+{
+  qnnp_hip_graph_destroy(graph);
 }

@@ -14,6 +14,7 @@ struct qnnp_state {
   int async;              /* 1: qnnp_run_operator only enqueues */
   int opt_gemm_kernel;    /* 0 auto, 1 generic, 2 big-tile */
   int opt_dwconv_kernel;  /* 0 auto, 1 generic, 2 LDS-tiled */
+  int opt_timing_graph;   /* 1: qnnp_gfx950_time_operator* replay a hipGraph of the launches (default) */
 };
 
 extern struct qnnp_state qnnp_state;
