@@ -97,7 +97,8 @@ __device__ __forceinline__ void igemm_stage_tile(
     const epi_v16i& acc, const int4 (&bias)[4], int32_t rowterm,
     uint8_t* lds_row,        /* LDS image + tile_row * pitch */
     uint32_t col0,           /* first channel of this 32-channel tile inside the workgroup tile */
-    uint32_t khalf, const IgemmParams& p)
+    uint32_t khalf, const IgemmParams& p,
+    bool write_ok = true)    /* false: take part in the half-wave exchange (all 64 lanes must), write nothing */
 {
   uint32_t pk[4];
 #pragma unroll
@@ -117,7 +118,9 @@ __device__ __forceinline__ void igemm_stage_tile(
   }
   const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
   const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
-  *reinterpret_cast<uint4*>(lds_row + col0 + khalf * 16) = make_uint4(s02[0], s02[1], s13[0], s13[1]);
+  if (write_ok) {
+    *reinterpret_cast<uint4*>(lds_row + col0 + khalf * 16) = make_uint4(s02[0], s02[1], s13[0], s13[1]);
+  }
 }
 
 /* Stream a staged [rows_valid][n_valid] uint8 tile (LDS, row pitch `pitch`) to global memory. */

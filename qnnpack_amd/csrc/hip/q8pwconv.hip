@@ -47,7 +47,7 @@ constexpr uint32_t kMaxLds = 64 * 1024;     // weights + bias: two workgroups pe
 
 /* KB = 32-deep K blocks (k_total <= 32 * KB); VEC = bytes per activation load (16, or 8 when rows are
  * only 8-byte aligned, e.g. 24 channels) */
-template <int KB, int VEC>
+template <int KB, int VEC, bool STAGED>
 __global__ __launch_bounds__(kThreads, (KB <= 5) ? 4 : 2)
 void q8_pw_stream_mfma_kernel(const IgemmParams p)
 {
@@ -86,6 +86,8 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
   __syncthreads();
   const uint8_t* lds_w = lds + lane * 16;
   const int4* lds_bias4 = reinterpret_cast<const int4*>(lds + nblocks * KB * 1024);
+  // per-wave image of a unit's 32 x n output block (store_mode 3 only; the launcher sizes it)
+  uint8_t* stage = lds + nblocks * KB * 1024 + ((p.n_pad * 4u + 1023u) & ~1023u) + wave * (32u * p.n);
 
   // ---- which of this lane's 16-byte K pieces exist (only the last block can be short) ----
   const uint8_t* pad16 = p.fill_table + 0x80 * 16;        // 16 bytes of a' == 0
@@ -181,8 +183,41 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
         }
       };
 
-      // direct 16-byte stores (32 rows x 32 bytes per instruction). Staging four blocks through LDS to store
-      // whole 128-byte lines was measured: 5 % faster on the widest-output layer, 15-30 % slower on the rest.
+      // Stores. A direct 16-byte store per lane writes 32 rows x 32 bytes per instruction: the L2 sees
+      // 32-byte partial-line writes, and that stream alone runs at 2.8 TB/s (55 us on the 16 -> 96 layer against
+      // 34 us for the same bytes stored contiguously -- ablation). With DENSE rows (stride == channels) the
+      // 32 x n block of a unit is one contiguous run of memory, so the wave drops its requantized 16-byte
+      // pieces into a private LDS image of it (ds_write_b128 in place of the global store) and copies the image
+      // out LINEARLY, 1 KiB per instruction: one ds_read_b128 + one global store per KiB extra.
+      if constexpr (STAGED) {
+        uint8_t* img = stage + row_in_block * p.n;
+        for (uint32_t nb = 0; nb < nblocks; nb++) {
+          v16i acc;
+          multiply(nb, acc);
+          // (every lane takes part in the half-wave exchange inside; n % 16 == 0: a lane's 16 channels exist or not)
+          igemm_stage_tile<decltype(shift0)::value, decltype(full)::value, false, true>(
+              acc, bias4, 0, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < p.n);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
+        const uint32_t rows_here = min(32u, p.rows - unit * 32u);
+        const uint32_t bytes = rows_here * p.n;
+        uint8_t* blk = p.output + static_cast<uint64_t>(unit) * 32u * p.n;
+        for (uint32_t o = lane * 16; o < bytes; o += 1024) {
+          *reinterpret_cast<uint4*>(blk + o) = *reinterpret_cast<const uint4*>(stage + o);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // read back before the next unit overwrites it
+        continue;
+      }
+#ifdef QNNP_ENABLE_ABLATION
+      if (p.izp_fill & 4u) {                              // measurement: CONTIGUOUS stores only (dense rows assumed)
+        uint8_t* blk = p.output + static_cast<uint64_t>(unit) * 32u * p.output_stride;
+        const uint32_t bytes = 32u * p.output_stride;
+        for (uint32_t o = lane * 16; o + 16 <= bytes; o += 1024) {
+          if (unit * 32u + 32u <= p.rows) *reinterpret_cast<uint4*>(blk + o) = make_uint4(a[0].x, a[0].y, a[0].z, a[0].w);
+        }
+        continue;
+      }
+#endif
       for (uint32_t nb = 0; nb < nblocks; nb++) {
         v16i acc;
 #ifdef QNNP_ENABLE_ABLATION
@@ -417,11 +452,11 @@ void q8_conv_stream_c3_kernel(const IgemmParams p)
   });
 }
 
-template <int KB, int VEC>
+template <int KB, int VEC, bool STAGED>
 int launch_pw(const IgemmParams& p, uint32_t lds_bytes, hipStream_t stream)
 {
   static int blocks_per_cu = 0;       // per instantiation; benign race (same value)
-  auto kernel = q8_pw_stream_mfma_kernel<KB, VEC>;
+  auto kernel = q8_pw_stream_mfma_kernel<KB, VEC, STAGED>;
   if (blocks_per_cu == 0) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     blocks_per_cu = (KB <= 5) ? 4 : 2;
@@ -448,18 +483,18 @@ int launch_pw(const IgemmParams& p, uint32_t lds_bytes, hipStream_t stream)
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
-template <int VEC>
+template <int VEC, bool STAGED>
 int dispatch_kb(const IgemmParams& p, uint32_t kb, uint32_t lds_bytes, hipStream_t stream)
 {
   switch (kb) {
-    case 1: return launch_pw<1, VEC>(p, lds_bytes, stream);
-    case 2: return launch_pw<2, VEC>(p, lds_bytes, stream);
-    case 3: return launch_pw<3, VEC>(p, lds_bytes, stream);
-    case 4: return launch_pw<4, VEC>(p, lds_bytes, stream);
-    case 5: return launch_pw<5, VEC>(p, lds_bytes, stream);
-    case 6: return launch_pw<6, VEC>(p, lds_bytes, stream);
-    case 7: return launch_pw<7, VEC>(p, lds_bytes, stream);
-    default: return launch_pw<8, VEC>(p, lds_bytes, stream);
+    case 1: return launch_pw<1, VEC, STAGED>(p, lds_bytes, stream);
+    case 2: return launch_pw<2, VEC, STAGED>(p, lds_bytes, stream);
+    case 3: return launch_pw<3, VEC, STAGED>(p, lds_bytes, stream);
+    case 4: return launch_pw<4, VEC, STAGED>(p, lds_bytes, stream);
+    case 5: return launch_pw<5, VEC, STAGED>(p, lds_bytes, stream);
+    case 6: return launch_pw<6, VEC, STAGED>(p, lds_bytes, stream);
+    case 7: return launch_pw<7, VEC, STAGED>(p, lds_bytes, stream);
+    default: return launch_pw<8, VEC, STAGED>(p, lds_bytes, stream);
   }
 }
 
@@ -524,12 +559,23 @@ int pwstream_gw_launch(const IgemmParams& p, hipStream_t stream, const char** na
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
-int pwstream_launch(const IgemmParams& p, uint32_t vec, hipStream_t stream, const char** name)
+int pwstream_launch(const IgemmParams& p0, uint32_t vec, hipStream_t stream, const char** name)
 {
+  IgemmParams p = p0;
   const uint32_t kb = (p.k_total + 31u) / 32u;
-  const uint32_t lds_bytes = pw_lds_bytes(p);
+  uint32_t lds_bytes = pw_lds_bytes(p);
+  // dense 16-byte-aligned rows wider than one 32-channel block: stage the unit's output block per wave and
+  // store it contiguously ("store_mode 3", private to this kernel), if the images fit beside the weights
+  const uint32_t stage_bytes = kWaves * 32u * p.n;
+  if (p.store_mode == 2 && p.output_stride == p.n && p.n > 32 && p.n <= 256 && lds_bytes + stage_bytes <= kMaxLds) {
+    p.store_mode = 3;
+    lds_bytes += stage_bytes;
+  }
   *name = "q8_pw_stream_mfma";
-  return vec == 16 ? dispatch_kb<16>(p, kb, lds_bytes, stream) : dispatch_kb<8>(p, kb, lds_bytes, stream);
+  if (p.store_mode == 3) {
+    return vec == 16 ? dispatch_kb<16, true>(p, kb, lds_bytes, stream) : dispatch_kb<8, true>(p, kb, lds_bytes, stream);
+  }
+  return vec == 16 ? dispatch_kb<16, false>(p, kb, lds_bytes, stream) : dispatch_kb<8, false>(p, kb, lds_bytes, stream);
 }
 
 }  // namespace qnnp
