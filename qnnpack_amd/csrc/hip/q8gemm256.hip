@@ -509,6 +509,43 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
   // ---- fused epilogue (igemm_epilogue.cuh); the requantization flavour is chosen once ----
   const uint32_t raw_to_centred = 128u * p.k_pad;      // sum(a') = sum(a) - 128 * k_pad
   requant_dispatch(p.rq, [&](auto shift0, auto full) {
+    if (p.store_mode == 2) {
+      // 16-byte aligned rows: a wave's (kTM*32) x 128-byte sub-tile is requantized into a private image in the
+      // (now idle) LDS ring and leaves as WHOLE 128-byte lines, eight rows per store instruction. Direct
+      // 16-byte stores would put 32-byte partial-line writes on the L2 (2.8 TB/s against 5+ for whole lines,
+      // measured on the pointwise kernel).
+      constexpr uint32_t kPitch = kTN * 32 + 16;           // +16: the 8-lane ds_write_b128 groups hit distinct banks
+      uint8_t* image = lds + wave * (kTM * 32 * kPitch);
+#pragma unroll
+      for (int tn = 0; tn < kTN; tn++) {
+        const uint32_t nb = nb0 + wn * kTN + tn;
+        if constexpr (kWM != 4) { if (tn > 0) load_bias(tn, bias4[0]); }
+        if (nb >= nblocks) continue;                       // wave-uniform
+#pragma unroll
+        for (int tm = 0; tm < kTM; tm++) {
+          const uint32_t row = frag_row0 + tm * 32;
+          const int32_t rowterm = p.row_coeff *
+              static_cast<int32_t>(static_cast<uint32_t>(lds_rowsum[row]) + static_cast<uint32_t>(lds_rowsum[kBM + row]) - raw_to_centred);
+          igemm_stage_tile<decltype(shift0)::value, decltype(full)::value, (ABL & 1) != 0>(
+              acc[tm][tn], bias4[kWM == 4 ? tn : 0], rowterm, image + (tm * 32 + (lane & 31u)) * kPitch, tn * 32, frag_khalf, p);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
+      const uint32_t m0 = m_tile * kBM + wm * (kTM * 32);
+      const uint32_t n0 = (nb0 + wn * kTN) * 32;
+      uint8_t* out0 = p.output + static_cast<uint64_t>(m0) * p.output_stride + static_cast<uint64_t>(g) * p.n + n0;
+#pragma unroll
+      for (int i = 0; i < (kTM * 32 * kTN * 2) / 64; i++) {
+        const uint32_t idx = i * 64 + lane;
+        const uint32_t r = idx / (kTN * 2);
+        const uint32_t c = idx % (kTN * 2);
+        const uint4 v = *reinterpret_cast<const uint4*>(image + r * kPitch + c * 16);
+        if (m0 + r < p.rows && n0 + c * 16 < p.n) {
+          *reinterpret_cast<uint4*>(out0 + static_cast<uint64_t>(r) * p.output_stride + c * 16) = v;
+        }
+      }
+      return;
+    }
     if constexpr (kWM == 4) {
 #pragma unroll
       for (int tm = 0; tm < kTM; tm++) {
