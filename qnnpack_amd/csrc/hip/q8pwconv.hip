@@ -363,24 +363,32 @@ void q8_conv_stream_c3_kernel(const IgemmParams p)
   const uint32_t fillpix = p.izp_fill;                     // {izp, izp, izp, 0x80}: padding tap, 4th byte = K padding
   const uint32_t raw_to_centred = 128u * 32u * KB;
 
-  // gather the lane's taps (kb*8 + khalf*4 + j, j = 0..3) of output pixel m
-  auto load_taps = [&](uint32_t unit, v4i (&a)[KB]) __attribute__((always_inline)) {
+  // The gather is two dependent loads (offset-table entry, then the pixel). They are split so that the table
+  // entries of unit u+2 and the pixels of unit u+1 are in flight while unit u is multiplied: no load waits on
+  // another one issued in the same iteration.
+  struct Taps { int32_t off[KB * 4]; const uint8_t* base; };
+  auto load_offsets = [&](uint32_t unit, Taps& t) __attribute__((always_inline)) {
     uint32_t m = unit * 32u + row_in_block;
     if (m >= p.rows) m = p.rows - 1;                       // clamped rows are never stored
     const uint32_t img = m / p.rows_per_image;
     const uint32_t pix = m - img * p.rows_per_image;
-    const uint8_t* base = p.input + static_cast<uint64_t>(img) * p.image_stride;
+    t.base = p.input + static_cast<uint64_t>(img) * p.image_stride;
     const int32_t* offs = p.offsets + static_cast<uint64_t>(pix) * p.ks;
+#pragma unroll
+    for (int i = 0; i < KB * 4; i++) {
+      const uint32_t tap = (i >> 2) * 8 + khalf * 4 + (i & 3);     // kb*8 + khalf*4 + j
+      t.off[i] = tap < p.ks ? offs[tap] : -2;                      // -2: beyond the kernel (K padding), -1: padding tap
+    }
+  };
+  auto load_pixels = [&](const Taps& t, v4i (&a)[KB]) __attribute__((always_inline)) {
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) {
       uint32_t v[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const uint32_t t = kb * 8 + khalf * 4 + j;
-        const bool tap = t < p.ks;
-        const int32_t off = offs[tap ? t : 0u];
-        const bool inside = tap && off >= 0;
-        const uint8_t* src = base + (inside ? off : 0);
+        const int32_t off = t.off[kb * 4 + j];
+        const bool inside = off >= 0;
+        const uint8_t* src = t.base + (inside ? off : 0);
         uint32_t x;
         if (src + 4 <= p.input_end) {
           x = *reinterpret_cast<const pw_u32_unaligned*>(src);
@@ -388,7 +396,7 @@ void q8_conv_stream_c3_kernel(const IgemmParams p)
           x = static_cast<uint32_t>(src[0]) | (static_cast<uint32_t>(src[1]) << 8) | (static_cast<uint32_t>(src[2]) << 16);
         }
         x = (x & 0x00FFFFFFu) | 0x80000000u;               // the slot's 4th byte is K padding: a' == 0
-        v[j] = tap ? (inside ? x : fillpix) : 0x80808080u;
+        v[j] = inside ? x : (off == -1 ? fillpix : 0x80808080u);
       }
       a[kb] = v4i{static_cast<int>(v[0]), static_cast<int>(v[1]), static_cast<int>(v[2]), static_cast<int>(v[3])};
     }
@@ -396,14 +404,22 @@ void q8_conv_stream_c3_kernel(const IgemmParams p)
 
   uint32_t unit = blockIdx.x * kWaves + wave;
   v4i a_next[KB];
-  if (unit < units) load_taps(unit, a_next);
+  Taps t_next;
+  if (unit < units) {
+    load_offsets(unit, t_next);
+    load_pixels(t_next, a_next);
+    if (unit + unit_stride < units) load_offsets(unit + unit_stride, t_next);
+  }
 
   requant_dispatch(p.rq, [&](auto shift0, auto full) {
     for (; unit < units; unit += unit_stride) {
       v4i a[KB];
 #pragma unroll
       for (int kb = 0; kb < KB; kb++) a[kb] = a_next[kb];
-      if (unit + unit_stride < units) load_taps(unit + unit_stride, a_next);
+      if (unit + unit_stride < units) {
+        load_pixels(t_next, a_next);                       // offsets landed one iteration ago
+        if (unit + 2 * unit_stride < units) load_offsets(unit + 2 * unit_stride, t_next);
+      }
 
       uint32_t rs = 0;
 #pragma unroll
