@@ -81,9 +81,8 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
           (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(p.bias2) + c * 16),
           (__attribute__((address_space(3))) void*) (lds_bias + c0 * 16), 16, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (no wait here: the first row block's loads are issued first, so both latencies overlap)
   }
-  __syncthreads();
   const uint8_t* lds_w = lds + lane * 16;
   const int4* lds_bias4 = reinterpret_cast<const int4*>(lds + nblocks * KB * 1024);
   // per-wave image of a unit's 32 x n output block (store_mode 3 only; the launcher sizes it)
@@ -128,6 +127,8 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
   uint32_t unit = blockIdx.x * kWaves + wave;
   v4i a_next[KB];
   if (unit < units) load_rows(unit, a_next);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // weights + bias are in LDS (and the first rows landed)
+  __syncthreads();
 
   requant_dispatch(p.rq, [&](auto shift0, auto full) {
     for (; unit < units; unit += unit_stride) {
@@ -352,9 +353,8 @@ void q8_conv_stream_c3_kernel(const IgemmParams p)
           (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(p.bias2) + c * 16),
           (__attribute__((address_space(3))) void*) (lds_bias + c0 * 16), 16, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (no wait here: the first unit's gather is issued first, so the latencies overlap)
   }
-  __syncthreads();
   const uint8_t* lds_w = lds + lane * 16;
   const int4* lds_bias4 = reinterpret_cast<const int4*>(lds + nblocks * KB * 1024);
 
@@ -410,6 +410,8 @@ void q8_conv_stream_c3_kernel(const IgemmParams p)
     load_pixels(t_next, a_next);
     if (unit + unit_stride < units) load_offsets(unit + unit_stride, t_next);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // weights + bias are in LDS
+  __syncthreads();
 
   requant_dispatch(p.rq, [&](auto shift0, auto full) {
     for (; unit < units; unit += unit_stride) {
