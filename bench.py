@@ -313,6 +313,15 @@ def main():
     roofline = {"bound": "mfma", "kernel": gemm_kernel, "achieved": round(achieved, 2), "peak": round(PEAK_I8_TOPS, 1),
                 "unit": "TOP/s", "frac": round(achieved / PEAK_I8_TOPS, 4), "traffic": traffic,
                 "launch_ms": round(ev_ms, 5), "algorithmic_bytes_per_launch": 3 * M * N + 4 * N}
+    if rank == 0:
+        # the bare-MFMA rate of this very chip, measured in this process: with random operands the power
+        # management holds a lower clock, so this -- not the nominal peak -- is what a kernel can reach at best
+        try:
+            roofline["mfma_only_random_operands"] = round(lib.mfma_probe(True, 6400), 1)
+            roofline["mfma_only_zero_operands"] = round(lib.mfma_probe(False, 6400), 1)
+            roofline["frac_of_mfma_only_random"] = round(achieved / roofline["mfma_only_random_operands"], 4)
+        except Exception as exc:  # noqa: BLE001
+            print(f"# mfma probe failed: {exc}", file=sys.stderr)
     lib.delete_operator(op)
     del a, c
 

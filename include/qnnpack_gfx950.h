@@ -61,6 +61,12 @@ enum qnnp_status qnnp_gfx950_time_operator_rotating(
     qnnp_operator_t op, size_t nsets, const void* const* inputs, void* const* outputs,
     int warmup, int iters, float* avg_ms_out);
 
+/* Diagnostic: the int8 rate (TOP/s) the whole chip sustains on a bare v_mfma_i32_32x32x32_i8 loop -- no LDS, no
+ * memory traffic -- with zero (random_operands = 0) or random operand data. On MI355X the two differ by ~30 %
+ * (power management lowers the clock on random data): the random figure is the practical ceiling a GEMM's
+ * fraction of the nominal peak should be read against. `iters` loop trips of 8 MFMAs per wave (12800 = ~4 ms). */
+enum qnnp_status qnnp_gfx950_mfma_probe(int random_operands, int iters, float* tops_out);
+
 /* hipGraph capture: between begin and end, qnnp_run_operator only RECORDS its launch (device pointers only; a
  * host-pointer operator returns invalid_parameter). The graph replays the whole sequence -- e.g. every layer of
  * a network -- as one submission: no per-launch dispatch gap, which on MI355X is as long as the small layers

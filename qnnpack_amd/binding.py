@@ -210,6 +210,8 @@ class Gfx950Library(QnnpackLibrary):
         L.qnnp_gfx950_graph_time.argtypes = [c_void_p, c_int, c_int, POINTER(c_float)]
         L.qnnp_gfx950_graph_destroy.restype = None
         L.qnnp_gfx950_graph_destroy.argtypes = [c_void_p]
+        L.qnnp_gfx950_mfma_probe.restype = c_int
+        L.qnnp_gfx950_mfma_probe.argtypes = [c_int, c_int, POINTER(c_float)]
         L.qnnp_gfx950_set_option.restype = c_int
         L.qnnp_gfx950_set_option.argtypes = [c_char_p, c_int]
         L.qnnp_gfx950_operator_kernel.restype = c_char_p
@@ -295,6 +297,12 @@ class Gfx950Library(QnnpackLibrary):
 
     def graph_destroy(self, graph: int) -> None:
         self.lib.qnnp_gfx950_graph_destroy(graph)
+
+    def mfma_probe(self, random_operands: bool, iters: int = 12800) -> float:
+        tops = c_float(0.0)
+        self._check("qnnp_gfx950_mfma_probe",
+                    self.lib.qnnp_gfx950_mfma_probe(1 if random_operands else 0, iters, ctypes.byref(tops)))
+        return float(tops.value)
 
     def set_option(self, key: str, value: int) -> None:
         self._check("qnnp_gfx950_set_option", self.lib.qnnp_gfx950_set_option(key.encode(), value))

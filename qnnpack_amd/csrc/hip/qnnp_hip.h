@@ -66,6 +66,9 @@ int qnnp_hip_timer_start(void* timer);
 int qnnp_hip_timer_stop_ms(void* timer, float* ms);
 void qnnp_hip_timer_destroy(void* timer);
 
+/* diagnostic: sustained rate (TOP/s) of a bare v_mfma_i32_32x32x32_i8 loop over `compute_units` workgroups */
+int qnnp_hip_mfma_probe(int random_operands, int iters, int compute_units, float* tops_out);
+
 /* hipGraph capture of operator launches on the library stream (a private stream stands in for the default
  * stream, which cannot be captured); replay = one submission, no per-launch gaps */
 int qnnp_hip_graph_capturing(void);

@@ -306,3 +306,14 @@ void qnnp_gfx950_graph_destroy(void* graph)
 {
   qnnp_hip_graph_destroy(graph);
 }
+
+/* ---- qnnpack_gfx950.h diagnostics --------------------------------------- */
+
+enum qnnp_status qnnp_gfx950_mfma_probe(int random_operands, int iters, float* tops_out)
+{
+  if (tops_out == NULL || iters <= 0) return qnnp_status_invalid_parameter;
+  if (!qnnp_state.initialized) return qnnp_status_uninitialized;
+  int cus = 0;
+  if (qnnp_hip_device_info(NULL, 0, &cus, NULL, NULL) != QNNP_HIP_OK || cus <= 0) return qnnp_status_unsupported_hardware;
+  return status_from_hip(qnnp_hip_mfma_probe(random_operands, iters, cus, tops_out));
+}
