@@ -29,9 +29,10 @@ namespace qnnp {
 
 typedef int epi_v16i __attribute__((ext_vector_type(16)));
 
-/* PRE_BIASED: the accumulator was INITIALISED with bias + row term (the MFMA adds into it), so the epilogue
- * skips those two adds per value; `bias` / `rowterm` are then ignored. */
-template <bool SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false, bool PRE_BIASED = false>
+/* PRE_BIASED: what the accumulator was INITIALISED with (the MFMA adds into it), i.e. which adds the epilogue
+ * skips: 0 = nothing (add bias and row term here), 1 = bias + row term (`bias` / `rowterm` ignored),
+ * 2 = bias only (add the row term here; `bias` ignored). */
+template <bool SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false, int PRE_BIASED = 0>
 __device__ __forceinline__ void igemm_store_tile(
     const epi_v16i& acc, const int4 (&bias)[4], int32_t rowterm,
     uint8_t* out_row,        /* output + m*stride + g*n */
@@ -44,11 +45,13 @@ __device__ __forceinline__ void igemm_store_tile(
 #pragma unroll
   for (int rg = 0; rg < 4; rg++) {
     int32_t v0 = acc[rg * 4 + 0], v1 = acc[rg * 4 + 1], v2 = acc[rg * 4 + 2], v3 = acc[rg * 4 + 3];
-    if constexpr (!PRE_BIASED) {
+    if constexpr (PRE_BIASED == 0) {
       v0 += rowterm + bias[rg].x;
       v1 += rowterm + bias[rg].y;
       v2 += rowterm + bias[rg].z;
       v3 += rowterm + bias[rg].w;
+    } else if constexpr (PRE_BIASED == 2) {
+      v0 += rowterm; v1 += rowterm; v2 += rowterm; v3 += rowterm;
     }
     if constexpr (NO_REQUANT) {
       pk[rg] = static_cast<uint32_t>(v0 ^ v1 ^ v2 ^ v3);   // measurement-only ablation
@@ -92,7 +95,7 @@ __device__ __forceinline__ void igemm_store_tile(
  * of a row, so full 128-byte lines (whole rows, for dense NHWC outputs) leave in one request.
  * `pitch` = tile width in bytes + 16 keeps the 8-lane ds_write_b128 groups on distinct banks.
  */
-template <bool SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false, bool PRE_BIASED = false>
+template <bool SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false, int PRE_BIASED = 0>
 __device__ __forceinline__ void igemm_stage_tile(
     const epi_v16i& acc, const int4 (&bias)[4], int32_t rowterm,
     uint8_t* lds_row,        /* LDS image + tile_row * pitch */
@@ -104,11 +107,13 @@ __device__ __forceinline__ void igemm_stage_tile(
 #pragma unroll
   for (int rg = 0; rg < 4; rg++) {
     int32_t v0 = acc[rg * 4 + 0], v1 = acc[rg * 4 + 1], v2 = acc[rg * 4 + 2], v3 = acc[rg * 4 + 3];
-    if constexpr (!PRE_BIASED) {
+    if constexpr (PRE_BIASED == 0) {
       v0 += rowterm + bias[rg].x;
       v1 += rowterm + bias[rg].y;
       v2 += rowterm + bias[rg].z;
       v3 += rowterm + bias[rg].w;
+    } else if constexpr (PRE_BIASED == 2) {
+      v0 += rowterm; v1 += rowterm; v2 += rowterm; v3 += rowterm;
     }
     if constexpr (NO_REQUANT) {
       pk[rg] = static_cast<uint32_t>(v0 ^ v1 ^ v2 ^ v3);

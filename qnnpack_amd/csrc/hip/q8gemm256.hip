@@ -216,13 +216,26 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
     for (int piece = 0; piece < kDma; piece++) stage_piece(kt, piece);
   };
 
+  // Accumulators start at the folded bias (the MFMAs add into them): the loads ride under the prologue's DMA
+  // wait instead of sitting exposed after the main loop, and the epilogue saves one add per value.
   v16i acc[kTM][kTN];
 #pragma unroll
-  for (int tm = 0; tm < kTM; tm++)
+  for (int tn = 0; tn < kTN; tn++) {
+    uint32_t nbb = n_tile * (kBN / 32) + wn * kTN + tn;
+    if (nbb >= nblocks) nbb = nblocks - 1;       // clamped blocks are never stored
 #pragma unroll
-    for (int tn = 0; tn < kTN; tn++)
+    for (int rg = 0; rg < 4; rg++) {
+      const uint32_t ncol = nbb * 32 + rg * 8 + (lane >> 5) * 4;
+      const int4 b = *reinterpret_cast<const int4*>(p.bias2 + static_cast<uint64_t>(g) * p.n_pad + ncol);
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0;
+      for (int tm = 0; tm < kTM; tm++) {
+        acc[tm][tn][rg * 4 + 0] = b.x;
+        acc[tm][tn][rg * 4 + 1] = b.y;
+        acc[tm][tn][rg * 4 + 2] = b.z;
+        acc[tm][tn][rg * 4 + 3] = b.w;
+      }
+    }
+  }
   uint32_t rs[kTM];
 #pragma unroll
   for (int tm = 0; tm < kTM; tm++) rs[tm] = 0;
@@ -476,25 +489,7 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 #undef QNNP_PIN
 
   QNNP_TRACE(p, blockIdx.x, 0, 2);
-  // ---- bias for this lane's 4-channel groups (issued before the barrier so the latency hides);
-  //      the 4-wave flavour has no registers to hold all of it and loads one 32-channel block at a time ----
-  constexpr int kBiasSets = kWM == 4 ? kTN : 1;
-  int4 bias4[kBiasSets][4];
-  auto load_bias = [&](int tn, int4 (&dst)[4]) __attribute__((always_inline)) {
-    uint32_t nb = nb0 + wn * kTN + tn;
-    if (nb >= nblocks) nb = nblocks - 1;       // clamped blocks are never stored
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) {
-      const uint32_t ncol = nb * 32 + rg * 8 + frag_khalf * 4;
-      dst[rg] = *reinterpret_cast<const int4*>(p.bias2 + static_cast<uint64_t>(g) * p.n_pad + ncol);
-    }
-  };
-  if constexpr (kWM == 4) {
-#pragma unroll
-    for (int tn = 0; tn < kTN; tn++) load_bias(tn, bias4[tn]);
-  } else {
-    load_bias(0, bias4[0]);
-  }
+  const int4 no_bias[4] = {};                 // (the bias is already in the accumulators)
 
   // ---- combine the row sums: 2 K halves (lane, lane+32) then the 2 channel-waves ----
 #pragma unroll
@@ -519,15 +514,14 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 #pragma unroll
       for (int tn = 0; tn < kTN; tn++) {
         const uint32_t nb = nb0 + wn * kTN + tn;
-        if constexpr (kWM != 4) { if (tn > 0) load_bias(tn, bias4[0]); }
         if (nb >= nblocks) continue;                       // wave-uniform
 #pragma unroll
         for (int tm = 0; tm < kTM; tm++) {
           const uint32_t row = frag_row0 + tm * 32;
           const int32_t rowterm = p.row_coeff *
               static_cast<int32_t>(static_cast<uint32_t>(lds_rowsum[row]) + static_cast<uint32_t>(lds_rowsum[kBM + row]) - raw_to_centred);
-          igemm_stage_tile<decltype(shift0)::value, decltype(full)::value, (ABL & 1) != 0>(
-              acc[tm][tn], bias4[kWM == 4 ? tn : 0], rowterm, image + (tm * 32 + (lane & 31u)) * kPitch, tn * 32, frag_khalf, p);
+          igemm_stage_tile<decltype(shift0)::value, decltype(full)::value, (ABL & 1) != 0, 2>(
+              acc[tm][tn], no_bias, rowterm, image + (tm * 32 + (lane & 31u)) * kPitch, tn * 32, frag_khalf, p);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
@@ -558,8 +552,8 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
         for (int tn = 0; tn < kTN; tn++) {
           const uint32_t nb = nb0 + wn * kTN + tn;
           if (nb >= nblocks) continue;       // wave-uniform
-          igemm_store_tile<decltype(shift0)::value, decltype(full)::value, (ABL & 1) != 0>(
-              acc[tm][tn], bias4[tn], rowterm, out_row, nb * 32, frag_khalf, m < p.rows, p);
+          igemm_store_tile<decltype(shift0)::value, decltype(full)::value, (ABL & 1) != 0, 2>(
+              acc[tm][tn], no_bias, rowterm, out_row, nb * 32, frag_khalf, m < p.rows, p);
         }
       }
     } else {
@@ -573,14 +567,13 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 #pragma unroll
       for (int tn = 0; tn < kTN; tn++) {
         const uint32_t nb = nb0 + wn * kTN + tn;
-        if (tn > 0) load_bias(tn, bias4[0]);
         if (nb >= nblocks) continue;         // wave-uniform
 #pragma unroll
         for (int tm = 0; tm < kTM; tm++) {
           const uint32_t m = m_tile * kBM + frag_row0 + tm * 32;
           uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride + static_cast<uint64_t>(g) * p.n;
-          igemm_store_tile<decltype(shift0)::value, decltype(full)::value, (ABL & 1) != 0>(
-              acc[tm][tn], bias4[0], rowterm[tm], out_row, nb * 32, frag_khalf, m < p.rows, p);
+          igemm_store_tile<decltype(shift0)::value, decltype(full)::value, (ABL & 1) != 0, 2>(
+              acc[tm][tn], no_bias, rowterm[tm], out_row, nb * 32, frag_khalf, m < p.rows, p);
         }
       }
     }
