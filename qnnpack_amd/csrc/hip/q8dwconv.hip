@@ -122,7 +122,10 @@ void q8_dwconv_direct_kernel(const DwParams p)
 // --------------------------------------------------------------------------
 // Kernel A: LDS-tiled
 // --------------------------------------------------------------------------
-constexpr int kDwThreads = 512;
+#ifndef QNNP_DW_THREADS
+#define QNNP_DW_THREADS 512
+#endif
+constexpr int kDwThreads = QNNP_DW_THREADS;
 
 /*
  * LDS image of the staged band: [input row][4-channel group][column] dwords, i.e. for one row and one
