@@ -421,7 +421,6 @@ void q8_dwconv_row3x3_kernel(const DwParams p)
     if (p.trace != nullptr) { asm volatile("" :: "v"(w0[0]), "v"(w1[1]), "v"(w2[2])); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
     QNNP_DW_TRACE(p, 2);
-#pragma unroll 4
     for (uint32_t ox = ox0; ox < ox1; ox++) {
       // next step's new columns; a wave takes the checked path if any of its lanes touches a border
       const int32_t nx = ix + 3;
@@ -511,7 +510,7 @@ int launch_row(const DwParams& p, hipStream_t stream)
 }
 
 // --------------------------------------------------------------------------
-// Kernel D: matrix cores, any kernel size / stride / dilation, C % 16 == 0
+// Kernel D: matrix cores, 3x3, any stride / dilation, C % 16 == 0
 // --------------------------------------------------------------------------
 /*
  * The VALU formulations above spend ~23 instructions per output (PMC: the kernel is 60-70 % VALU-busy and
@@ -650,7 +649,7 @@ void q8_dwconv_mfma_kernel(const DwParams p)
 bool plan_mfma(const DwParams& p, const struct qnnp_hip_dwconv_args* a)
 {
   if (a->dwm_x == nullptr || a->dwm_bias == nullptr || a->dwm_parts < 1 || a->dwm_parts > 3) return false;
-  if (!((p.KH == 3 && p.KW == 3) || (p.KH == 5 && p.KW == 5))) return false;
+  if (!(p.KH == 3 && p.KW == 3)) return false;     // (25 taps x 4 operand registers do not fit beside the accumulators)
   if (p.C % 16 != 0 || p.in_stride % 16 != 0 || reinterpret_cast<uintptr_t>(p.input) % 16 != 0) return false;
   const uint64_t in_bytes = static_cast<uint64_t>(p.batch) * p.H * p.W * p.in_stride;
   const uint64_t out_px = static_cast<uint64_t>(p.batch) * p.OH * p.OW;
@@ -787,8 +786,8 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
   else if (p.C % 4 == 0 && p.out_stride % 4 == 0 && out_addr % 4 == 0) p.store_mode = 1;
   if (a->variant == 4) {
     if (!plan_mfma(p, a)) return QNNP_HIP_EINVAL;
-    if (kernel_name != nullptr) *kernel_name = k33 ? "q8_dwconv_mfma_3x3" : "q8_dwconv_mfma_5x5";
-    return k33 ? launch_mfma<3, 3>(p, stream) : launch_mfma<5, 5>(p, stream);
+    if (kernel_name != nullptr) *kernel_name = "q8_dwconv_mfma_3x3";
+    return launch_mfma<3, 3>(p, stream);
   }
   // Order of preference (same-box A/B over the MobileNetV2 layers: the LDS-tiled and the sliding-window
   // kernel are within +-10 % of each other, LDS ahead on the small late layers): LDS-tiled, then the
