@@ -89,7 +89,8 @@ void qnnp_gfx950_graph_destroy(void* graph);
  *                    6 = its global-operand flavour (one wave per 32x32 block; small problems with long K),
  *                    7 = its 3-channel-image convolution flavour (first layers; in-register tap gather)
  *   "dwconv_kernel": 0 = auto, 1 = generic direct kernel, 2 = LDS-tiled kernel, 3 = register sliding-window kernel (3x3),
- *                    4 = matrix-core kernel (diagonal MFMA operands; 3x3, channels % 16 == 0)
+ *                    4 = matrix-core kernel (diagonal MFMA operands; 3x3, channels % 16 == 0), tap operands gathered
+ *                        from global memory, 5 = the same with the input band staged in LDS first
  *   "timing_graph":  1 (default) = qnnp_gfx950_time_operator* time a hipGraph replay of the launches (kernel
  *                    time without per-launch dispatch gaps); 0 = a plain back-to-back launch loop
  * Unknown key -> invalid_parameter. Kernel choices apply to operators set up afterwards. */

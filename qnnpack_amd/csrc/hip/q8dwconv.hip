@@ -675,6 +675,292 @@ int launch_mfma(const DwParams& p, hipStream_t stream)
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
+// --------------------------------------------------------------------------
+// Kernel F: matrix cores + LDS-staged band (3x3, any stride / dilation, C % 16 == 0)
+// --------------------------------------------------------------------------
+/*
+ * Kernel D showed that the diagonal-MFMA formulation needs only ~9-18 MFMAs per 1024 outputs (never the
+ * bottleneck) but drowned in per-tap address arithmetic and 16-byte gathers. Here the two good halves are
+ * joined: the band of ONE 32-channel block is staged into LDS like kernel A -- once per input byte, coalesced
+ * 16-byte vectors, padding materialised, bytes already recentred (a' = a ^ 0x80), natural [row][column][32
+ * channels] layout -- and every tap operand of a 32-pixel tile is then ONE ds_read_b128 at a constant offset
+ * from the lane's base (lane l = pixel l % 32, channels 16*(l / 32)..+15): no select, no xor, no address math in
+ * the tap loop. The diagonal weight operands of the workgroup's channel block live in REGISTERS (part 0; the
+ * rare taps whose w - kzp needs a second / third int8 part fetch that operand from LDS, guarded by a per-tap
+ * bit mask found at start-up). Per 1024 outputs: 9 LDS reads, 9+ MFMAs, ~100 VALU (requantization + pack).
+ * Workgroup (4 waves) = image x band of output rows x one 32-channel block; a wave takes tiles of 32 consecutive
+ * output positions of the band.
+ */
+constexpr int kMlThreads = 256;
+constexpr int kMlMaxVec = 6;          // 16-byte staging vectors a thread holds for the NEXT band (24 VGPRs)
+
+/*
+ * PERSISTENT and software-pipelined: with one band per workgroup every workgroup of the grid is in the same phase
+ * at the same time (all load, then all compute, then all store: HBM idles while the VALUs work and vice versa,
+ * and the last partial round of workgroups runs on a nearly empty chip -- three structurally different kernels
+ * all measured the same 2 TB/s). Here a workgroup keeps its channel block and walks (image, band) pairs; the
+ * global loads of the NEXT band are issued into registers before the current band is multiplied out of LDS.
+ */
+template <int PARTS>
+__global__ __launch_bounds__(kMlThreads, 4)
+void q8_dwconv_mfma_lds_kernel(const DwParams p)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t tile[];   // [IR][IC][32] a' bytes, then extra weight parts
+  const uint32_t tid = threadIdx.x;
+  QNNP_DW_TRACE(p, 0);
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
+  const uint32_t m = lane & 31u;
+  const uint32_t khalf = lane >> 5;
+  uint32_t b;
+  {
+    const uint32_t nwg = gridDim.x;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t idx = blockIdx.x >> 3;
+    const uint32_t q = nwg >> 3, r = nwg & 7u;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // channel blocks of a band share an XCD / L2
+  }
+  // the grid is a multiple of the channel-block count: workgroup b owns block b % cblocks for its whole life
+  const uint32_t cblocks = p.slabs;
+  const uint32_t cb = b % cblocks;
+  const uint32_t pair0 = b / cblocks;
+  const uint32_t pair_stride = gridDim.x / cblocks;
+  const uint32_t segs = p.PP;                                      // column segments per output row
+  const uint32_t npairs = p.batch * p.bands * segs;               // work items of this channel block: (image, band, segment)
+  const uint32_t band_bytes = p.IR * p.IC * 32u;
+  uint8_t* w_extra = tile + band_bytes;                            // [(part - 1) * 9 + tap] fragments of 1 KiB
+  const uint32_t fill = p.izp * 0x01010101u;
+  const bool my_chan_ok = cb * 32u + (tid & 1u) * 16u < p.C;     // C % 16 == 0: this thread's 16 channels exist or not
+  // this thread's first staging pixel (tid / 2) inside a band and the advance of 128 pixels, both item-independent
+  const uint32_t px0_row = (tid >> 1) / p.IC;
+  const uint32_t px0_col = (tid >> 1) - px0_row * p.IC;
+  const uint32_t step_row = (kMlThreads / 2) / p.IC;
+  const uint32_t step_col = (kMlThreads / 2) - step_row * p.IC;
+
+  // ---- staging, phase 1: global -> registers for one (image, band) pair ----
+  uint4 st_val[kMlMaxVec];
+  uint32_t st_nvec = 0;
+  auto stage_load = [&](uint32_t pair) __attribute__((always_inline)) {
+    const uint32_t seg = pair % segs;
+    const uint32_t nb = pair / segs;
+    const uint32_t n = nb / p.bands;
+    const uint32_t band = nb - n * p.bands;
+    const uint32_t oy0 = band * p.TOH;
+    const uint32_t toh = min(p.TOH, p.OH - oy0);
+    const uint32_t ir = (toh - 1) * p.sh + 2 * p.dh + 1;          // rows actually needed
+    st_nvec = ir * p.IC * 2u;                                     // (a short last segment stages a few unused columns)
+    const int32_t iy_base = static_cast<int32_t>(oy0 * p.sh) - static_cast<int32_t>(p.pad_top);
+    const int32_t ix_base = static_cast<int32_t>(seg * p.CS * p.sw) - static_cast<int32_t>(p.pad_left);   // CS = outputs per segment
+    const uint8_t* img = p.input + static_cast<uint64_t>(n) * p.H * p.W * p.in_stride + cb * 32u + (tid & 1u) * 16u;
+    // vector v = tid + u * 256 is pixel (tid / 2 + u * 128), half tid % 2: its (row, column) inside the band is
+    // walked incrementally from the thread's first pixel -- no division per vector (the address arithmetic of
+    // this phase was as long as the multiply phase when it divided)
+    uint32_t iyl = px0_row, ixl = px0_col;
+#pragma unroll
+    for (int u = 0; u < kMlMaxVec; u++) {
+      const uint32_t v = tid + u * kMlThreads;
+      const int32_t iy = iy_base + static_cast<int32_t>(iyl);
+      const int32_t ix = ix_base + static_cast<int32_t>(ixl);
+      const bool inb = v < st_nvec && my_chan_ok &&
+          iy >= 0 && iy < static_cast<int32_t>(p.H) && ix >= 0 && ix < static_cast<int32_t>(p.W);
+      st_val[u] = make_uint4(fill, fill, fill, fill);
+      if (inb) {
+        st_val[u] = *reinterpret_cast<const uint4*>(
+            img + (static_cast<uint32_t>(iy) * p.W + static_cast<uint32_t>(ix)) * p.in_stride);
+      }
+      ixl += step_col;
+      iyl += step_row;
+      if (ixl >= p.IC) { ixl -= p.IC; iyl += 1; }
+    }
+  };
+  // ---- staging, phase 2: registers -> LDS, recentred; [pixel][half] is exactly the vector order ----
+  auto stage_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < kMlMaxVec; u++) {
+      const uint32_t v = tid + u * kMlThreads;
+      if (v < st_nvec) {
+        uint4 x = st_val[u];
+        x.x ^= 0x80808080u; x.y ^= 0x80808080u; x.z ^= 0x80808080u; x.w ^= 0x80808080u;
+        *reinterpret_cast<uint4*>(tile + v * 16u) = x;
+      }
+    }
+  };
+
+  uint32_t pair = pair0;
+  if (pair < npairs) stage_load(pair);
+
+  // ---- diagonal weight operands: lane (c = l % 32, k half = l / 32) holds bytes k = 16*half + j, non-zero only
+  //      at k == c. Part 0 in registers, further parts in LDS with a mask of the taps that need them ----
+  // (all weight bytes are fetched first, back to back: one exposed memory latency instead of 9 * PARTS)
+  uint32_t xb[PARTS * 9];
+#pragma unroll
+  for (int i = 0; i < PARTS * 9; i++) {
+    xb[i] = static_cast<uint8_t>(p.dwm_x[static_cast<size_t>(i) * p.c_pad32 + cb * 32 + m]);   // [part][tap][channel]
+  }
+  auto diag = [&](uint32_t x) __attribute__((always_inline)) {
+    const bool mine = (m >> 4) == khalf;
+    const uint32_t val = mine ? x << ((m & 3u) * 8u) : 0u;
+    const uint32_t dw = (m & 15u) >> 2;
+    dw_v4i v;
+    v.x = static_cast<int>(dw == 0 ? val : 0u);
+    v.y = static_cast<int>(dw == 1 ? val : 0u);
+    v.z = static_cast<int>(dw == 2 ? val : 0u);
+    v.w = static_cast<int>(dw == 3 ? val : 0u);
+    return v;
+  };
+  // all parts live in LDS (fragment (part * 9 + tap) of 1 KiB): with the next band's vectors held in registers
+  // there is no room for nine operand quads; the reads ride beside the MFMAs
+  uint32_t extra_mask = 0;                                         // bit (part - 1) * 9 + tap: that operand is not all zero
+#pragma unroll
+  for (int part = 0; part < PARTS; part++) {
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const dw_v4i v = diag(xb[part * 9 + t]);
+      if (part > 0) {
+        const bool nz = (v.x | v.y | v.z | v.w) != 0;
+        if (__builtin_amdgcn_ballot_w64(nz) != 0) extra_mask |= 1u << ((part - 1) * 9 + t);
+      }
+      if (part == 0) {
+        if (wave == 0) *reinterpret_cast<dw_v4i*>(w_extra + t * 1024 + lane * 16) = v;
+      } else {
+        // parts beyond the first are needed by few taps: kept as 32 bytes per (part, tap), the operand is
+        // rebuilt from its byte on demand
+        if (tid < 32) w_extra[9 * 1024 + ((part - 1) * 9 + t) * 32 + tid] = static_cast<uint8_t>(xb[part * 9 + t]);
+      }
+    }
+  }
+  // folded bias of the block: 32 int32 in LDS behind the weight parts (re-read per tile: registers are scarce)
+  int32_t* lds_bias = reinterpret_cast<int32_t*>(w_extra + 9 * 1024 + (PARTS - 1) * 9 * 32);
+  if (tid < 32) lds_bias[tid] = p.dwm_bias[cb * 32 + tid];
+
+  qnnp::IgemmParams ep;                                             // only what the shared epilogue reads
+  ep.n = p.C;
+  ep.store_mode = p.store_mode;
+  ep.rq = p.rq;
+  const uint32_t row_pitch = p.IC * 32u;
+
+  QNNP_DW_TRACE(p, 1);
+  qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
+    uint32_t trace_item = 0;
+    for (bool first = true; pair < npairs; pair += pair_stride, first = false, trace_item++) {
+      if (!first) __syncthreads();              // every reader of the previous band is done
+      stage_store();
+      __syncthreads();
+      if (pair + pair_stride < npairs) stage_load(pair + pair_stride);   // flies while this band is multiplied
+
+      const uint32_t seg = pair % segs;
+      const uint32_t nb = pair / segs;
+      const uint32_t n = nb / p.bands;
+      const uint32_t band = nb - n * p.bands;
+      const uint32_t oy0 = band * p.TOH;
+      const uint32_t toh = min(p.TOH, p.OH - oy0);
+      const uint32_t ox0 = seg * p.CS;
+      const uint32_t ow = min(p.CS, p.OW - ox0);                     // output columns of this segment
+      const uint32_t npos = toh * ow;
+      const uint32_t ntiles = (npos + 31u) / 32u;
+      uint8_t* out_band = p.output + ((static_cast<uint64_t>(n) * p.OH + oy0) * p.OW + ox0) * p.out_stride;
+      for (uint32_t t = wave; t < ntiles; t += kMlThreads / 64) {
+        const uint32_t pos = t * 32u + m;
+        const bool valid = pos < npos;
+        const uint32_t pc = valid ? pos : npos - 1;
+        const uint32_t oyl = pc / ow;
+        const uint32_t ox = pc - oyl * ow;
+        const uint8_t* base = tile + (oyl * p.sh) * row_pitch + (ox * p.sw) * 32u + khalf * 16u;
+        uint32_t w_off = lane * 16;                // opaque per tile: keeps the compiler from hoisting the nine
+        asm volatile("" : "+v"(w_off));            // loop-invariant operand reads (36 VGPRs) out of the loop
+        dw_v16i acc;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int4 bv = *reinterpret_cast<const int4*>(&lds_bias[rg * 8 + khalf * 4]);
+          acc[rg * 4 + 0] = bv.x; acc[rg * 4 + 1] = bv.y; acc[rg * 4 + 2] = bv.z; acc[rg * 4 + 3] = bv.w;
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+#pragma unroll
+          for (int kx = 0; kx < 3; kx++) {
+            const dw_v4i a = *reinterpret_cast<const dw_v4i*>(base + (ky * p.dh) * row_pitch + (kx * p.dw) * 32u);
+            const dw_v4i w0 = *reinterpret_cast<const dw_v4i*>(w_extra + (ky * 3 + kx) * 1024 + w_off);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, a, acc, 0, 0, 0);
+            if constexpr (PARTS > 1) {
+#pragma unroll
+              for (int part = 1; part < PARTS; part++) {
+                if ((extra_mask >> ((part - 1) * 9 + ky * 3 + kx)) & 1u) {      // wave-uniform, rarely taken
+                  const dw_v4i w = diag(w_extra[9 * 1024 + ((part - 1) * 9 + ky * 3 + kx) * 32 + m]);
+                  acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a, acc, 0, 0, 0);
+                }
+              }
+            }
+          }
+        }
+        uint8_t* out_row = out_band + (static_cast<uint64_t>(oyl) * p.OW + ox) * p.out_stride;
+        const int4 unused[4] = {};
+        qnnp::igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 1>(
+            acc, unused, 0, out_row, cb * 32, khalf, valid, ep);
+      }
+      if (trace_item < 3) QNNP_DW_TRACE(p, 2 + trace_item);
+    }
+  });
+  QNNP_DW_TRACE(p, 5);
+}
+
+// geometry of kernel F: `slabs` = 32-channel blocks; work item = (image, band of TOH output rows, segment of CS
+// output columns, `PP` segments per row); the staged band is IR x IC pixels of 32 bytes
+bool plan_mfma_lds(DwParams& p, const struct qnnp_hip_dwconv_args* a)
+{
+  if (a->dwm_x == nullptr || a->dwm_bias == nullptr || a->dwm_parts < 1 || a->dwm_parts > 3) return false;
+  if (!(p.KH == 3 && p.KW == 3)) return false;
+  if (p.C % 16 != 0 || p.in_stride % 16 != 0 || reinterpret_cast<uintptr_t>(p.input) % 16 != 0) return false;
+  const uint32_t halo_r = 2 * p.dh + 1, halo_c = 2 * p.dw + 1;
+  // the next band is held in registers: at most kMlMaxVec vectors of 16 bytes per thread = `cap` pixels; pick the
+  // 2-D band (rows x column segment) that re-reads the least halo
+  const uint32_t cap = static_cast<uint32_t>(kMlMaxVec * kMlThreads) / 2u;
+  uint32_t best_segs = 0, best_toh = 0, best_ow = 0, best_ic = 0;
+  double best_amp = 1e30;
+  for (uint32_t segs = 1; segs <= 8 && segs <= p.OW; segs++) {
+    const uint32_t ow = (p.OW + segs - 1) / segs;
+    const uint32_t ic = (ow - 1) * p.sw + halo_c;
+    if (cap / ic < halo_r) continue;
+    uint32_t toh = (cap / ic - halo_r) / p.sh + 1;
+    if (toh > p.OH) toh = p.OH;
+    const double amp = (static_cast<double>((toh - 1) * p.sh + halo_r) / (toh * p.sh)) * (static_cast<double>(ic) / (ow * p.sw));
+    if (amp < best_amp * 0.97) { best_amp = amp; best_segs = segs; best_toh = toh; best_ow = ow; best_ic = ic; }
+  }
+  if (best_segs == 0) return false;
+  p.slabs = p.c_pad32 / 32;
+  uint32_t toh = best_toh;
+  // a few items per (persistent) workgroup, so that the pipeline has something to overlap and the shares are even
+  while (toh > 1 && static_cast<uint64_t>(p.batch) * ((p.OH + toh - 1) / toh) * best_segs * p.slabs < 3u * 4u * p.cu_count) toh = (toh + 1) / 2;
+  p.TOH = toh;
+  p.CS = best_ow;
+  p.PP = (p.OW + best_ow - 1) / best_ow;
+  p.IC = best_ic;
+  p.bands = (p.OH + toh - 1) / toh;
+  p.IR = (toh - 1) * p.sh + halo_r;
+  const uint64_t items = static_cast<uint64_t>(p.batch) * p.bands * p.PP * p.slabs;
+  const uint64_t image_bytes = static_cast<uint64_t>(p.H) * p.W * p.in_stride;      // 32-bit offsets inside an image
+  return items < (UINT64_C(1) << 31) && image_bytes < (UINT64_C(1) << 32);
+}
+
+int launch_mfma_lds(const DwParams& p, hipStream_t stream)
+{
+  const size_t lds_bytes = static_cast<size_t>(p.IR) * p.IC * 32u + 9u * 1024u + (p.dwm_parts - 1) * 9u * 32u + 128u;
+  // persistent: four workgroups per CU (<= 128 VGPRs), a multiple of the channel-block count
+  const uint32_t items = p.batch * p.bands * p.PP * p.slabs;
+  uint32_t per_cu = static_cast<uint32_t>((160u * 1024u) / (lds_bytes > 0 ? lds_bytes : 1));
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  uint32_t blocks = p.cu_count * per_cu;
+  if (blocks > items) blocks = items;
+  blocks = (blocks / p.slabs) * p.slabs;
+  if (blocks == 0) blocks = p.slabs;
+  switch (p.dwm_parts) {
+    case 1: hipLaunchKernelGGL((q8_dwconv_mfma_lds_kernel<1>), dim3(blocks), dim3(kMlThreads), lds_bytes, stream, p); break;
+    case 2: hipLaunchKernelGGL((q8_dwconv_mfma_lds_kernel<2>), dim3(blocks), dim3(kMlThreads), lds_bytes, stream, p); break;
+    default: hipLaunchKernelGGL((q8_dwconv_mfma_lds_kernel<3>), dim3(blocks), dim3(kMlThreads), lds_bytes, stream, p); break;
+  }
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
 constexpr uint32_t kDwLdsBudgetDefault = 48 * 1024;   // bytes per workgroup (3 workgroups per CU)
 
 // Pick slab width / band height for kernel A. Returns false if the shape does not fit.
@@ -784,10 +1070,21 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
   p.store_mode = 0;
   if (p.C % 16 == 0 && p.out_stride % 16 == 0 && out_addr % 16 == 0) p.store_mode = 2;
   else if (p.C % 4 == 0 && p.out_stride % 4 == 0 && out_addr % 4 == 0) p.store_mode = 1;
+  if (a->variant == 5) {
+    if (!plan_mfma_lds(p, a)) return QNNP_HIP_EINVAL;
+    if (kernel_name != nullptr) *kernel_name = "q8_dwconv_mfma_lds_3x3";
+    return launch_mfma_lds(p, stream);
+  }
   if (a->variant == 4) {
     if (!plan_mfma(p, a)) return QNNP_HIP_EINVAL;
     if (kernel_name != nullptr) *kernel_name = "q8_dwconv_mfma_3x3";
     return launch_mfma<3, 3>(p, stream);
+  }
+  // Large images with few channels (MobileNetV2 layers 2 and 5): the matrix-core kernel with the LDS-staged band
+  // measured 8-10 % ahead of the VALU kernels; everywhere else it is level or behind (same-box A/B).
+  if (a->variant == 0 && k33 && p.OW >= 56 && p.C <= 96 && plan_mfma_lds(p, a)) {
+    if (kernel_name != nullptr) *kernel_name = "q8_dwconv_mfma_lds_3x3";
+    return launch_mfma_lds(p, stream);
   }
   // Order of preference (same-box A/B over the MobileNetV2 layers: the LDS-tiled and the sliding-window
   // kernel are within +-10 % of each other, LDS ahead on the small late layers): LDS-tiled, then the

@@ -153,7 +153,7 @@ struct qnnp_hip_dwconv_args {
   uint32_t input_stride, output_stride;
   uint32_t input_zero_point;
   struct qnnp_hip_requant rq;
-  int variant;                /* 0 auto, 1 generic direct, 2 LDS-tiled, 3 register sliding window (3x3), 4 matrix-core */
+  int variant;                /* 0 auto, 1 generic direct, 2 LDS-tiled, 3 register sliding window (3x3), 4 matrix-core (gather), 5 matrix-core (LDS band) */
 };
 int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* args, const char** kernel_name);
 

@@ -43,9 +43,10 @@ CASES = [
 ]
 
 
-@pytest.fixture()
-def mf(qnnp):
-    qnnp.set_option("dwconv_kernel", 4)
+@pytest.fixture(params=[4, 5], ids=["gather", "lds"])
+def mf(qnnp, request):
+    """4 = tap operands gathered from global memory, 5 = band staged in LDS first"""
+    qnnp.set_option("dwconv_kernel", request.param)
     yield qnnp
     qnnp.set_option("dwconv_kernel", 0)
 
