@@ -691,7 +691,10 @@ int launch_mfma(const DwParams& p, hipStream_t stream)
  * Workgroup (4 waves) = image x band of output rows x one 32-channel block; a wave takes tiles of 32 consecutive
  * output positions of the band.
  */
-constexpr int kMlThreads = 256;
+#ifndef QNNP_ML_THREADS
+#define QNNP_ML_THREADS 256
+#endif
+constexpr int kMlThreads = QNNP_ML_THREADS;
 constexpr int kMlMaxVec = 6;          // 16-byte staging vectors a thread holds for the NEXT band (24 VGPRs)
 
 /*
