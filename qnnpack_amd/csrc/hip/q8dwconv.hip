@@ -74,6 +74,7 @@ struct DwParams {
   const int32_t* dwm_bias;
   uint32_t dwm_parts, c_pad32;
   uint32_t store_mode;   // as igemm_epilogue.cuh: 2 = 16-byte stores, 1 = dword stores, 0 = byte stores
+  uint32_t abl;          // measurement builds only: bit 0 = no stores, bit 1 = no global loads (kernel F)
   unsigned long long* trace;   // measurement builds only (QNNP_ENABLE_ABLATION + env QNNP_GFX950_TRACE)
   qnnp::RequantDev rq;
 };
@@ -764,7 +765,7 @@ void q8_dwconv_mfma_lds_kernel(const DwParams p)
       const uint32_t v = tid + u * kMlThreads;
       const int32_t iy = iy_base + static_cast<int32_t>(iyl);
       const int32_t ix = ix_base + static_cast<int32_t>(ixl);
-      const bool inb = v < st_nvec && my_chan_ok &&
+      const bool inb = v < st_nvec && my_chan_ok && !(p.abl & 2u) &&
           iy >= 0 && iy < static_cast<int32_t>(p.H) && ix >= 0 && ix < static_cast<int32_t>(p.W);
       st_val[u] = make_uint4(fill, fill, fill, fill);
       if (inb) {
@@ -864,8 +865,8 @@ void q8_dwconv_mfma_lds_kernel(const DwParams p)
       uint8_t* out_band = p.output + ((static_cast<uint64_t>(n) * p.OH + oy0) * p.OW + ox0) * p.out_stride;
       for (uint32_t t = wave; t < ntiles; t += kMlThreads / 64) {
         const uint32_t pos = t * 32u + m;
-        const bool valid = pos < npos;
-        const uint32_t pc = valid ? pos : npos - 1;
+        const bool valid = pos < npos && !(p.abl & 1u);
+        const uint32_t pc = pos < npos ? pos : npos - 1;
         const uint32_t oyl = pc / ow;
         const uint32_t ox = pc - oyl * ow;
         const uint8_t* base = tile + (oyl * p.sh) * row_pitch + (ox * p.sw) * 32u + khalf * 16u;
@@ -1049,8 +1050,10 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
   p.CS = p.TOH = p.IR = p.IC = p.PP = p.bands = p.slabs = 0;
   p.rq = qnnp::make_requant_dev(a->rq);
   p.trace = nullptr;
+  p.abl = 0;
 #ifdef QNNP_ENABLE_ABLATION
   p.trace = static_cast<unsigned long long*>(qnnp_hip_trace_buffer());
+  if (const char* env = getenv("QNNP_DW_ABL")) p.abl = static_cast<uint32_t>(atoi(env));
 #endif
   {
     int cus = 0;
