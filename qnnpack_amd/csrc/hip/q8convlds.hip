@@ -24,6 +24,7 @@
  * fragment feeds two MFMAs) x all output channels (<= 128).
  */
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <stdint.h>
 
@@ -65,7 +66,11 @@ inline Plan make_plan(const IgemmParams& p, const ConvGeom& g)
   return pl;
 }
 
-template <int TN>
+/* PIPE: the next work item's input band is loaded into registers (<= kPipeVec vectors per thread) while the
+ * current one is multiplied -- staging was 40 % of an item's time as a separate phase (in-kernel stamps). */
+constexpr int kPipeVec = 8;
+
+template <int TN, bool PIPE>
 __global__ __launch_bounds__(kThreads, 2)
 void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32_t blocks_per_image,
                              const uint32_t total_items, const uint32_t ic, const uint32_t w_bytes)
@@ -84,6 +89,59 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
     const uint4* src = reinterpret_cast<const uint4*>(p.packed_w);
     uint4* dst = reinterpret_cast<uint4*>(w_lds);
     for (uint32_t i = tid; i < (w_bytes >> 4); i += kThreads) dst[i] = src[i];
+  }
+
+  // ---- pipelined staging (PIPE): global -> registers for one item, registers -> LDS (re-centred, swizzled) ----
+  uint4 st_val[PIPE ? kPipeVec : 1];
+  uint32_t st_dst[PIPE ? kPipeVec : 1];                             // 0xFFFFFFFF = nothing held
+  auto stage_load = [&](uint32_t item) __attribute__((always_inline)) {
+    const uint32_t cin = p.kc;
+    const uint32_t log_cin = 31u - __builtin_clz(cin);
+    const uint32_t cpp = cin >> 4;
+    const uint32_t log_ppr = 4u - (log_cin - 4u);
+    const uint32_t img = item / blocks_per_image;
+    const uint32_t blk = item - img * blocks_per_image;
+    const uint32_t p0 = blk * kPosPerBlock;
+    const uint32_t p_end = min(p0 + kPosPerBlock, ohw);
+    const uint32_t y_first = p0 / g.OW;
+    const uint32_t y_last = (p_end - 1) / g.OW;
+    const int32_t iy0 = static_cast<int32_t>(y_first * g.sh) - static_cast<int32_t>(g.pad_top);
+    const uint32_t ir = (y_last - y_first) * g.sh + (g.KH - 1) * g.dh + 1;
+    const uint32_t nvec = ir * ic * cpp;
+    const uint8_t* image = p.input + static_cast<uint64_t>(img) * p.image_stride;
+    const uint32_t raw_fill = (p.izp_fill & 0xFFu) * 0x01010101u;
+#pragma unroll
+    for (int u = 0; u < (PIPE ? kPipeVec : 1); u++) {
+      const uint32_t v = tid + u * kThreads;
+      const bool live = v < nvec;
+      const uint32_t c = v & (cpp - 1);
+      const uint32_t q = v >> (log_cin - 4);               // pixel index inside the band
+      const uint32_t iyl = q / ic;
+      const uint32_t ixl = q - iyl * ic;
+      const int32_t iy = iy0 + static_cast<int32_t>(iyl);
+      const int32_t ix = static_cast<int32_t>(ixl) - static_cast<int32_t>(g.pad_left);
+      const bool inb = live && iy >= 0 && iy < static_cast<int32_t>(g.H) && ix >= 0 && ix < static_cast<int32_t>(g.W);
+      st_val[u] = make_uint4(raw_fill, raw_fill, raw_fill, raw_fill);
+      if (inb) {
+        st_val[u] = *reinterpret_cast<const uint4*>(
+            image + (static_cast<uint64_t>(static_cast<uint32_t>(iy)) * g.W + static_cast<uint32_t>(ix)) * p.input_stride + c * 16);
+      }
+      const uint32_t swz = (q >> log_ppr) & (cpp - 1);
+      st_dst[u] = live ? (q << log_cin) + ((c ^ swz) << 4) : 0xFFFFFFFFu;
+    }
+  };
+  auto stage_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < (PIPE ? kPipeVec : 1); u++) {
+      if (st_dst[u] != 0xFFFFFFFFu) {
+        uint4 x = st_val[u];
+        x.x ^= kFlip; x.y ^= kFlip; x.z ^= kFlip; x.w ^= kFlip;
+        *reinterpret_cast<uint4*>(in_lds + st_dst[u]) = x;
+      }
+    }
+  };
+  if constexpr (PIPE) {
+    if (blockIdx.x < total_items) stage_load(blockIdx.x);
   }
 
   // persistent: work item = (image, 256-position block); items of one image are consecutive
@@ -109,7 +167,9 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
   // ---- stage the input band (re-centred, swizzled) ----
   // Batches of kStageBatch vectors per thread: all global loads of a batch are issued before the first
   // LDS write, so a thread keeps kStageBatch loads in flight instead of one (the loop is latency-bound).
-  {
+  if constexpr (PIPE) {
+    stage_store();                                   // this item's band was loaded during the previous item
+  } else {
     constexpr int kStageBatch = 8;
     const uint32_t nvec = ir * ic * cpp;
     const uint8_t* image = p.input + static_cast<uint64_t>(img) * p.image_stride;
@@ -182,6 +242,9 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
 
   __syncthreads();
   QNNP_TRACE(p, blockIdx.x, item_no, 2);
+  if constexpr (PIPE) {
+    if (item + gridDim.x < total_items) stage_load(item + gridDim.x);   // flies under the K loop and the epilogue
+  }
 
   const uint32_t kblocks = p.k_pad / 32;
   const uint32_t cblocks = cin >> 5;
@@ -248,12 +311,12 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
   }
 }
 
-template <int TN>
-int launch(const IgemmParams& p, const ConvGeom& g, const Plan& pl, uint32_t batch, hipStream_t stream)
+template <int TN, bool PIPE>
+int launch_one(const IgemmParams& p, const ConvGeom& g, const Plan& pl, uint32_t batch, hipStream_t stream)
 {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_lds_mfma_kernel<TN>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_lds_mfma_kernel<TN, PIPE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       (void) hipGetLastError();
     }
@@ -262,9 +325,19 @@ int launch(const IgemmParams& p, const ConvGeom& g, const Plan& pl, uint32_t bat
   const uint32_t total_items = batch * pl.blocks_per_image;
   const uint32_t resident = p.cu_count * (kLdsLimit >= 2 * pl.lds_bytes ? 2u : 1u);
   const uint32_t grid = total_items < resident ? total_items : resident;
-  hipLaunchKernelGGL((q8_conv_lds_mfma_kernel<TN>), dim3(grid), dim3(kThreads),
+  hipLaunchKernelGGL((q8_conv_lds_mfma_kernel<TN, PIPE>), dim3(grid), dim3(kThreads),
                      pl.lds_bytes, stream, p, g, pl.blocks_per_image, total_items, pl.ic, pl.w_bytes);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+template <int TN>
+int launch(const IgemmParams& p, const ConvGeom& g, const Plan& pl, uint32_t batch, hipStream_t stream)
+{
+  // the pipelined flavour needs the whole band of an item in kPipeVec 16-byte vectors per thread
+  const uint32_t band_vectors = pl.ir_max * pl.ic * (p.kc >> 4);
+  static const bool no_pipe = getenv("QNNP_CONVLDS_NOPIPE") != nullptr;  // TEMP A/B
+  if (!no_pipe && band_vectors <= static_cast<uint32_t>(kPipeVec * kThreads)) return launch_one<TN, true>(p, g, pl, batch, stream);
+  return launch_one<TN, false>(p, g, pl, batch, stream);
 }
 
 }  // namespace
