@@ -87,7 +87,8 @@ void qnnp_gfx950_graph_destroy(void* graph);
  *                    4 = the 256x256 kernel in its 4-wave flavour (one wave per SIMD, 128x128 per wave),
  *                    5 = barrier-free streaming kernel for short-K pointwise / fully-connected layers,
  *                    6 = its global-operand flavour (one wave per 32x32 block; small problems with long K),
- *                    7 = its 3-channel-image convolution flavour (first layers; in-register tap gather)
+ *                    7 = its 3-channel-image convolution flavour (first layers; in-register tap gather),
+ *                    8 = wave-per-8x8-block direct-convolution MFMA kernel (small windows, <= 64 channels, dense output)
  *   "dwconv_kernel": 0 = auto, 1 = generic direct kernel, 2 = LDS-tiled kernel, 3 = register sliding-window kernel (3x3),
  *                    4 = matrix-core kernel (diagonal MFMA operands; 3x3, channels % 16 == 0), tap operands gathered
  *                        from global memory, 5 = the same with the input band staged in LDS first

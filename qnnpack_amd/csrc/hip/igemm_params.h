@@ -76,6 +76,10 @@ struct ConvGeom {
 bool convlds_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32_t vec);
 int convlds_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipStream_t stream, const char** name);
 
+/* q8convwave.hip */
+bool convwave_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32_t vec, uint32_t batch);
+int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipStream_t stream, const char** name);
+
 /* q8pwconv.hip */
 bool pwstream_supported(const IgemmParams& p, uint32_t groups, uint32_t vec);
 int pwstream_launch(const IgemmParams& p, uint32_t vec, hipStream_t stream, const char** name);

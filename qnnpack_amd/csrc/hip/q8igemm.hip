@@ -530,6 +530,17 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   geom.dh = a->dilation_height; geom.dw = a->dilation_width; geom.pad_top = a->pad_top; geom.pad_left = a->pad_left;
   const bool lds_ok = a->offsets != nullptr && !pad3 && a->rows_per_image > 0 &&
       a->output_stride % 16 == 0 && qnnp::convlds_supported(p, geom, a->groups, vec);
+  // Opt-in alternative for the small-window, <= 64-channel ones: one wave per 8x8 block of positions, no
+  // barriers (q8convwave.hip). Measured 12 % SLOWER than the LDS-tiled kernel on configs[2] (41.9 vs 37.2 us,
+  // same box), so it is never selected automatically.
+  const bool wave_ok = a->variant == 8 && a->offsets != nullptr && !pad3 && a->rows_per_image > 0 && p.store_mode == 2 &&
+      qnnp::convwave_supported(p, geom, a->groups, vec, a->rows / a->rows_per_image);
+  if (a->variant == 8 && !wave_ok) return QNNP_HIP_EINVAL;
+  if (wave_ok) {
+    const int rc_wave = qnnp::convwave_launch(p, geom, a->rows / a->rows_per_image, stream, &name);
+    if (kernel_name != nullptr) *kernel_name = name;
+    return rc_wave;
+  }
   if (a->variant == 3 && !lds_ok) return QNNP_HIP_EINVAL;
   if (lds_ok && (a->variant == 3 || (a->variant == 0 && a->kernel_height * a->kernel_width > 1))) {
     const int rc_lds = qnnp::convlds_launch(p, geom, a->rows / a->rows_per_image, stream, &name);

@@ -1,53 +1,90 @@
-// Measurement tool (not part of the product): issue cost of the integer VALU instructions the Q31
-// requantization can be built from, on gfx950. Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_valu.hip -o /tmp/ubench_valu
+// measurement tool: issue cost (cycles per wave-instruction) of the integer / fp64 instructions a Q31
+// requantization could be built from. 1 and 4 waves per SIMD; 8 independent chains per lane.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <vector>
 
-#define REP16(x) x x x x x x x x x x x x x x x x
+#define REP 64
 template <int OP>
-__global__ void k(int* out, int iters, int a0, int b0) {
-  int a = a0 + threadIdx.x, b = b0, c = threadIdx.x;
-  long long acc = c;
-  int lo = c, hi = c + 1;
-  for (int i = 0; i < iters; i++) {
-    if (OP == 0) { REP16(asm volatile("v_add_u32 %0, %1, %0" : "+v"(lo) : "v"(a));) }
-    if (OP == 1) { REP16(asm volatile("v_mul_lo_u32 %0, %1, %0" : "+v"(lo) : "v"(a));) }
-    if (OP == 2) { REP16(asm volatile("v_mul_hi_i32 %0, %1, %0" : "+v"(lo) : "v"(a));) }
-    if (OP == 3) { REP16(asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");) }
-    if (OP == 4) { REP16(asm volatile("v_mul_i32_i24 %0, %1, %0" : "+v"(lo) : "v"(a));) }
-    if (OP == 5) { REP16(asm volatile("v_mul_hi_i32_i24 %0, %1, %0" : "+v"(lo) : "v"(a));) }
-    if (OP == 6) { REP16(asm volatile("v_ashrrev_i64 %0, 5, %0" : "+v"(acc));) }
-    if (OP == 7) { REP16(asm volatile("v_alignbit_b32 %0, %1, %0, 31" : "+v"(lo) : "v"(hi));) }
-    if (OP == 8) { REP16(asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");) }
-    if (OP == 9) { REP16(asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(lo) : "v"(a), "v"(b));) }
-    if (OP == 10) { REP16(asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc) : "v"(acc));) }
-    if (OP == 11) { REP16(asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(acc) : "v"(lo));) }
-    if (OP == 12) { double d; REP16(asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(acc));) }
-    if (OP == 13) { REP16(asm volatile("v_dot4c_i32_i8 %0, %1, %2" : "+v"(lo) : "v"(a), "v"(b));) }
-    if (OP == 14) { REP16(asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(lo) : "v"(a), "v"(b));) }
+__global__ void k(uint32_t* out, int iters, uint32_t seed)
+{
+  uint32_t a[8]; uint64_t w[8]; double d[8];
+  for (int i = 0; i < 8; i++) { a[i] = seed * (threadIdx.x + 1) + i * 77; w[i] = a[i]; d[i] = a[i]; }
+  uint32_t m = seed | 0x40000001u;
+  uint64_t t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int r = 0; r < REP / 8; r++) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if (OP == 0) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(w[i]) : "v"(a[i]), "v"(m) : "vcc");
+        if (OP == 1) asm volatile("v_mul_hi_i32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+        if (OP == 2) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+        if (OP == 3) asm volatile("v_mul_hi_i32_i24 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+        if (OP == 4) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+        if (OP == 5) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(d[i]) : "v"(d[(i + 1) & 7]));
+        if (OP == 6) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(d[i]) : "v"(a[i]));
+        if (OP == 7) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(a[i]) : "v"(d[i]));
+        if (OP == 8) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+        if (OP == 9) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[i]) : "v"(a[i]), "v"(m) : "vcc");
+        if (OP == 10) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(m));
+        if (OP == 11) asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(a[i]));
+        if (OP == 12) asm volatile("v_sub_co_u32 %0, vcc, %0, %1\n\tv_subb_co_u32 %2, vcc, %2, %1, vcc" : "+v"(a[i]), "+v"(m), "+v"(a[(i + 1) & 7]) : : "vcc");
+        if (OP == 13) asm volatile("v_cvt_pk_i16_i32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+        if (OP == 14) asm volatile("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(a[i]) : "v"(m));
+        if (OP == 15) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(w[i]));
+        if (OP == 16) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(m));
+      }
+    }
   }
-  out[blockIdx.x * blockDim.x + threadIdx.x] = lo + hi + (int) acc + (int) (acc >> 32);
+  uint64_t t1 = __builtin_readcyclecounter();
+  uint32_t acc = 0;
+  for (int i = 0; i < 8; i++) acc ^= a[i] ^ (uint32_t) w[i] ^ (uint32_t) (w[i] >> 32) ^ (uint32_t) d[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+  if (threadIdx.x == 0 && blockIdx.x == 0) { out[1 << 20] = (uint32_t) (t1 - t0); }
 }
-template <int OP> void run(const char* name, int* d) {
-  const int iters = 2000, blocks = 256 * 8, threads = 256;   // 8 waves/SIMD worth of independent chains
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  k<OP><<<blocks, threads>>>(d, 10, 3, 5);
-  hipDeviceSynchronize();
-  hipEventRecord(e0);
-  k<OP><<<blocks, threads>>>(d, iters, 3, 5);
-  hipEventRecord(e1); hipEventSynchronize(e1);
-  float ms; hipEventElapsedTime(&ms, e0, e1);
-  // 32 waves per CU (8 per SIMD); each wave issues iters*16 dependent ops; SIMD time-slices the waves.
-  double wave_insts_per_simd = 8.0 * iters * 16;
-  double ns_per_inst = ms * 1e6 / wave_insts_per_simd;
-  printf("%-18s %8.3f ms  %6.2f ns per wave-instruction per SIMD (= %5.1f cycles @2.4GHz)\n", name, ms, ns_per_inst, ns_per_inst * 2.4);
+
+template <int OP>
+void run(const char* name, uint32_t* d_out)
+{
+  for (int waves_per_simd : {1, 4}) {
+    const int threads = 256;                      // 4 waves = 1 per SIMD
+    const int blocks = 256 * waves_per_simd;      // one CU gets waves_per_simd blocks (roughly)
+    const int iters = 200;
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(threads), 0, 0, d_out, iters, 12345u);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(threads), 0, 0, d_out, iters, 12345u);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    uint32_t cyc; hipMemcpy(&cyc, d_out + (1 << 20), 4, hipMemcpyDeviceToHost);
+    const double n_instr = (double) iters * REP * (OP == 12 ? 2 : 1);
+    printf("%-22s waves/SIMD=%d  cycles/instr (block 0, own clock) = %6.2f   wall %.3f ms\n", name, waves_per_simd,
+           cyc / n_instr, ms);
+  }
 }
-int main() {
-  int* d; hipMalloc(&d, 256 * 8 * 256 * 4);
-  run<0>("v_add_u32", d); run<1>("v_mul_lo_u32", d); run<2>("v_mul_hi_i32", d); run<3>("v_mad_i64_i32", d);
-  run<8>("v_mad_u64_u32", d); run<4>("v_mul_i32_i24", d); run<5>("v_mul_hi_i32_i24", d); run<6>("v_ashrrev_i64", d);
-  run<7>("v_alignbit_b32", d); run<9>("v_med3_i32", d); run<10>("v_lshl_add_u64", d); run<11>("v_cvt_f64_i32", d);
-  run<12>("v_fma_f64", d); run<13>("v_dot4c_i32_i8", d); run<14>("v_perm_b32", d);
+
+int main()
+{
+  uint32_t* d_out; hipMalloc(&d_out, ((1 << 20) + 16) * 4);
+  run<8>("v_add_u32", d_out);
+  run<0>("v_mad_i64_i32", d_out);
+  run<9>("v_mad_u64_u32", d_out);
+  run<1>("v_mul_hi_i32", d_out);
+  run<2>("v_mul_lo_u32", d_out);
+  run<3>("v_mul_hi_i32_i24", d_out);
+  run<4>("v_mul_i32_i24", d_out);
+  run<5>("v_fma_f64", d_out);
+  run<6>("v_cvt_f64_i32", d_out);
+  run<7>("v_cvt_i32_f64", d_out);
+  run<10>("v_add3_u32", d_out);
+  run<11>("v_ashrrev_i32", d_out);
+  run<12>("sub_co+subb_co (x2)", d_out);
+  run<13>("v_cvt_pk_i16_i32", d_out);
+  run<14>("v_pk_add_i16 clamp", d_out);
+  run<15>("v_lshlrev_b64", d_out);
+  run<16>("v_fma_f32", d_out);
   return 0;
 }
