@@ -108,6 +108,52 @@ enum qnnp_status qnnp_setup_convolution2d_nhwc_q8(
     size_t output_stride,
     pthreadpool_t threadpool);
 
+/* reference include/qnnpack.h:78-105. Transposed convolution:
+ *   output extent = stride * (input - 1) + adjustment + (kernel - 1) * dilation + 1 - (padding before + after)
+ * kernel: [groups][group_input_channels][kernel_height][kernel_width][group_output_channels] uint8
+ *         (test/deconvolution-operator-tester.h:411 -- note: input channel OUTERMOST, unlike convolution)
+ * bias:   [groups * group_output_channels] int32 */
+enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8(
+    uint32_t input_padding_top,
+    uint32_t input_padding_right,
+    uint32_t input_padding_bottom,
+    uint32_t input_padding_left,
+    uint32_t adjustment_height,
+    uint32_t adjustment_width,
+    uint32_t kernel_height,
+    uint32_t kernel_width,
+    uint32_t stride_height,
+    uint32_t stride_width,
+    uint32_t dilation_height,
+    uint32_t dilation_width,
+    uint32_t groups,
+    size_t group_input_channels,
+    size_t group_output_channels,
+    uint8_t input_zero_point,
+    float input_scale,
+    uint8_t kernel_zero_point,
+    float kernel_scale,
+    const uint8_t* kernel,
+    const int32_t* bias,
+    uint8_t output_zero_point,
+    float output_scale,
+    uint8_t output_min,
+    uint8_t output_max,
+    uint32_t flags,
+    qnnp_operator_t* deconvolution);
+
+/* reference include/qnnpack.h:107-116 */
+enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8(
+    qnnp_operator_t deconvolution,
+    size_t batch_size,
+    size_t input_height,
+    size_t input_width,
+    const uint8_t* input,
+    size_t input_stride,
+    uint8_t* output,
+    size_t output_stride,
+    pthreadpool_t threadpool);
+
 /* reference include/qnnpack.h:118-132. kernel: [output_channels][input_channels] */
 enum qnnp_status qnnp_create_fully_connected_nc_q8(
     size_t input_channels,

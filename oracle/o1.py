@@ -60,6 +60,11 @@ def lib():
         L.oracle_conv_output_dim.argtypes = [c_size_t] * 4
         L.oracle_conv2d_acc.restype = None
         L.oracle_conv2d_acc.argtypes = [POINTER(ConvShape), c_void_p, c_void_p, c_void_p, c_uint8, c_uint8, c_void_p]
+        L.oracle_deconv_output_dim.restype = c_size_t
+        L.oracle_deconv_output_dim.argtypes = [c_size_t] * 6
+        L.oracle_deconv2d_acc.restype = None
+        L.oracle_deconv2d_acc.argtypes = [POINTER(ConvShape), c_uint32, c_uint32, c_void_p, c_void_p, c_void_p,
+                                          c_uint8, c_uint8, c_void_p]
         L.oracle_requantize_rows.restype = c_int
         L.oracle_requantize_rows.argtypes = [c_size_t, c_size_t, c_void_p, c_float, c_uint8, c_uint8, c_uint8,
                                              c_void_p, c_size_t]
@@ -141,6 +146,29 @@ def conv2d_acc(s: ConvShape, input: np.ndarray, kernel: np.ndarray, bias: np.nda
     acc = np.empty((s.batch, oh, ow, s.groups * s.group_output_channels), dtype=np.int32)
     lib().oracle_conv2d_acc(ctypes.byref(s), input.ctypes.data, kernel.ctypes.data, bias.ctypes.data, izp, kzp,
                             acc.ctypes.data)
+    return acc
+
+
+def deconv_output_hw(s: ConvShape, adjustment=(0, 0)):
+    """src/deconvolution.c:25-37, :253-258"""
+    L = lib()
+    oh = L.oracle_deconv_output_dim(s.input_height, s.pad_top + s.pad_bottom, adjustment[0], s.kernel_height,
+                                    s.dilation_height, s.stride_height)
+    ow = L.oracle_deconv_output_dim(s.input_width, s.pad_left + s.pad_right, adjustment[1], s.kernel_width,
+                                    s.dilation_width, s.stride_width)
+    return int(oh), int(ow)
+
+
+def deconv2d_acc(s: ConvShape, adjustment, input: np.ndarray, kernel: np.ndarray, bias: np.ndarray,
+                 izp: int, kzp: int) -> np.ndarray:
+    """test/deconvolution-operator-tester.h:383-419. kernel [g][ic][ky][kx][oc]; returns acc [N, OH, OW, G*GOC]."""
+    oh, ow = deconv_output_hw(s, adjustment)
+    input = np.ascontiguousarray(input, dtype=np.uint8)
+    kernel = np.ascontiguousarray(kernel, dtype=np.uint8)
+    bias = np.ascontiguousarray(bias, dtype=np.int32)
+    acc = np.empty((s.batch, oh, ow, s.groups * s.group_output_channels), dtype=np.int32)
+    lib().oracle_deconv2d_acc(ctypes.byref(s), adjustment[0], adjustment[1], input.ctypes.data, kernel.ctypes.data,
+                              bias.ctypes.data, izp, kzp, acc.ctypes.data)
     return acc
 
 

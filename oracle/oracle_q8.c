@@ -149,6 +149,61 @@ void oracle_conv2d_acc(
   }
 }
 
+/* src/deconvolution.c:25-37 */
+size_t oracle_deconv_output_dim(
+    size_t input, size_t padding, size_t adjustment, size_t kernel, size_t dilation, size_t stride)
+{
+  const size_t effective = (kernel - 1) * dilation + 1;
+  return stride * (input - 1) + adjustment + effective - padding;
+}
+
+/* test/deconvolution-operator-tester.h:383-419 */
+void oracle_deconv2d_acc(
+    const struct oracle_conv_shape* s, uint32_t adjustment_height, uint32_t adjustment_width,
+    const uint8_t* input, const uint8_t* kernel, const int32_t* bias,
+    uint8_t izp, uint8_t kzp, int32_t* acc)
+{
+  const size_t OH = oracle_deconv_output_dim(s->input_height, (size_t) s->pad_top + s->pad_bottom, adjustment_height,
+      s->kernel_height, s->dilation_height, s->stride_height);
+  const size_t OW = oracle_deconv_output_dim(s->input_width, (size_t) s->pad_left + s->pad_right, adjustment_width,
+      s->kernel_width, s->dilation_width, s->stride_width);
+  const size_t G = s->groups, GIC = s->group_input_channels, GOC = s->group_output_channels;
+  const size_t KH = s->kernel_height, KW = s->kernel_width;
+  const ptrdiff_t rows = (ptrdiff_t) (s->batch * OH);
+
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (ptrdiff_t row = 0; row < rows; row++) {
+    const size_t i = (size_t) row / OH;
+    const size_t oy = (size_t) row % OH;
+    for (size_t ox = 0; ox < OW; ox++) {
+      int32_t* out = acc + (((i * OH + oy) * OW + ox) * G) * GOC;
+      for (size_t g = 0; g < G; g++) {
+        for (size_t oc = 0; oc < GOC; oc++) {
+          uint32_t sum = (uint32_t) bias[g * GOC + oc];        /* :388-389 */
+          for (size_t ky = 0; ky < KH; ky++) {
+            /* :399-401, size_t arithmetic: a negative y wraps, its quotient fails `< input_height` */
+            const size_t y = oy + s->pad_top - ky * s->dilation_height;
+            const size_t iy = y / s->stride_height;
+            if (iy * s->stride_height != y || iy >= s->input_height) continue;
+            for (size_t kx = 0; kx < KW; kx++) {
+              const size_t x = ox + s->pad_left - kx * s->dilation_width;   /* :403-405 */
+              const size_t ix = x / s->stride_width;
+              if (ix * s->stride_width != x || ix >= s->input_width) continue;
+              const uint8_t* in = input +
+                  ((i * s->input_height + iy) * s->input_width + ix) * s->input_pixel_stride + g * GIC;
+              for (size_t ic = 0; ic < GIC; ic++) {
+                const uint8_t kv = kernel[(((g * GIC + ic) * KH + ky) * KW + kx) * GOC + oc];   /* :411 */
+                sum += (uint32_t) (((int32_t) in[ic] - (int32_t) izp) * ((int32_t) kv - (int32_t) kzp));
+              }
+            }
+          }
+          out[g * GOC + oc] = (int32_t) sum;
+        }
+      }
+    }
+  }
+}
+
 int oracle_requantize_rows(
     size_t rows, size_t cols, const int32_t* acc,
     float scale, uint8_t ozp, uint8_t omin, uint8_t omax,

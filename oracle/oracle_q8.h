@@ -82,6 +82,18 @@ void oracle_conv2d_acc(
     const uint8_t* input, const uint8_t* kernel, const int32_t* bias,
     uint8_t izp, uint8_t kzp, int32_t* acc);
 
+/* src/deconvolution.c:25-37: stride*(input-1) + adjustment + (kernel-1)*dilation + 1 - padding */
+size_t oracle_deconv_output_dim(
+    size_t input, size_t padding, size_t adjustment, size_t kernel, size_t dilation, size_t stride);
+
+/* test/deconvolution-operator-tester.h:383-419 (transposed convolution, the tester's ground truth).
+ * kernel layout [g][ic][ky][kx][oc] (:411); acc layout [n][oy][ox][g*GOC + oc]. `s` holds the INPUT
+ * geometry; pads are the amounts removed from the full output; stride_* is the deconvolution stride. */
+void oracle_deconv2d_acc(
+    const struct oracle_conv_shape* s, uint32_t adjustment_height, uint32_t adjustment_width,
+    const uint8_t* input, const uint8_t* kernel, const int32_t* bias,
+    uint8_t izp, uint8_t kzp, int32_t* acc);
+
 /* Requantize a [rows][cols] accumulator matrix into out rows of out_stride bytes. */
 int oracle_requantize_rows(
     size_t rows, size_t cols, const int32_t* acc,

@@ -67,6 +67,13 @@ class QnnpackLibrary:
         L.qnnp_setup_convolution2d_nhwc_q8.restype = c_int
         L.qnnp_setup_convolution2d_nhwc_q8.argtypes = [
             c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]
+        L.qnnp_create_deconvolution2d_nhwc_q8.restype = c_int
+        L.qnnp_create_deconvolution2d_nhwc_q8.argtypes = (
+            [c_uint32] * 13 + [c_size_t, c_size_t, c_uint8, c_float, c_uint8, c_float, c_void_p, c_void_p,
+                               c_uint8, c_float, c_uint8, c_uint8, c_uint32, POINTER(c_void_p)])
+        L.qnnp_setup_deconvolution2d_nhwc_q8.restype = c_int
+        L.qnnp_setup_deconvolution2d_nhwc_q8.argtypes = [
+            c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]
         L.qnnp_create_fully_connected_nc_q8.restype = c_int
         L.qnnp_create_fully_connected_nc_q8.argtypes = [
             c_size_t, c_size_t, c_uint8, c_float, c_uint8, c_float, c_void_p, c_void_p,
@@ -124,6 +131,42 @@ class QnnpackLibrary:
         st = self.setup_convolution2d_nhwc_q8_status(*args)
         if st != Status.success:
             raise QnnpackError("qnnp_setup_convolution2d_nhwc_q8", st)
+
+    def create_deconvolution2d_nhwc_q8_status(
+            self, pad_top, pad_right, pad_bottom, pad_left, adjustment_height, adjustment_width,
+            kernel_height, kernel_width, stride_height, stride_width, dilation_height, dilation_width,
+            groups, group_input_channels, group_output_channels,
+            input_zero_point, input_scale, kernel_zero_point, kernel_scale,
+            kernel, bias, output_zero_point, output_scale, output_min, output_max, flags=0):
+        """kernel: [groups][group_input_channels][kh][kw][group_output_channels] (reference include/qnnpack.h:78-105)."""
+        kernel = None if kernel is None else np.ascontiguousarray(kernel, dtype=np.uint8)
+        bias = None if bias is None else np.ascontiguousarray(bias, dtype=np.int32)
+        handle = c_void_p(None)
+        st = self.lib.qnnp_create_deconvolution2d_nhwc_q8(
+            pad_top, pad_right, pad_bottom, pad_left, adjustment_height, adjustment_width,
+            kernel_height, kernel_width, stride_height, stride_width, dilation_height, dilation_width,
+            groups, group_input_channels, group_output_channels,
+            input_zero_point, input_scale, kernel_zero_point, kernel_scale,
+            address_of(kernel), address_of(bias),
+            output_zero_point, output_scale, output_min, output_max, flags, ctypes.byref(handle))
+        return Status(st), handle.value
+
+    def create_deconvolution2d_nhwc_q8(self, *args, **kwargs) -> int:
+        st, handle = self.create_deconvolution2d_nhwc_q8_status(*args, **kwargs)
+        if st != Status.success:
+            raise QnnpackError("qnnp_create_deconvolution2d_nhwc_q8", st)
+        return handle
+
+    def setup_deconvolution2d_nhwc_q8_status(
+            self, op, batch_size, input_height, input_width, input, input_stride, output, output_stride) -> Status:
+        return Status(self.lib.qnnp_setup_deconvolution2d_nhwc_q8(
+            op, batch_size, input_height, input_width, address_of(input), input_stride,
+            address_of(output), output_stride, None))
+
+    def setup_deconvolution2d_nhwc_q8(self, *args) -> None:
+        st = self.setup_deconvolution2d_nhwc_q8_status(*args)
+        if st != Status.success:
+            raise QnnpackError("qnnp_setup_deconvolution2d_nhwc_q8", st)
 
     def create_fully_connected_nc_q8_status(
             self, input_channels, output_channels, input_zero_point, input_scale,

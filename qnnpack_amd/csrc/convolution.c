@@ -308,7 +308,7 @@ enum qnnp_status qnnp_setup_convolution2d_nhwc_q8(
     qnnp_log_error("qnnp_setup_convolution2d_nhwc_q8 failed because QNNPACK is not properly initialized");
     return qnnp_status_uninitialized;
   }
-  if (op == NULL) {
+  if (op == NULL || op->transposed) {
     return qnnp_status_invalid_parameter;
   }
 

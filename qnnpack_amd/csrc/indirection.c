@@ -50,3 +50,41 @@ void qnnp_indirection_init_conv2d_offsets(const struct qnnp_operator* op, int32_
     }
   }
 }
+
+/*
+ * Deconvolution: replaces qnnp_indirection_init_deconv2d (reference src/indirection.c:134-190). Output pixel
+ * (oy, ox) receives tap (ky, kx) from input pixel (y / stride_h, x / stride_w) with
+ * y = oy + pad_top - ky*dilation_h, x likewise, when both divisions are exact and the pixel exists
+ * (:171-177, same size_t arithmetic: a negative y wraps to a huge value whose quotient fails `< extent`);
+ * every other tap reads the zero point (:181) = a padding entry here.
+ */
+void qnnp_indirection_init_deconv2d_offsets(const struct qnnp_operator* op, int32_t* table)
+{
+  const size_t input_height = op->input_height;
+  const size_t input_width = op->input_width;
+  const size_t output_height = op->output_height;
+  const size_t output_width = op->output_width;
+  const size_t kernel_height = op->kernel_height;
+  const size_t kernel_width = op->kernel_width;
+  const size_t taps = kernel_height * kernel_width;
+
+  for (size_t oy = 0; oy < output_height; oy++) {
+    for (size_t ox = 0; ox < output_width; ox++) {
+      int32_t* entry = table + (oy * output_width + ox) * taps;
+      for (size_t ky = 0; ky < kernel_height; ky++) {
+        const size_t y = oy + op->input_padding_top - ky * op->dilation_height;
+        const size_t iy = y / op->stride_height;
+        const int row_ok = iy * op->stride_height == y && iy < input_height;
+        for (size_t kx = 0; kx < kernel_width; kx++) {
+          const size_t x = ox + op->input_padding_left - kx * op->dilation_width;
+          const size_t ix = x / op->stride_width;
+          if (row_ok && ix * op->stride_width == x && ix < input_width) {
+            entry[ky * kernel_width + kx] = (int32_t) ((iy * input_width + ix) * op->input_pixel_stride);
+          } else {
+            entry[ky * kernel_width + kx] = QNNP_OFFSET_PADDING;
+          }
+        }
+      }
+    }
+  }
+}

@@ -37,6 +37,9 @@ struct qnnp_operator {
   uint32_t groups;
   size_t group_input_channels;
   size_t group_output_channels;
+  uint32_t adjustment_height;  /* deconvolution only (reference operator.h:45-46) */
+  uint32_t adjustment_width;
+  int transposed;              /* 1: deconvolution -- the offset table is the transposed-convolution one */
 
   /* bound at setup (reference operator.h:59-73): caller-owned, not copied */
   size_t input_height;

@@ -233,3 +233,69 @@ def strided_view(flat: np.ndarray, rows: int, channels: int, stride: int) -> np.
     if rows == 0:
         return np.zeros((0, channels), dtype=flat.dtype)
     return np.lib.stride_tricks.as_strided(flat, shape=(rows, channels), strides=(stride, 1), writeable=False)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Deconvolution (transposed convolution): test/deconvolution.cc, in file order. `ConvCase.subsampling` is the
+# deconvolution stride, `padding` the amounts removed from the full output.
+@dataclass(frozen=True)
+class DeconvCase(ConvCase):
+    adjustment: Tuple[int, int] = (0, 0)
+
+
+DECONV_CASES = [
+    DeconvCase("d_zero_batch", (5, 5), (1, 1), gic=2, goc=2, batch=0),
+    DeconvCase("d_1x1", (27, 29), (1, 1), gic=23, goc=19),
+    DeconvCase("d_1x1_with_qmin", (27, 29), (1, 1), gic=23, goc=19, qmin=128),
+    DeconvCase("d_1x1_with_qmax", (27, 29), (1, 1), gic=23, goc=19, qmax=128),
+    DeconvCase("d_1x1_with_input_stride", (27, 29), (1, 1), gic=23, goc=19, input_pixel_stride=28),
+    DeconvCase("d_1x1_with_output_stride", (27, 29), (1, 1), gic=23, goc=19, output_pixel_stride=29),
+    DeconvCase("d_1x1_with_batch", (13, 14), (1, 1), gic=23, goc=19, batch=3),
+    DeconvCase("d_grouped_1x1", (24, 25), (1, 1), groups=2, gic=17, goc=19),
+    DeconvCase("d_1x3", (20, 19), (1, 3), _pad(w=1), gic=17, goc=15),
+    DeconvCase("d_grouped_1x3", (20, 19), (1, 3), _pad(w=1), groups=2, gic=17, goc=15),
+    DeconvCase("d_3x1", (19, 20), (3, 1), _pad(h=1), gic=17, goc=15),
+    DeconvCase("d_grouped_3x1", (19, 20), (3, 1), _pad(h=1), groups=2, gic=17, goc=15),
+    DeconvCase("d_3x3", (13, 12), (3, 3), _pad(1, 1), gic=15, goc=17),
+    DeconvCase("d_3x3_with_input_stride", (13, 12), (3, 3), _pad(1, 1), gic=15, goc=17, input_pixel_stride=22),
+    DeconvCase("d_3x3_with_output_stride", (13, 12), (3, 3), _pad(1, 1), gic=15, goc=17, output_pixel_stride=23),
+    DeconvCase("d_3x3_with_batch", (10, 9), (3, 3), _pad(1, 1), gic=15, goc=17, batch=3),
+    DeconvCase("d_grouped_3x3", (10, 11), (3, 3), _pad(1, 1), groups=2, gic=14, goc=13),
+    DeconvCase("d_3x3s2", (19, 21), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=27, goc=19),
+    DeconvCase("d_3x3s1x2", (13, 13), (3, 3), _pad(1, 1), subsampling=(1, 2), gic=27, goc=19),
+    DeconvCase("d_3x3s2x1", (13, 13), (3, 3), _pad(1, 1), subsampling=(2, 1), gic=27, goc=19),
+    DeconvCase("d_3x3d2", (13, 14), (3, 3), _pad(2, 2), dilation=(2, 2), gic=27, goc=19),
+    DeconvCase("d_3x3d1x2", (14, 15), (3, 3), _pad(1, 2), dilation=(1, 2), gic=27, goc=19),
+    DeconvCase("d_3x3d2x1", (15, 14), (3, 3), _pad(2, 1), dilation=(2, 1), gic=27, goc=19),
+]
+
+# Beyond the reference's list: output adjustment, the usual 2x upsampling layers (2x2 s2, 4x4 s2 p1), aligned
+# channel counts (the 16-byte activation-vector path), zero-point / clamp corners, asymmetric padding.
+EXTRA_DECONV_CASES = [
+    DeconvCase("dx_3x3s2_adjust", (9, 8), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=8, goc=8, adjustment=(1, 1)),
+    DeconvCase("dx_3x3s3_adjust_2x1", (6, 7), (3, 3), subsampling=(3, 3), gic=5, goc=7, adjustment=(2, 1)),
+    DeconvCase("dx_2x2s2_c64_n32", (14, 14), (2, 2), subsampling=(2, 2), gic=64, goc=32, batch=2),
+    DeconvCase("dx_4x4s2p1_c32_n16", (11, 13), (4, 4), _pad(1, 1), subsampling=(2, 2), gic=32, goc=16, batch=2),
+    DeconvCase("dx_3x3_c128_n64", (8, 9), (3, 3), _pad(1, 1), gic=128, goc=64),
+    DeconvCase("dx_3x3s2_zp_0_255", (7, 7), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=16, goc=16, izp=0, kzp=255),
+    DeconvCase("dx_3x3s2_zp_255_0", (7, 7), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=16, goc=16, izp=255, kzp=0),
+    DeconvCase("dx_3x3_asym_pad", (9, 10), (3, 3), (2, 0, 0, 1), gic=12, goc=20),
+    DeconvCase("dx_5x5s2d2", (6, 6), (5, 5), _pad(2, 2), subsampling=(2, 2), dilation=(2, 2), gic=9, goc=11),
+    DeconvCase("dx_grouped_2x2s2", (10, 10), (2, 2), subsampling=(2, 2), groups=4, gic=8, goc=6, batch=2),
+    DeconvCase("dx_3x3s2_qmin_qmax", (8, 8), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=16, goc=24, qmin=40, qmax=200),
+    DeconvCase("dx_1x1s2", (6, 5), (1, 1), subsampling=(2, 2), gic=10, goc=12),
+]
+
+
+def deconv_tensors(case: DeconvCase):
+    """Seeded input / kernel / bias; kernel in the deconvolution layout [g][ic][kh][kw][oc]
+    (test/deconvolution-operator-tester.h:355, :411)."""
+    rng = np.random.default_rng(seed_for(case.name))
+    H, W = case.input_size
+    pixels = case.batch * H * W
+    in_len = max(pixels - 1, 0) * case.in_stride + case.groups * case.gic if pixels else 0
+    inp = rng.integers(0, 256, size=in_len, dtype=np.uint8)
+    kernel = rng.integers(0, 256, size=(case.groups, case.gic, case.kernel_size[0], case.kernel_size[1], case.goc),
+                          dtype=np.uint8)
+    bias = rng.integers(-10000, 10001, size=case.groups * case.goc, dtype=np.int32)
+    return inp, kernel, bias

@@ -10,7 +10,8 @@ from __future__ import annotations
 
 import numpy as np
 
-from _cases import ConvCase, FcCase, conv_tensors, fc_tensors, output_quantization, strided_view
+from _cases import (ConvCase, DeconvCase, FcCase, conv_tensors, deconv_tensors, fc_tensors, output_quantization,
+                    strided_view)
 from oracle import o1
 
 FILL = 0xA5  # the testers pre-fill outputs with 0xA5 (convolution-operator-tester.h:361)
@@ -65,6 +66,60 @@ def conv_run(lib, case: ConvCase, quant, out_hw, inp=None, kernel=None, bias=Non
             host_out = out if out.size else np.zeros(1, np.uint8)
             lib.setup_convolution2d_nhwc_q8(op, case.batch, case.input_size[0], case.input_size[1],
                                             host_in, case.in_stride, host_out, case.out_stride)
+            lib.run_operator(op, threadpool)
+        kernel_name = lib.operator_kernel(op) if hasattr(lib, "operator_kernel") else None
+    finally:
+        lib.delete_operator(op)
+    return out, kernel_name
+
+
+def deconv_expected(case: DeconvCase, inp=None, kernel=None, bias=None):
+    """Oracle output buffer for a deconvolution case (test/deconvolution-operator-tester.h:383-446 flow)."""
+    if inp is None:
+        inp, kernel, bias = deconv_tensors(case)
+    H, W = case.input_size
+    shape = o1.conv_shape(case.batch, H, W, case.padding, case.kernel_size, case.subsampling, case.dilation,
+                          case.groups, case.gic, case.goc, case.in_stride)
+    oh, ow = o1.deconv_output_hw(shape, case.adjustment)
+    cout = case.groups * case.goc
+    if case.batch == 0:
+        return np.zeros(0, np.uint8), (np.float32(900 / 255.0), 0), (oh, ow)
+    acc = o1.deconv2d_acc(shape, case.adjustment, inp, kernel, bias, case.izp, case.kzp)
+    oscale, ozp = output_quantization(acc)
+    rows = case.batch * oh * ow
+    out = np.full((rows - 1) * case.out_stride + cout, FILL, dtype=np.uint8)
+    req_scale = np.float32(np.float32(1.0) * np.float32(1.0) / oscale)
+    o1.requantize_rows(acc.reshape(rows, cout), req_scale, ozp, case.qmin, case.qmax, out, case.out_stride)
+    return out, (oscale, ozp), (oh, ow)
+
+
+def deconv_run(lib, case: DeconvCase, quant, out_hw, inp=None, kernel=None, bias=None,
+               to_device=None, from_device=None, threadpool=None):
+    if inp is None:
+        inp, kernel, bias = deconv_tensors(case)
+    oscale, ozp = quant
+    oh, ow = out_hw
+    cout = case.groups * case.goc
+    rows = case.batch * oh * ow
+    out = np.full(max(rows - 1, 0) * case.out_stride + cout if rows else 0, FILL, dtype=np.uint8)
+    op = lib.create_deconvolution2d_nhwc_q8(
+        case.padding[0], case.padding[1], case.padding[2], case.padding[3],
+        case.adjustment[0], case.adjustment[1],
+        case.kernel_size[0], case.kernel_size[1], case.subsampling[0], case.subsampling[1],
+        case.dilation[0], case.dilation[1], case.groups, case.gic, case.goc,
+        case.izp, 1.0, case.kzp, 1.0, kernel, bias, ozp, float(oscale), case.qmin, case.qmax, 0)
+    try:
+        if to_device is not None and rows:
+            d_in, d_out = to_device(inp), to_device(out)
+            lib.setup_deconvolution2d_nhwc_q8(op, case.batch, case.input_size[0], case.input_size[1],
+                                              d_in, case.in_stride, d_out, case.out_stride)
+            lib.run_operator(op, threadpool)
+            out = from_device(d_out)
+        else:
+            host_in = inp if inp.size else np.zeros(1, np.uint8)
+            host_out = out if out.size else np.zeros(1, np.uint8)
+            lib.setup_deconvolution2d_nhwc_q8(op, case.batch, case.input_size[0], case.input_size[1],
+                                              host_in, case.in_stride, host_out, case.out_stride)
             lib.run_operator(op, threadpool)
         kernel_name = lib.operator_kernel(op) if hasattr(lib, "operator_kernel") else None
     finally:

@@ -21,10 +21,11 @@ def declared_functions(header):
 
 def test_headers_declare_the_reference_entry_points():
     names = declared_functions("qnnpack.h")
-    # reference include/qnnpack.h:34-36, 40-76, 118-140, 327-332 (hot-path subset)
+    # reference include/qnnpack.h:34-36, 40-76, 78-116, 118-140, 327-332 (hot-path subset + deconvolution)
     assert names == sorted([
         "qnnp_initialize", "qnnp_deinitialize",
         "qnnp_create_convolution2d_nhwc_q8", "qnnp_setup_convolution2d_nhwc_q8",
+        "qnnp_create_deconvolution2d_nhwc_q8", "qnnp_setup_deconvolution2d_nhwc_q8",
         "qnnp_create_fully_connected_nc_q8", "qnnp_setup_fully_connected_nc_q8",
         "qnnp_run_operator", "qnnp_delete_operator"])
 
@@ -56,6 +57,9 @@ def test_no_gpu_means_unsupported_hardware_not_a_fallback(product):
     bias = np.zeros(4, np.int32)
     st, handle = product.create_fully_connected_nc_q8_status(4, 4, 0, 1.0, 0, 1.0, kernel, bias, 0, 2.0, 0, 255)
     assert st == Status.uninitialized and not handle       # reference fully-connected.c:44-47
+    st, handle = product.create_deconvolution2d_nhwc_q8_status(
+        0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 4, 4, 0, 1.0, 0, 1.0, kernel, bias, 0, 2.0, 0, 255)
+    assert st == Status.uninitialized and not handle       # reference deconvolution.c:69-72
     st, handle = product.create_convolution2d_nhwc_q8_status(
         0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 4, 4, 0, 1.0, 0, 1.0, kernel, bias, 0, 2.0, 0, 255)
     assert st == Status.uninitialized and not handle       # reference convolution.c:69-72
