@@ -180,6 +180,53 @@ enum qnnp_status qnnp_setup_fully_connected_nc_q8(
     uint8_t* output,
     size_t output_stride);
 
+/* reference include/qnnpack.h:142-151. Averages `width` pixels of `channels` bytes per image (NWC). */
+enum qnnp_status qnnp_create_global_average_pooling_nwc_q8(
+    size_t channels,
+    uint8_t input_zero_point,
+    float input_scale,
+    uint8_t output_zero_point,
+    float output_scale,
+    uint8_t output_min,
+    uint8_t output_max,
+    uint32_t flags,
+    qnnp_operator_t* global_average_pooling);
+
+/* reference include/qnnpack.h:153-160. input_stride: bytes between pixels; output_stride: between images. */
+enum qnnp_status qnnp_setup_global_average_pooling_nwc_q8(
+    qnnp_operator_t global_average_pooling,
+    size_t batch_size,
+    size_t width,
+    const uint8_t* input,
+    size_t input_stride,
+    uint8_t* output,
+    size_t output_stride);
+
+/* reference include/qnnpack.h:234-245. Quantized element-wise sum of two [batch][channels] tensors. */
+enum qnnp_status qnnp_create_add_nc_q8(
+    size_t channels,
+    uint8_t a_zero_point,
+    float a_scale,
+    uint8_t b_zero_point,
+    float b_scale,
+    uint8_t sum_zero_point,
+    float sum_scale,
+    uint8_t sum_min,
+    uint8_t sum_max,
+    uint32_t flags,
+    qnnp_operator_t* add);
+
+/* reference include/qnnpack.h:247-255 */
+enum qnnp_status qnnp_setup_add_nc_q8(
+    qnnp_operator_t add,
+    size_t batch_size,
+    const uint8_t* a,
+    size_t a_stride,
+    const uint8_t* b,
+    size_t b_stride,
+    uint8_t* sum,
+    size_t sum_stride);
+
 /* reference include/qnnpack.h:327-329. `threadpool` is accepted and ignored:
  * the operator runs as HIP kernels on the library's stream. Synchronous by
  * default (outputs complete on return); see qnnpack_gfx950.h for async mode. */

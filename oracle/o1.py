@@ -76,6 +76,13 @@ def lib():
         L.oracle_convolution2d_q8.argtypes = [POINTER(ConvShape), c_uint8, c_float, c_uint8, c_float,
                                               c_void_p, c_void_p, c_uint8, c_float, c_uint8, c_uint8,
                                               c_void_p, c_void_p, c_size_t]
+        L.oracle_add_q8.restype = c_int
+        L.oracle_add_q8.argtypes = [c_size_t, c_size_t, c_uint8, c_float, c_uint8, c_float, c_uint8, c_float,
+                                    c_uint8, c_uint8, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t]
+        L.oracle_global_average_pooling_q8.restype = c_int
+        L.oracle_global_average_pooling_q8.argtypes = [c_size_t, c_size_t, c_size_t, c_uint8, c_float, c_uint8,
+                                                       c_float, c_uint8, c_uint8, c_void_p, c_size_t, c_void_p,
+                                                       c_size_t]
         L.oracle_set_threads.restype = None
         L.oracle_set_threads.argtypes = [c_int]
         L.oracle_get_threads.restype = c_int
@@ -183,4 +190,23 @@ def requantize_rows(acc: np.ndarray, scale: float, ozp: int, omin: int, omax: in
     if lib().oracle_requantize_rows(rows, cols, acc.ctypes.data, np.float32(scale), ozp, omin, omax,
                                     out.ctypes.data, out_stride) != 0:
         raise ValueError(f"scale {scale} outside [2**-32, 1)")
+    return out
+
+
+def add_q8(batch, channels, a_zp, a_scale, b_zp, b_scale, y_zp, y_scale, y_min, y_max,
+           a: np.ndarray, a_stride: int, b: np.ndarray, b_stride: int, y: np.ndarray, y_stride: int) -> np.ndarray:
+    """src/qnnpack/requantization.h:327-360, :400-413, :500-522 -- writes into the flat strided buffer `y`."""
+    if lib().oracle_add_q8(batch, channels, a_zp, np.float32(a_scale), b_zp, np.float32(b_scale), y_zp,
+                           np.float32(y_scale), y_min, y_max, a.ctypes.data, a_stride, b.ctypes.data, b_stride,
+                           y.ctypes.data, y_stride) != 0:
+        raise ValueError("scale ratio outside [2**-14, 2**8)")
+    return y
+
+
+def global_average_pooling_q8(batch, width, channels, izp, iscale, ozp, oscale, omin, omax,
+                              inp: np.ndarray, in_stride: int, out: np.ndarray, out_stride: int) -> np.ndarray:
+    """src/global-average-pooling.c:138-145 + src/qnnpack/requantization.h:200-222, :482-498."""
+    if lib().oracle_global_average_pooling_q8(batch, width, channels, izp, np.float32(iscale), ozp, np.float32(oscale),
+                                              omin, omax, inp.ctypes.data, in_stride, out.ctypes.data, out_stride) != 0:
+        raise ValueError("scale outside [2**-32, 256)")
     return out

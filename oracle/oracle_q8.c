@@ -4,6 +4,8 @@
  */
 #include "oracle_q8.h"
 
+#include <math.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -261,4 +263,94 @@ int oracle_convolution2d_q8(
   const int rc = oracle_requantize_rows(rows, cols, acc, scale, ozp, omin, omax, output, output_pixel_stride);
   free(acc);
   return rc;
+}
+
+/* ---- element-wise add ------------------------------------------------------------------------------- */
+
+static inline float f32_from_bits(uint32_t bits) {
+  float f;
+  memcpy(&f, &bits, sizeof(f));
+  return f;
+}
+
+int oracle_add_q8(
+    size_t batch, size_t channels,
+    uint8_t a_zero_point, float a_scale, uint8_t b_zero_point, float b_scale,
+    uint8_t y_zero_point, float y_scale, uint8_t y_min, uint8_t y_max,
+    const uint8_t* a, size_t a_stride, const uint8_t* b, size_t b_stride, uint8_t* y, size_t y_stride)
+{
+  /* src/add.c:73-89 */
+  const float a_output_scale = a_scale / y_scale;
+  const float b_output_scale = b_scale / y_scale;
+  if (a_output_scale < 0x1.0p-14f || a_output_scale >= 0x1.0p+8f) return -1;
+  if (b_output_scale < 0x1.0p-14f || b_output_scale >= 0x1.0p+8f) return -1;
+  /* src/qnnpack/requantization.h:341-359 */
+  const float max_output_scale = a_output_scale > b_output_scale ? a_output_scale : b_output_scale;
+  const int32_t max_scale_exponent = (int32_t) (f32_bits(max_output_scale) >> 23) - 127;
+  const uint32_t shift = (uint32_t) (21 - max_scale_exponent);
+  const float scale_multiplier = f32_from_bits((uint32_t) (21 - max_scale_exponent + 127) << 23);
+  const uint32_t a_multiplier = (uint32_t) (int32_t) lrintf(a_output_scale * scale_multiplier);
+  const uint32_t b_multiplier = (uint32_t) (int32_t) lrintf(b_output_scale * scale_multiplier);
+  /* :400-413 (scalar member) */
+  const uint32_t remainder_mask = (UINT32_C(1) << shift) - UINT32_C(1);
+  const uint32_t remainder_threshold = remainder_mask >> 1;
+  const int32_t zero_point_product =
+      (int32_t) -(a_multiplier * (uint32_t) a_zero_point + b_multiplier * (uint32_t) b_zero_point);
+
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (ptrdiff_t r = 0; r < (ptrdiff_t) batch; r++) {
+    for (size_t c = 0; c < channels; c++) {
+      /* :500-522 */
+      const uint8_t av = a[(size_t) r * a_stride + c], bv = b[(size_t) r * b_stride + c];
+      int32_t acc = (int32_t) ((uint32_t) zero_point_product + (uint32_t) av * a_multiplier + (uint32_t) bv * b_multiplier);
+      const int32_t rem = (acc & (int32_t) remainder_mask) - (int32_t) (acc < 0);
+      acc = asr32(acc, shift) + (int32_t) (rem > (int32_t) remainder_threshold);
+      int32_t v = acc + (int32_t) y_zero_point;
+      if (v >= (int32_t) y_max) v = (int32_t) y_max;
+      if (v <= (int32_t) y_min) v = (int32_t) y_min;
+      y[(size_t) r * y_stride + c] = (uint8_t) v;
+    }
+  }
+  return 0;
+}
+
+/* ---- global average pooling ------------------------------------------------------------------------- */
+
+int oracle_global_average_pooling_q8(
+    size_t batch, size_t width, size_t channels,
+    uint8_t input_zero_point, float input_scale, uint8_t output_zero_point, float output_scale,
+    uint8_t output_min, uint8_t output_max,
+    const uint8_t* input, size_t input_stride, uint8_t* output, size_t output_stride)
+{
+  /* src/global-average-pooling.c:138-145 */
+  const int32_t bias = -(int32_t) width * (int32_t) (uint32_t) input_zero_point;
+  const float scale = input_scale / (output_scale * (float) width);
+  if (!(scale >= 0x1.0p-32f) || !(scale < 256.0f)) return -1;
+  /* src/qnnpack/requantization.h:210-222, :252-265 */
+  const uint32_t scale_bits = f32_bits(scale);
+  const int32_t multiplier = ((int32_t) scale_bits & INT32_C(0x007FFFFF)) | INT32_C(0x00800000);
+  const uint32_t right_shift = (uint32_t) (127 + 23 - (int32_t) (scale_bits >> 23));
+  const int64_t rounding = INT64_C(1) << (right_shift - 1);
+  const int32_t min_less_zp = (int32_t) (uint32_t) output_min - (int32_t) (uint32_t) output_zero_point;
+  const int32_t max_less_zp = (int32_t) (uint32_t) output_max - (int32_t) (uint32_t) output_zero_point;
+
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (ptrdiff_t i = 0; i < (ptrdiff_t) batch; i++) {
+    for (size_t c = 0; c < channels; c++) {
+      int32_t n = bias;
+      for (size_t w = 0; w < width; w++) {
+        n += (int32_t) input[((size_t) i * width + w) * input_stride + c];
+      }
+      /* :482-498 */
+      const int64_t product = (int64_t) n * (int64_t) multiplier;
+      const int64_t adjusted = product - (int64_t) (n < 0);
+      int64_t shifted = adjusted + rounding;
+      shifted = shifted >= 0 ? shifted >> right_shift : ~(~shifted >> right_shift);   /* asr_s64 */
+      n = (int32_t) shifted;
+      if (n < min_less_zp) n = min_less_zp;
+      if (n > max_less_zp) n = max_less_zp;
+      output[(size_t) i * output_stride + c] = (uint8_t) (n + (int32_t) output_zero_point);
+    }
+  }
+  return 0;
 }

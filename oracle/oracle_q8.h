@@ -117,6 +117,27 @@ int oracle_convolution2d_q8(
     uint8_t ozp, float output_scale, uint8_t omin, uint8_t omax,
     const uint8_t* input, uint8_t* output, size_t output_pixel_stride);
 
+/* Quantized element-wise add, the whole operator. Parameters: the scalar member of
+ * qnnp_compute_add_quantization_params (src/qnnpack/requantization.h:327-360, :400-413); arithmetic:
+ * qnnp_add_quantize (:500-522), which test/vadd-microkernel-tester.h:180,194 asserts every microkernel equals.
+ * Validation as src/add.c:73-89. Returns 0, or -1 when a scale ratio is outside [2^-14, 2^8). */
+int oracle_add_q8(
+    size_t batch, size_t channels,
+    uint8_t a_zero_point, float a_scale, uint8_t b_zero_point, float b_scale,
+    uint8_t y_zero_point, float y_scale, uint8_t y_min, uint8_t y_max,
+    const uint8_t* a, size_t a_stride, const uint8_t* b, size_t b_stride, uint8_t* y, size_t y_stride);
+
+/* Global average pooling, the whole operator: n = -width*izp + sum over the image's `width` pixels
+ * (src/global-average-pooling.c:138-145, src/operator-run.c:981-1016), then qnnp_avgpool_quantize
+ * (src/qnnpack/requantization.h:482-498) with the scalar parameters of :200-222, :252-265 for
+ * scale = input_scale / (output_scale * width); test/gavgpool-microkernel-tester.h:177,198 asserts every
+ * microkernel equals it. Returns 0, or -1 when the scale is outside [2^-32, 256). */
+int oracle_global_average_pooling_q8(
+    size_t batch, size_t width, size_t channels,
+    uint8_t input_zero_point, float input_scale, uint8_t output_zero_point, float output_scale,
+    uint8_t output_min, uint8_t output_max,
+    const uint8_t* input, size_t input_stride, uint8_t* output, size_t output_stride);
+
 /* OpenMP thread count used by the loops above (cpu_baseline "cores"). */
 void oracle_set_threads(int n);
 int oracle_get_threads(void);

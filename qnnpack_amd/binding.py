@@ -74,6 +74,17 @@ class QnnpackLibrary:
         L.qnnp_setup_deconvolution2d_nhwc_q8.restype = c_int
         L.qnnp_setup_deconvolution2d_nhwc_q8.argtypes = [
             c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]
+        L.qnnp_create_global_average_pooling_nwc_q8.restype = c_int
+        L.qnnp_create_global_average_pooling_nwc_q8.argtypes = [
+            c_size_t, c_uint8, c_float, c_uint8, c_float, c_uint8, c_uint8, c_uint32, POINTER(c_void_p)]
+        L.qnnp_setup_global_average_pooling_nwc_q8.restype = c_int
+        L.qnnp_setup_global_average_pooling_nwc_q8.argtypes = [
+            c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t]
+        L.qnnp_create_add_nc_q8.restype = c_int
+        L.qnnp_create_add_nc_q8.argtypes = [
+            c_size_t, c_uint8, c_float, c_uint8, c_float, c_uint8, c_float, c_uint8, c_uint8, c_uint32, POINTER(c_void_p)]
+        L.qnnp_setup_add_nc_q8.restype = c_int
+        L.qnnp_setup_add_nc_q8.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t]
         L.qnnp_create_fully_connected_nc_q8.restype = c_int
         L.qnnp_create_fully_connected_nc_q8.argtypes = [
             c_size_t, c_size_t, c_uint8, c_float, c_uint8, c_float, c_void_p, c_void_p,
@@ -167,6 +178,53 @@ class QnnpackLibrary:
         st = self.setup_deconvolution2d_nhwc_q8_status(*args)
         if st != Status.success:
             raise QnnpackError("qnnp_setup_deconvolution2d_nhwc_q8", st)
+
+    def create_global_average_pooling_nwc_q8_status(
+            self, channels, input_zero_point, input_scale, output_zero_point, output_scale,
+            output_min, output_max, flags=0):
+        handle = c_void_p(None)
+        st = self.lib.qnnp_create_global_average_pooling_nwc_q8(
+            channels, input_zero_point, input_scale, output_zero_point, output_scale, output_min, output_max, flags,
+            ctypes.byref(handle))
+        return Status(st), handle.value
+
+    def create_global_average_pooling_nwc_q8(self, *args, **kwargs) -> int:
+        st, handle = self.create_global_average_pooling_nwc_q8_status(*args, **kwargs)
+        if st != Status.success:
+            raise QnnpackError("qnnp_create_global_average_pooling_nwc_q8", st)
+        return handle
+
+    def setup_global_average_pooling_nwc_q8_status(self, op, batch_size, width, input, input_stride,
+                                                   output, output_stride) -> Status:
+        return Status(self.lib.qnnp_setup_global_average_pooling_nwc_q8(
+            op, batch_size, width, address_of(input), input_stride, address_of(output), output_stride))
+
+    def setup_global_average_pooling_nwc_q8(self, *args) -> None:
+        st = self.setup_global_average_pooling_nwc_q8_status(*args)
+        if st != Status.success:
+            raise QnnpackError("qnnp_setup_global_average_pooling_nwc_q8", st)
+
+    def create_add_nc_q8_status(self, channels, a_zero_point, a_scale, b_zero_point, b_scale,
+                                sum_zero_point, sum_scale, sum_min, sum_max, flags=0):
+        handle = c_void_p(None)
+        st = self.lib.qnnp_create_add_nc_q8(channels, a_zero_point, a_scale, b_zero_point, b_scale,
+                                            sum_zero_point, sum_scale, sum_min, sum_max, flags, ctypes.byref(handle))
+        return Status(st), handle.value
+
+    def create_add_nc_q8(self, *args, **kwargs) -> int:
+        st, handle = self.create_add_nc_q8_status(*args, **kwargs)
+        if st != Status.success:
+            raise QnnpackError("qnnp_create_add_nc_q8", st)
+        return handle
+
+    def setup_add_nc_q8_status(self, op, batch_size, a, a_stride, b, b_stride, sum, sum_stride) -> Status:
+        return Status(self.lib.qnnp_setup_add_nc_q8(
+            op, batch_size, address_of(a), a_stride, address_of(b), b_stride, address_of(sum), sum_stride))
+
+    def setup_add_nc_q8(self, *args) -> None:
+        st = self.setup_add_nc_q8_status(*args)
+        if st != Status.success:
+            raise QnnpackError("qnnp_setup_add_nc_q8", st)
 
     def create_fully_connected_nc_q8_status(
             self, input_channels, output_channels, input_zero_point, input_scale,

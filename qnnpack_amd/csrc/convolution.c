@@ -274,22 +274,6 @@ error:
   return status;
 }
 
-/* Decide where a caller pointer lives and (re)size the staging buffer that a
- * host pointer needs. Returns 0 on success. */
-static int bind_endpoint(const void* ptr, size_t span, int* on_device, void** stage, size_t* capacity)
-{
-  *on_device = qnnp_hip_is_device_pointer(ptr);
-  if (*on_device) return 0;
-  if (*capacity < span) {
-    qnnp_hip_free(*stage);
-    *capacity = 0;
-    *stage = qnnp_hip_alloc(span);
-    if (*stage == NULL) return -1;
-    *capacity = span;
-  }
-  return 0;
-}
-
 enum qnnp_status qnnp_setup_convolution2d_nhwc_q8(
     qnnp_operator_t op,
     size_t batch_size,
@@ -364,8 +348,8 @@ enum qnnp_status qnnp_setup_convolution2d_nhwc_q8(
 
   op->input_span = (batch_size * input_size - 1) * input_pixel_stride + in_channels;
   op->output_span = (batch_size * output_size - 1) * output_pixel_stride + out_channels;
-  if (bind_endpoint(input, op->input_span, &op->input_on_device, &op->d_stage_in, &op->stage_in_capacity) != 0 ||
-      bind_endpoint(output, op->output_span, &op->output_on_device, &op->d_stage_out, &op->stage_out_capacity) != 0) {
+  if (qnnp_bind_endpoint(input, op->input_span, &op->input_on_device, &op->d_stage_in, &op->stage_in_capacity) != 0 ||
+      qnnp_bind_endpoint(output, op->output_span, &op->output_on_device, &op->d_stage_out, &op->stage_out_capacity) != 0) {
     qnnp_log_error("failed to allocate device staging for host tensors (%zu + %zu bytes)",
         op->input_span, op->output_span);
     return qnnp_status_out_of_memory;

@@ -157,6 +157,61 @@ struct qnnp_hip_dwconv_args {
 };
 int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* args, const char** kernel_name);
 
+/* ---- q8 element-wise add and global average pooling ("next" row 4) --------------
+ * HBM-bound byte kernels (q8pointwise.hip).
+ *
+ * add: replaces q8vadd_ukernel__sse2 (src/q8vadd/sse2.c) + the qnnp_ukernel_type_add case of
+ * qnnp_run_operator (src/operator-run.c). Normative arithmetic = qnnp_add_quantize
+ * (src/qnnpack/requantization.h:500-522; the microkernel tester asserts equality with it,
+ * test/vadd-microkernel-tester.h:180,194):
+ *   acc = zero_point_product + a*a_multiplier + b*b_multiplier            (32-bit wrap-around)
+ *   acc = asr(acc, shift) + (((acc & mask) - (acc < 0)) > (mask >> 1))
+ *   sum = min(max(acc + y_zero_point, y_min), y_max)
+ */
+struct qnnp_hip_add_params {
+  uint32_t a_multiplier, b_multiplier;
+  int32_t zero_point_product;
+  uint32_t shift;
+  int32_t remainder_mask, remainder_threshold;
+  int32_t y_zero_point, y_min, y_max;
+};
+struct qnnp_hip_vadd_args {
+  const uint8_t* a;
+  const uint8_t* b;
+  uint8_t* sum;
+  uint64_t rows;
+  uint32_t channels;
+  uint64_t a_stride, b_stride, sum_stride;
+  struct qnnp_hip_add_params params;
+};
+int qnnp_hip_vadd_run(const struct qnnp_hip_vadd_args* args, const char** kernel_name);
+
+/* global average pooling: replaces q8gavgpool_ukernel_{up8x7,mp8x7p7q,up8xm}__sse2 (src/q8gavgpool/) + the
+ * qnnp_ukernel_type_global_average_pooling case (src/operator-run.c:981-1016). For image i and channel c:
+ *   n   = bias + sum_w input[(i*width + w)*input_stride + c]              bias = -width * input_zero_point
+ *   out = qnnp_avgpool_quantize(n)  (src/qnnpack/requantization.h:482-498; asserted equal by
+ *         test/gavgpool-microkernel-tester.h:177,198):
+ *         n = asr64(n*multiplier - (n < 0) + rounding, right_shift); clamp to [min, max] - zp; + zp
+ */
+struct qnnp_hip_avgpool_params {
+  int32_t bias;
+  int32_t multiplier;
+  int64_t rounding;
+  uint32_t right_shift;
+  int32_t output_min_less_zero_point, output_max_less_zero_point, output_zero_point;
+};
+struct qnnp_hip_gavgpool_args {
+  const uint8_t* input;
+  uint8_t* output;
+  uint64_t batch;
+  uint64_t width;             /* pixels averaged per image */
+  uint32_t channels;
+  uint64_t input_stride;      /* bytes between pixels */
+  uint64_t output_stride;     /* bytes between images */
+  struct qnnp_hip_avgpool_params params;
+};
+int qnnp_hip_gavgpool_run(const struct qnnp_hip_gavgpool_args* args, const char** kernel_name);
+
 #ifdef __cplusplus
 }
 #endif

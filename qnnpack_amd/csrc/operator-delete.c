@@ -23,6 +23,7 @@ enum qnnp_status qnnp_delete_operator(qnnp_operator_t op)
   qnnp_hip_free(op->d_dwm_bias);
   qnnp_hip_free(op->d_offsets);
   qnnp_hip_free(op->d_stage_in);
+  qnnp_hip_free(op->d_stage_in2);
   qnnp_hip_free(op->d_stage_out);
   free(op);
   return qnnp_status_success;

@@ -34,7 +34,21 @@ static enum qnnp_status status_from_hip(int rc)
 
 /* Enqueue the operator's kernel on the library stream, reading `input` and
  * writing `output` (both device pointers). */
-static int launch(struct qnnp_operator* op, const void* input, void* output)
+int qnnp_bind_endpoint(const void* ptr, size_t span, int* on_device, void** stage, size_t* capacity)
+{
+  *on_device = qnnp_hip_is_device_pointer(ptr);
+  if (*on_device) return 0;
+  if (*capacity < span) {
+    qnnp_hip_free(*stage);
+    *capacity = 0;
+    *stage = qnnp_hip_alloc(span);
+    if (*stage == NULL) return -1;
+    *capacity = span;
+  }
+  return 0;
+}
+
+static int launch(struct qnnp_operator* op, const void* input, const void* input2, void* output)
 {
   switch (op->ukernel_type) {
     case qnnp_ukernel_type_dwconv:
@@ -118,6 +132,37 @@ static int launch(struct qnnp_operator* op, const void* input, void* output)
       };
       return qnnp_hip_igemm_run(&args, &op->kernel_name);
     }
+    case qnnp_ukernel_type_add:
+    {
+      /* reference operator-run.c, case qnnp_ukernel_type_add (q8vadd over rows of `channels` bytes) */
+      const struct qnnp_hip_vadd_args args = {
+        .a = (const uint8_t*) input,
+        .b = (const uint8_t*) input2,
+        .sum = (uint8_t*) output,
+        .rows = op->batch_size,
+        .channels = (uint32_t) op->channels,
+        .a_stride = op->input_pixel_stride,
+        .b_stride = op->input2_pixel_stride,
+        .sum_stride = op->output_pixel_stride,
+        .params = op->add_params,
+      };
+      return qnnp_hip_vadd_run(&args, &op->kernel_name);
+    }
+    case qnnp_ukernel_type_global_average_pooling:
+    {
+      /* reference operator-run.c:981-1016 */
+      const struct qnnp_hip_gavgpool_args args = {
+        .input = (const uint8_t*) input,
+        .output = (uint8_t*) output,
+        .batch = op->batch_size,
+        .width = op->input_width,
+        .channels = (uint32_t) op->channels,
+        .input_stride = op->input_pixel_stride,
+        .output_stride = op->output_pixel_stride,
+        .params = op->avgpool_params,
+      };
+      return qnnp_hip_gavgpool_run(&args, &op->kernel_name);
+    }
     default:
       return QNNP_HIP_EINVAL;
   }
@@ -141,8 +186,9 @@ enum qnnp_status qnnp_run_operator(qnnp_operator_t op, pthreadpool_t threadpool)
   }
 
   const void* input = op->input;
+  const void* input2 = op->input2;
   void* output = op->output;
-  const int staged = !op->input_on_device || !op->output_on_device;
+  const int staged = !op->input_on_device || !op->output_on_device || (op->input2 != NULL && !op->input2_on_device);
   const int capturing = qnnp_hip_graph_capturing();
   if (capturing && staged) {
     return qnnp_status_invalid_parameter;  /* a graph can only hold device-pointer launches */
@@ -154,8 +200,14 @@ enum qnnp_status qnnp_run_operator(qnnp_operator_t op, pthreadpool_t threadpool)
     }
     input = op->d_stage_in;
   }
+  if (op->input2 != NULL && !op->input2_on_device) {
+    if (qnnp_hip_h2d(op->d_stage_in2, op->input2, op->input2_span, 1) != QNNP_HIP_OK) {
+      return qnnp_status_invalid_parameter;
+    }
+    input2 = op->d_stage_in2;
+  }
   if (!op->output_on_device) {
-    const size_t out_channels = (size_t) op->groups * op->group_output_channels;
+    const size_t out_channels = op->channels != 0 ? op->channels : (size_t) op->groups * op->group_output_channels;
     if (op->output_pixel_stride != out_channels) {
       /* keep the caller's bytes between pixels intact across the round trip */
       if (qnnp_hip_h2d(op->d_stage_out, op->output, op->output_span, 1) != QNNP_HIP_OK) {
@@ -165,7 +217,7 @@ enum qnnp_status qnnp_run_operator(qnnp_operator_t op, pthreadpool_t threadpool)
     output = op->d_stage_out;
   }
 
-  const int rc = launch(op, input, output);
+  const int rc = launch(op, input, input2, output);
   if (rc != QNNP_HIP_OK) {
     return status_from_hip(rc);
   }
@@ -213,7 +265,7 @@ enum qnnp_status qnnp_gfx950_time_operator_rotating(
     int rc = QNNP_HIP_OK;
     size_t gset = 0;
     for (int i = 0; i < iters && rc == QNNP_HIP_OK; i++) {
-      rc = launch(op, inputs[gset], outputs[gset]);
+      rc = launch(op, inputs[gset], op->input2, outputs[gset]);
       gset = (gset + 1) % nsets;
     }
     void* graph = NULL;
@@ -238,13 +290,13 @@ enum qnnp_status qnnp_gfx950_time_operator_rotating(
   enum qnnp_status status = qnnp_status_success;
   size_t set = 0;
   for (int i = 0; i < warmup && status == qnnp_status_success; i++) {
-    status = status_from_hip(launch(op, inputs[set], outputs[set]));
+    status = status_from_hip(launch(op, inputs[set], op->input2, outputs[set]));
     set = (set + 1) % nsets;
   }
   if (status == qnnp_status_success) {
     qnnp_hip_timer_start(timer);
     for (int i = 0; i < iters && status == qnnp_status_success; i++) {
-      status = status_from_hip(launch(op, inputs[set], outputs[set]));
+      status = status_from_hip(launch(op, inputs[set], op->input2, outputs[set]));
       set = (set + 1) % nsets;
     }
     float ms = 0.0f;

@@ -19,6 +19,8 @@ enum qnnp_ukernel_type {
   qnnp_ukernel_type_conv,
   qnnp_ukernel_type_dwconv,
   qnnp_ukernel_type_gemm,
+  qnnp_ukernel_type_add,
+  qnnp_ukernel_type_global_average_pooling,
 };
 
 struct qnnp_operator {
@@ -51,6 +53,18 @@ struct qnnp_operator {
   size_t output_pixel_stride;
   void* output;
 
+  /* add / global average pooling (reference operator.h:58, 66-67, 75-100) */
+  size_t channels;
+  const void* input2;
+  size_t input2_pixel_stride;
+  uint8_t output_zero_point;
+  uint8_t output_min;
+  uint8_t output_max;
+  float input_scale;
+  float output_scale;
+  struct qnnp_hip_add_params add_params;
+  struct qnnp_hip_avgpool_params avgpool_params;
+
   uint8_t input_zero_point;
   uint8_t kernel_zero_point;
   struct qnnp_hip_requant requant;
@@ -79,9 +93,17 @@ struct qnnp_operator {
   size_t stage_in_capacity;
   void* d_stage_out;
   size_t stage_out_capacity;
+  int input2_on_device;   /* add: the second operand */
+  void* d_stage_in2;
+  size_t stage_in2_capacity;
+  size_t input2_span;
   size_t input_span;      /* bytes of caller input touched by the operator */
   size_t output_span;     /* bytes of caller output the operator may write */
 
   int variant;            /* kernel-variant option captured at setup */
   const char* kernel_name;
 };
+
+/* Decide where a caller pointer lives and (re)size the device staging buffer a host pointer needs.
+ * Returns 0 on success. (operator-run.c) */
+int qnnp_bind_endpoint(const void* ptr, size_t span, int* on_device, void** stage, size_t* capacity);

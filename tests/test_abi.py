@@ -21,12 +21,15 @@ def declared_functions(header):
 
 def test_headers_declare_the_reference_entry_points():
     names = declared_functions("qnnpack.h")
-    # reference include/qnnpack.h:34-36, 40-76, 78-116, 118-140, 327-332 (hot-path subset + deconvolution)
+    # reference include/qnnpack.h:34-36, 40-76, 78-116, 118-140, 142-160, 234-255, 327-332
+    # (hot-path subset + the "next" rows of SURVEY 8f: deconvolution, global average pooling, add)
     assert names == sorted([
         "qnnp_initialize", "qnnp_deinitialize",
         "qnnp_create_convolution2d_nhwc_q8", "qnnp_setup_convolution2d_nhwc_q8",
         "qnnp_create_deconvolution2d_nhwc_q8", "qnnp_setup_deconvolution2d_nhwc_q8",
         "qnnp_create_fully_connected_nc_q8", "qnnp_setup_fully_connected_nc_q8",
+        "qnnp_create_global_average_pooling_nwc_q8", "qnnp_setup_global_average_pooling_nwc_q8",
+        "qnnp_create_add_nc_q8", "qnnp_setup_add_nc_q8",
         "qnnp_run_operator", "qnnp_delete_operator"])
 
 
@@ -57,6 +60,10 @@ def test_no_gpu_means_unsupported_hardware_not_a_fallback(product):
     bias = np.zeros(4, np.int32)
     st, handle = product.create_fully_connected_nc_q8_status(4, 4, 0, 1.0, 0, 1.0, kernel, bias, 0, 2.0, 0, 255)
     assert st == Status.uninitialized and not handle       # reference fully-connected.c:44-47
+    st, handle = product.create_add_nc_q8_status(4, 0, 1.0, 0, 1.0, 0, 1.0, 0, 255)
+    assert st == Status.uninitialized and not handle       # reference add.c:36-39
+    st, handle = product.create_global_average_pooling_nwc_q8_status(4, 0, 1.0, 0, 1.0, 0, 255)
+    assert st == Status.uninitialized and not handle       # reference global-average-pooling.c:34-37
     st, handle = product.create_deconvolution2d_nhwc_q8_status(
         0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 4, 4, 0, 1.0, 0, 1.0, kernel, bias, 0, 2.0, 0, 255)
     assert st == Status.uninitialized and not handle       # reference deconvolution.c:69-72
