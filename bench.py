@@ -107,6 +107,65 @@ class ConvLayer:
         self.inputs = self.outputs = None
 
 
+def next_rows_bench(lib, torch, batch, warmup, iters):
+    """The operators SURVEY.md section 8f ranks after the hot path, on MobileNetV2-sized tensors: kernel time
+    (rotating buffers, > 512 MB between reuses) and algorithmic GB/s. All three are HBM-bound byte kernels except
+    the deconvolution, which runs the offset-table MFMA kernel (stride 2: three taps in four are padding)."""
+    out = {}
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(77)
+
+    def rotating(nbytes_in, nbytes_out, min_between=512 << 20):
+        nsets = min(64, max(1, -(-min_between // (nbytes_in + nbytes_out))))
+        ins = [torch.randint(0, 256, (nbytes_in,), dtype=torch.uint8, device="cuda", generator=gen) for _ in range(nsets)]
+        outs = [torch.empty(nbytes_out, dtype=torch.uint8, device="cuda") for _ in range(nsets)]
+        return ins, outs
+
+    # residual add of the 56x56x24 bottleneck output (reference bench/add.cc shape family)
+    rows, ch = batch * 56 * 56, 24
+    ins, outs = rotating(rows * ch, rows * ch)
+    b_operand = torch.randint(0, 256, (rows * ch,), dtype=torch.uint8, device="cuda", generator=gen)
+    op = lib.create_add_nc_q8(ch, 121, 0.75, 127, 1.25, 133, 0.96875, 0, 255, 0)
+    lib.setup_add_nc_q8(op, rows, ins[0], ch, b_operand, ch, outs[0], ch)
+    lib.run_operator(op)
+    ms = lib.time_operator_rotating(op, ins, outs, warmup, iters)
+    out["q8add_56x56x24"] = {"kernel": lib.operator_kernel(op), "ms": round(ms, 5), "bytes": 3 * rows * ch,
+                             "gbs": round(3 * rows * ch / (ms * 1e-3) / 1e9, 1)}
+    lib.delete_operator(op)
+
+    # global average pooling in front of the classifier: 7x7x1280
+    width, ch = 49, 1280
+    ins, outs = rotating(batch * width * ch, batch * ch, min_between=64 << 20)
+    op = lib.create_global_average_pooling_nwc_q8(ch, 121, 1.0, 133, 1.0, 0, 255, 0)
+    lib.setup_global_average_pooling_nwc_q8(op, batch, width, ins[0], ch, outs[0], ch)
+    lib.run_operator(op)
+    ms = lib.time_operator_rotating(op, ins, outs, warmup, iters)
+    nbytes = batch * width * ch + batch * ch
+    out["q8gavgpool_7x7x1280"] = {"kernel": lib.operator_kernel(op), "ms": round(ms, 5), "bytes": nbytes,
+                                  "gbs": round(nbytes / (ms * 1e-3) / 1e9, 1)}
+    lib.delete_operator(op)
+
+    # 2x upsampling deconvolution 28x28x64 -> 56x56x32 (2x2 kernel, stride 2)
+    H = W = 28
+    cin, cout = 64, 32
+    rng = np.random.default_rng(78)
+    kernel = rng.integers(0, 256, size=(1, cin, 2, 2, cout), dtype=np.uint8)
+    bias = rng.integers(-10000, 10001, size=cout, dtype=np.int32)
+    ins, outs = rotating(batch * H * W * cin, batch * 4 * H * W * cout)
+    op = lib.create_deconvolution2d_nhwc_q8(0, 0, 0, 0, 0, 0, 2, 2, 2, 2, 1, 1, 1, cin, cout,
+                                            127, 0.5, 127, 0.5, kernel, bias, 127, 0.5, 0, 255, 0)
+    lib.setup_deconvolution2d_nhwc_q8(op, batch, H, W, ins[0], cin, outs[0], cout)
+    lib.run_operator(op)
+    ms = lib.time_operator_rotating(op, ins, outs, warmup, iters)
+    nbytes = batch * H * W * cin + batch * 4 * H * W * cout
+    useful_ops = 2 * batch * H * W * 4 * cin * cout          # every input pixel meets each of the 2x2 taps once
+    out["q8deconv_2x2s2_28x28x64_32"] = {"kernel": lib.operator_kernel(op), "ms": round(ms, 5), "bytes": nbytes,
+                                         "gbs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                                         "useful_tops": round(useful_ops / (ms * 1e-3) / 1e12, 2)}
+    lib.delete_operator(op)
+    return out
+
+
 def cpu_baseline_gemm(seconds_budget=12.0):
     """Reference SSE2 q8gemm (qnnp_fully_connected_nc_q8 of the compiled reference) on the host cores:
     a 512-row slice of the same 4096^3 problem (same N, K, data distribution), all cores via the
@@ -390,6 +449,9 @@ def main():
         extra["q8dwconv_mobilenetv2_layers"] = {
             "hbm_gbs": round(dw_bytes / (dw_ms * 1e-3) / 1e9, 1), "ms": round(dw_ms, 4),
             "frac_of_hbm_peak": round(dw_bytes / (dw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+
+        # ---------------------------------------------------------- SURVEY 8f "next" rows: deconvolution, add, pooling
+        extra["next_rows"] = next_rows_bench(lib, torch, my_batch, args.warmup, max(args.steps // 2, 5))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -70,7 +70,10 @@ inline Plan make_plan(const IgemmParams& p, const ConvGeom& g)
  * current one is multiplied -- staging was 40 % of an item's time as a separate phase (in-kernel stamps). */
 constexpr int kPipeVec = 8;
 
-template <int TN, bool PIPE>
+/* ABL: measurement-only ablation mask (builds with -DQNNP_ENABLE_ABLATION, env QNNP_CONV_ABL; scripts/gpu_convabl.sh):
+ * 1 no row-sum v_dot4, 2 linear (conflict-free, address-free) A reads, 4 no weight reads, 8 no MFMA, 16 no stores,
+ * 32 no staging. Results are wrong by design; only the time is read. */
+template <int TN, bool PIPE, int ABL = 0>
 __global__ __launch_bounds__(kThreads, 2)
 void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32_t blocks_per_image,
                              const uint32_t total_items, const uint32_t ic, const uint32_t w_bytes)
@@ -168,7 +171,7 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
   // Batches of kStageBatch vectors per thread: all global loads of a batch are issued before the first
   // LDS write, so a thread keeps kStageBatch loads in flight instead of one (the loop is latency-bound).
   if constexpr (PIPE) {
-    stage_store();                                   // this item's band was loaded during the previous item
+    if constexpr (!(ABL & 32)) stage_store();                                   // this item's band was loaded during the previous item
   } else {
     constexpr int kStageBatch = 8;
     const uint32_t nvec = ir * ic * cpp;
@@ -243,7 +246,7 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
   __syncthreads();
   QNNP_TRACE(p, blockIdx.x, item_no, 2);
   if constexpr (PIPE) {
-    if (item + gridDim.x < total_items) stage_load(item + gridDim.x);   // flies under the K loop and the epilogue
+    if constexpr (!(ABL & 32)) if (item + gridDim.x < total_items) stage_load(item + gridDim.x);   // flies under the K loop and the epilogue
   }
 
   const uint32_t kblocks = p.k_pad / 32;
@@ -264,13 +267,16 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
         v4i af[2];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-          af[j] = *reinterpret_cast<const v4i*>(in_lds + abase[j] + ((((cb << 1) | khalf) ^ aswz[j]) << 4));
+          if constexpr (ABL & 2) af[j] = *reinterpret_cast<const v4i*>(in_lds + lane * 16 + j * 1024 + cb * 2048);
+          else af[j] = *reinterpret_cast<const v4i*>(in_lds + abase[j] + ((((cb << 1) | khalf) ^ aswz[j]) << 4));
         }
         v4i wf[TN];
 #pragma unroll
         for (int tn = 0; tn < TN; tn++) {
-          wf[tn] = *reinterpret_cast<const v4i*>(w_lane + (tn * kblocks + kb) * 1024);
+          if constexpr (ABL & 4) wf[tn] = v4i{static_cast<int>(lane), static_cast<int>(kb), tn, 3};
+          else wf[tn] = *reinterpret_cast<const v4i*>(w_lane + (tn * kblocks + kb) * 1024);
         }
+        if constexpr (!(ABL & 1))
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           int32_t s = rs[j];
@@ -284,7 +290,8 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
         for (int j = 0; j < 2; j++)
 #pragma unroll
           for (int tn = 0; tn < TN; tn++)
-            acc[j][tn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[tn], af[j], acc[j][tn], 0, 0, 0);
+            if constexpr (ABL & 8) acc[j][tn][0] += wf[tn].x ^ af[j].x ^ wf[tn].w ^ af[j].w;
+            else acc[j][tn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[tn], af[j], acc[j][tn], 0, 0, 0);
       }
     }
   }
@@ -301,7 +308,7 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
 #pragma unroll
       for (int tn = 0; tn < TN; tn++) {
         igemm_store_tile<decltype(shift0)::value, decltype(full)::value>(
-            acc[j][tn], bias4[tn], rowterm, out_row, tn * 32, khalf, valid[j], p);
+            acc[j][tn], bias4[tn], rowterm, out_row, tn * 32, khalf, (ABL & 16) ? false : valid[j], p);
       }
     }
   });
@@ -311,12 +318,12 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
   }
 }
 
-template <int TN, bool PIPE>
+template <int TN, bool PIPE, int ABL = 0>
 int launch_one(const IgemmParams& p, const ConvGeom& g, const Plan& pl, uint32_t batch, hipStream_t stream)
 {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_lds_mfma_kernel<TN, PIPE>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_lds_mfma_kernel<TN, PIPE, ABL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       (void) hipGetLastError();
     }
@@ -325,7 +332,7 @@ int launch_one(const IgemmParams& p, const ConvGeom& g, const Plan& pl, uint32_t
   const uint32_t total_items = batch * pl.blocks_per_image;
   const uint32_t resident = p.cu_count * (kLdsLimit >= 2 * pl.lds_bytes ? 2u : 1u);
   const uint32_t grid = total_items < resident ? total_items : resident;
-  hipLaunchKernelGGL((q8_conv_lds_mfma_kernel<TN, PIPE>), dim3(grid), dim3(kThreads),
+  hipLaunchKernelGGL((q8_conv_lds_mfma_kernel<TN, PIPE, ABL>), dim3(grid), dim3(kThreads),
                      pl.lds_bytes, stream, p, g, pl.blocks_per_image, total_items, pl.ic, pl.w_bytes);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
@@ -335,8 +342,28 @@ int launch(const IgemmParams& p, const ConvGeom& g, const Plan& pl, uint32_t bat
 {
   // the pipelined flavour needs the whole band of an item in kPipeVec 16-byte vectors per thread
   const uint32_t band_vectors = pl.ir_max * pl.ic * (p.kc >> 4);
-  static const bool no_pipe = getenv("QNNP_CONVLDS_NOPIPE") != nullptr;  // TEMP A/B
-  if (!no_pipe && band_vectors <= static_cast<uint32_t>(kPipeVec * kThreads)) return launch_one<TN, true>(p, g, pl, batch, stream);
+  // (TN >= 3: 96-128 accumulator registers leave no room for the held band -- the pipelined flavour spills)
+  if constexpr (TN <= 2) {
+#ifdef QNNP_ENABLE_ABLATION
+    if constexpr (TN == 2) {
+      static const int abl = getenv("QNNP_CONV_ABL") ? atoi(getenv("QNNP_CONV_ABL")) : 0;
+      switch (abl) {
+        case 1: return launch_one<TN, true, 1>(p, g, pl, batch, stream);
+        case 2: return launch_one<TN, true, 2>(p, g, pl, batch, stream);
+        case 4: return launch_one<TN, true, 4>(p, g, pl, batch, stream);
+        case 7: return launch_one<TN, true, 7>(p, g, pl, batch, stream);
+        case 8: return launch_one<TN, true, 8>(p, g, pl, batch, stream);
+        case 16: return launch_one<TN, true, 16>(p, g, pl, batch, stream);
+        case 32: return launch_one<TN, true, 32>(p, g, pl, batch, stream);
+        case 48: return launch_one<TN, true, 48>(p, g, pl, batch, stream);
+        case 55: return launch_one<TN, true, 55>(p, g, pl, batch, stream);
+        case 63: return launch_one<TN, true, 63>(p, g, pl, batch, stream);
+        default: break;
+      }
+    }
+#endif
+    if (band_vectors <= static_cast<uint32_t>(kPipeVec * kThreads)) return launch_one<TN, true>(p, g, pl, batch, stream);
+  }
   return launch_one<TN, false>(p, g, pl, batch, stream);
 }
 

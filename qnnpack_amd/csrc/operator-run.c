@@ -258,6 +258,9 @@ enum qnnp_status qnnp_gfx950_time_operator_rotating(
       return qnnp_status_invalid_parameter;
     }
   }
+  if (op->input2 != NULL && !op->input2_on_device) {
+    return qnnp_status_invalid_parameter;   /* add: the second operand is not rotated and must be device memory */
+  }
   /* Preferred: record the `iters` launches into a hipGraph and time its replay -- one submission, so the
    * figure is kernel time, not the host's per-launch dispatch gap (5-8 us, as large as the small layers).
    * Falls back to a plain launch loop if the capture is refused. */
