@@ -163,6 +163,19 @@ def next_rows_bench(lib, torch, batch, warmup, iters):
                                          "gbs": round(nbytes / (ms * 1e-3) / 1e9, 1),
                                          "useful_tops": round(useful_ops / (ms * 1e-3) / 1e12, 2)}
     lib.delete_operator(op)
+
+    # the same upsampling with a 3x3 kernel (stride 2, padding 1, output adjustment 1): four phase GEMMs of 1/2/2/4 taps
+    kernel = rng.integers(0, 256, size=(1, cin, 3, 3, cout), dtype=np.uint8)
+    op = lib.create_deconvolution2d_nhwc_q8(1, 1, 1, 1, 1, 1, 3, 3, 2, 2, 1, 1, 1, cin, cout,
+                                            127, 0.5, 127, 0.5, kernel, bias, 127, 0.5, 0, 255, 0)
+    lib.setup_deconvolution2d_nhwc_q8(op, batch, H, W, ins[0], cin, outs[0], cout)
+    lib.run_operator(op)
+    ms = lib.time_operator_rotating(op, ins, outs, warmup, iters)
+    useful_ops = 2 * batch * H * W * 9 * cin * cout
+    out["q8deconv_3x3s2_28x28x64_32"] = {"kernel": lib.operator_kernel(op), "ms": round(ms, 5), "bytes": nbytes,
+                                         "gbs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                                         "useful_tops": round(useful_ops / (ms * 1e-3) / 1e12, 2)}
+    lib.delete_operator(op)
     return out
 
 

@@ -15,6 +15,12 @@
  *           indirection.c (deconvolution flavour);
  *   run   : the generic offset-table MFMA implicit-GEMM kernel (q8igemm.hip) -- the geometry-derived
  *           convolution kernels do not apply, the operator pins "gemm_kernel" = 1.
+ * STRIDED deconvolutions are split by output phase: all output pixels with the same
+ * ((oy + pad_top) % stride_h, (ox + pad_left) % stride_w) see the same taps -- those with
+ * ky*dil_h = phase_y (mod stride_h), likewise in x -- so each of the stride_h*stride_w phases is a dense
+ * implicit GEMM over its own sub-kernel, offset table and output-pixel list (the kernel scatters GEMM rows
+ * through that list). One table over all taps would spend (stride_h*stride_w - 1)/(stride_h*stride_w) of the
+ * MFMA work and of the operand gathers on taps that are padding by construction (3/4 at stride 2).
  * Status codes and their order follow the reference (deconvolution.c:69-129, :225-243).
  */
 #include <math.h>
@@ -173,8 +179,127 @@ enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8(
   }
 
   const uint32_t kc_slot = (uint32_t) gic;
-  const uint32_t k_total = (uint32_t) (kernel_size * kc_slot);
   const uint32_t n_pad = qnnp_round_up_u32((uint32_t) goc, 32);
+  const uint32_t phases = stride_height * stride_width;
+  if (phases > 1 && phases <= QNNP_MAX_DECONV_PHASES && kernel_size <= 64) {
+    /* one packed sub-kernel per output phase */
+    const size_t b_bytes = sizeof(int32_t) * (size_t) groups * n_pad;
+    uint8_t* sub = (uint8_t*) malloc(group_weights * groups + gic * goc * groups);
+    host_bias = malloc(b_bytes);
+    if (sub == NULL || host_bias == NULL) {
+      free(sub);
+      qnnp_log_error("failed to allocate %zu bytes for the phase kernels", group_weights * groups);
+      goto error;
+    }
+    for (uint32_t py = 0; py < stride_height; py++) {
+      for (uint32_t px = 0; px < stride_width; px++) {
+        struct qnnp_deconv_phase* ph = &op->phase[py * stride_width + px];
+        uint32_t taps = 0;
+        for (uint32_t ky = 0; ky < kernel_height; ky++) {
+          if ((ky * dilation_height) % stride_height != py) continue;
+          for (uint32_t kx = 0; kx < kernel_width; kx++) {
+            if ((kx * dilation_width) % stride_width != px) continue;
+            ph->tap_ky[taps] = (uint8_t) ky;
+            ph->tap_kx[taps] = (uint8_t) kx;
+            taps++;
+          }
+        }
+        const int empty = taps == 0;
+        if (empty) {
+          /* no tap ever reaches this phase: one tap of weight == kernel zero point, always padding (255 = no tap) */
+          ph->tap_ky[0] = ph->tap_kx[0] = 255;
+          taps = 1;
+        }
+        ph->taps = taps;
+        for (size_t g = 0; g < groups; g++) {
+          for (size_t oc = 0; oc < goc; oc++) {
+            for (uint32_t t = 0; t < taps; t++) {
+              uint8_t* dst = sub + ((g * goc + oc) * taps + t) * gic;
+              if (empty) {
+                memset(dst, kernel_zero_point, gic);
+              } else {
+                const size_t tap = (size_t) ph->tap_ky[t] * kernel_width + ph->tap_kx[t];
+                memcpy(dst, conv_order + g * group_weights + (oc * kernel_size + tap) * gic, gic);
+              }
+            }
+          }
+        }
+        ph->k_pad = qnnp_round_up_u32(taps * kc_slot, 64);
+        const size_t w_bytes = qnnp_igemm_packed_weights_size(groups, n_pad, ph->k_pad);
+        void* packed = malloc(w_bytes);
+        int ok = packed != NULL;
+        if (ok) {
+          qnnp_pack_igemm_w_slots(groups, (uint32_t) goc, taps, (uint32_t) gic, kc_slot, n_pad, ph->k_pad,
+              input_zero_point, kernel_zero_point, sub, bias, (int8_t*) packed, host_bias);
+          ph->d_weights = qnnp_hip_alloc(w_bytes);
+          ph->d_bias = (int32_t*) qnnp_hip_alloc(b_bytes);
+          ok = ph->d_weights != NULL && ph->d_bias != NULL &&
+              qnnp_hip_h2d(ph->d_weights, packed, w_bytes, 0) == QNNP_HIP_OK &&
+              qnnp_hip_h2d(ph->d_bias, host_bias, b_bytes, 0) == QNNP_HIP_OK;
+        }
+        free(packed);
+        op->deconv_phases = py * stride_width + px + 1;   /* so that delete frees what exists so far */
+        if (!ok) {
+          free(sub);
+          qnnp_log_error("failed to place %zu bytes of packed phase weights on the device", w_bytes + b_bytes);
+          goto error;
+        }
+      }
+    }
+    free(sub);
+    op->n_pad = n_pad;
+    op->kc_slot = kc_slot;
+
+    /* Kernel == stride (the usual 2x upsampling): every output pixel has exactly one tap and every input pixel
+     * feeds stride_h*stride_w output pixels, so the whole operator is ONE pointwise GEMM over the input pixels with
+     * phases * n_pad columns (phase-major) whose 32-channel blocks are stored depth-to-space (q8pwconv.hip).
+     * Packed beside the phase kernels; the run falls back to those if the streaming kernel cannot take the tensors. */
+    const bool any_padding =
+        (input_padding_top | input_padding_right | input_padding_bottom | input_padding_left) != 0;
+    const uint32_t d2s_cols = phases * n_pad;
+    const uint32_t d2s_k_pad = qnnp_round_up_u32((uint32_t) gic, 64);
+    if (groups == 1 && kernel_height == stride_height && kernel_width == stride_width &&
+        dilation_height == 1 && dilation_width == 1 && !any_padding &&
+        adjustment_height == 0 && adjustment_width == 0 && gic <= 256 && gic % 16 == 0 &&
+        (size_t) d2s_cols * ((gic + 31) / 32 * 32) + (size_t) d2s_cols * 4 + 1024 <= 64 * 1024) {
+      uint8_t* mat = (uint8_t*) malloc((size_t) d2s_cols * gic);
+      int32_t* cols_bias = (int32_t*) calloc(d2s_cols, sizeof(int32_t));
+      const size_t dw_bytes = qnnp_igemm_packed_weights_size(1, d2s_cols, d2s_k_pad);
+      const size_t db_bytes = sizeof(int32_t) * d2s_cols;
+      void* packed = malloc(dw_bytes);
+      int32_t* packed_bias = (int32_t*) malloc(db_bytes);
+      int ok = mat != NULL && cols_bias != NULL && packed != NULL && packed_bias != NULL;
+      if (ok) {
+        memset(mat, kernel_zero_point, (size_t) d2s_cols * gic);     /* padding columns: w - kzp == 0 */
+        for (uint32_t ph = 0; ph < phases; ph++) {
+          const size_t tap = (size_t) (ph / stride_width) * kernel_width + ph % stride_width;   /* (ky, kx) = (py, px) */
+          for (size_t oc = 0; oc < goc; oc++) {
+            memcpy(mat + ((size_t) ph * n_pad + oc) * gic, conv_order + (oc * kernel_size + tap) * gic, gic);
+            cols_bias[(size_t) ph * n_pad + oc] = bias[oc];
+          }
+        }
+        qnnp_pack_igemm_w_slots(1, d2s_cols, 1, (uint32_t) gic, kc_slot, d2s_cols, d2s_k_pad,
+            input_zero_point, kernel_zero_point, mat, cols_bias, (int8_t*) packed, packed_bias);
+        op->d_weights = qnnp_hip_alloc(dw_bytes);
+        op->d_bias = (int32_t*) qnnp_hip_alloc(db_bytes);
+        ok = op->d_weights != NULL && op->d_bias != NULL &&
+            qnnp_hip_h2d(op->d_weights, packed, dw_bytes, 0) == QNNP_HIP_OK &&
+            qnnp_hip_h2d(op->d_bias, packed_bias, db_bytes, 0) == QNNP_HIP_OK;
+      }
+      free(mat);
+      free(cols_bias);
+      free(packed);
+      free(packed_bias);
+      if (!ok) {
+        qnnp_log_error("failed to place %zu bytes of packed depth-to-space weights on the device", dw_bytes + db_bytes);
+        goto error;
+      }
+      op->k_pad = d2s_k_pad;
+      op->deconv_d2s = 1;
+    }
+    goto packed_done;
+  }
+  const uint32_t k_total = (uint32_t) (kernel_size * kc_slot);
   const uint32_t k_pad = qnnp_round_up_u32(k_total, 64);
   const size_t w_bytes = qnnp_igemm_packed_weights_size(groups, n_pad, k_pad);
   const size_t b_bytes = sizeof(int32_t) * (size_t) groups * n_pad;
@@ -197,6 +322,7 @@ enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8(
     qnnp_log_error("failed to place %zu bytes of packed weights on the device", w_bytes + b_bytes);
     goto error;
   }
+packed_done:
   free(conv_order);
   free(host_weights);
   free(host_bias);
@@ -317,6 +443,73 @@ enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8(
   }
 
   op->variant = 1;   /* the offset-table kernel: the table, not the geometry, defines this operator */
+  if (op->deconv_phases != 0) {
+    if (op->offsets_in_h == input_height && op->offsets_in_w == input_width &&
+        op->offsets_in_stride == input_pixel_stride) {
+      return qnnp_status_success;  /* tables are pointer- and batch-invariant */
+    }
+    op->offsets_in_h = 0;
+    const size_t sh = op->stride_height, sw = op->stride_width;
+    for (uint32_t i = 0; i < op->deconv_phases; i++) {
+      struct qnnp_deconv_phase* ph = &op->phase[i];
+      const size_t py = i / sw, px = i % sw;
+      /* first output row / column of the phase: (o + pad) % stride == phase */
+      const size_t oy0 = (py + sh - op->input_padding_top % sh) % sh;
+      const size_t ox0 = (px + sw - op->input_padding_left % sw) % sw;
+      const size_t rows_y = oy0 < op->output_height ? (op->output_height - oy0 + sh - 1) / sh : 0;
+      const size_t rows_x = ox0 < op->output_width ? (op->output_width - ox0 + sw - 1) / sw : 0;
+      ph->rows = rows_y * rows_x;
+      if (ph->rows == 0) continue;
+      int32_t* host_offsets = (int32_t*) malloc(sizeof(int32_t) * ph->rows * ph->taps);
+      int32_t* host_rows = (int32_t*) malloc(sizeof(int32_t) * ph->rows);
+      if (host_offsets == NULL || host_rows == NULL) {
+        free(host_offsets);
+        free(host_rows);
+        qnnp_log_error("failed to allocate %zu bytes for a phase table", sizeof(int32_t) * ph->rows * (ph->taps + 1));
+        return qnnp_status_out_of_memory;
+      }
+      size_t r = 0;
+      for (size_t oy = oy0; oy < op->output_height; oy += sh) {
+        for (size_t ox = ox0; ox < op->output_width; ox += sw, r++) {
+          host_rows[r] = (int32_t) (oy * op->output_width + ox);
+          for (uint32_t t = 0; t < ph->taps; t++) {
+            int32_t entry = QNNP_OFFSET_PADDING;
+            if (ph->tap_ky[t] != 255) {
+              /* reference src/indirection.c:171-177; the divisions are exact by construction of the phase */
+              const size_t y = oy + op->input_padding_top - (size_t) ph->tap_ky[t] * op->dilation_height;
+              const size_t x = ox + op->input_padding_left - (size_t) ph->tap_kx[t] * op->dilation_width;
+              const size_t iy = y / sh, ix = x / sw;
+              if (iy * sh == y && iy < input_height && ix * sw == x && ix < input_width) {
+                entry = (int32_t) ((iy * input_width + ix) * input_pixel_stride);
+              }
+            }
+            host_offsets[r * ph->taps + t] = entry;
+          }
+        }
+      }
+      if (ph->rows_capacity < ph->rows) {
+        qnnp_hip_free(ph->d_offsets);
+        qnnp_hip_free(ph->d_out_rows);
+        ph->rows_capacity = 0;
+        ph->d_offsets = (int32_t*) qnnp_hip_alloc(sizeof(int32_t) * ph->rows * ph->taps);
+        ph->d_out_rows = (int32_t*) qnnp_hip_alloc(sizeof(int32_t) * ph->rows);
+        if (ph->d_offsets != NULL && ph->d_out_rows != NULL) ph->rows_capacity = ph->rows;
+      }
+      const int ok = ph->rows_capacity >= ph->rows &&
+          qnnp_hip_h2d(ph->d_offsets, host_offsets, sizeof(int32_t) * ph->rows * ph->taps, 0) == QNNP_HIP_OK &&
+          qnnp_hip_h2d(ph->d_out_rows, host_rows, sizeof(int32_t) * ph->rows, 0) == QNNP_HIP_OK;
+      free(host_offsets);
+      free(host_rows);
+      if (!ok) {
+        qnnp_log_error("failed to place a phase table on the device");
+        return qnnp_status_out_of_memory;
+      }
+    }
+    op->offsets_in_h = input_height;
+    op->offsets_in_w = input_width;
+    op->offsets_in_stride = input_pixel_stride;
+    return qnnp_status_success;
+  }
   const size_t kernel_size = (size_t) op->kernel_height * op->kernel_width;
   const size_t entries = output_size * kernel_size;
   const bool same_geometry = op->d_offsets != NULL &&

@@ -62,6 +62,12 @@ struct IgemmParams {
   uint32_t cu_count;       // compute units of the bound device (persistent-grid sizing)
   unsigned long long* trace;  // measurement builds only (QNNP_ENABLE_ABLATION + env QNNP_GFX950_TRACE): cycle stamps
   const uint8_t* fill_table; // [256][16]: entry v = 16 bytes of value v (LDS-DMA padding sources)
+  const int32_t* out_rows;   // optional (generic kernel): output pixel of GEMM row `pix` inside its image, else NULL
+  uint32_t out_image_rows;   // with out_rows: output pixels per image
+  // depth-to-space stores of the pointwise streaming kernel (deconvolution with kernel == stride): GEMM row m is
+  // input pixel (img, iy, ix); its channel block nb belongs to phase nb / d2s_nbpp = (py, px) and is stored at output
+  // pixel (img, iy*d2s_sh + py, ix*d2s_sw + px), channels (nb % d2s_nbpp)*32.. of p.n. d2s_sh == 0: off.
+  uint32_t d2s_sh, d2s_sw, d2s_in_h, d2s_in_w, d2s_nbpp;
   RequantDev rq;
 };
 

@@ -360,7 +360,7 @@ void q8_igemm_mfma_kernel(const IgemmParams p)
     __syncthreads();
 
     // ---- fused epilogue (igemm_epilogue.cuh); the requantization flavour is chosen once per tile ----
-    if (p.store_mode == 2) {
+    if (p.store_mode == 2 && p.out_rows == nullptr) {
       // staged: requantized tile -> LDS (row-major image of the output) -> line-sized coalesced stores
       qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
 #pragma unroll
@@ -391,7 +391,13 @@ void q8_igemm_mfma_kernel(const IgemmParams p)
           const uint32_t row = frag_row0 + tm * 32;
           const uint32_t m = m_tile * BM + row;
           const int32_t rowterm = p.row_coeff * lds_rowsum[row];
-          uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride + static_cast<uint64_t>(g) * p.n;
+          uint64_t out_pixel = m;
+          if (p.out_rows != nullptr && m < p.rows) {          // scattered rows (deconvolution phases)
+            const uint32_t img_m = m / p.rows_per_image;
+            out_pixel = static_cast<uint64_t>(img_m) * p.out_image_rows +
+                        static_cast<uint32_t>(p.out_rows[m - img_m * p.rows_per_image]);
+          }
+          uint8_t* out_row = p.output + out_pixel * p.output_stride + static_cast<uint64_t>(g) * p.n;
 #pragma unroll
           for (int tn = 0; tn < TN; tn++) {
             const uint32_t nb = nb0 + tn;
@@ -473,6 +479,20 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   p.packed_w = a->packed_w;
   p.bias2 = a->bias2;
   p.offsets = a->offsets;
+  p.d2s_sh = a->d2s_stride_h;
+  p.d2s_sw = a->d2s_stride_w;
+  p.d2s_in_h = a->d2s_input_h;
+  p.d2s_in_w = a->d2s_input_w;
+  p.d2s_nbpp = 0;
+  if (a->d2s_stride_h != 0) {
+    const uint32_t phases = a->d2s_stride_h * a->d2s_stride_w;
+    if (a->offsets != nullptr || a->groups != 1 || phases == 0 || a->n_pad % (32u * phases) != 0 ||
+        a->d2s_input_h == 0 || a->d2s_input_w == 0) return QNNP_HIP_EINVAL;
+    p.d2s_nbpp = a->n_pad / 32u / phases;
+  }
+  p.out_rows = a->out_rows;
+  p.out_image_rows = a->out_image_rows;
+  if (a->out_rows != nullptr && (a->offsets == nullptr || a->variant != 1 || a->rows_per_image == 0)) return QNNP_HIP_EINVAL;
   p.rows = a->rows;
   p.rows_per_image = a->rows_per_image;
   p.image_stride = a->image_stride;
@@ -556,8 +576,9 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
     return rc_c3;
   }
   // Short-K pointwise / fully-connected layers over many rows: barrier-free streaming kernel.
-  const bool pw_ok = !pad3 && qnnp::pwstream_supported(p, a->groups, vec);
-  if (a->variant == 5 && !pw_ok) return QNNP_HIP_EINVAL;
+  const bool pw_ok = !pad3 && qnnp::pwstream_supported(p, a->groups, vec) && (p.d2s_sh == 0 || vec == 16);
+  if ((a->variant == 5 || p.d2s_sh != 0) && !pw_ok) return QNNP_HIP_EINVAL;   /* depth-to-space exists in this kernel only */
+  if (p.d2s_sh != 0 && a->variant != 5) return QNNP_HIP_EINVAL;
   if (pw_ok && (a->variant == 5 || (a->variant == 0 && a->rows >= 2048))) {
     const int rc_pw = qnnp::pwstream_launch(p, vec, stream, &name);
     if (kernel_name != nullptr) *kernel_name = name;

@@ -47,7 +47,9 @@ constexpr uint32_t kMaxLds = 64 * 1024;     // weights + bias: two workgroups pe
 
 /* KB = 32-deep K blocks (k_total <= 32 * KB); VEC = bytes per activation load (16, or 8 when rows are
  * only 8-byte aligned, e.g. 24 channels) */
-template <int KB, int VEC, bool STAGED>
+/* D2S: depth-to-space stores (igemm_params.h) -- a deconvolution whose kernel equals its stride is this pointwise
+ * GEMM with stride_h*stride_w times the channels, each phase's block landing on its own output pixel. */
+template <int KB, int VEC, bool STAGED, bool D2S = false>
 __global__ __launch_bounds__(kThreads, (KB <= 5) ? 4 : 2)
 void q8_pw_stream_mfma_kernel(const IgemmParams p)
 {
@@ -156,6 +158,14 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
       const uint32_t m = unit * 32u + row_in_block;
       uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride;
       bool row_ok = m < p.rows;
+      if constexpr (D2S) {
+        // input pixel (img, iy, ix) -> output pixel (img, iy*sh, ix*sw); the phase offset is added per channel block
+        const uint32_t mm = row_ok ? m : 0u;
+        const uint32_t rowi = mm / p.d2s_in_w;             // img * in_h + iy
+        const uint32_t ix = mm - rowi * p.d2s_in_w;
+        const uint64_t out_pixel = (static_cast<uint64_t>(rowi) * p.d2s_sh * p.d2s_in_w + ix) * p.d2s_sw;
+        out_row = p.output + out_pixel * p.output_stride;
+      }
 #ifdef QNNP_ENABLE_ABLATION
       if (p.izp_fill & 1u) row_ok = false;                // measurement: no stores
 #endif
@@ -229,6 +239,15 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
         }
 #endif
         multiply(nb, acc);
+        if constexpr (D2S) {
+          const uint32_t phase = nb / p.d2s_nbpp;
+          const uint32_t py = phase / p.d2s_sw;
+          const uint32_t px = phase - py * p.d2s_sw;
+          uint8_t* phase_row = out_row + (static_cast<uint64_t>(py) * (p.d2s_in_w * p.d2s_sw) + px) * p.output_stride;
+          igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, true>(
+              acc, bias4, 0, phase_row, (nb - phase * p.d2s_nbpp) * 32, khalf, row_ok, p);
+          continue;
+        }
         igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, true>(
             acc, bias4, 0, out_row, nb * 32, khalf, row_ok, p);
       }
@@ -470,11 +489,11 @@ void q8_conv_stream_c3_kernel(const IgemmParams p)
   });
 }
 
-template <int KB, int VEC, bool STAGED>
+template <int KB, int VEC, bool STAGED, bool D2S = false>
 int launch_pw(const IgemmParams& p, uint32_t lds_bytes, hipStream_t stream)
 {
   static int blocks_per_cu = 0;       // per instantiation; benign race (same value)
-  auto kernel = q8_pw_stream_mfma_kernel<KB, VEC, STAGED>;
+  auto kernel = q8_pw_stream_mfma_kernel<KB, VEC, STAGED, D2S>;
   if (blocks_per_cu == 0) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     blocks_per_cu = (KB <= 5) ? 4 : 2;
@@ -513,6 +532,20 @@ int dispatch_kb(const IgemmParams& p, uint32_t kb, uint32_t lds_bytes, hipStream
     case 6: return launch_pw<6, VEC, STAGED>(p, lds_bytes, stream);
     case 7: return launch_pw<7, VEC, STAGED>(p, lds_bytes, stream);
     default: return launch_pw<8, VEC, STAGED>(p, lds_bytes, stream);
+  }
+}
+
+int dispatch_kb_d2s(const IgemmParams& p, uint32_t kb, uint32_t lds_bytes, hipStream_t stream)
+{
+  switch (kb) {
+    case 1: return launch_pw<1, 16, false, true>(p, lds_bytes, stream);
+    case 2: return launch_pw<2, 16, false, true>(p, lds_bytes, stream);
+    case 3: return launch_pw<3, 16, false, true>(p, lds_bytes, stream);
+    case 4: return launch_pw<4, 16, false, true>(p, lds_bytes, stream);
+    case 5: return launch_pw<5, 16, false, true>(p, lds_bytes, stream);
+    case 6: return launch_pw<6, 16, false, true>(p, lds_bytes, stream);
+    case 7: return launch_pw<7, 16, false, true>(p, lds_bytes, stream);
+    default: return launch_pw<8, 16, false, true>(p, lds_bytes, stream);
   }
 }
 
@@ -588,6 +621,15 @@ int pwstream_launch(const IgemmParams& p0, uint32_t vec, hipStream_t stream, con
   if (p.store_mode == 2 && p.output_stride == p.n && p.n > 32 && p.n <= 256 && lds_bytes + stage_bytes <= kMaxLds) {
     p.store_mode = 3;
     lds_bytes += stage_bytes;
+  }
+  if (p.d2s_sh != 0) {
+    if (vec != 16) return QNNP_HIP_EINVAL;
+    if (p.store_mode == 3) {
+      p.store_mode = 2;
+      lds_bytes -= stage_bytes;
+    }
+    *name = "q8_pw_stream_d2s_mfma";
+    return dispatch_kb_d2s(p, kb, lds_bytes, stream);
   }
   *name = "q8_pw_stream_mfma";
   if (p.store_mode == 3) {

@@ -117,6 +117,14 @@ struct qnnp_hip_igemm_args {
   uint32_t input_zero_point;
   struct qnnp_hip_requant rq;
   int variant;                /* 0 auto, 1 generic, 2 big-tile LDS-DMA, 3 LDS-tiled direct convolution */
+  /* optional scatter of the GEMM rows (conv + variant 1 only; deconvolution phases): row m of image img is written to
+   * output pixel img * out_image_rows + out_rows[m % rows_per_image] instead of pixel m. NULL = rows are pixels. */
+  const int32_t* out_rows;
+  uint32_t out_image_rows;
+  /* optional depth-to-space stores (gemm form + the streaming kernel only; deconvolution with kernel == stride):
+   * n_pad = stride_h*stride_w*round_up(n, 32) packed columns, phase-major; row m = input pixel (img, iy, ix) writes
+   * its phase (py, px) block to output pixel (img, iy*stride_h + py, ix*stride_w + px). d2s_stride_h == 0: off. */
+  uint32_t d2s_stride_h, d2s_stride_w, d2s_input_h, d2s_input_w;
   /* convolution geometry (conv only; lets the LDS-tiled kernel address the input directly) */
   uint32_t input_height, input_width, output_height, output_width;
   uint32_t kernel_height, kernel_width, stride_height, stride_width, dilation_height, dilation_width;

@@ -22,6 +22,12 @@ enum qnnp_status qnnp_delete_operator(qnnp_operator_t op)
   qnnp_hip_free(op->d_dwm_x);
   qnnp_hip_free(op->d_dwm_bias);
   qnnp_hip_free(op->d_offsets);
+  for (uint32_t i = 0; i < op->deconv_phases && i < QNNP_MAX_DECONV_PHASES; i++) {
+    qnnp_hip_free(op->phase[i].d_weights);
+    qnnp_hip_free(op->phase[i].d_bias);
+    qnnp_hip_free(op->phase[i].d_offsets);
+    qnnp_hip_free(op->phase[i].d_out_rows);
+  }
   qnnp_hip_free(op->d_stage_in);
   qnnp_hip_free(op->d_stage_in2);
   qnnp_hip_free(op->d_stage_out);

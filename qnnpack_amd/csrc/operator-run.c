@@ -93,6 +93,81 @@ static int launch(struct qnnp_operator* op, const void* input, const void* input
       const int is_conv = op->ukernel_type == qnnp_ukernel_type_conv;
       const uint32_t output_size = (uint32_t) (op->output_height * op->output_width);
       const uint32_t taps = is_conv ? op->kernel_height * op->kernel_width : 1;
+      if (op->transposed && op->deconv_d2s) {
+        /* kernel == stride: one pointwise GEMM over the input pixels, stored depth-to-space (deconvolution.c) */
+        const uint32_t phases = op->stride_height * op->stride_width;
+        const struct qnnp_hip_igemm_args dargs = {
+          .input = (const uint8_t*) input,
+          .output = (uint8_t*) output,
+          .packed_w = (const int8_t*) op->d_weights,
+          .bias2 = op->d_bias,
+          .offsets = NULL,
+          .rows = (uint32_t) (op->batch_size * op->input_height * op->input_width),
+          .rows_per_image = (uint32_t) (op->input_height * op->input_width),
+          .image_stride = 0,
+          .groups = 1,
+          .n = (uint32_t) op->group_output_channels,
+          .n_pad = op->n_pad * phases,
+          .kc = (uint32_t) op->group_input_channels,
+          .kc_slot = op->kc_slot,
+          .input_bytes = op->input_span,
+          .ks = 1,
+          .k_total = op->kc_slot,
+          .k_pad = op->k_pad,
+          .input_stride = (uint32_t) op->input_pixel_stride,
+          .output_stride = (uint32_t) op->output_pixel_stride,
+          .row_coeff = 128 - (int32_t) op->kernel_zero_point,
+          .input_zero_point = op->input_zero_point,
+          .rq = op->requant,
+          .variant = 5,
+          .d2s_stride_h = op->stride_height,
+          .d2s_stride_w = op->stride_width,
+          .d2s_input_h = (uint32_t) op->input_height,
+          .d2s_input_w = (uint32_t) op->input_width,
+        };
+        const int rc_d2s = qnnp_hip_igemm_run(&dargs, &op->kernel_name);
+        if (rc_d2s != QNNP_HIP_EINVAL) {
+          return rc_d2s;
+        }
+        /* the streaming kernel cannot take these tensors (alignment): the phase GEMMs below can */
+      }
+      if (op->transposed && op->deconv_phases != 0) {
+        /* strided deconvolution: one dense implicit GEMM per output phase (deconvolution.c) */
+        int rc_phase = QNNP_HIP_OK;
+        for (uint32_t i = 0; i < op->deconv_phases && rc_phase == QNNP_HIP_OK; i++) {
+          const struct qnnp_deconv_phase* ph = &op->phase[i];
+          if (ph->rows == 0) continue;
+          const struct qnnp_hip_igemm_args pargs = {
+            .input = (const uint8_t*) input,
+            .output = (uint8_t*) output,
+            .packed_w = (const int8_t*) ph->d_weights,
+            .bias2 = ph->d_bias,
+            .offsets = ph->d_offsets,
+            .rows = (uint32_t) (op->batch_size * ph->rows),
+            .rows_per_image = (uint32_t) ph->rows,
+            .image_stride = (uint64_t) op->input_height * op->input_width * op->input_pixel_stride,
+            .groups = op->groups,
+            .n = (uint32_t) op->group_output_channels,
+            .n_pad = op->n_pad,
+            .kc = (uint32_t) op->group_input_channels,
+            .kc_slot = op->kc_slot,
+            .input_bytes = op->input_span,
+            .ks = ph->taps,
+            .k_total = ph->taps * op->kc_slot,
+            .k_pad = ph->k_pad,
+            .input_stride = (uint32_t) op->input_pixel_stride,
+            .output_stride = (uint32_t) op->output_pixel_stride,
+            .row_coeff = 128 - (int32_t) op->kernel_zero_point,
+            .input_zero_point = op->input_zero_point,
+            .rq = op->requant,
+            .variant = 1,
+            .out_rows = ph->d_out_rows,
+            .out_image_rows = output_size,
+          };
+          rc_phase = qnnp_hip_igemm_run(&pargs, &op->kernel_name);
+        }
+        return rc_phase;
+      }
       const struct qnnp_hip_igemm_args args = {
         .input = (const uint8_t*) input,
         .output = (uint8_t*) output,

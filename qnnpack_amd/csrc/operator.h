@@ -23,6 +23,21 @@ enum qnnp_ukernel_type {
   qnnp_ukernel_type_global_average_pooling,
 };
 
+/* One output phase of a strided deconvolution (deconvolution.c): the output pixels whose (oy + pad_top) % stride_h
+ * and (ox + pad_left) % stride_w are (py, px) see the same sub-kernel, so each phase is a dense implicit GEMM. */
+#define QNNP_MAX_DECONV_PHASES 16
+struct qnnp_deconv_phase {
+  void* d_weights;          /* packed sub-kernel (MFMA fragment panels) */
+  int32_t* d_bias;          /* bias folded for the sub-kernel's taps */
+  uint32_t k_pad;
+  uint32_t taps;            /* sub-kernel taps (>= 1; a phase without taps gets one all-padding tap) */
+  uint8_t tap_ky[64], tap_kx[64];
+  int32_t* d_offsets;       /* [rows][taps] */
+  int32_t* d_out_rows;      /* [rows] output pixel inside the image */
+  size_t rows;              /* output pixels of this phase per image (0: phase absent for this geometry) */
+  size_t rows_capacity;
+};
+
 struct qnnp_operator {
   /* geometry fixed at create (reference operator.h:40-57) */
   size_t batch_size;
@@ -42,6 +57,10 @@ struct qnnp_operator {
   uint32_t adjustment_height;  /* deconvolution only (reference operator.h:45-46) */
   uint32_t adjustment_width;
   int transposed;              /* 1: deconvolution -- the offset table is the transposed-convolution one */
+  uint32_t deconv_phases;      /* 0: one table over all taps; else stride_h * stride_w phase GEMMs */
+  int deconv_d2s;              /* 1: kernel == stride, no padding: also packed as ONE pointwise GEMM with
+                                * depth-to-space stores (d_weights / d_bias / n_pad / k_pad), tried first at run */
+  struct qnnp_deconv_phase phase[QNNP_MAX_DECONV_PHASES];
 
   /* bound at setup (reference operator.h:59-73): caller-owned, not copied */
   size_t input_height;

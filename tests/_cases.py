@@ -284,6 +284,19 @@ EXTRA_DECONV_CASES = [
     DeconvCase("dx_grouped_2x2s2", (10, 10), (2, 2), subsampling=(2, 2), groups=4, gic=8, goc=6, batch=2),
     DeconvCase("dx_3x3s2_qmin_qmax", (8, 8), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=16, goc=24, qmin=40, qmax=200),
     DeconvCase("dx_1x1s2", (6, 5), (1, 1), subsampling=(2, 2), gic=10, goc=12),
+    # kernel == stride, no padding: the single-GEMM depth-to-space path (q8_pw_stream_d2s_mfma)
+    DeconvCase("dx_d2s_2x2_c16_n19", (9, 7), (2, 2), subsampling=(2, 2), gic=16, goc=19, batch=3),
+    DeconvCase("dx_d2s_2x2_c32_n64_rows", (33, 35), (2, 2), subsampling=(2, 2), gic=32, goc=64, batch=2),
+    DeconvCase("dx_d2s_3x3s3_c48_n8", (5, 6), (3, 3), subsampling=(3, 3), gic=48, goc=8),
+    DeconvCase("dx_d2s_2x1_c64_n40", (8, 9), (2, 1), subsampling=(2, 1), gic=64, goc=40, batch=2),
+    DeconvCase("dx_d2s_1x2_c16_n16", (4, 11), (1, 2), subsampling=(1, 2), gic=16, goc=16),
+    DeconvCase("dx_d2s_strided_pixels", (7, 6), (2, 2), subsampling=(2, 2), gic=32, goc=24, batch=2,
+               input_pixel_stride=48, output_pixel_stride=40),
+    DeconvCase("dx_d2s_zp_qrange", (6, 6), (2, 2), subsampling=(2, 2), gic=16, goc=32, izp=3, kzp=250, qmin=30, qmax=220),
+    DeconvCase("dx_d2s_c256_n32", (5, 5), (2, 2), subsampling=(2, 2), gic=256, goc=32),
+    # same shape family but NOT eligible (unaligned channels / rows): falls back to the phase GEMMs
+    DeconvCase("dx_phase_2x2_c10_n12", (6, 5), (2, 2), subsampling=(2, 2), gic=10, goc=12, batch=2),
+    DeconvCase("dx_phase_2x2_unaligned_rows", (6, 5), (2, 2), subsampling=(2, 2), gic=16, goc=16, input_pixel_stride=20),
 ]
 
 

@@ -17,7 +17,9 @@ def test_deconvolution_matches_oracle_device_tensors(qnnp, case):
     expected, quant, out_hw = deconv_expected(case)
     out, kname = deconv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
     if case.batch:
-        assert kname is not None and kname.startswith("q8_igemm_mfma"), kname
+        expect = "q8_pw_stream_d2s_mfma" if (case.name.startswith("dx_d2s_") or case.name == "dx_2x2s2_c64_n32") \
+            else "q8_igemm_mfma"
+        assert kname is not None and kname.startswith(expect), kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 
 
