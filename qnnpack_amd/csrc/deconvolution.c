@@ -362,6 +362,48 @@ error:
   return status;
 }
 
+/* The device-side description of the phase GEMMs of the geometry and batch bound to `op`: all non-empty phases run
+ * as ONE launch of the offset-table kernel (blockIdx.y = phase), so that the small per-phase problems fill the chip
+ * together and a workgroup's next tile overlaps its current epilogue. */
+static enum qnnp_status upload_phase_table(struct qnnp_operator* op)
+{
+  struct qnnp_hip_igemm_phase table[QNNP_MAX_DECONV_PHASES];
+  uint32_t n = 0;
+  op->phase_max_rows = 0;
+  op->phase_max_k_pad = 0;
+  for (uint32_t i = 0; i < op->deconv_phases; i++) {
+    const struct qnnp_deconv_phase* ph = &op->phase[i];
+    if (ph->rows == 0) continue;
+    table[n].packed_w = (const int8_t*) ph->d_weights;
+    table[n].bias2 = ph->d_bias;
+    table[n].offsets = ph->d_offsets;
+    table[n].out_rows = ph->d_out_rows;
+    table[n].rows = (uint32_t) (op->batch_size * ph->rows);
+    table[n].rows_per_image = (uint32_t) ph->rows;
+    table[n].ks = ph->taps;
+    table[n].k_total = ph->taps * op->kc_slot;
+    table[n].k_pad = ph->k_pad;
+    table[n].reserved = 0;
+    if (ph->rows > op->phase_max_rows) op->phase_max_rows = ph->rows;
+    if (ph->k_pad > op->phase_max_k_pad) op->phase_max_k_pad = ph->k_pad;
+    n++;
+  }
+  op->phase_table_entries = n;
+  if (n == 0) return qnnp_status_success;
+  if (op->d_phase_table == NULL) {
+    op->d_phase_table = qnnp_hip_alloc(sizeof(table));
+    if (op->d_phase_table == NULL) {
+      qnnp_log_error("failed to allocate %zu bytes for the phase table", sizeof(table));
+      return qnnp_status_out_of_memory;
+    }
+  }
+  if (qnnp_hip_h2d(op->d_phase_table, table, sizeof(struct qnnp_hip_igemm_phase) * n, 0) != QNNP_HIP_OK) {
+    qnnp_log_error("failed to upload the phase table");
+    return qnnp_status_out_of_memory;
+  }
+  return qnnp_status_success;
+}
+
 enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8(
     qnnp_operator_t op,
     size_t batch_size,
@@ -446,7 +488,7 @@ enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8(
   if (op->deconv_phases != 0) {
     if (op->offsets_in_h == input_height && op->offsets_in_w == input_width &&
         op->offsets_in_stride == input_pixel_stride) {
-      return qnnp_status_success;  /* tables are pointer- and batch-invariant */
+      return upload_phase_table(op);  /* offset tables are pointer- and batch-invariant; the row counts are not */
     }
     op->offsets_in_h = 0;
     const size_t sh = op->stride_height, sw = op->stride_width;
@@ -508,7 +550,7 @@ enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8(
     op->offsets_in_h = input_height;
     op->offsets_in_w = input_width;
     op->offsets_in_stride = input_pixel_stride;
-    return qnnp_status_success;
+    return upload_phase_table(op);
   }
   const size_t kernel_size = (size_t) op->kernel_height * op->kernel_width;
   const size_t entries = output_size * kernel_size;

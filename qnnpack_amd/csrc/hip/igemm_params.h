@@ -64,6 +64,8 @@ struct IgemmParams {
   const uint8_t* fill_table; // [256][16]: entry v = 16 bytes of value v (LDS-DMA padding sources)
   const int32_t* out_rows;   // optional (generic kernel): output pixel of GEMM row `pix` inside its image, else NULL
   uint32_t out_image_rows;   // with out_rows: output pixels per image
+  const qnnp_hip_igemm_phase* phases;  // optional (generic kernel): blockIdx.y = phase * phase_groups + group
+  uint32_t phase_groups;
   // depth-to-space stores of the pointwise streaming kernel (deconvolution with kernel == stride): GEMM row m is
   // input pixel (img, iy, ix); its channel block nb belongs to phase nb / d2s_nbpp = (py, px) and is stored at output
   // pixel (img, iy*d2s_sh + py, ix*d2s_sw + px), channels (nb % d2s_nbpp)*32.. of p.n. d2s_sh == 0: off.

@@ -103,8 +103,22 @@ __device__ __forceinline__ void fill_vec(uint32_t fill, uint32_t (&w)[4], int j)
  */
 template <int WM, int WN, int TM, int TN, int VEC, bool IS_CONV, bool PAD3 = false>
 __global__ __launch_bounds__(WM * WN * 64, (TM * TN >= 4) ? 2 : 3)
-void q8_igemm_mfma_kernel(const IgemmParams p)
+void q8_igemm_mfma_kernel(const IgemmParams p_in)
 {
+  // phase table (strided deconvolutions): blockIdx.y picks one of several GEMM descriptions sharing this launch
+  IgemmParams p = p_in;
+  if (p_in.phases != nullptr) {
+    const qnnp_hip_igemm_phase ph = p_in.phases[blockIdx.y / p_in.phase_groups];
+    p.packed_w = ph.packed_w;
+    p.bias2 = ph.bias2;
+    p.offsets = ph.offsets;
+    p.out_rows = ph.out_rows;
+    p.rows = ph.rows;
+    p.rows_per_image = ph.rows_per_image;
+    p.ks = ph.ks;
+    p.k_total = ph.k_total;
+    p.k_pad = ph.k_pad;
+  }
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
@@ -125,7 +139,7 @@ void q8_igemm_mfma_kernel(const IgemmParams p)
   const uint32_t wave = tid >> 6;
   const uint32_t wm = wave / WN;
   const uint32_t wn = wave % WN;
-  const uint32_t g = blockIdx.y;
+  const uint32_t g = p_in.phases != nullptr ? blockIdx.y % p_in.phase_groups : blockIdx.y;
 
   // XCD-aware bijective remap: consecutive logical ids (which share activation row tiles) land on the
   // same XCD / L2 (hardware: block b -> XCD b % 8).
@@ -434,7 +448,7 @@ int launch_generic(const IgemmParams& p, uint32_t groups, hipStream_t stream)
   uint32_t ctas_m = target / (tiles_n * groups);
   if (ctas_m < 1) ctas_m = 1;
   if (ctas_m > tiles_m) ctas_m = tiles_m;
-  const dim3 grid(ctas_m * tiles_n, groups, 1);
+  const dim3 grid(ctas_m * tiles_n, groups, 1);     // (with a phase table `groups` is the number of phases)
   const dim3 block(WM * WN * 64, 1, 1);
   hipLaunchKernelGGL((q8_igemm_mfma_kernel<WM, WN, TM, TN, VEC, IS_CONV, PAD3>), grid, block, 0, stream, p);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
@@ -492,7 +506,11 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   }
   p.out_rows = a->out_rows;
   p.out_image_rows = a->out_image_rows;
-  if (a->out_rows != nullptr && (a->offsets == nullptr || a->variant != 1 || a->rows_per_image == 0)) return QNNP_HIP_EINVAL;
+  p.phases = a->phases;
+  p.phase_groups = a->groups;
+  if (a->phases != nullptr && (a->nphases == 0 || a->nphases * a->groups > 65535u || a->variant != 1 ||
+                               a->offsets == nullptr)) return QNNP_HIP_EINVAL;
+  if (a->out_rows != nullptr && a->phases == nullptr && (a->offsets == nullptr || a->variant != 1 || a->rows_per_image == 0)) return QNNP_HIP_EINVAL;
   p.rows = a->rows;
   p.rows_per_image = a->rows_per_image;
   p.image_stride = a->image_stride;
@@ -608,7 +626,7 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
     if (pad3) {
       rc = dispatch_tile<4, true, true>(p, a->groups, stream, &name);
     } else {
-      rc = (a->offsets != nullptr) ? dispatch_vec<true>(p, a->groups, vec, stream, &name)
+      rc = (a->offsets != nullptr) ? dispatch_vec<true>(p, a->phases != nullptr ? a->nphases * a->groups : a->groups, vec, stream, &name)
                                    : dispatch_vec<false>(p, a->groups, vec, stream, &name);
     }
   }

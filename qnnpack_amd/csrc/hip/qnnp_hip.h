@@ -93,6 +93,22 @@ void qnnp_hip_graph_destroy(void* graph);
  *   conv : input[img*image_stride + offsets[pix*ks + tap] + g*kc + ch], or the
  *          input zero point where offsets[...] < 0 (padding)   (img = m / rows_per_image).
  */
+/* One entry of an optional device-resident phase table (deconvolution.c): the launch covers `nphases` independent
+ * implicit GEMMs that share input, output, channel counts and requantization but have their own packed weights,
+ * folded bias, offset table, output-pixel list and row count (blockIdx.y = phase * groups + group). */
+struct qnnp_hip_igemm_phase {
+  const int8_t* packed_w;
+  const int32_t* bias2;
+  const int32_t* offsets;
+  const int32_t* out_rows;
+  uint32_t rows;              /* batch * rows_per_image */
+  uint32_t rows_per_image;
+  uint32_t ks;
+  uint32_t k_total;
+  uint32_t k_pad;
+  uint32_t reserved;
+};
+
 struct qnnp_hip_igemm_args {
   const uint8_t* input;
   uint8_t* output;
@@ -121,6 +137,11 @@ struct qnnp_hip_igemm_args {
    * output pixel img * out_image_rows + out_rows[m % rows_per_image] instead of pixel m. NULL = rows are pixels. */
   const int32_t* out_rows;
   uint32_t out_image_rows;
+  /* optional phase table (device memory, conv + variant 1 only): see struct qnnp_hip_igemm_phase. With it, `rows`
+   * is the LARGEST phase's row count (grid sizing), `k_pad` the largest k_pad, and the per-phase fields above are
+   * ignored. */
+  const struct qnnp_hip_igemm_phase* phases;
+  uint32_t nphases;
   /* optional depth-to-space stores (gemm form + the streaming kernel only; deconvolution with kernel == stride):
    * n_pad = stride_h*stride_w*round_up(n, 32) packed columns, phase-major; row m = input pixel (img, iy, ix) writes
    * its phase (py, px) block to output pixel (img, iy*stride_h + py, ix*stride_w + px). d2s_stride_h == 0: off. */

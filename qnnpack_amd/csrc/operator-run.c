@@ -132,41 +132,38 @@ static int launch(struct qnnp_operator* op, const void* input, const void* input
         /* the streaming kernel cannot take these tensors (alignment): the phase GEMMs below can */
       }
       if (op->transposed && op->deconv_phases != 0) {
-        /* strided deconvolution: one dense implicit GEMM per output phase (deconvolution.c) */
-        int rc_phase = QNNP_HIP_OK;
-        for (uint32_t i = 0; i < op->deconv_phases && rc_phase == QNNP_HIP_OK; i++) {
-          const struct qnnp_deconv_phase* ph = &op->phase[i];
-          if (ph->rows == 0) continue;
-          const struct qnnp_hip_igemm_args pargs = {
-            .input = (const uint8_t*) input,
-            .output = (uint8_t*) output,
-            .packed_w = (const int8_t*) ph->d_weights,
-            .bias2 = ph->d_bias,
-            .offsets = ph->d_offsets,
-            .rows = (uint32_t) (op->batch_size * ph->rows),
-            .rows_per_image = (uint32_t) ph->rows,
-            .image_stride = (uint64_t) op->input_height * op->input_width * op->input_pixel_stride,
-            .groups = op->groups,
-            .n = (uint32_t) op->group_output_channels,
-            .n_pad = op->n_pad,
-            .kc = (uint32_t) op->group_input_channels,
-            .kc_slot = op->kc_slot,
-            .input_bytes = op->input_span,
-            .ks = ph->taps,
-            .k_total = ph->taps * op->kc_slot,
-            .k_pad = ph->k_pad,
-            .input_stride = (uint32_t) op->input_pixel_stride,
-            .output_stride = (uint32_t) op->output_pixel_stride,
-            .row_coeff = 128 - (int32_t) op->kernel_zero_point,
-            .input_zero_point = op->input_zero_point,
-            .rq = op->requant,
-            .variant = 1,
-            .out_rows = ph->d_out_rows,
-            .out_image_rows = output_size,
-          };
-          rc_phase = qnnp_hip_igemm_run(&pargs, &op->kernel_name);
-        }
-        return rc_phase;
+        /* strided deconvolution: one dense implicit GEMM per output phase, all in one launch (deconvolution.c) */
+        if (op->phase_table_entries == 0) return QNNP_HIP_OK;
+        const struct qnnp_deconv_phase* ph0 = &op->phase[0];
+        const struct qnnp_hip_igemm_args pargs = {
+          .input = (const uint8_t*) input,
+          .output = (uint8_t*) output,
+          .packed_w = (const int8_t*) ph0->d_weights,         /* per-phase fields come from the table */
+          .bias2 = ph0->d_bias,
+          .offsets = (const int32_t*) op->d_phase_table,        /* non-NULL marks the convolution form */
+          .rows = (uint32_t) (op->batch_size * op->phase_max_rows),
+          .rows_per_image = (uint32_t) op->phase_max_rows,
+          .image_stride = (uint64_t) op->input_height * op->input_width * op->input_pixel_stride,
+          .groups = op->groups,
+          .n = (uint32_t) op->group_output_channels,
+          .n_pad = op->n_pad,
+          .kc = (uint32_t) op->group_input_channels,
+          .kc_slot = op->kc_slot,
+          .input_bytes = op->input_span,
+          .ks = 1,
+          .k_total = op->kc_slot,
+          .k_pad = op->phase_max_k_pad,
+          .input_stride = (uint32_t) op->input_pixel_stride,
+          .output_stride = (uint32_t) op->output_pixel_stride,
+          .row_coeff = 128 - (int32_t) op->kernel_zero_point,
+          .input_zero_point = op->input_zero_point,
+          .rq = op->requant,
+          .variant = 1,
+          .out_image_rows = output_size,
+          .phases = (const struct qnnp_hip_igemm_phase*) op->d_phase_table,
+          .nphases = op->phase_table_entries,
+        };
+        return qnnp_hip_igemm_run(&pargs, &op->kernel_name);
       }
       const struct qnnp_hip_igemm_args args = {
         .input = (const uint8_t*) input,

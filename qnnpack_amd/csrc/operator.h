@@ -58,6 +58,10 @@ struct qnnp_operator {
   uint32_t adjustment_width;
   int transposed;              /* 1: deconvolution -- the offset table is the transposed-convolution one */
   uint32_t deconv_phases;      /* 0: one table over all taps; else stride_h * stride_w phase GEMMs */
+  void* d_phase_table;         /* device array of struct qnnp_hip_igemm_phase, one per non-empty phase (setup) */
+  uint32_t phase_table_entries;
+  size_t phase_max_rows;       /* largest phase, rows per image */
+  uint32_t phase_max_k_pad;
   int deconv_d2s;              /* 1: kernel == stride, no padding: also packed as ONE pointwise GEMM with
                                 * depth-to-space stores (d_weights / d_bias / n_pad / k_pad), tried first at run */
   struct qnnp_deconv_phase phase[QNNP_MAX_DECONV_PHASES];
