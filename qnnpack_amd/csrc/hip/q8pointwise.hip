@@ -113,7 +113,23 @@ void q8_gavgpool_kernel(const qnnp_hip_gavgpool_args p, const uint32_t chunks, c
   for (int i = 0; i < VEC; i++) acc[i] = 0;
   if (live) {
     const uint8_t* px = p.input + image * p.width * p.input_stride + c;
-    for (uint64_t w = slice; w < p.width; w += split) {
+    uint64_t w = slice;
+    if constexpr (VEC == 4) {
+      // four pixels in flight per lane: the loop is a chain of dependent-latency loads otherwise
+      for (; w + 3 * static_cast<uint64_t>(split) < p.width; w += 4 * static_cast<uint64_t>(split)) {
+        uint32_t x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[u] = *reinterpret_cast<const uint32_t*>(px + (w + u * static_cast<uint64_t>(split)) * p.input_stride);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          acc[0] += x[u] & 0xFFu;
+          acc[1] += (x[u] >> 8) & 0xFFu;
+          acc[2] += (x[u] >> 16) & 0xFFu;
+          acc[3] += x[u] >> 24;
+        }
+      }
+    }
+    for (; w < p.width; w += split) {
       if constexpr (VEC == 4) {
         const uint32_t x = *reinterpret_cast<const uint32_t*>(px + w * p.input_stride);
         acc[0] += x & 0xFFu;
