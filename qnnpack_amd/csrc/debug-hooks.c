@@ -80,12 +80,19 @@ void qnnp_debug_requant_fast(
     size_t count, const int32_t* acc, float scale, uint8_t zero_point, uint8_t qmin, uint8_t qmax, uint8_t* out)
 {
   const struct qnnp_hip_requant rq = qnnp_compute_requant(scale, zero_point, qmin, qmax);
-  const struct qnnp_requant_fast f = qnnp_requant_fast_init(rq.multiplier, rq.shift);
+  /* exactly what make_requant_dev (hip/requant.cuh) hands the kernels: zero point folded into the addend when it
+   * fits, clamp bounds in the output domain */
+  struct qnnp_requant_fast f = qnnp_requant_fast_init(rq.multiplier, rq.shift);
+  const int folded = qnnp_requant_fast_fold_zero_point(&f, (uint32_t) rq.output_zero_point);
+  const int32_t zp_late = folded ? 0 : rq.output_zero_point;
+  int32_t lo = rq.output_min_less_zero_point + (folded ? rq.output_zero_point : 0);
+  const int32_t hi = rq.output_max_less_zero_point + (folded ? rq.output_zero_point : 0);
+  if (lo > hi) lo = hi;
   for (size_t i = 0; i < count; i++) {
     int32_t y = qnnp_requant_scale(acc[i], f);
-    if (y < rq.output_min_less_zero_point) y = rq.output_min_less_zero_point;
-    if (y > rq.output_max_less_zero_point) y = rq.output_max_less_zero_point;
-    out[i] = (uint8_t) (y + rq.output_zero_point);
+    if (y < lo) y = lo;
+    if (y > hi) y = hi;
+    out[i] = (uint8_t) (y + zp_late);
   }
 }
 

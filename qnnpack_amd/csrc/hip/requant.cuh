@@ -31,33 +31,45 @@
 
 namespace qnnp {
 
-/* kernel-argument form of struct qnnp_hip_requant */
+/* kernel-argument form of struct qnnp_hip_requant. The output zero point is folded into the rounding addend of `f`
+ * (requant_math.h), so the scale functions return y + zp directly; `zp_late` is the zero point still to be added
+ * (0 when folded, i.e. always except for scales below 2^-23 and the single largest one) after the clamp, whose
+ * bounds are in the domain of what the scale functions return. */
 struct RequantDev {
   qnnp_requant_fast f;
-  int32_t min_less_zp;
-  int32_t max_less_zp;
-  int32_t zp;
-  uint32_t full_range;   /* 1: clamp is exactly [0, 255] -> saturating packs */
+  int32_t qmin;
+  int32_t qmax;
+  int32_t zp_late;
+  uint32_t full_range;   /* 1: zero point folded and clamp exactly [0, 255] -> saturating packs, nothing else */
 };
 
 inline RequantDev make_requant_dev(const qnnp_hip_requant& rq)
 {
   RequantDev d;
   d.f = qnnp_requant_fast_init(rq.multiplier, rq.shift);
-  d.min_less_zp = rq.output_min_less_zero_point;
-  d.max_less_zp = rq.output_max_less_zero_point;
-  d.zp = rq.output_zero_point;
-  d.full_range = (rq.output_min_less_zero_point + rq.output_zero_point == 0 &&
-                  rq.output_max_less_zero_point + rq.output_zero_point == 255) ? 1u : 0u;
+  const int folded = qnnp_requant_fast_fold_zero_point(&d.f, static_cast<uint32_t>(rq.output_zero_point));
+  d.zp_late = folded ? 0 : rq.output_zero_point;
+  // bounds in the domain of what the scale functions return: output domain when folded, output - zp otherwise
+  // (the late addition comes AFTER the clamp: y + zp could wrap for |y| near 2^31)
+  d.qmin = rq.output_min_less_zero_point + (folded ? rq.output_zero_point : 0);
+  d.qmax = rq.output_max_less_zero_point + (folded ? rq.output_zero_point : 0);
+  if (d.qmin > d.qmax) d.qmin = d.qmax;          // min(max(y, lo), hi) == hi then; keeps the median form equivalent
+  d.full_range = (folded && d.qmin == 0 && d.qmax == 255) ? 1u : 0u;
   return d;
+}
+
+/* clamp(x, lo, hi) as ONE instruction (lo <= hi): the compiler cannot prove the order of two run-time bounds and
+ * emits max + min otherwise. gfx9 VOP3 reads at most one SGPR: lo comes from a scalar, hi from a vector register. */
+__device__ __forceinline__ int32_t clamp_med3(int32_t x, int32_t lo, int32_t hi)
+{
+  int32_t r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(lo), "v"(hi));
+  return r;
 }
 
 __device__ __forceinline__ int32_t q31_requantize(int32_t n, const RequantDev& rq)
 {
-  int32_t y = qnnp_requant_scale(n, rq.f);
-  y = max(y, rq.min_less_zp);
-  y = min(y, rq.max_less_zp);
-  return y + rq.zp;  // in [0, 255]
+  return clamp_med3(qnnp_requant_scale(n, rq.f), rq.qmin, rq.qmax) + rq.zp_late;  // in [0, 255]
 }
 
 /*
@@ -78,22 +90,20 @@ __device__ __forceinline__ uint32_t q31_requantize_pack4(
     y2 = qnnp_requant_scale_sn(n2, rq.f); y3 = qnnp_requant_scale_sn(n3, rq.f);
   }
   if constexpr (FULL_RANGE) {
-    // clamp to [0, 255] == saturation, two values per instruction:
-    //   i32 -> i16 (signed saturation) -> + zero point (saturating packed add) -> u8 (unsigned saturation).
-    // Saturating BEFORE the zero-point add keeps y + zp from wrapping for |y| near 2^31, and cannot
-    // change the result: a saturated +-32767 still lands outside [0, 255] on the correct side.
+    // the y's already carry the zero point; clamp to [0, 255] == saturation, two values per instruction:
+    //   i32 -> i16 (signed saturation) -> u8 (unsigned saturation).
+    // The first saturation cannot change the result: +-32767 still lands outside [0, 255] on the correct side.
     const auto p01 = __builtin_amdgcn_cvt_pk_i16(y0, y1);
     const auto p23 = __builtin_amdgcn_cvt_pk_i16(y2, y3);
-    const uint32_t zp2 = static_cast<uint32_t>(rq.zp) * 0x00010001u;
     uint32_t lo, hi;
-    asm("v_pk_add_i16 %0, %1, %2 clamp\n\tv_sat_pk_u8_i16 %0, %0" : "=&v"(lo) : "v"(p01), "s"(zp2));
-    asm("v_pk_add_i16 %0, %1, %2 clamp\n\tv_sat_pk_u8_i16 %0, %0" : "=&v"(hi) : "v"(p23), "s"(zp2));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(lo) : "v"(p01));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(hi) : "v"(p23));
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);   // {lo.b0, lo.b1, hi.b0, hi.b1}
   } else {
-    y0 = min(max(y0, rq.min_less_zp), rq.max_less_zp) + rq.zp;
-    y1 = min(max(y1, rq.min_less_zp), rq.max_less_zp) + rq.zp;
-    y2 = min(max(y2, rq.min_less_zp), rq.max_less_zp) + rq.zp;
-    y3 = min(max(y3, rq.min_less_zp), rq.max_less_zp) + rq.zp;
+    y0 = clamp_med3(y0, rq.qmin, rq.qmax) + rq.zp_late;
+    y1 = clamp_med3(y1, rq.qmin, rq.qmax) + rq.zp_late;
+    y2 = clamp_med3(y2, rq.qmin, rq.qmax) + rq.zp_late;
+    y3 = clamp_med3(y3, rq.qmin, rq.qmax) + rq.zp_late;
     return static_cast<uint32_t>(y0) | (static_cast<uint32_t>(y1) << 8) | (static_cast<uint32_t>(y2) << 16) |
            (static_cast<uint32_t>(y3) << 24);
   }

@@ -56,10 +56,31 @@ QNNP_HD struct qnnp_requant_fast qnnp_requant_fast_init(int32_t multiplier, uint
 /* arithmetic shift right of a signed value (gcc, clang and hipcc all implement >> on signed as arithmetic) */
 QNNP_HD int32_t qnnp_asr32(int32_t x, uint32_t n) { return x >> n; }
 
-/* y = requantized value BEFORE clamping and zero-point addition; shift == 0 form */
+/*
+ * Fold the output zero point into the rounding addend, so that the scale functions below return y + zp and the
+ * kernels spend no instruction on the addition:
+ *   s == 0 :  (n*M + 2^30 + zp*2^31) >> 31                       == q + zp
+ *   s >= 1 :  high32(n*(M+1) + A - u + zp*2^(31+s)) >> (s-1)      == y + zp   (zp*2^(31+s) is a multiple of 2^(32+s-1))
+ * Needs zp*2^(31+s) < 2^61 beside |n*(M+1)| < 2^62 and A <= 2^61: s <= 22 (zp < 2^8). Returns 1 if folded; 0 leaves
+ * `f` untouched (scales below 2^-23, or the one scale whose q + zp could wrap: the caller adds the zero point itself).
+ */
+QNNP_HD int qnnp_requant_fast_fold_zero_point(struct qnnp_requant_fast* f, uint32_t zero_point)
+{
+  if (f->shift > 22 || zero_point > 255) return 0;
+  /* s == 0 returns the 32-bit q + zp: with the single largest multiplier (scale 1 - 2^-24) q reaches 2^31 - 129 and
+   * the sum would wrap; one mantissa step lower q <= 2^31 - 257 and q + 255 still fits */
+  if (f->shift == 0 && (uint32_t) f->multiplier > UINT32_C(0x7FFFFF00)) return 0;
+  const uint64_t addend = (((uint64_t) f->addend_hi << 32) | f->addend_lo) + ((uint64_t) zero_point << (31 + f->shift));
+  f->addend_lo = (uint32_t) addend;
+  f->addend_hi = (uint32_t) (addend >> 32);
+  return 1;
+}
+
+/* y = requantized value BEFORE clamping (plus the zero point if it was folded in); shift == 0 form */
 QNNP_HD int32_t qnnp_requant_scale_s0(int32_t n, const struct qnnp_requant_fast f)
 {
-  const int64_t p = (int64_t) n * (int64_t) f.multiplier + INT64_C(0x40000000);
+  const int64_t addend = (int64_t) (((uint64_t) f.addend_hi << 32) | f.addend_lo);   /* 2^30 (+ zp * 2^31) */
+  const int64_t p = (int64_t) n * (int64_t) f.multiplier + addend;
   return (int32_t) (uint32_t) ((uint64_t) p >> 31);
 }
 
