@@ -14,7 +14,10 @@ Secondary numbers travel in the same JSON line under "extra" (not separate bench
   * q8conv 3x3 56x56x64->64 batch 128 (configs[2]),
   * the MobileNetV2 depthwise layers (configs[3]) as HBM GB/s,
   * the 31-layer MobileNetV2 conv sweep (configs[4], bench/convolution.cc:453-536) as images/s with the
-    batch sharded across ranks (no collective), each layer timed as its own operator like the reference bench.
+    batch sharded across ranks (no collective), each layer timed as its own operator like the reference bench,
+  * "mobilenetv2_network": the WHOLE network (examples/mobilenetv2.py: 52 convolutions, 10 residual adds, global
+    average pooling, classifier = 64 chained operators) as one hipGraph replay, images/s,
+  * "next_rows": the operators SURVEY.md section 8f ranks after the hot path (deconvolution, add, pooling).
 
 "roofline" is for the dominant kernel of the headline workload, timed with HIP events on the launch
 stream inside this process. "cpu_baseline" times the reference's own SSE2 path (oracle/_ref, built from
@@ -105,6 +108,32 @@ class ConvLayer:
     def close(self):
         self.lib.delete_operator(self.op)
         self.inputs = self.outputs = None
+
+
+def network_bench(lib, torch, batch, total_batch, world, warmup, iters):
+    """Every operator of a real quantized MobileNetV2 forward pass (examples/mobilenetv2.py: 52 convolutions, 10 residual
+    adds, global average pooling, classifier), chained on device buffers with their true dependencies and replayed as one
+    hipGraph. Unlike the 31-shape sweep each tensor is produced by the previous operator, so it may still sit in the
+    256 MB Infinity Cache when it is consumed."""
+    from examples import mobilenetv2 as mnv2
+    from qnnpack_amd.shard import job_time_ms
+    plan = mnv2.build_plan()
+    net = mnv2.DeviceNetwork(lib, torch, plan, batch)
+    try:
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(91)
+        net.buffers[0].copy_(torch.randint(0, 256, (net.buffers[0].numel(),), dtype=torch.uint8, device="cuda", generator=gen))
+        net.run()
+        net.capture()
+        ms = net.time_ms(max(warmup, 2), iters)
+        job_ms = job_time_ms(ms, world)
+        act = mnv2.algorithmic_bytes(plan, batch)
+        return {"operators": len(plan.ops), "images_per_s": round(total_batch / (job_ms * 1e-3), 1),
+                "batch_per_gpu": batch, "ms_per_batch": round(job_ms, 4), "timed_as": "one hipGraph replay of the chained operators",
+                "activation_gbs": round(act / (ms * 1e-3) / 1e9, 1), "tops": round(mnv2.operations(plan, batch) / (ms * 1e-3) / 1e12, 2),
+                "kernels": sorted(set(net.kernels.values()))}
+    finally:
+        net.close()
 
 
 def next_rows_bench(lib, torch, batch, warmup, iters):
@@ -462,6 +491,10 @@ def main():
         extra["q8dwconv_mobilenetv2_layers"] = {
             "hbm_gbs": round(dw_bytes / (dw_ms * 1e-3) / 1e9, 1), "ms": round(dw_ms, 4),
             "frac_of_hbm_peak": round(dw_bytes / (dw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+
+        # ---------------------------------------------------------- the whole network (64 chained operators, one hipGraph)
+        extra["mobilenetv2_network"] = network_bench(lib, torch, my_batch, total_batch, world, args.warmup,
+                                                     max(args.steps // 2, 5))
 
         # ---------------------------------------------------------- SURVEY 8f "next" rows: deconvolution, add, pooling
         extra["next_rows"] = next_rows_bench(lib, torch, my_batch, args.warmup, max(args.steps // 2, 5))

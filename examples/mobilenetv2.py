@@ -1,0 +1,210 @@
+"""A whole quantized MobileNetV2 (width 1.0) through the QNNPACK C ABI on gfx950.
+
+The reference's benchmark (bench/convolution.cc:453-536) times the network's 31 DISTINCT convolution shapes one
+by one. This module chains the real thing -- 52 convolutions (first 3x3, 17 inverted-residual blocks, last 1x1), the
+10 residual adds, global average pooling and the classifier -- on device buffers, every operator created through
+`include/qnnpack.h`, and replays the 65 launches as ONE hipGraph (`qnnp_gfx950_graph_*`). It is a caller of the
+library, not part of it: `bench.py` reports its images/s next to the per-layer sweep, and
+`tests/test_gpu_network.py` checks every intermediate tensor against the scalar oracle, layer by layer.
+
+Quantization: every weighted operator is created with input / kernel scale 1 and an output scale + zero point handed
+in per operator (`Quant`): the bench uses the reference bench's constants, the parity test derives them from the
+oracle's accumulators exactly as the reference's operator testers do.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+# torchvision / the paper's table 2: (expansion t, output channels c, repeats n, first stride s)
+BLOCKS = [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1)]
+
+
+@dataclass
+class Op:
+    kind: str                      # "conv" | "add" | "gap" | "fc"
+    name: str
+    src: Tuple[int, ...]           # tensor ids read
+    dst: int                       # tensor id written
+    # convolution geometry (kind == "conv")
+    hw: Tuple[int, int] = (0, 0)
+    k: int = 1
+    stride: int = 1
+    groups: int = 1
+    gic: int = 0
+    goc: int = 0
+    channels: int = 0              # add / gap / fc output width
+    width: int = 0                 # gap: pixels per image
+
+
+@dataclass
+class Quant:
+    """Per-operator quantization handed to create: zero points of the operands, output scale / zero point / clamp."""
+    in_zp: int = 127
+    in2_zp: int = 127
+    kernel_zp: int = 127
+    out_scale: float = 2.0         # input and kernel scales are 1: requantization scale = 1 / out_scale (0.5, the
+                                   # reference bench's 0.5 * 0.5 / 0.5, bench/convolution.cc:71-74)
+    out_zp: int = 127
+    qmin: int = 0
+    qmax: int = 255
+
+
+@dataclass
+class Plan:
+    ops: List[Op] = field(default_factory=list)
+    shapes: Dict[int, Tuple[int, int, int]] = field(default_factory=dict)   # tensor id -> (H, W, C); H = W = 1 after pooling
+    weights: Dict[str, Tuple[np.ndarray, np.ndarray]] = field(default_factory=dict)
+
+
+def _out_hw(h, k, s):
+    pad = k // 2
+    return (h + 2 * pad - k) // s + 1
+
+
+def build_plan(input_hw: int = 224, classes: int = 1000, seed: int = 0x51A0) -> Plan:
+    rng = np.random.default_rng(seed)
+    plan = Plan()
+    tid = 0
+    plan.shapes[0] = (input_hw, input_hw, 3)
+
+    def conv(name, src, k, stride, groups, gic, goc):
+        nonlocal tid
+        h, w, c = plan.shapes[src]
+        assert c == groups * gic, (name, c, groups, gic)
+        tid += 1
+        oh, ow = _out_hw(h, k, stride), _out_hw(w, k, stride)
+        plan.shapes[tid] = (oh, ow, groups * goc)
+        plan.ops.append(Op("conv", name, (src,), tid, hw=(h, w), k=k, stride=stride, groups=groups, gic=gic, goc=goc))
+        plan.weights[name] = (rng.integers(0, 256, size=(groups, goc, k, k, gic), dtype=np.uint8),
+                              rng.integers(-10000, 10001, size=groups * goc, dtype=np.int32))
+        return tid
+
+    x = conv("conv0_3x3s2", 0, 3, 2, 1, 3, 32)
+    cin = 32
+    b = 0
+    for t, c, n, s in BLOCKS:
+        for i in range(n):
+            stride = s if i == 0 else 1
+            inp = x
+            hidden = cin * t
+            if t != 1:
+                x = conv(f"b{b}_expand", x, 1, 1, 1, cin, hidden)
+            x = conv(f"b{b}_dw", x, 3, stride, hidden, 1, 1)
+            x = conv(f"b{b}_project", x, 1, 1, 1, hidden, c)
+            if stride == 1 and cin == c:
+                tid += 1
+                plan.shapes[tid] = plan.shapes[x]
+                plan.ops.append(Op("add", f"b{b}_add", (inp, x), tid, channels=c))
+                x = tid
+            cin = c
+            b += 1
+    x = conv("conv_last_1x1", x, 1, 1, 1, cin, 1280)
+    h, w, c = plan.shapes[x]
+    tid += 1
+    plan.shapes[tid] = (1, 1, c)
+    plan.ops.append(Op("gap", "global_average_pooling", (x,), tid, channels=c, width=h * w))
+    x = tid
+    tid += 1
+    plan.shapes[tid] = (1, 1, classes)
+    plan.ops.append(Op("fc", "classifier", (x,), tid, gic=c, channels=classes))
+    plan.weights["classifier"] = (rng.integers(0, 256, size=(classes, c), dtype=np.uint8),
+                                  rng.integers(-10000, 10001, size=classes, dtype=np.int32))
+    return plan
+
+
+def tensor_bytes(plan: Plan, tid: int, batch: int) -> int:
+    h, w, c = plan.shapes[tid]
+    return batch * h * w * c
+
+
+def algorithmic_bytes(plan: Plan, batch: int) -> int:
+    """Activation bytes every operator reads and writes (weights excluded), the figure a per-operator HBM roofline uses."""
+    total = 0
+    for op in plan.ops:
+        total += sum(tensor_bytes(plan, s, batch) for s in op.src) + tensor_bytes(plan, op.dst, batch)
+    return total
+
+
+def operations(plan: Plan, batch: int) -> int:
+    """2 * MACs of the convolutions and the classifier, the reference's op count (bench/convolution.cc:100-104)."""
+    ops = 0
+    for op in plan.ops:
+        if op.kind == "conv":
+            oh, ow, _ = plan.shapes[op.dst]
+            ops += 2 * batch * oh * ow * op.groups * op.gic * op.goc * op.k * op.k
+        elif op.kind == "fc":
+            ops += 2 * batch * op.gic * op.channels
+    return ops
+
+
+class DeviceNetwork:
+    """The plan's operators created through the C ABI and bound to device buffers (one per tensor)."""
+
+    def __init__(self, lib, torch, plan: Plan, batch: int, quant: Optional[Dict[str, Quant]] = None):
+        self.lib, self.plan, self.batch = lib, plan, batch
+        self.buffers = {t: torch.empty(tensor_bytes(plan, t, batch), dtype=torch.uint8, device="cuda")
+                        for t in plan.shapes}
+        self.handles = []
+        self.kernels = {}
+        quant = quant or {}
+        for op in plan.ops:
+            q = quant.get(op.name, Quant())
+            src = [self.buffers[s] for s in op.src]
+            dst = self.buffers[op.dst]
+            if op.kind == "conv":
+                kernel, bias = plan.weights[op.name]
+                pad = op.k // 2
+                h = lib.create_convolution2d_nhwc_q8(pad, pad, pad, pad, op.k, op.k, op.stride, op.stride, 1, 1,
+                                                     op.groups, op.gic, op.goc, q.in_zp, 1.0, q.kernel_zp, 1.0,
+                                                     kernel, bias, q.out_zp, float(q.out_scale), q.qmin, q.qmax, 0)
+                cin, cout = op.groups * op.gic, op.groups * op.goc
+                lib.setup_convolution2d_nhwc_q8(h, batch, op.hw[0], op.hw[1], src[0], cin, dst, cout)
+            elif op.kind == "add":
+                h = lib.create_add_nc_q8(op.channels, q.in_zp, 1.0, q.in2_zp, 1.0, q.out_zp, float(q.out_scale),
+                                         q.qmin, q.qmax, 0)
+                hh, ww, c = plan.shapes[op.dst]
+                lib.setup_add_nc_q8(h, batch * hh * ww, src[0], c, src[1], c, dst, c)
+            elif op.kind == "gap":
+                h = lib.create_global_average_pooling_nwc_q8(op.channels, q.in_zp, 1.0, q.out_zp, float(q.out_scale),
+                                                             q.qmin, q.qmax, 0)
+                lib.setup_global_average_pooling_nwc_q8(h, batch, op.width, src[0], op.channels, dst, op.channels)
+            else:
+                kernel, bias = plan.weights[op.name]
+                h = lib.create_fully_connected_nc_q8(op.gic, op.channels, q.in_zp, 1.0, q.kernel_zp, 1.0, kernel, bias,
+                                                     q.out_zp, float(q.out_scale), q.qmin, q.qmax, 0)
+                lib.setup_fully_connected_nc_q8(h, batch, src[0], op.gic, dst, op.channels)
+            self.handles.append(h)
+        self.graph = None
+
+    def run(self):
+        """One forward pass, operator by operator."""
+        for op, h in zip(self.plan.ops, self.handles):
+            self.lib.run_operator(h)
+            self.kernels[op.name] = self.lib.operator_kernel(h)
+
+    def capture(self):
+        """Record the whole forward pass into one hipGraph (device pointers only; nothing runs yet)."""
+        self.lib.graph_begin()
+        for h in self.handles:
+            self.lib.run_operator(h)
+        self.graph = self.lib.graph_end()
+        return self.graph
+
+    def replay(self):
+        self.lib.graph_launch(self.graph)
+        self.lib.graph_synchronize(self.graph)
+
+    def time_ms(self, warmup: int, iters: int) -> float:
+        return self.lib.graph_time(self.graph, warmup, iters)
+
+    def close(self):
+        if self.graph is not None:
+            self.lib.graph_destroy(self.graph)
+            self.graph = None
+        for h in self.handles:
+            self.lib.delete_operator(h)
+        self.handles = []
+        self.buffers = {}
