@@ -8,11 +8,12 @@
  * header links against libqnnpack_gfx950.so unchanged. Each prototype cites
  * the reference declaration it replaces (pytorch/QNNPACK tree).
  *
- * Scope: only the operators on the q8 conv/GEMM hot
- * path are provided -- convolution2d_nhwc_q8 (which covers 1x1 "gemm",
- * general "conv" and depthwise "dwconv") and fully_connected_nc_q8. The other
- * reference operators (pooling, add, clamp, LUT ops, deconvolution, ...) are
- * not part of this library.
+ * Scope (SURVEY.md sections 8b, 8f): the operators on the q8 conv/GEMM hot
+ * path -- convolution2d_nhwc_q8 (which covers 1x1 "gemm", general "conv" and
+ * depthwise "dwconv") and fully_connected_nc_q8 -- plus the rows ranked next:
+ * deconvolution2d_nhwc_q8, add_nc_q8 and global_average_pooling_nwc_q8. The
+ * other reference operators (windowed pooling, clamp, LUT ops, ...) are not
+ * part of this library.
  *
  * Pointer contract specific to this build: `input` / `output` passed to
  * qnnp_setup_* may be either
@@ -66,177 +67,95 @@ enum qnnp_status qnnp_deinitialize(void);
 /* reference include/qnnpack.h:38 */
 typedef struct qnnp_operator* qnnp_operator_t;
 
-/* reference include/qnnpack.h:40-65.
- * kernel: [groups][group_output_channels][kernel_height][kernel_width][group_input_channels] uint8
- * bias:   [groups * group_output_channels] int32 */
-enum qnnp_status qnnp_create_convolution2d_nhwc_q8(
-    uint32_t input_padding_top,
-    uint32_t input_padding_right,
-    uint32_t input_padding_bottom,
-    uint32_t input_padding_left,
-    uint32_t kernel_height,
-    uint32_t kernel_width,
-    uint32_t subsampling_height,
-    uint32_t subsampling_width,
-    uint32_t dilation_height,
-    uint32_t dilation_width,
-    uint32_t groups,
-    size_t group_input_channels,
-    size_t group_output_channels,
-    uint8_t input_zero_point,
-    float input_scale,
-    uint8_t kernel_zero_point,
-    float kernel_scale,
-    const uint8_t* kernel,
-    const int32_t* bias,
-    uint8_t output_zero_point,
-    float output_scale,
-    uint8_t output_min,
-    uint8_t output_max,
-    uint32_t flags,
-    qnnp_operator_t* convolution);
+/*
+ * Argument groups shared by the create functions below (same order and types as the reference):
+ *   padding          top, right, bottom, left (uint32 each)
+ *   window           kernel h, w; subsampling / stride h, w; dilation h, w (uint32 each)
+ *   channels         groups (uint32), input channels per group, output channels per group (size_t)
+ *   quantization     input zero point (uint8) + scale (float), kernel zero point + scale,
+ *                    [kernel, bias: host pointers, copied], output zero point + scale, output min, max (uint8)
+ *   flags            accepted and ignored, as in the reference
+ *   last argument    receives the handle, written only on success
+ */
 
-/* reference include/qnnpack.h:67-76 */
+/* reference include/qnnpack.h:40-65. kernel: [groups][group_output_channels][kh][kw][group_input_channels] uint8;
+ * bias: [groups * group_output_channels] int32 */
+enum qnnp_status qnnp_create_convolution2d_nhwc_q8(
+    uint32_t input_padding_top, uint32_t input_padding_right, uint32_t input_padding_bottom, uint32_t input_padding_left,
+    uint32_t kernel_height, uint32_t kernel_width, uint32_t subsampling_height, uint32_t subsampling_width,
+    uint32_t dilation_height, uint32_t dilation_width,
+    uint32_t groups, size_t group_input_channels, size_t group_output_channels,
+    uint8_t input_zero_point, float input_scale, uint8_t kernel_zero_point, float kernel_scale,
+    const uint8_t* kernel, const int32_t* bias,
+    uint8_t output_zero_point, float output_scale, uint8_t output_min, uint8_t output_max,
+    uint32_t flags, qnnp_operator_t* convolution);
+
+/* reference include/qnnpack.h:67-76. Strides are in bytes between pixels; `threadpool` is ignored. */
 enum qnnp_status qnnp_setup_convolution2d_nhwc_q8(
-    qnnp_operator_t convolution,
-    size_t batch_size,
-    size_t input_height,
-    size_t input_width,
-    const uint8_t* input,
-    size_t input_stride,
-    uint8_t* output,
-    size_t output_stride,
-    pthreadpool_t threadpool);
+    qnnp_operator_t convolution, size_t batch_size, size_t input_height, size_t input_width,
+    const uint8_t* input, size_t input_stride, uint8_t* output, size_t output_stride, pthreadpool_t threadpool);
 
 /* reference include/qnnpack.h:78-105. Transposed convolution:
  *   output extent = stride * (input - 1) + adjustment + (kernel - 1) * dilation + 1 - (padding before + after)
- * kernel: [groups][group_input_channels][kernel_height][kernel_width][group_output_channels] uint8
- *         (test/deconvolution-operator-tester.h:411 -- note: input channel OUTERMOST, unlike convolution)
+ * kernel: [groups][group_input_channels][kh][kw][group_output_channels] uint8
+ *         (test/deconvolution-operator-tester.h:411 -- input channel OUTERMOST, unlike convolution)
  * bias:   [groups * group_output_channels] int32 */
 enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8(
-    uint32_t input_padding_top,
-    uint32_t input_padding_right,
-    uint32_t input_padding_bottom,
-    uint32_t input_padding_left,
-    uint32_t adjustment_height,
-    uint32_t adjustment_width,
-    uint32_t kernel_height,
-    uint32_t kernel_width,
-    uint32_t stride_height,
-    uint32_t stride_width,
-    uint32_t dilation_height,
-    uint32_t dilation_width,
-    uint32_t groups,
-    size_t group_input_channels,
-    size_t group_output_channels,
-    uint8_t input_zero_point,
-    float input_scale,
-    uint8_t kernel_zero_point,
-    float kernel_scale,
-    const uint8_t* kernel,
-    const int32_t* bias,
-    uint8_t output_zero_point,
-    float output_scale,
-    uint8_t output_min,
-    uint8_t output_max,
-    uint32_t flags,
-    qnnp_operator_t* deconvolution);
+    uint32_t input_padding_top, uint32_t input_padding_right, uint32_t input_padding_bottom, uint32_t input_padding_left,
+    uint32_t adjustment_height, uint32_t adjustment_width,
+    uint32_t kernel_height, uint32_t kernel_width, uint32_t stride_height, uint32_t stride_width,
+    uint32_t dilation_height, uint32_t dilation_width,
+    uint32_t groups, size_t group_input_channels, size_t group_output_channels,
+    uint8_t input_zero_point, float input_scale, uint8_t kernel_zero_point, float kernel_scale,
+    const uint8_t* kernel, const int32_t* bias,
+    uint8_t output_zero_point, float output_scale, uint8_t output_min, uint8_t output_max,
+    uint32_t flags, qnnp_operator_t* deconvolution);
 
 /* reference include/qnnpack.h:107-116 */
 enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8(
-    qnnp_operator_t deconvolution,
-    size_t batch_size,
-    size_t input_height,
-    size_t input_width,
-    const uint8_t* input,
-    size_t input_stride,
-    uint8_t* output,
-    size_t output_stride,
-    pthreadpool_t threadpool);
+    qnnp_operator_t deconvolution, size_t batch_size, size_t input_height, size_t input_width,
+    const uint8_t* input, size_t input_stride, uint8_t* output, size_t output_stride, pthreadpool_t threadpool);
 
-/* reference include/qnnpack.h:118-132. kernel: [output_channels][input_channels] */
+/* reference include/qnnpack.h:118-132. kernel: [output_channels][input_channels] uint8; bias: [output_channels] */
 enum qnnp_status qnnp_create_fully_connected_nc_q8(
-    size_t input_channels,
-    size_t output_channels,
-    uint8_t input_zero_point,
-    float input_scale,
-    uint8_t kernel_zero_point,
-    float kernel_scale,
-    const uint8_t* kernel,
-    const int32_t* bias,
-    uint8_t output_zero_point,
-    float output_scale,
-    uint8_t output_min,
-    uint8_t output_max,
-    uint32_t flags,
-    qnnp_operator_t* fully_connected);
+    size_t input_channels, size_t output_channels,
+    uint8_t input_zero_point, float input_scale, uint8_t kernel_zero_point, float kernel_scale,
+    const uint8_t* kernel, const int32_t* bias,
+    uint8_t output_zero_point, float output_scale, uint8_t output_min, uint8_t output_max,
+    uint32_t flags, qnnp_operator_t* fully_connected);
 
-/* reference include/qnnpack.h:134-140 */
+/* reference include/qnnpack.h:134-140. Strides are in bytes between rows. */
 enum qnnp_status qnnp_setup_fully_connected_nc_q8(
-    qnnp_operator_t fully_connected,
-    size_t batch_size,
-    const uint8_t* input,
-    size_t input_stride,
-    uint8_t* output,
-    size_t output_stride);
+    qnnp_operator_t fully_connected, size_t batch_size,
+    const uint8_t* input, size_t input_stride, uint8_t* output, size_t output_stride);
 
 /* reference include/qnnpack.h:142-151. Averages `width` pixels of `channels` bytes per image (NWC). */
 enum qnnp_status qnnp_create_global_average_pooling_nwc_q8(
-    size_t channels,
-    uint8_t input_zero_point,
-    float input_scale,
-    uint8_t output_zero_point,
-    float output_scale,
-    uint8_t output_min,
-    uint8_t output_max,
-    uint32_t flags,
-    qnnp_operator_t* global_average_pooling);
+    size_t channels, uint8_t input_zero_point, float input_scale, uint8_t output_zero_point, float output_scale,
+    uint8_t output_min, uint8_t output_max, uint32_t flags, qnnp_operator_t* global_average_pooling);
 
 /* reference include/qnnpack.h:153-160. input_stride: bytes between pixels; output_stride: between images. */
 enum qnnp_status qnnp_setup_global_average_pooling_nwc_q8(
-    qnnp_operator_t global_average_pooling,
-    size_t batch_size,
-    size_t width,
-    const uint8_t* input,
-    size_t input_stride,
-    uint8_t* output,
-    size_t output_stride);
+    qnnp_operator_t global_average_pooling, size_t batch_size, size_t width,
+    const uint8_t* input, size_t input_stride, uint8_t* output, size_t output_stride);
 
 /* reference include/qnnpack.h:234-245. Quantized element-wise sum of two [batch][channels] tensors. */
 enum qnnp_status qnnp_create_add_nc_q8(
-    size_t channels,
-    uint8_t a_zero_point,
-    float a_scale,
-    uint8_t b_zero_point,
-    float b_scale,
-    uint8_t sum_zero_point,
-    float sum_scale,
-    uint8_t sum_min,
-    uint8_t sum_max,
-    uint32_t flags,
-    qnnp_operator_t* add);
+    size_t channels, uint8_t a_zero_point, float a_scale, uint8_t b_zero_point, float b_scale,
+    uint8_t sum_zero_point, float sum_scale, uint8_t sum_min, uint8_t sum_max,
+    uint32_t flags, qnnp_operator_t* add);
 
 /* reference include/qnnpack.h:247-255 */
 enum qnnp_status qnnp_setup_add_nc_q8(
-    qnnp_operator_t add,
-    size_t batch_size,
-    const uint8_t* a,
-    size_t a_stride,
-    const uint8_t* b,
-    size_t b_stride,
-    uint8_t* sum,
-    size_t sum_stride);
+    qnnp_operator_t add, size_t batch_size,
+    const uint8_t* a, size_t a_stride, const uint8_t* b, size_t b_stride, uint8_t* sum, size_t sum_stride);
 
-/* reference include/qnnpack.h:327-329. `threadpool` is accepted and ignored:
- * the operator runs as HIP kernels on the library's stream. Synchronous by
- * default (outputs complete on return); see qnnpack_gfx950.h for async mode. */
-enum qnnp_status qnnp_run_operator(
-    qnnp_operator_t op,
-    pthreadpool_t threadpool);
+/* reference include/qnnpack.h:327-329. `threadpool` is accepted and ignored: the launch covers the whole operator.
+ * Synchronous by default (outputs complete on return); see qnnpack_gfx950.h for the asynchronous mode. */
+enum qnnp_status qnnp_run_operator(qnnp_operator_t op, pthreadpool_t threadpool);
 
-/* reference include/qnnpack.h:331-332 */
-enum qnnp_status qnnp_delete_operator(
-    qnnp_operator_t op);
+/* reference include/qnnpack.h:331-332. NULL -> invalid_parameter (src/operator-delete.c:17-19). */
+enum qnnp_status qnnp_delete_operator(qnnp_operator_t op);
 
 #ifdef __cplusplus
 } /* extern "C" */
