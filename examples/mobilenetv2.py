@@ -140,10 +140,32 @@ def operations(plan: Plan, batch: int) -> int:
     return ops
 
 
-class DeviceNetwork:
-    """The plan's operators created through the C ABI and bound to device buffers (one per tensor)."""
+def blocks_of(plan: Plan):
+    """The inverted-residual blocks of the plan as index tuples (expand | None, depthwise, project, add | None)."""
+    out = []
+    ops = plan.ops
+    i = 0
+    while i < len(ops):
+        op = ops[i]
+        if op.kind == "conv" and op.name.endswith("_dw"):
+            ex = i - 1 if i > 0 and ops[i - 1].name.endswith("_expand") else None
+            pr = i + 1
+            ad = i + 2 if i + 2 < len(ops) and ops[i + 2].kind == "add" else None
+            out.append((ex, i, pr, ad))
+            i = (ad if ad is not None else pr) + 1
+        else:
+            i += 1
+    return out
 
-    def __init__(self, lib, torch, plan: Plan, batch: int, quant: Optional[Dict[str, Quant]] = None):
+
+class DeviceNetwork:
+    """The plan's operators created through the C ABI and bound to device buffers (one per tensor).
+
+    fuse=True additionally builds one fused operator per inverted-residual block from the stand-alone operators
+    (qnnp_gfx950_create_fused_block) and runs it in their place wherever the fused kernel takes the block; the
+    expanded tensors of those blocks are then never written."""
+
+    def __init__(self, lib, torch, plan: Plan, batch: int, quant: Optional[Dict[str, Quant]] = None, fuse: bool = False):
         self.lib, self.plan, self.batch = lib, plan, batch
         self.buffers = {t: torch.empty(tensor_bytes(plan, t, batch), dtype=torch.uint8, device="cuda")
                         for t in plan.shapes}
@@ -178,17 +200,55 @@ class DeviceNetwork:
                 lib.setup_fully_connected_nc_q8(h, batch, src[0], op.gic, dst, op.channels)
             self.handles.append(h)
         self.graph = None
+        # execution schedule: (name, handle) in order; fused blocks replace their members
+        self.fused = {}
+        self.fused_handles = []
+        self.schedule = [(op.name, h) for op, h in zip(plan.ops, self.handles)]
+        if fuse:
+            from qnnpack_amd import QnnpackError
+            replaced = {}
+            for ex, dw, pr, ad in blocks_of(plan):
+                first = ex if ex is not None else dw
+                last = ad if ad is not None else pr
+                try:
+                    fh = lib.create_fused_block(self.handles[ex] if ex is not None else None, self.handles[dw],
+                                                self.handles[pr], self.handles[ad] if ad is not None else None)
+                except QnnpackError:
+                    continue
+                src = plan.ops[first].src[0]
+                dst = plan.ops[last].dst
+                hh, ww, cin = plan.shapes[src]
+                cout = plan.shapes[dst][2]
+                try:
+                    lib.setup_fused_block(fh, batch, hh, ww, self.buffers[src], cin, self.buffers[dst], cout)
+                except QnnpackError:
+                    lib.delete_operator(fh)
+                    continue
+                self.fused_handles.append(fh)
+                name = plan.ops[dw].name.replace("_dw", "_fused")
+                self.fused[name] = (first, last)
+                replaced[first] = (name, fh, last)
+            schedule, i = [], 0
+            while i < len(plan.ops):
+                if i in replaced:
+                    name, fh, last = replaced[i]
+                    schedule.append((name, fh))
+                    i = last + 1
+                else:
+                    schedule.append((plan.ops[i].name, self.handles[i]))
+                    i += 1
+            self.schedule = schedule
 
     def run(self):
         """One forward pass, operator by operator."""
-        for op, h in zip(self.plan.ops, self.handles):
+        for name, h in self.schedule:
             self.lib.run_operator(h)
-            self.kernels[op.name] = self.lib.operator_kernel(h)
+            self.kernels[name] = self.lib.operator_kernel(h)
 
     def capture(self):
         """Record the whole forward pass into one hipGraph (device pointers only; nothing runs yet)."""
         self.lib.graph_begin()
-        for h in self.handles:
+        for _, h in self.schedule:
             self.lib.run_operator(h)
         self.graph = self.lib.graph_end()
         return self.graph
@@ -204,7 +264,10 @@ class DeviceNetwork:
         if self.graph is not None:
             self.lib.graph_destroy(self.graph)
             self.graph = None
+        for h in self.fused_handles:
+            self.lib.delete_operator(h)
         for h in self.handles:
             self.lib.delete_operator(h)
         self.handles = []
+        self.fused_handles = []
         self.buffers = {}

@@ -81,6 +81,20 @@ enum qnnp_status qnnp_gfx950_graph_synchronize(void* graph);
 enum qnnp_status qnnp_gfx950_graph_time(void* graph, int warmup, int iters, float* avg_ms_out);
 void qnnp_gfx950_graph_destroy(void* graph);
 
+/* Fused inverted-residual block (no reference counterpart):
+ *     [1x1 expand ->] 3x3 depthwise (padding 1, stride 1 | 2) -> 1x1 project [-> quantized add with the block input]
+ * as ONE operator; the expanded tensors stay in LDS. Built FROM stand-alone operators created with qnnpack.h
+ * (`expand` and `residual_add` may be NULL): it borrows their packed weights and quantization parameters, so the
+ * result is bit-identical to running them in sequence, and they must outlive it. Run / delete with
+ * qnnp_run_operator / qnnp_delete_operator. unsupported_parameter (from create or setup) = outside the fused
+ * kernel's range (channel multiples, LDS) -- keep using the stand-alone operators for that block. */
+enum qnnp_status qnnp_gfx950_create_fused_block(
+    qnnp_operator_t expand, qnnp_operator_t depthwise, qnnp_operator_t project, qnnp_operator_t residual_add,
+    qnnp_operator_t* fused);
+enum qnnp_status qnnp_gfx950_setup_fused_block(
+    qnnp_operator_t fused, size_t batch_size, size_t input_height, size_t input_width,
+    const uint8_t* input, size_t input_stride, uint8_t* output, size_t output_stride);
+
 /* Kernel-variant control for A/B measurement and tests. Keys:
  *   "gemm_kernel":   0 = auto, 1 = generic MFMA implicit-GEMM kernel, 2 = 256x256 LDS-DMA MFMA kernel,
  *                    3 = LDS-tiled direct-convolution MFMA kernel (convolutions only),

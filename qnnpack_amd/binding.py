@@ -313,6 +313,10 @@ class Gfx950Library(QnnpackLibrary):
         L.qnnp_gfx950_graph_destroy.argtypes = [c_void_p]
         L.qnnp_gfx950_mfma_probe.restype = c_int
         L.qnnp_gfx950_mfma_probe.argtypes = [c_int, c_int, POINTER(c_float)]
+        L.qnnp_gfx950_create_fused_block.restype = c_int
+        L.qnnp_gfx950_create_fused_block.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]
+        L.qnnp_gfx950_setup_fused_block.restype = c_int
+        L.qnnp_gfx950_setup_fused_block.argtypes = [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t]
         L.qnnp_gfx950_set_option.restype = c_int
         L.qnnp_gfx950_set_option.argtypes = [c_char_p, c_int]
         L.qnnp_gfx950_operator_kernel.restype = c_char_p
@@ -375,6 +379,28 @@ class Gfx950Library(QnnpackLibrary):
         self._check("qnnp_gfx950_time_operator_rotating",
                     self.lib.qnnp_gfx950_time_operator_rotating(op, n, ins, outs, warmup, iters, ctypes.byref(ms)))
         return float(ms.value)
+
+    # ---- fused inverted-residual block (qnnpack_gfx950.h) ----
+    def create_fused_block_status(self, expand, depthwise, project, residual_add=None):
+        handle = c_void_p(None)
+        st = self.lib.qnnp_gfx950_create_fused_block(expand, depthwise, project, residual_add, ctypes.byref(handle))
+        return Status(st), handle.value
+
+    def create_fused_block(self, expand, depthwise, project, residual_add=None) -> int:
+        st, handle = self.create_fused_block_status(expand, depthwise, project, residual_add)
+        if st != Status.success:
+            raise QnnpackError("qnnp_gfx950_create_fused_block", st)
+        return handle
+
+    def setup_fused_block_status(self, op, batch_size, input_height, input_width, input, input_stride,
+                                 output, output_stride) -> Status:
+        return Status(self.lib.qnnp_gfx950_setup_fused_block(
+            op, batch_size, input_height, input_width, address_of(input), input_stride, address_of(output), output_stride))
+
+    def setup_fused_block(self, *args) -> None:
+        st = self.setup_fused_block_status(*args)
+        if st != Status.success:
+            raise QnnpackError("qnnp_gfx950_setup_fused_block", st)
 
     # ---- hipGraph capture of operator launches (qnnpack_gfx950.h) ----
     def graph_begin(self) -> None:

@@ -292,8 +292,10 @@ enum qnnp_status qnnp_setup_convolution2d_nhwc_q8(
     qnnp_log_error("qnnp_setup_convolution2d_nhwc_q8 failed because QNNPACK is not properly initialized");
     return qnnp_status_uninitialized;
   }
-  if (op == NULL || op->transposed) {
-    return qnnp_status_invalid_parameter;
+  if (op == NULL || op->transposed || op->kernel_height == 0 ||
+      (op->ukernel_type != qnnp_ukernel_type_conv && op->ukernel_type != qnnp_ukernel_type_dwconv &&
+       op->ukernel_type != qnnp_ukernel_type_gemm)) {
+    return qnnp_status_invalid_parameter;   /* not a handle from qnnp_create_convolution2d_nhwc_q8 */
   }
 
   /* reference convolution.c:396-399 */

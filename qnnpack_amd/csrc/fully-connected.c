@@ -166,8 +166,8 @@ enum qnnp_status qnnp_setup_fully_connected_nc_q8(
     qnnp_log_error("qnnp_setup_fully_connected_nc_q8 failed because QNNPACK is not properly initialized");
     return qnnp_status_uninitialized;
   }
-  if (op == NULL) {
-    return qnnp_status_invalid_parameter;
+  if (op == NULL || op->ukernel_type != qnnp_ukernel_type_gemm || op->transposed || op->group_input_channels == 0) {
+    return qnnp_status_invalid_parameter;   /* not a handle from a fully connected / 1x1 create */
   }
 
   /* reference fully-connected.c:144-147 */

@@ -1,0 +1,183 @@
+/*
+ * fused-block.c -- qnnp_gfx950_create_fused_block / qnnp_gfx950_setup_fused_block (include/qnnpack_gfx950.h):
+ * an inverted-residual block [1x1 expand ->] 3x3 depthwise -> 1x1 project [-> + input] as ONE operator whose
+ * intermediates never leave the chip (hip/q8fused.hip). SURVEY.md section 8f, row 2; no reference counterpart --
+ * the reference runs the three (four) operators one after another (bench/convolution.cc:464-471 lists the shape
+ * triples).
+ *
+ * The fused operator is BUILT FROM the stand-alone operators, created through the regular API: it borrows their
+ * packed device weights, folded biases and requantization parameters, so its result is bit-identical to running them
+ * in sequence by construction of the arithmetic, and a caller can fall back to exactly those operators when create or
+ * setup reports unsupported_parameter. The source operators must outlive the fused one.
+ */
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <qnnpack.h>
+#include <qnnpack_gfx950.h>
+
+#include "hip/qnnp_hip.h"
+#include "log.h"
+#include "operator.h"
+#include "state.h"
+
+static int is_pointwise(const struct qnnp_operator* op)
+{
+  return op != NULL && op->ukernel_type == qnnp_ukernel_type_gemm && !op->transposed && op->groups == 1 &&
+      op->kernel_height == 1 && op->kernel_width == 1 && op->kc_slot == op->group_input_channels;
+}
+
+static struct qnnp_hip_fused_args fused_args(const struct qnnp_operator* op, const void* input, void* output)
+{
+  const struct qnnp_operator* ex = op->fused_expand;
+  const struct qnnp_operator* dw = op->fused_depthwise;
+  const struct qnnp_operator* pr = op->fused_project;
+  struct qnnp_hip_fused_args a;
+  a.input = (const uint8_t*) input;
+  a.output = (uint8_t*) output;
+  a.batch = (uint32_t) op->batch_size;
+  a.input_height = (uint32_t) op->input_height;
+  a.input_width = (uint32_t) op->input_width;
+  a.output_height = (uint32_t) op->output_height;
+  a.output_width = (uint32_t) op->output_width;
+  a.input_channels = (uint32_t) (ex != NULL ? ex->group_input_channels : dw->groups);
+  a.hidden_channels = dw->groups;
+  a.output_channels = (uint32_t) pr->group_output_channels;
+  a.input_stride = (uint32_t) op->input_pixel_stride;
+  a.output_stride = (uint32_t) op->output_pixel_stride;
+  a.stride = dw->stride_height;
+  a.has_expand = ex != NULL;
+  a.expand_w = ex != NULL ? (const int8_t*) ex->d_weights : NULL;
+  a.expand_bias2 = ex != NULL ? ex->d_bias : NULL;
+  a.expand_k_pad = ex != NULL ? ex->k_pad : 0;
+  a.expand_n_pad = ex != NULL ? ex->n_pad : 0;
+  a.expand_row_coeff = ex != NULL ? 128 - (int32_t) ex->kernel_zero_point : 0;
+  a.expand_rq = ex != NULL ? ex->requant : dw->requant;
+  a.dw_wadj = (const int16_t*) dw->d_weights;
+  a.dw_bias1 = dw->d_bias;
+  a.dw_c_pad = dw->c_pad;
+  a.dw_input_zero_point = dw->input_zero_point;
+  a.dw_rq = dw->requant;
+  a.project_w = (const int8_t*) pr->d_weights;
+  a.project_bias2 = pr->d_bias;
+  a.project_k_pad = pr->k_pad;
+  a.project_n_pad = pr->n_pad;
+  a.project_row_coeff = 128 - (int32_t) pr->kernel_zero_point;
+  a.project_rq = pr->requant;
+  a.has_residual = op->fused_add != NULL;
+  if (op->fused_add != NULL) {
+    a.add = op->fused_add->add_params;
+  } else {
+    const struct qnnp_hip_add_params none = {0};
+    a.add = none;
+  }
+  return a;
+}
+
+enum qnnp_status qnnp_gfx950_create_fused_block(
+    qnnp_operator_t expand, qnnp_operator_t depthwise, qnnp_operator_t project, qnnp_operator_t residual_add,
+    qnnp_operator_t* fused_out)
+{
+  if (!qnnp_state.initialized) {
+    qnnp_log_error("qnnp_gfx950_create_fused_block failed because QNNPACK is not properly initialized");
+    return qnnp_status_uninitialized;
+  }
+  if (depthwise == NULL || project == NULL || fused_out == NULL) {
+    return qnnp_status_invalid_parameter;
+  }
+  /* the shapes the fused kernel is written for; anything else stays with the stand-alone operators */
+  if (depthwise->ukernel_type != qnnp_ukernel_type_dwconv ||
+      depthwise->kernel_height != 3 || depthwise->kernel_width != 3 ||
+      depthwise->dilation_height != 1 || depthwise->dilation_width != 1 ||
+      depthwise->stride_height != depthwise->stride_width || depthwise->stride_height > 2 ||
+      depthwise->input_padding_top != 1 || depthwise->input_padding_left != 1 ||
+      depthwise->input_padding_bottom != 1 || depthwise->input_padding_right != 1 ||
+      !is_pointwise(project) || project->group_input_channels != depthwise->groups ||
+      (expand != NULL && (!is_pointwise(expand) || expand->group_output_channels != depthwise->groups))) {
+    qnnp_log_error("failed to create fused block: operators are not a [1x1 ->] 3x3 depthwise (pad 1) -> 1x1 chain");
+    return qnnp_status_unsupported_parameter;
+  }
+  if (residual_add != NULL) {
+    const size_t cin = expand != NULL ? expand->group_input_channels : depthwise->groups;
+    if (residual_add->ukernel_type != qnnp_ukernel_type_add || residual_add->channels != project->group_output_channels ||
+        cin != project->group_output_channels || depthwise->stride_height != 1) {
+      qnnp_log_error("failed to create fused block: the residual add does not match the block's input / output");
+      return qnnp_status_unsupported_parameter;
+    }
+  }
+  qnnp_operator_t op = calloc(1, sizeof(struct qnnp_operator));
+  if (op == NULL) {
+    qnnp_log_error("failed to allocate %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
+    return qnnp_status_out_of_memory;
+  }
+  op->fused_expand = expand;
+  op->fused_depthwise = depthwise;
+  op->fused_project = project;
+  op->fused_add = residual_add;
+  op->channels = project->group_output_channels;
+  op->ukernel_type = qnnp_ukernel_type_fused_block;
+  *fused_out = op;
+  return qnnp_status_success;
+}
+
+enum qnnp_status qnnp_gfx950_setup_fused_block(
+    qnnp_operator_t op, size_t batch_size, size_t input_height, size_t input_width,
+    const uint8_t* input, size_t input_stride, uint8_t* output, size_t output_stride)
+{
+  if (!qnnp_state.initialized) {
+    return qnnp_status_uninitialized;
+  }
+  if (op == NULL || op->ukernel_type != qnnp_ukernel_type_fused_block) {
+    return qnnp_status_invalid_parameter;
+  }
+  if (batch_size == 0) {
+    op->batch_size = 0;
+    return qnnp_status_success;
+  }
+  const size_t cin = op->fused_expand != NULL ? op->fused_expand->group_input_channels : op->fused_depthwise->groups;
+  const size_t cout = op->fused_project->group_output_channels;
+  if (input_height == 0 || input_width == 0 || input == NULL || output == NULL ||
+      input_stride < cin || output_stride < cout) {
+    qnnp_log_error("failed to setup fused block: zero extent, NULL tensor or stride smaller than the channel count");
+    return qnnp_status_invalid_parameter;
+  }
+  const size_t s = op->fused_depthwise->stride_height;
+  op->batch_size = batch_size;
+  op->input_height = input_height;
+  op->input_width = input_width;
+  op->input = input;
+  op->input_pixel_stride = input_stride;
+  op->output_height = (input_height + 2 - 3) / s + 1;
+  op->output_width = (input_width + 2 - 3) / s + 1;
+  op->output = output;
+  op->output_pixel_stride = output_stride;
+  const size_t in_pixels = batch_size * input_height * input_width;
+  const size_t out_pixels = batch_size * op->output_height * op->output_width;
+  if (in_pixels > (size_t) UINT32_MAX / 2 || in_pixels * input_stride > (size_t) UINT32_MAX) {
+    qnnp_log_error("failed to setup fused block: %zu pixels exceed the device kernel's index range", in_pixels);
+    return qnnp_status_unsupported_parameter;
+  }
+  op->input_span = (in_pixels - 1) * input_stride + cin;
+  op->output_span = (out_pixels - 1) * output_stride + cout;
+  if (qnnp_bind_endpoint(input, op->input_span, &op->input_on_device, &op->d_stage_in, &op->stage_in_capacity) != 0 ||
+      qnnp_bind_endpoint(output, op->output_span, &op->output_on_device, &op->d_stage_out, &op->stage_out_capacity) != 0) {
+    return qnnp_status_out_of_memory;
+  }
+  /* does the kernel take this block (LDS plan, channel multiples, alignment)? */
+  const struct qnnp_hip_fused_args probe = fused_args(op, op->input_on_device ? input : op->d_stage_in,
+      op->output_on_device ? (void*) output : op->d_stage_out);
+  if (!qnnp_hip_fused_block_supported(&probe)) {
+    op->batch_size = 0;
+    op->input = NULL;
+    qnnp_log_error("failed to setup fused block: shape outside the fused kernel's range; use the stand-alone operators");
+    return qnnp_status_unsupported_parameter;
+  }
+  return qnnp_status_success;
+}
+
+int qnnp_fused_block_launch(struct qnnp_operator* op, const void* input, void* output)
+{
+  const struct qnnp_hip_fused_args args = fused_args(op, input, output);
+  return qnnp_hip_fused_block_run(&args, &op->kernel_name);
+}

@@ -22,6 +22,7 @@
 
 #include <stdint.h>
 
+#include "add_math.cuh"
 #include "igemm_params.h"
 #include "requant.cuh"
 
@@ -32,14 +33,17 @@ typedef int epi_v16i __attribute__((ext_vector_type(16)));
 /* PRE_BIASED: what the accumulator was INITIALISED with (the MFMA adds into it), i.e. which adds the epilogue
  * skips: 0 = nothing (add bias and row term here), 1 = bias + row term (`bias` / `rowterm` ignored),
  * 2 = bias only (add the row term here; `bias` ignored). */
-template <bool SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false, int PRE_BIASED = 0>
+/* RESIDUAL: the requantized bytes are then summed (qnnp_add_quantize, operand b) with the bytes at `res_row`
+ * (operand a; same channel offsets as the output row, 4-byte aligned) before they are stored. */
+template <bool SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false, int PRE_BIASED = 0, bool RESIDUAL = false>
 __device__ __forceinline__ void igemm_store_tile(
     const epi_v16i& acc, const int4 (&bias)[4], int32_t rowterm,
     uint8_t* out_row,        /* output + m*stride + g*n */
     uint32_t ncol0,          /* first channel of this 32-channel tile */
     uint32_t khalf,          /* lane >> 5 */
     bool row_ok,             /* m < rows */
-    const IgemmParams& p)
+    const IgemmParams& p,
+    const uint8_t* res_row = nullptr, const qnnp_hip_add_params* add = nullptr)
 {
   uint32_t pk[4];
 #pragma unroll
@@ -57,6 +61,12 @@ __device__ __forceinline__ void igemm_store_tile(
       pk[rg] = static_cast<uint32_t>(v0 ^ v1 ^ v2 ^ v3);   // measurement-only ablation
     } else {
       pk[rg] = q31_requantize_pack4<SHIFT0, FULL_RANGE>(v0, v1, v2, v3, p.rq);
+    }
+    if constexpr (RESIDUAL) {
+      const uint32_t c = ncol0 + rg * 8 + khalf * 4;
+      if (c < p.n) {                                         // (n % 4 == 0 for a residual block)
+        pk[rg] = add_quantize4(*reinterpret_cast<const uint32_t*>(res_row + c), pk[rg], *add);
+      }
     }
   }
   if (p.store_mode == 2) {
@@ -96,11 +106,11 @@ __device__ __forceinline__ void igemm_store_tile(
  * `pitch` = tile width in bytes + 16 keeps the 8-lane ds_write_b128 groups on distinct banks.
  */
 template <bool SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false, int PRE_BIASED = 0>
-__device__ __forceinline__ void igemm_stage_tile(
+__device__ __forceinline__ void igemm_stage_tile_rq(
     const epi_v16i& acc, const int4 (&bias)[4], int32_t rowterm,
     uint8_t* lds_row,        /* LDS image + tile_row * pitch */
     uint32_t col0,           /* first channel of this 32-channel tile inside the workgroup tile */
-    uint32_t khalf, const IgemmParams& p,
+    uint32_t khalf, const RequantDev& rq,
     bool write_ok = true)    /* false: take part in the half-wave exchange (all 64 lanes must), write nothing */
 {
   uint32_t pk[4];
@@ -118,7 +128,7 @@ __device__ __forceinline__ void igemm_stage_tile(
     if constexpr (NO_REQUANT) {
       pk[rg] = static_cast<uint32_t>(v0 ^ v1 ^ v2 ^ v3);
     } else {
-      pk[rg] = q31_requantize_pack4<SHIFT0, FULL_RANGE>(v0, v1, v2, v3, p.rq);
+      pk[rg] = q31_requantize_pack4<SHIFT0, FULL_RANGE>(v0, v1, v2, v3, rq);
     }
   }
   const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
@@ -126,6 +136,14 @@ __device__ __forceinline__ void igemm_stage_tile(
   if (write_ok) {
     *reinterpret_cast<uint4*>(lds_row + col0 + khalf * 16) = make_uint4(s02[0], s02[1], s13[0], s13[1]);
   }
+}
+
+template <bool SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false, int PRE_BIASED = 0>
+__device__ __forceinline__ void igemm_stage_tile(
+    const epi_v16i& acc, const int4 (&bias)[4], int32_t rowterm, uint8_t* lds_row, uint32_t col0,
+    uint32_t khalf, const IgemmParams& p, bool write_ok = true)
+{
+  igemm_stage_tile_rq<SHIFT0, FULL_RANGE, NO_REQUANT, PRE_BIASED>(acc, bias, rowterm, lds_row, col0, khalf, p.rq, write_ok);
 }
 
 /* Stream a staged [rows_valid][n_valid] uint8 tile (LDS, row pitch `pitch`) to global memory. */

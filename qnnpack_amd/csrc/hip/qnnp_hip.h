@@ -241,6 +241,37 @@ struct qnnp_hip_gavgpool_args {
 };
 int qnnp_hip_gavgpool_run(const struct qnnp_hip_gavgpool_args* args, const char** kernel_name);
 
+/* ---- fused inverted-residual block ---------------------------------------
+ * [pointwise expand ->] depthwise 3x3 (pad 1, stride 1 | 2) -> pointwise project [-> + block input], one launch,
+ * the expanded tensors live only in LDS (q8fused.hip). Arithmetic per stage is that of the stand-alone operators
+ * (each intermediate is requantized to uint8 exactly as if it had been stored), so the result is bit-identical to
+ * running them one after another. Weights / biases are the device images the stand-alone operators packed.
+ */
+struct qnnp_hip_fused_args {
+  const uint8_t* input;
+  uint8_t* output;
+  uint32_t batch, input_height, input_width, output_height, output_width;
+  uint32_t input_channels, hidden_channels, output_channels;
+  uint32_t input_stride, output_stride;       /* bytes between pixels */
+  uint32_t stride;                            /* of the depthwise stage */
+  /* expand (has_expand == 0: the depthwise stage reads the input, hidden_channels == input_channels) */
+  uint32_t has_expand;
+  const int8_t* expand_w; const int32_t* expand_bias2; uint32_t expand_k_pad; uint32_t expand_n_pad;
+  int32_t expand_row_coeff; struct qnnp_hip_requant expand_rq;
+  /* depthwise */
+  const int16_t* dw_wadj; const int32_t* dw_bias1; uint32_t dw_c_pad; uint32_t dw_input_zero_point;
+  struct qnnp_hip_requant dw_rq;
+  /* project */
+  const int8_t* project_w; const int32_t* project_bias2; uint32_t project_k_pad; uint32_t project_n_pad;
+  int32_t project_row_coeff; struct qnnp_hip_requant project_rq;
+  /* residual: output = add(a = block input, b = project output) */
+  uint32_t has_residual;
+  struct qnnp_hip_add_params add;
+};
+/* QNNP_HIP_EINVAL when the block does not fit the kernel (LDS, channel multiples) -- callers keep the unfused form */
+int qnnp_hip_fused_block_run(const struct qnnp_hip_fused_args* args, const char** kernel_name);
+int qnnp_hip_fused_block_supported(const struct qnnp_hip_fused_args* args);
+
 #ifdef __cplusplus
 }
 #endif

@@ -204,6 +204,8 @@ static int launch(struct qnnp_operator* op, const void* input, const void* input
       };
       return qnnp_hip_igemm_run(&args, &op->kernel_name);
     }
+    case qnnp_ukernel_type_fused_block:
+      return qnnp_fused_block_launch(op, input, output);
     case qnnp_ukernel_type_add:
     {
       /* reference operator-run.c, case qnnp_ukernel_type_add (q8vadd over rows of `channels` bytes) */

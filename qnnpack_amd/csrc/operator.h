@@ -21,6 +21,7 @@ enum qnnp_ukernel_type {
   qnnp_ukernel_type_gemm,
   qnnp_ukernel_type_add,
   qnnp_ukernel_type_global_average_pooling,
+  qnnp_ukernel_type_fused_block,
 };
 
 /* One output phase of a strided deconvolution (deconvolution.c): the output pixels whose (oy + pad_top) % stride_h
@@ -76,6 +77,12 @@ struct qnnp_operator {
   size_t output_pixel_stride;
   void* output;
 
+  /* fused inverted-residual block (fused-block.c): BORROWED handles of the stand-alone operators it was built from */
+  const struct qnnp_operator* fused_expand;     /* may be NULL */
+  const struct qnnp_operator* fused_depthwise;
+  const struct qnnp_operator* fused_project;
+  const struct qnnp_operator* fused_add;        /* may be NULL */
+
   /* add / global average pooling (reference operator.h:58, 66-67, 75-100) */
   size_t channels;
   const void* input2;
@@ -130,3 +137,6 @@ struct qnnp_operator {
 /* Decide where a caller pointer lives and (re)size the device staging buffer a host pointer needs.
  * Returns 0 on success. (operator-run.c) */
 int qnnp_bind_endpoint(const void* ptr, size_t span, int* on_device, void** stage, size_t* capacity);
+
+/* fused-block.c */
+int qnnp_fused_block_launch(struct qnnp_operator* op, const void* input, void* output);
