@@ -110,7 +110,7 @@ class ConvLayer:
         self.inputs = self.outputs = None
 
 
-def network_bench(lib, torch, batch, total_batch, world, warmup, iters):
+def network_bench(lib, torch, batch, total_batch, world, warmup, iters, fuse=False):
     """Every operator of a real quantized MobileNetV2 forward pass (examples/mobilenetv2.py: 52 convolutions, 10 residual
     adds, global average pooling, classifier), chained on device buffers with their true dependencies and replayed as one
     hipGraph. Unlike the 31-shape sweep each tensor is produced by the previous operator, so it may still sit in the
@@ -118,7 +118,7 @@ def network_bench(lib, torch, batch, total_batch, world, warmup, iters):
     from examples import mobilenetv2 as mnv2
     from qnnpack_amd.shard import job_time_ms
     plan = mnv2.build_plan()
-    net = mnv2.DeviceNetwork(lib, torch, plan, batch)
+    net = mnv2.DeviceNetwork(lib, torch, plan, batch, fuse=fuse)
     try:
         gen = torch.Generator(device="cuda")
         gen.manual_seed(91)
@@ -128,7 +128,8 @@ def network_bench(lib, torch, batch, total_batch, world, warmup, iters):
         ms = net.time_ms(max(warmup, 2), iters)
         job_ms = job_time_ms(ms, world)
         act = mnv2.algorithmic_bytes(plan, batch)
-        return {"operators": len(plan.ops), "images_per_s": round(total_batch / (job_ms * 1e-3), 1),
+        return {"operators": len(plan.ops), "launches": len(net.schedule), "fused_blocks": len(net.fused),
+                "images_per_s": round(total_batch / (job_ms * 1e-3), 1),
                 "batch_per_gpu": batch, "ms_per_batch": round(job_ms, 4), "timed_as": "one hipGraph replay of the chained operators",
                 "activation_gbs": round(act / (ms * 1e-3) / 1e9, 1), "tops": round(mnv2.operations(plan, batch) / (ms * 1e-3) / 1e12, 2),
                 "kernels": sorted(set(net.kernels.values()))}
@@ -495,6 +496,9 @@ def main():
         # ---------------------------------------------------------- the whole network (64 chained operators, one hipGraph)
         extra["mobilenetv2_network"] = network_bench(lib, torch, my_batch, total_batch, world, args.warmup,
                                                      max(args.steps // 2, 5))
+        # the same network with every inverted-residual block as ONE fused operator (qnnp_gfx950_create_fused_block)
+        extra["mobilenetv2_network_fused"] = network_bench(lib, torch, my_batch, total_batch, world, args.warmup,
+                                                           max(args.steps // 2, 5), fuse=True)
 
         # ---------------------------------------------------------- SURVEY 8f "next" rows: deconvolution, add, pooling
         extra["next_rows"] = next_rows_bench(lib, torch, my_batch, args.warmup, max(args.steps // 2, 5))

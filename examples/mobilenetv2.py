@@ -219,9 +219,8 @@ class DeviceNetwork:
                 dst = plan.ops[last].dst
                 hh, ww, cin = plan.shapes[src]
                 cout = plan.shapes[dst][2]
-                try:
-                    lib.setup_fused_block(fh, batch, hh, ww, self.buffers[src], cin, self.buffers[dst], cout)
-                except QnnpackError:
+                st = lib.setup_fused_block_status(fh, batch, hh, ww, self.buffers[src], cin, self.buffers[dst], cout)
+                if st != 0:                       # outside the fused kernel's range: the stand-alone operators run it
                     lib.delete_operator(fh)
                     continue
                 self.fused_handles.append(fh)

@@ -170,7 +170,7 @@ enum qnnp_status qnnp_gfx950_setup_fused_block(
   if (!qnnp_hip_fused_block_supported(&probe)) {
     op->batch_size = 0;
     op->input = NULL;
-    qnnp_log_error("failed to setup fused block: shape outside the fused kernel's range; use the stand-alone operators");
+    qnnp_log_info("fused block: shape outside the fused kernel range; use the stand-alone operators");
     return qnnp_status_unsupported_parameter;
   }
   return qnnp_status_success;
