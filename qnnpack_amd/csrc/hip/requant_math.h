@@ -76,12 +76,18 @@ QNNP_HD int qnnp_requant_fast_fold_zero_point(struct qnnp_requant_fast* f, uint3
   return 1;
 }
 
-/* y = requantized value BEFORE clamping (plus the zero point if it was folded in); shift == 0 form */
+/* y = requantized value BEFORE clamping (plus the zero point if it was folded in); shift == 0 form.
+ * q = (n*M + A) >> 31 with A = 2^30 (+ zp*2^31), low 32 bits. Doubling numerator and denominator puts q in the HIGH
+ * word of a 64-bit product, which saves the funnel shift -- but 2M does not fit a signed 32-bit operand. Use
+ * 2M - 2^32 instead (it does: [-2^31, -2]):  n*(2M - 2^32) + 2A  =  (n*2M + 2A) - n*2^32, and n*2^32 is a whole
+ * number of high-word units, so  q = high32(n*(2M - 2^32) + 2A) + n  (mod 2^32), for every n. One v_mad_i64_i32 and
+ * one add; |n*(2M - 2^32)| <= 2^62, 2A < 2^41. */
 QNNP_HD int32_t qnnp_requant_scale_s0(int32_t n, const struct qnnp_requant_fast f)
 {
-  const int64_t addend = (int64_t) (((uint64_t) f.addend_hi << 32) | f.addend_lo);   /* 2^30 (+ zp * 2^31) */
-  const int64_t p = (int64_t) n * (int64_t) f.multiplier + addend;
-  return (int32_t) (uint32_t) ((uint64_t) p >> 31);
+  const int64_t addend2 = (int64_t) ((((uint64_t) f.addend_hi << 32) | f.addend_lo) << 1);
+  const int32_t m2 = (int32_t) ((uint32_t) f.multiplier << 1);            /* 2M - 2^32 as a two's-complement int32 */
+  const int64_t t = (int64_t) n * (int64_t) m2 + addend2;
+  return (int32_t) ((uint32_t) ((uint64_t) t >> 32) + (uint32_t) n);
 }
 
 /* shift >= 1 form */
