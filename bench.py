@@ -75,7 +75,7 @@ def conv_geometry(H, W, KH, KW, S, D):
 class ConvLayer:
     """One qnnp convolution operator with device-resident synthetic tensors (rotating buffer sets)."""
 
-    def __init__(self, lib, torch, batch, H, W, KH, KW, S, D, G, GIC, GOC, seed, min_bytes_between_reuse=0):
+    def __init__(self, lib, torch, batch, H, W, KH, KW, S, D, G, GIC, GOC, seed, min_bytes_between_reuse=0, out_scale=0.5):
         self.lib = lib
         (pt, pr, pb, pl), oh, ow = conv_geometry(H, W, KH, KW, S, D)
         rng = np.random.default_rng(seed)
@@ -83,7 +83,7 @@ class ConvLayer:
         bias = rng.integers(-10000, 10001, size=G * GOC, dtype=np.int32)
         # quantization parameters of the reference bench (bench/convolution.cc:71-74)
         self.op = lib.create_convolution2d_nhwc_q8(pt, pr, pb, pl, KH, KW, S, S, D, D, G, GIC, GOC,
-                                                   127, 0.5, 127, 0.5, kernel, bias, 127, 0.5, 0, 255, 0)
+                                                   127, 0.5, 127, 0.5, kernel, bias, 127, out_scale, 0, 255, 0)
         self.batch, self.H, self.W = batch, H, W
         self.cin, self.cout = G * GIC, G * GOC
         self.in_bytes = batch * H * W * self.cin
@@ -330,6 +330,8 @@ def main():
     ap.add_argument("--gemm-kernel", type=int, default=0, help="0 auto, 1 generic MFMA kernel, 2 big-tile kernel")
     ap.add_argument("--dw-kernel", type=int, default=0,
                     help="measurement aid: 0 auto, 1 direct, 2 LDS-tiled, 3 register sliding window (depthwise layers)")
+    ap.add_argument("--out-scale", type=float, default=0.5,
+                    help="--layer mode only: output scale (requantization scale = 0.25 / this; 0.5 = the reference bench)")
     ap.add_argument("--layer", type=int, default=0,
                     help="measurement aid: time only MobileNetV2 sweep layer N (1-based) and print a short JSON line")
     args = ap.parse_args()
@@ -365,7 +367,7 @@ def main():
         # layer 99 = BASELINE configs[2]: 3x3 s1 conv 56x56x64 -> 64
         H, W, KH, KW, S, D, G, GIC, GOC = (56, 56, 3, 3, 1, 1, 1, 64, 64) if args.layer == 99 else MOBILENETV2[args.layer - 1]
         layer = ConvLayer(lib, torch, args.sweep_batch, H, W, KH, KW, S, D, G, GIC, GOC, seed=100 + args.layer,
-                          min_bytes_between_reuse=512 << 20)
+                          min_bytes_between_reuse=512 << 20, out_scale=args.out_scale)
         ms = layer.time_ms(args.warmup, args.steps)
         b = layer.in_bytes + layer.out_bytes
         print(json.dumps({"layer": args.layer, "shape": [H, W, KH, S, G, GIC, GOC], "kernel": layer.kernel,
