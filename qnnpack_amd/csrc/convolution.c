@@ -261,6 +261,8 @@ enum qnnp_status qnnp_create_convolution2d_nhwc_q8(
   op->input_zero_point = input_zero_point;
   op->kernel_zero_point = kernel_zero_point;
   op->requant = qnnp_compute_requant(convolution_scale, output_zero_point, output_min, output_max);
+  op->requant.accumulator_bits = qnnp_accumulator_bits(bias, (size_t) groups * group_output_channels,
+      kernel_size * group_input_channels);
   op->ukernel_type = ukernel_type;
 
   /* reference convolution.c:372: the handle is written only on success */

@@ -76,14 +76,33 @@ void qnnp_debug_compute_requant(
 }
 
 /* the device requantization arithmetic (hip/requant_math.h) evaluated on the host: scale, clamp, add zero point */
+void qnnp_debug_requant_fast_bits(
+    size_t count, const int32_t* acc, float scale, uint8_t zero_point, uint8_t qmin, uint8_t qmax,
+    uint32_t accumulator_bits, uint8_t* out, int* bounded_out);
+
 void qnnp_debug_requant_fast(
     size_t count, const int32_t* acc, float scale, uint8_t zero_point, uint8_t qmin, uint8_t qmax, uint8_t* out)
+{
+  qnnp_debug_requant_fast_bits(count, acc, scale, zero_point, qmin, qmax, 0, out, NULL);
+}
+
+uint32_t qnnp_debug_accumulator_bits(const int32_t* bias, size_t count, size_t reduction_length)
+{
+  return qnnp_accumulator_bits(bias, count, reduction_length);
+}
+
+/* same with a caller-stated accumulator bound (0 = unknown): exercises the bounded rounding sequence on the host */
+void qnnp_debug_requant_fast_bits(
+    size_t count, const int32_t* acc, float scale, uint8_t zero_point, uint8_t qmin, uint8_t qmax,
+    uint32_t accumulator_bits, uint8_t* out, int* bounded_out)
 {
   const struct qnnp_hip_requant rq = qnnp_compute_requant(scale, zero_point, qmin, qmax);
   /* exactly what make_requant_dev (hip/requant.cuh) hands the kernels: zero point folded into the addend when it
    * fits, clamp bounds in the output domain */
   struct qnnp_requant_fast f = qnnp_requant_fast_init(rq.multiplier, rq.shift);
   const int folded = qnnp_requant_fast_fold_zero_point(&f, (uint32_t) rq.output_zero_point);
+  const int bounded = qnnp_requant_fast_enable_bounded(&f, (uint32_t) rq.output_zero_point, folded, accumulator_bits);
+  if (bounded_out != NULL) *bounded_out = bounded;
   const int32_t zp_late = folded ? 0 : rq.output_zero_point;
   int32_t lo = rq.output_min_less_zero_point + (folded ? rq.output_zero_point : 0);
   const int32_t hi = rq.output_max_less_zero_point + (folded ? rq.output_zero_point : 0);

@@ -348,6 +348,8 @@ packed_done:
   op->input_zero_point = input_zero_point;
   op->kernel_zero_point = kernel_zero_point;
   op->requant = qnnp_compute_requant(deconvolution_scale, output_zero_point, output_min, output_max);
+  op->requant.accumulator_bits = qnnp_accumulator_bits(bias, (size_t) groups * group_output_channels,
+      kernel_size * group_input_channels);
   op->ukernel_type = qnnp_ukernel_type_conv;   /* reference deconvolution.c:203 */
   op->transposed = 1;
 

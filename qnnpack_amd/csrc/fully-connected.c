@@ -141,6 +141,7 @@ enum qnnp_status qnnp_create_fully_connected_nc_q8(
   op->input_zero_point = input_zero_point;
   op->kernel_zero_point = kernel_zero_point;
   op->requant = qnnp_compute_requant(requantization_scale, output_zero_point, output_min, output_max);
+  op->requant.accumulator_bits = qnnp_accumulator_bits(bias, output_channels, input_channels);
   op->ukernel_type = qnnp_ukernel_type_gemm;
 
   *fully_connected_out = op;

@@ -35,7 +35,7 @@ typedef int epi_v16i __attribute__((ext_vector_type(16)));
  * 2 = bias only (add the row term here; `bias` ignored). */
 /* RESIDUAL: the requantized bytes are then summed (qnnp_add_quantize, operand b) with the bytes at `res_row`
  * (operand a; same channel offsets as the output row, 4-byte aligned) before they are stored. */
-template <bool SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false, int PRE_BIASED = 0, bool RESIDUAL = false>
+template <int SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false, int PRE_BIASED = 0, bool RESIDUAL = false>
 __device__ __forceinline__ void igemm_store_tile(
     const epi_v16i& acc, const int4 (&bias)[4], int32_t rowterm,
     uint8_t* out_row,        /* output + m*stride + g*n */
@@ -105,7 +105,7 @@ __device__ __forceinline__ void igemm_store_tile(
  * of a row, so full 128-byte lines (whole rows, for dense NHWC outputs) leave in one request.
  * `pitch` = tile width in bytes + 16 keeps the 8-lane ds_write_b128 groups on distinct banks.
  */
-template <bool SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false, int PRE_BIASED = 0>
+template <int SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false, int PRE_BIASED = 0>
 __device__ __forceinline__ void igemm_stage_tile_rq(
     const epi_v16i& acc, const int4 (&bias)[4], int32_t rowterm,
     uint8_t* lds_row,        /* LDS image + tile_row * pitch */
@@ -138,7 +138,7 @@ __device__ __forceinline__ void igemm_stage_tile_rq(
   }
 }
 
-template <bool SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false, int PRE_BIASED = 0>
+template <int SHIFT0, bool FULL_RANGE, bool NO_REQUANT = false, int PRE_BIASED = 0>
 __device__ __forceinline__ void igemm_stage_tile(
     const epi_v16i& acc, const int4 (&bias)[4], int32_t rowterm, uint8_t* lds_row, uint32_t col0,
     uint32_t khalf, const IgemmParams& p, bool write_ok = true)

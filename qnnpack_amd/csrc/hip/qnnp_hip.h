@@ -36,6 +36,8 @@ struct qnnp_hip_requant {
   int32_t output_min_less_zero_point;
   int32_t output_max_less_zero_point;
   int32_t output_zero_point;
+  uint32_t accumulator_bits;    /* |accumulator| < 2^accumulator_bits for every input (host-side bound from |bias| and the
+                                 * reduction length), or 0 = unknown: lets the device pick a cheaper rounding sequence */
 };
 
 /* ---- runtime ---------------------------------------------------------- */

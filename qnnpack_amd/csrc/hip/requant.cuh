@@ -48,6 +48,7 @@ inline RequantDev make_requant_dev(const qnnp_hip_requant& rq)
   RequantDev d;
   d.f = qnnp_requant_fast_init(rq.multiplier, rq.shift);
   const int folded = qnnp_requant_fast_fold_zero_point(&d.f, static_cast<uint32_t>(rq.output_zero_point));
+  (void) qnnp_requant_fast_enable_bounded(&d.f, static_cast<uint32_t>(rq.output_zero_point), folded, rq.accumulator_bits);
   d.zp_late = folded ? 0 : rq.output_zero_point;
   // bounds in the domain of what the scale functions return: output domain when folded, output - zp otherwise
   // (the late addition comes AFTER the clamp: y + zp could wrap for |y| near 2^31)
@@ -74,17 +75,25 @@ __device__ __forceinline__ int32_t q31_requantize(int32_t n, const RequantDev& r
 
 /*
  * Four results packed little-endian into one dword (channel c at byte c).
- * SHIFT0 / FULL_RANGE are the two per-operator facts that change the instruction sequence; kernels
- * branch on them ONCE (requant_dispatch) instead of once per element.
+ * The rounding sequence (kRq*) and FULL_RANGE are the per-operator facts that change the instruction sequence;
+ * kernels branch on them ONCE (requant_dispatch) instead of once per element.
  */
-template <bool SHIFT0, bool FULL_RANGE>
+/* rounding sequences (first template argument, chosen once per operator by requant_dispatch) */
+constexpr int kRqShift0 = 1;     // shift == 0
+constexpr int kRqGeneral = 0;    // shift >= 1, any accumulator
+constexpr int kRqBounded = 2;    // shift >= 1, accumulators bounded at create time (requant_math.h)
+
+template <int SHIFT0, bool FULL_RANGE>
 __device__ __forceinline__ uint32_t q31_requantize_pack4(
     int32_t n0, int32_t n1, int32_t n2, int32_t n3, const RequantDev& rq)
 {
   int32_t y0, y1, y2, y3;
-  if constexpr (SHIFT0) {
+  if constexpr (SHIFT0 == kRqShift0) {
     y0 = qnnp_requant_scale_s0(n0, rq.f); y1 = qnnp_requant_scale_s0(n1, rq.f);
     y2 = qnnp_requant_scale_s0(n2, rq.f); y3 = qnnp_requant_scale_s0(n3, rq.f);
+  } else if constexpr (SHIFT0 == kRqBounded) {
+    y0 = qnnp_requant_scale_sn_bounded(n0, rq.f); y1 = qnnp_requant_scale_sn_bounded(n1, rq.f);
+    y2 = qnnp_requant_scale_sn_bounded(n2, rq.f); y3 = qnnp_requant_scale_sn_bounded(n3, rq.f);
   } else {
     y0 = qnnp_requant_scale_sn(n0, rq.f); y1 = qnnp_requant_scale_sn(n1, rq.f);
     y2 = qnnp_requant_scale_sn(n2, rq.f); y3 = qnnp_requant_scale_sn(n3, rq.f);
@@ -113,10 +122,15 @@ __device__ __forceinline__ uint32_t q31_requantize_pack4(
 template <typename F>
 __device__ __forceinline__ void requant_dispatch(const RequantDev& rq, F&& f)
 {
+  using Shift0 = std::integral_constant<int, kRqShift0>;
+  using General = std::integral_constant<int, kRqGeneral>;
+  using Bounded = std::integral_constant<int, kRqBounded>;
   if (rq.f.shift == 0) {
-    if (rq.full_range) f(std::true_type{}, std::true_type{}); else f(std::true_type{}, std::false_type{});
+    if (rq.full_range) f(Shift0{}, std::true_type{}); else f(Shift0{}, std::false_type{});
+  } else if (rq.f.bounded && rq.full_range) {
+    f(Bounded{}, std::true_type{});            // (the bounded form is instantiated for the common clamp only)
   } else {
-    if (rq.full_range) f(std::false_type{}, std::true_type{}); else f(std::false_type{}, std::false_type{});
+    if (rq.full_range) f(General{}, std::true_type{}); else f(General{}, std::false_type{});
   }
 }
 

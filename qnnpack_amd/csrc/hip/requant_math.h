@@ -39,6 +39,9 @@ struct qnnp_requant_fast {
   uint32_t addend_lo;          /* low / high word of 2^30 + 2^(30+s)   (shift >= 1) */
   uint32_t addend_hi;
   uint32_t shift;              /* s */
+  uint32_t bounded_lo;         /* low / high word of the bounded form's addend (qnnp_requant_fast_enable_bounded) */
+  uint32_t bounded_hi;
+  uint32_t bounded;            /* 1: |accumulator| is known to be small enough for qnnp_requant_scale_sn_bounded */
 };
 
 QNNP_HD struct qnnp_requant_fast qnnp_requant_fast_init(int32_t multiplier, uint32_t shift)
@@ -50,6 +53,9 @@ QNNP_HD struct qnnp_requant_fast qnnp_requant_fast_init(int32_t multiplier, uint
   f.addend_lo = (uint32_t) addend;
   f.addend_hi = (uint32_t) (addend >> 32);
   f.shift = shift;
+  f.bounded_lo = 0;
+  f.bounded_hi = 0;
+  f.bounded = 0;
   return f;
 }
 
@@ -100,7 +106,43 @@ QNNP_HD int32_t qnnp_requant_scale_sn(int32_t n, const struct qnnp_requant_fast 
   return qnnp_asr32(hi, f.shift - 1);
 }
 
+/*
+ * Bounded form for shift >= 1 -- four instructions per value instead of six -- for operators whose accumulators are
+ * known (at create time, from |bias| and the reduction length) to stay below 2^accumulator_bits:
+ *   with T0 = n*M + 2^30 + 2^(30+s) (+ zp*2^(31+s)),  y = floor((T0 - (n<0)*2^31) / 2^(31+s))
+ *                                                       = floor((floor(T0 / 2^31) - (n<0)) / 2^s)      (nested floors)
+ *   R = floor(T0 / 2^31) = high32(2*T0) = high32(n*(2M - 2^32) + 2*addend) + n       (as in the shift-0 form)
+ *   y = (R + (n >> 31)) >> s                                                          (both shifts arithmetic)
+ * R must fit 32 bits: |R| <= |n| + 2^(s-1) + zp*2^s + 1, hence the bound; s <= 20 keeps 2*addend below 2^62.
+ * Enabled only together with the folded zero point. Returns 1 if enabled.
+ */
+QNNP_HD int qnnp_requant_fast_enable_bounded(struct qnnp_requant_fast* f, uint32_t zero_point, int zero_point_folded,
+                                             uint32_t accumulator_bits)
+{
+  if (f->shift < 1 || f->shift > 20 || !zero_point_folded || zero_point > 255) return 0;
+  if (accumulator_bits == 0 || accumulator_bits > 30) return 0;
+  /* 2^30 + 2^19 + 255*2^20 + 1 < 2^31 */
+  const uint64_t addend2 = ((((uint64_t) f->addend_hi << 32) | f->addend_lo)) << 1;   /* folded addend, doubled */
+  f->bounded_lo = (uint32_t) addend2;
+  f->bounded_hi = (uint32_t) (addend2 >> 32);
+  f->bounded = 1;
+  return 1;
+}
+
+QNNP_HD int32_t qnnp_requant_scale_sn_bounded(int32_t n, const struct qnnp_requant_fast f)
+{
+  int64_t addend2 = (int64_t) (((uint64_t) f.bounded_hi << 32) | f.bounded_lo);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(addend2));      /* keep it one 64-bit operand of the multiply-add */
+#endif
+  const int32_t m2 = (int32_t) ((uint32_t) f.multiplier << 1);            /* 2M - 2^32 */
+  const int64_t t = (int64_t) n * (int64_t) m2 + addend2;
+  const int32_t r = (int32_t) ((uint32_t) ((uint64_t) t >> 32) + (uint32_t) n);
+  return qnnp_asr32(r + qnnp_asr32(n, 31), f.shift);
+}
+
 QNNP_HD int32_t qnnp_requant_scale(int32_t n, const struct qnnp_requant_fast f)
 {
-  return f.shift == 0 ? qnnp_requant_scale_s0(n, f) : qnnp_requant_scale_sn(n, f);
+  if (f.shift == 0) return qnnp_requant_scale_s0(n, f);
+  return f.bounded ? qnnp_requant_scale_sn_bounded(n, f) : qnnp_requant_scale_sn(n, f);
 }

@@ -115,6 +115,60 @@ def test_device_requantization_arithmetic_matches_oracle(product):
             assert np.array_equal(out, o1.q31_requantize(acc, scale, zp, qmin, qmax)), (scale, zp, qmin, qmax)
 
 
+def test_bounded_requantization_sequence_matches_oracle(product):
+    """hip/requant_math.h, qnnp_requant_scale_sn_bounded: the four-instruction rounding sequence the kernels use when
+    the operator's accumulators are bounded at create time (|acc| < 2^bits, bits <= 30, 1 <= shift <= 20)."""
+    import ctypes
+    L = product.lib
+    fn = L.qnnp_debug_requant_fast_bits
+    fn.restype = None
+    fn.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_float, ctypes.c_uint8, ctypes.c_uint8, ctypes.c_uint8,
+                   ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    rng = np.random.default_rng(12)
+    for bits in (30, 27, 17):
+        lim = 2 ** bits
+        acc = rng.integers(-lim + 1, lim, size=1 << 19).astype(np.int32)
+        acc[:6] = [-lim + 1, lim - 1, 0, -1, 1, -(lim // 2)]
+        ties = []
+        for s in range(1, 21):
+            for k in range(-12, 13):
+                ties += [v for v in ((k << s) + (1 << (s - 1)) + d for d in (-1, 0, 1)) if -lim < v < lim]
+        acc[6:6 + len(ties)] = np.array(ties, dtype=np.int64).astype(np.int32)
+        for scale in [0.49999997, 0.25, 0.3, 1 / 255.0, 0.0031, 2.0 ** -12, 1.7e-5, 2.0 ** -20, 1.9e-6]:
+            for zp, qmin, qmax in [(0, 0, 255), (127, 0, 255), (255, 0, 255), (100, 128, 255), (7, 5, 9)]:
+                out = np.empty(acc.size, np.uint8)
+                bounded = ctypes.c_int(-1)
+                fn(acc.size, acc.ctypes.data, np.float32(scale), zp, qmin, qmax, bits, out.ctypes.data, ctypes.byref(bounded))
+                assert bounded.value == 1, (scale, bits)          # all of these qualify (shift 1..20)
+                assert np.array_equal(out, o1.q31_requantize(acc, scale, zp, qmin, qmax)), (bits, scale, zp, qmin, qmax)
+    # and it is refused where its preconditions fail: unknown / too wide a bound, shift 0, shift > 20
+    acc = rng.integers(-2**31, 2**31, size=1 << 12).astype(np.int32)
+    out = np.empty(acc.size, np.uint8)
+    for scale, bits in [(0.25, 0), (0.25, 31), (0.75, 20), (2.0 ** -22, 20), (2.0 ** -31, 20)]:
+        bounded = ctypes.c_int(-1)
+        fn(acc.size, acc.ctypes.data, np.float32(scale), 9, 0, 255, bits, out.ctypes.data, ctypes.byref(bounded))
+        assert bounded.value == 0, (scale, bits)
+        assert np.array_equal(out, o1.q31_requantize(acc, scale, 9, 0, 255)), (scale, bits)
+
+
+def test_accumulator_bound(product):
+    """requantization.h, qnnp_accumulator_bits: |bias| + K * 255^2 < 2^bits, 0 when it does not fit 31 bits."""
+    import ctypes
+    fn = product.lib.qnnp_debug_accumulator_bits
+    fn.restype = ctypes.c_uint32
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]
+
+    def bits(bias, k):
+        b = np.asarray(bias, dtype=np.int32)
+        return fn(b.ctypes.data, b.size, k)
+
+    for bias, k in [([0], 1), ([10000, -10000], 1280), ([-2**31], 9), ([2**30], 4096), ([5, -7, 3], 27), ([0], 33000)]:
+        bound = max(abs(int(v)) for v in bias) + k * 65025 + 1
+        expect = next(b for b in range(64) if (1 << b) >= bound)
+        assert bits(bias, k) == (expect if expect <= 31 else 0), (bias, k)
+    assert bits([10000], 1280) == 27 and bits([0], 9) == 20
+
+
 @pytest.mark.parametrize("izp,kzp", [(127, 127), (0, 255), (255, 0), (3, 128), (128, 1)])
 def test_depthwise_matrix_core_weight_parts(product, izp, kzp):
     """qnnp_pack_dwconv_mfma (pack.h): int8 parts sum to w - kzp, the part count is minimal, and the folded bias
