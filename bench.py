@@ -486,6 +486,9 @@ def main():
             "images_per_s": round(total_batch / (job_sweep_ms * 1e-3), 1), "batch_per_gpu": my_batch,
             "ms_per_batch": round(job_sweep_ms, 4), "timed_as": "one hipGraph replay of the 31 operators" if graph_ms is not None else "sum of per-layer times",
             "sum_of_layer_ms": round(sum_of_layers_ms, 4),
+            # the reference bench's own accounting (each layer its own timed run, SURVEY.md 8d: N / sum of layer times);
+            # `images_per_s` above is the more conservative whole-sequence replay, inter-kernel gaps included
+            "images_per_s_by_sum_of_layers": round(my_batch / (sum_of_layers_ms * 1e-3) * world, 1),
             "hbm_gbs": round(act_bytes / (sweep_ms * 1e-3) / 1e9, 1),
             "frac_of_hbm_peak": round(act_bytes / (sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
             "tops": round(total_ops / (sweep_ms * 1e-3) / 1e12, 2),
