@@ -274,9 +274,13 @@ void q8_dwconv_lds_kernel(const DwParams p)
   const uint32_t tap_row_bytes = p.dh * row_bytes;
   const uint32_t tap_col_bytes = p.dw * 4;
   // the requantization flavour (shift == 0? clamp == [0,255]?) is chosen once, outside the position loop
+  // the LDS address of a position's first tap walks along with (ox, oyl): no multiplies inside the loop
+  uint32_t base_off = (oyl * p.sh) * row_bytes + c4 * line_bytes + (ox * p.sw) * 4;
+  const uint32_t d_base = (d_oy * p.sh) * row_bytes + (d_ox * p.sw) * 4;
+  const uint32_t wrap_base = p.sh * row_bytes - (p.OW * p.sw) * 4;      // one row down, OW columns back
   qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
     for (uint32_t pos = slot; pos < npos; pos += nslots) {
-      const uint8_t* base = tile + (oyl * p.sh) * row_bytes + c4 * line_bytes + (ox * p.sw) * 4;
+      const uint8_t* base = tile + base_off;
       uint32_t in[TAPS];
 #pragma unroll
       for (int ky = 0; ky < KH; ky++) {
@@ -310,8 +314,8 @@ void q8_dwconv_lds_kernel(const DwParams p)
       *reinterpret_cast<uint32_t*>(out_ptr) = packed;
       out_ptr += out_step;
       ox += d_ox;
-      oyl += d_oy;
-      if (ox >= p.OW) { ox -= p.OW; oyl += 1; }
+      base_off += d_base;
+      if (ox >= p.OW) { ox -= p.OW; base_off += wrap_base; }
     }
   });
   QNNP_DW_TRACE(p, 3);
