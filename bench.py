@@ -342,11 +342,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    torch.cuda.set_device(local_rank)              # before the process group: RCCL binds to the current device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
-    torch.cuda.set_device(local_rank)
     torch.zeros(1, device="cuda")
 
     import qnnpack_amd
