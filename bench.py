@@ -2,7 +2,9 @@
 """bench.py -- throughput of the q8 conv/GEMM hot path on MI355X, one process per GPU.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU; RANK/LOCAL_RANK/WORLD_SIZE from env)
+    (N > 1: one rank per GPU. Under torch.distributed.run the ranks come from RANK/LOCAL_RANK/WORLD_SIZE; started
+     plainly, bench.py re-launches ITSELF under torch.distributed.run with N ranks on 127.0.0.1. Fewer than N
+     visible GPUs, or a WORLD_SIZE that disagrees with --gpus, is an error -- never a silent 1-GPU run.)
 
 Headline (BASELINE.json `metric`, configs[1]): int8 TOPS of q8gemm M=N=K=4096 (uint8 in, int32 MFMA
 accumulate, fused Q31 requantize, uint8 out) through qnnp_*_fully_connected_nc_q8. A "step" is one
@@ -19,8 +21,10 @@ Secondary numbers travel in the same JSON line under "extra" (not separate bench
     average pooling, classifier = 64 chained operators) as one hipGraph replay, images/s,
   * "next_rows": the operators SURVEY.md section 8f ranks after the hot path (deconvolution, add, pooling).
 
-"roofline" is for the dominant kernel of the headline workload, timed with HIP events on the launch
-stream inside this process. "cpu_baseline" times the reference's own SSE2 path (oracle/_ref, built from
+The timed region is EXACTLY K steps between barriers (wall clock, max over ranks -> `value`), bracketed on the
+launch stream by HIP events as well (-> "roofline", same launches). It directly follows >= 250 ms of the same GEMM
+replayed as a hipGraph (five batches, median reported as roofline.sustained_launch_ms), so the chip is in its
+sustained clock / power state, not in a boost burst. "cpu_baseline" times the reference's own SSE2 path (oracle/_ref, built from
 the reference sources) on this box's host cores on a bounded sample -- rank 0, N = 1 only.
 Inputs are synthetic uniform-random uint8 already resident in HBM when the timed region starts.
 """
@@ -29,6 +33,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -319,6 +325,25 @@ def cpu_baseline_sweep(batch=16, seconds_budget=10.0, threads=None):
                       f"{best_threads}-thread pthreadpool (OpenMP shim; best of 8..{host} threads), {dt:.1f} s"}
 
 
+def spawn_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` without a launcher: re-run this file under torch.distributed.run, one rank per GPU.
+    Fails loudly when the node has fewer than N GPUs (a 1-GPU number must never be reported as an N-GPU one)."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} requested but this node shows {have} GPU(s); refusing to run fewer ranks",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -335,6 +360,13 @@ def main():
     ap.add_argument("--layer", type=int, default=0,
                     help="measurement aid: time only MobileNetV2 sweep layer N (1-based) and print a short JSON line")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started plainly with --gpus N: become the launcher of N ranks (one process per GPU, RCCL over xGMI for
+        # the harness barrier only -- the data path has no collective)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -343,6 +375,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-GPU run as {args.gpus}")
+    if torch.cuda.device_count() < max(world, local_rank + 1):
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)              # before the process group: RCCL binds to the current device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -392,18 +428,31 @@ def main():
     for _ in range(args.warmup):
         lib.run_operator(op)
     torch.cuda.synchronize()
+    # Sustained state first: the same GEMM replayed as a hipGraph of 64 launches, five event-bracketed batches of
+    # >= 50 ms each (median reported). The K timed steps follow at once, so they run at the sustained clock.
+    lib.graph_begin()
+    for _ in range(64):
+        lib.run_operator(op)
+    graph = lib.graph_end()
+    sustained_ms = lib.graph_time(graph, 1, 12) / 64.0          # 5 batches x 12 replays x 64 launches
+    lib.graph_destroy(graph)
+    stream = torch.cuda.current_stream()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # the launch stream IS torch's current stream (set_stream above)
+    torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev0.record(stream)
     for _ in range(args.steps):
         lib.run_operator(op)
+    ev1.record(stream)
     torch.cuda.synchronize()
     local_ms = (time.perf_counter() - t0) * 1e3 / args.steps
     barrier()
     ms_per_step = job_time_ms(local_ms, world)
     gemm_kernel = lib.operator_kernel(op)
-    # kernel-only duration with HIP events on the launch stream (same launches, same data)
-    ev_ms = lib.time_operator(op, 3, max(args.steps, 20))
+    # the same K launches by HIP events on the launch stream: kernel time without the host's share of the region
+    ev_ms = ev0.elapsed_time(ev1) / args.steps
     gemm_ops = 2.0 * M * N * K
     value = world * gemm_ops / (ms_per_step * 1e-3) / 1e12
     achieved = gemm_ops / (ev_ms * 1e-3) / 1e12
@@ -416,13 +465,18 @@ def main():
             traffic = None
     roofline = {"bound": "mfma", "kernel": gemm_kernel, "achieved": round(achieved, 2), "peak": round(PEAK_I8_TOPS, 1),
                 "unit": "TOP/s", "frac": round(achieved / PEAK_I8_TOPS, 4), "traffic": traffic,
-                "launch_ms": round(ev_ms, 5), "algorithmic_bytes_per_launch": 3 * M * N + 4 * N}
+                "launch_ms": round(ev_ms, 5), "algorithmic_bytes_per_launch": 3 * M * N + 4 * N,
+                "timed_as": "HIP events around the K timed steps (the launches `value` is computed from)",
+                "sustained_launch_ms": round(sustained_ms, 5),
+                "sustained_tops": round(gemm_ops / (sustained_ms * 1e-3) / 1e12, 2),
+                "sustained_as": "median of 5 batches of 12 replays of a 64-launch hipGraph (>= 50 ms per batch), run right before the timed steps"}
     if rank == 0:
         # the bare-MFMA rate of this very chip, measured in this process: with random operands the power
         # management holds a lower clock, so this -- not the nominal peak -- is what a kernel can reach at best
         try:
-            roofline["mfma_only_random_operands"] = round(lib.mfma_probe(True, 6400), 1)
-            roofline["mfma_only_zero_operands"] = round(lib.mfma_probe(False, 6400), 1)
+            dbg = qnnpack_amd.load_debug()   # measurement companion library, not the product
+            roofline["mfma_only_random_operands"] = round(dbg.mfma_probe(True, 6400), 1)
+            roofline["mfma_only_zero_operands"] = round(dbg.mfma_probe(False, 6400), 1)
             roofline["frac_of_mfma_only_random"] = round(achieved / roofline["mfma_only_random_operands"], 4)
         except Exception as exc:  # noqa: BLE001
             print(f"# mfma probe failed: {exc}", file=sys.stderr)
@@ -433,7 +487,7 @@ def main():
     if not args.no_extra:
         lib.set_async(False)
         # ---------------------------------------------------------- configs[2]: 3x3 conv 56x56x64->64, batch 128
-        layer = ConvLayer(lib, torch, 128, 56, 56, 3, 3, 1, 1, 1, 64, 64, seed=3, min_bytes_between_reuse=320 << 20)
+        layer = ConvLayer(lib, torch, 128, 56, 56, 3, 3, 1, 1, 1, 64, 64, seed=3, min_bytes_between_reuse=544 << 20)
         ms = layer.time_ms(3, 20)
         extra["q8conv_3x3_56x56x64_b128"] = {
             "kernel": layer.kernel, "ms": round(ms, 4), "tops": round(layer.ops / (ms * 1e-3) / 1e12, 2),
@@ -497,6 +551,26 @@ def main():
         extra["q8dwconv_mobilenetv2_layers"] = {
             "hbm_gbs": round(dw_bytes / (dw_ms * 1e-3) / 1e9, 1), "ms": round(dw_ms, 4),
             "frac_of_hbm_peak": round(dw_bytes / (dw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+
+        # ---------------------------------------------------------- depthwise 5x5 / dilated 3x3 and a
+        # realistic requantization scale (shift >= 1 epilogue; the reference bench's 0.5 takes the shift-0 one)
+        more = {}
+        for name, (H, W, KH, KW, S, D, G, GIC, GOC), oscale in [
+                ("dw5x5_56x56x72_s2", (56, 56, 5, 5, 2, 1, 72, 1, 1), 0.5),      # MobileNetV3-large
+                ("dw5x5_28x28x240_s1", (28, 28, 5, 5, 1, 1, 240, 1, 1), 0.5),
+                ("dw5x5_14x14x672_s1", (14, 14, 5, 5, 1, 1, 672, 1, 1), 0.5),
+                ("dw3x3_dil2_28x28x192", (28, 28, 3, 3, 1, 2, 192, 1, 1), 0.5),   # dilated (DeepLab-style)
+                ("dw3x3_56x56x144_scale0.0125", (56, 56, 3, 3, 1, 1, 144, 1, 1), 20.0),
+                ("pw_112x112x16_96_scale0.0125", (112, 112, 1, 1, 1, 1, 1, 16, 96), 20.0)]:
+            layer = ConvLayer(lib, torch, my_batch, H, W, KH, KW, S, D, G, GIC, GOC, seed=700 + len(more),
+                              min_bytes_between_reuse=512 << 20, out_scale=oscale)
+            ms = layer.time_ms(2, 10)
+            b = layer.in_bytes + layer.out_bytes
+            more[name] = {"kernel": layer.kernel, "ms": round(ms, 4), "gbs": round(b / (ms * 1e-3) / 1e9, 1),
+                          "frac_of_hbm_peak": round(b / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                          "requant_scale": round(0.25 / oscale, 6)}
+            layer.close()
+        extra["q8dwconv_5x5_dilated_and_realistic_scale"] = more
 
         # ---------------------------------------------------------- the whole network (64 chained operators, one hipGraph)
         extra["mobilenetv2_network"] = network_bench(lib, torch, my_batch, total_batch, world, args.warmup,

@@ -22,21 +22,35 @@
 extern "C" {
 #endif
 
-/* Select the HIP device ordinal the library binds to. Must be called before
- * qnnp_initialize (otherwise invalid_parameter). Default: env QNNP_GFX950_DEVICE,
- * else the calling thread's current HIP device. One process drives one GPU;
- * multi-GPU = one process per GPU with the batch sharded by the caller. */
+/* Devices. The library keeps one context (launch stream, asynchrony flag) per gfx950 GPU of the node.
+ *   BEFORE qnnp_initialize: names the PRIMARY device qnnp_initialize binds (default: env QNNP_GFX950_DEVICE,
+ *     else the calling thread's current HIP device).
+ *   AFTER qnnp_initialize: binds `device` on first use and makes it the CALLING THREAD's device: operators the
+ *     thread creates from now on live there, and set_stream / set_async / synchronize / malloc / memcpy /
+ *     graph_begin act on it. Threads that never call it use the primary device.
+ * An operator remembers its device: setup / run / delete may be called from any thread, whatever that thread's
+ * current HIP device is (it is restored on return). Tensors handed to setup must be host memory or memory of the
+ * operator's device (another GPU's memory -> invalid_parameter). Batches shard across the GPUs of a node without
+ * a collective -- every output pixel depends on one image (reference src/operator-run.c:675-679, 797-802,
+ * 837-842) -- so both "one process per GPU" (bench.py) and "one process, one host thread per GPU" work.
+ * invalid_parameter: negative ordinal, or not a usable gfx950 device. */
 enum qnnp_status qnnp_gfx950_set_device(int device);
-int qnnp_gfx950_get_device(void);
+int qnnp_gfx950_get_device(void);      /* the calling thread's device, -1 before qnnp_initialize */
+int qnnp_gfx950_device_count(void);    /* HIP devices visible to the process */
+
+/* Threads: as in the reference (run contexts are stack-local, src/operator-run.c:783-795) DISTINCT operators may
+ * be created, set up, run and deleted from different threads concurrently, on the same device or different ones.
+ * One operator must not be used by two threads at once. set_option is configuration, read at setup time. */
 
 /* Stream all subsequent qnnp_run_operator launches (and host-pointer staging
- * copies) are enqueued on. NULL = the device's default stream. */
+ * copies) on the calling thread's device are enqueued on. NULL = the device's default stream. */
 enum qnnp_status qnnp_gfx950_set_stream(void* hip_stream);
 
 /* async = 1: qnnp_run_operator only enqueues work and returns; the caller
  * synchronises (qnnp_gfx950_synchronize or its own stream sync). Requires device
  * pointers for input/output (host pointers force a synchronous staged run).
- * async = 0 (default): reference semantics, outputs complete on return. */
+ * async = 0 (default): reference semantics, outputs complete on return.
+ * A property of the calling thread's device context. */
 enum qnnp_status qnnp_gfx950_set_async(int async);
 enum qnnp_status qnnp_gfx950_synchronize(void);
 
@@ -50,7 +64,8 @@ enum qnnp_status qnnp_gfx950_memset(void* dst_device, int value, size_t bytes);
 /* Time `iters` back-to-back qnnp_run_operator launches of one operator with hipEvents, after `warmup`
  * untimed launches; writes the AVERAGE milliseconds per launch. Device pointers only. By default the
  * launches are recorded into a hipGraph and its replay is timed (option "timing_graph"), so the figure is
- * kernel time -- what rocprofv3 reports per kernel -- not the host's per-launch dispatch gap. */
+ * kernel time -- what rocprofv3 reports per kernel -- not the host's per-launch dispatch gap. The replay is
+ * timed five times, each with its own event pair, and the MEDIAN is reported. */
 enum qnnp_status qnnp_gfx950_time_operator(
     qnnp_operator_t op, int warmup, int iters, float* avg_ms_out);
 
@@ -61,19 +76,15 @@ enum qnnp_status qnnp_gfx950_time_operator_rotating(
     qnnp_operator_t op, size_t nsets, const void* const* inputs, void* const* outputs,
     int warmup, int iters, float* avg_ms_out);
 
-/* Diagnostic: the int8 rate (TOP/s) the whole chip sustains on a bare v_mfma_i32_32x32x32_i8 loop -- no LDS, no
- * memory traffic -- with zero (random_operands = 0) or random operand data. On MI355X the two differ by ~30 %
- * (power management lowers the clock on random data): the random figure is the practical ceiling a GEMM's
- * fraction of the nominal peak should be read against. `iters` loop trips of 8 MFMAs per wave (12800 = ~4 ms). */
-enum qnnp_status qnnp_gfx950_mfma_probe(int random_operands, int iters, float* tops_out);
-
 /* hipGraph capture: between begin and end, qnnp_run_operator only RECORDS its launch (device pointers only; a
  * host-pointer operator returns invalid_parameter). The graph replays the whole sequence -- e.g. every layer of
  * a network -- as one submission: no per-launch dispatch gap, which on MI355X is as long as the small layers
  * themselves. Replays run on the stream given to qnnp_gfx950_set_stream at capture time (a private stream
  * stands in for the default stream, which cannot be captured): synchronous unless qnnp_gfx950_set_async(1),
  * then qnnp_gfx950_graph_synchronize. Operators and their buffers must outlive the graph.
- * qnnp_gfx950_graph_time: average milliseconds per replay, hipEvents on the replay stream. */
+ * The capture belongs to the calling THREAD (its launches are recorded, other threads keep running normally).
+ * qnnp_gfx950_graph_time: milliseconds per replay, hipEvents on the replay stream -- five batches of `iters`
+ * replays after `warmup` untimed ones, the median batch / iters. */
 enum qnnp_status qnnp_gfx950_graph_begin(void);
 enum qnnp_status qnnp_gfx950_graph_end(void** graph_out);
 enum qnnp_status qnnp_gfx950_graph_launch(void* graph);

@@ -18,16 +18,24 @@ from .binding import Gfx950Library, QnnpackError, QnnpackLibrary, Status, addres
 
 __all__ = [
     "Gfx950Library", "QnnpackLibrary", "QnnpackError", "Status", "address_of",
-    "library_path", "build", "load",
+    "library_path", "debug_library_path", "build", "load", "load_debug",
 ]
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libqnnpack_gfx950.so"
+_DBG_NAME = "libqnnpack_gfx950_dbg.so"
 _loaded = None
+_loaded_debug = None
 
 
 def library_path() -> str:
     return os.path.join(_PKG_DIR, _LIB_NAME)
+
+
+def debug_library_path() -> str:
+    """The measurement companion: debug hooks (create-time host logic for the CPU test tier) and the bare-MFMA
+    probe. Never linked by the product; tests and bench.py load it beside it."""
+    return os.path.join(_PKG_DIR, _DBG_NAME)
 
 
 def build(verbose: bool = False) -> str:
@@ -66,3 +74,36 @@ def load() -> Gfx950Library:
                 "There is no CPU fallback.")
         _loaded = Gfx950Library(path)
     return _loaded
+
+
+def load_debug():
+    """ctypes handle of libqnnpack_gfx950_dbg.so (once per process). Wrapped so that callers written against
+    a library object (`.lib.<symbol>`) work unchanged."""
+    global _loaded_debug
+    if _loaded_debug is None:
+        import ctypes
+        try:
+            import torch  # noqa: F401  -- same HIP runtime as the product (see load())
+        except Exception:
+            pass
+        path = debug_library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make -C qnnpack_amd/csrc`.")
+
+        class _Debug:
+            pass
+        dbg = _Debug()
+        dbg.path = path
+        dbg.lib = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+        dbg.lib.qnnp_gfx950_mfma_probe.restype = ctypes.c_int
+        dbg.lib.qnnp_gfx950_mfma_probe.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+
+        def mfma_probe(random_operands: bool, iters: int = 12800) -> float:
+            tops = ctypes.c_float(0.0)
+            rc = dbg.lib.qnnp_gfx950_mfma_probe(1 if random_operands else 0, iters, ctypes.byref(tops))
+            if rc != 0:
+                raise RuntimeError(f"qnnp_gfx950_mfma_probe -> {rc}")
+            return float(tops.value)
+        dbg.mfma_probe = mfma_probe
+        _loaded_debug = dbg
+    return _loaded_debug

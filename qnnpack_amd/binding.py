@@ -280,6 +280,8 @@ class Gfx950Library(QnnpackLibrary):
         L.qnnp_gfx950_set_device.restype = c_int
         L.qnnp_gfx950_set_device.argtypes = [c_int]
         L.qnnp_gfx950_get_device.restype = c_int
+        L.qnnp_gfx950_device_count.restype = c_int
+        L.qnnp_gfx950_device_count.argtypes = []
         L.qnnp_gfx950_set_stream.restype = c_int
         L.qnnp_gfx950_set_stream.argtypes = [c_void_p]
         L.qnnp_gfx950_set_async.restype = c_int
@@ -311,8 +313,6 @@ class Gfx950Library(QnnpackLibrary):
         L.qnnp_gfx950_graph_time.argtypes = [c_void_p, c_int, c_int, POINTER(c_float)]
         L.qnnp_gfx950_graph_destroy.restype = None
         L.qnnp_gfx950_graph_destroy.argtypes = [c_void_p]
-        L.qnnp_gfx950_mfma_probe.restype = c_int
-        L.qnnp_gfx950_mfma_probe.argtypes = [c_int, c_int, POINTER(c_float)]
         L.qnnp_gfx950_create_fused_block.restype = c_int
         L.qnnp_gfx950_create_fused_block.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]
         L.qnnp_gfx950_setup_fused_block.restype = c_int
@@ -334,6 +334,9 @@ class Gfx950Library(QnnpackLibrary):
 
     def get_device(self) -> int:
         return self.lib.qnnp_gfx950_get_device()
+
+    def device_count(self) -> int:
+        return self.lib.qnnp_gfx950_device_count()
 
     def set_stream(self, stream: Optional[int]) -> None:
         self._check("qnnp_gfx950_set_stream", self.lib.qnnp_gfx950_set_stream(stream))
@@ -424,12 +427,6 @@ class Gfx950Library(QnnpackLibrary):
 
     def graph_destroy(self, graph: int) -> None:
         self.lib.qnnp_gfx950_graph_destroy(graph)
-
-    def mfma_probe(self, random_operands: bool, iters: int = 12800) -> float:
-        tops = c_float(0.0)
-        self._check("qnnp_gfx950_mfma_probe",
-                    self.lib.qnnp_gfx950_mfma_probe(1 if random_operands else 0, iters, ctypes.byref(tops)))
-        return float(tops.value)
 
     def set_option(self, key: str, value: int) -> None:
         self._check("qnnp_gfx950_set_option", self.lib.qnnp_gfx950_set_option(key.encode(), value))

@@ -57,7 +57,7 @@ static struct qnnp_hip_add_params compute_add_params(
   return p;
 }
 
-enum qnnp_status qnnp_create_add_nc_q8(
+static enum qnnp_status qnnp_create_add_nc_q8_impl(
     size_t channels,
     uint8_t a_zero_point,
     float a_scale,
@@ -117,6 +117,7 @@ enum qnnp_status qnnp_create_add_nc_q8(
   }
 
   qnnp_operator_t op = calloc(1, sizeof(struct qnnp_operator));
+  if (op != NULL) op->device = qnnp_hip_device();   /* the context this create runs in (entry point below) */
   if (op == NULL) {
     qnnp_log_error("failed to allocate %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
     return qnnp_status_out_of_memory;
@@ -129,7 +130,7 @@ enum qnnp_status qnnp_create_add_nc_q8(
   return qnnp_status_success;
 }
 
-enum qnnp_status qnnp_setup_add_nc_q8(
+static enum qnnp_status qnnp_setup_add_nc_q8_impl(
     qnnp_operator_t op,
     size_t batch_size,
     const uint8_t* a,
@@ -159,6 +160,7 @@ enum qnnp_status qnnp_setup_add_nc_q8(
   }
 
   /* reference add.c:138-146 */
+  op->setup_valid = 0;   /* until every check, allocation and upload below has succeeded */
   op->batch_size = batch_size;
   op->input = a;
   op->input_pixel_stride = a_stride;
@@ -170,12 +172,72 @@ enum qnnp_status qnnp_setup_add_nc_q8(
   op->input_span = (batch_size - 1) * a_stride + channels;
   op->input2_span = (batch_size - 1) * b_stride + channels;
   op->output_span = (batch_size - 1) * sum_stride + channels;
-  if (qnnp_bind_endpoint(a, op->input_span, &op->input_on_device, &op->d_stage_in, &op->stage_in_capacity) != 0 ||
-      qnnp_bind_endpoint(b, op->input2_span, &op->input2_on_device, &op->d_stage_in2, &op->stage_in2_capacity) != 0 ||
-      qnnp_bind_endpoint(sum, op->output_span, &op->output_on_device, &op->d_stage_out, &op->stage_out_capacity) != 0) {
-    qnnp_log_error("failed to allocate device staging for host tensors (%zu + %zu + %zu bytes)",
-        op->input_span, op->input2_span, op->output_span);
-    return qnnp_status_out_of_memory;
+  {
+    enum qnnp_status bound = qnnp_status_success;
+    if (bound == qnnp_status_success) bound = qnnp_bind_endpoint(a, op->input_span, &op->input_on_device, &op->d_stage_in, &op->stage_in_capacity);
+    if (bound == qnnp_status_success) bound = qnnp_bind_endpoint(b, op->input2_span, &op->input2_on_device, &op->d_stage_in2, &op->stage_in2_capacity);
+    if (bound == qnnp_status_success) bound = qnnp_bind_endpoint(sum, op->output_span, &op->output_on_device, &op->d_stage_out, &op->stage_out_capacity);
+    if (bound != qnnp_status_success) {
+      qnnp_log_error("failed to bind the tensors: device staging for host memory could not be allocated, or a tensor "
+          "lives on a different device than the operator");
+      return bound;
+    }
   }
   return qnnp_status_success;
+}
+
+/* ---- public entry points: run the implementation inside the right device context ------------------
+ * create: the calling thread's selected device (qnnp_gfx950_set_device, default = the primary one) becomes the
+ * operator's device; setup: the operator's device. The previous HIP device of the thread is restored on return. */
+
+enum qnnp_status qnnp_create_add_nc_q8(
+    size_t channels,
+    uint8_t a_zero_point,
+    float a_scale,
+    uint8_t b_zero_point,
+    float b_scale,
+    uint8_t sum_zero_point,
+    float sum_scale,
+    uint8_t sum_min,
+    uint8_t sum_max,
+    uint32_t flags,
+    qnnp_operator_t* add_out)
+{
+  if (!qnnp_state.initialized) {
+    return qnnp_create_add_nc_q8_impl(channels, a_zero_point, a_scale, b_zero_point, b_scale, sum_zero_point, sum_scale, sum_min, sum_max, flags, add_out);   /* logs and answers qnnp_status_uninitialized */
+  }
+  const int token = qnnp_hip_enter(qnnp_hip_device());
+  if (token < 0) {
+    return qnnp_status_unsupported_hardware;
+  }
+  const enum qnnp_status status = qnnp_create_add_nc_q8_impl(channels, a_zero_point, a_scale, b_zero_point, b_scale, sum_zero_point, sum_scale, sum_min, sum_max, flags, add_out);
+  qnnp_hip_leave(token);
+  return status;
+}
+
+enum qnnp_status qnnp_setup_add_nc_q8(
+    qnnp_operator_t op,
+    size_t batch_size,
+    const uint8_t* a,
+    size_t a_stride,
+    const uint8_t* b,
+    size_t b_stride,
+    uint8_t* sum,
+    size_t sum_stride)
+{
+  if (!qnnp_state.initialized || op == NULL) {
+    return qnnp_setup_add_nc_q8_impl(op, batch_size, a, a_stride, b, b_stride, sum, sum_stride);   /* answers qnnp_status_uninitialized / invalid_parameter */
+  }
+  const int token = qnnp_hip_enter(op->device);
+  if (token < 0) {
+    return qnnp_status_invalid_parameter;   /* not a live operator of this library instance */
+  }
+  const enum qnnp_status status = qnnp_setup_add_nc_q8_impl(op, batch_size, a, a_stride, b, b_stride, sum, sum_stride);
+  /* the implementation cleared setup_valid where it began to change the operator: a failed setup leaves it
+   * unrunnable instead of half updated (run answers invalid_parameter) */
+  if (status == qnnp_status_success) {
+    op->setup_valid = 1;
+  }
+  qnnp_hip_leave(token);
+  return status;
 }

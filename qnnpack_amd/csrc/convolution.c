@@ -44,7 +44,7 @@ static inline bool scale_is_valid(float scale)
   return scale > 0.0f && isnormal(scale);
 }
 
-enum qnnp_status qnnp_create_convolution2d_nhwc_q8(
+static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
     uint32_t input_padding_top,
     uint32_t input_padding_right,
     uint32_t input_padding_bottom,
@@ -141,6 +141,7 @@ enum qnnp_status qnnp_create_convolution2d_nhwc_q8(
 
   status = qnnp_status_out_of_memory;
   op = calloc(1, sizeof(struct qnnp_operator));
+  if (op != NULL) op->device = qnnp_hip_device();   /* the context this create runs in (entry point below) */
   if (op == NULL) {
     qnnp_log_error("failed to allocate %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
     goto error;
@@ -276,7 +277,7 @@ error:
   return status;
 }
 
-enum qnnp_status qnnp_setup_convolution2d_nhwc_q8(
+static enum qnnp_status qnnp_setup_convolution2d_nhwc_q8_impl(
     qnnp_operator_t op,
     size_t batch_size,
     size_t input_height,
@@ -328,6 +329,8 @@ enum qnnp_status qnnp_setup_convolution2d_nhwc_q8(
   }
 
   /* reference convolution.c:409-426 */
+  op->setup_valid = 0;   /* until every check, allocation and upload below has succeeded */
+  op->dw_plan.key = 0;   /* depthwise launch plan: recomputed at the next run */
   op->batch_size = batch_size;
   op->input_height = input_height;
   op->input_width = input_width;
@@ -352,11 +355,15 @@ enum qnnp_status qnnp_setup_convolution2d_nhwc_q8(
 
   op->input_span = (batch_size * input_size - 1) * input_pixel_stride + in_channels;
   op->output_span = (batch_size * output_size - 1) * output_pixel_stride + out_channels;
-  if (qnnp_bind_endpoint(input, op->input_span, &op->input_on_device, &op->d_stage_in, &op->stage_in_capacity) != 0 ||
-      qnnp_bind_endpoint(output, op->output_span, &op->output_on_device, &op->d_stage_out, &op->stage_out_capacity) != 0) {
-    qnnp_log_error("failed to allocate device staging for host tensors (%zu + %zu bytes)",
-        op->input_span, op->output_span);
-    return qnnp_status_out_of_memory;
+  {
+    enum qnnp_status bound = qnnp_status_success;
+    if (bound == qnnp_status_success) bound = qnnp_bind_endpoint(input, op->input_span, &op->input_on_device, &op->d_stage_in, &op->stage_in_capacity);
+    if (bound == qnnp_status_success) bound = qnnp_bind_endpoint(output, op->output_span, &op->output_on_device, &op->d_stage_out, &op->stage_out_capacity);
+    if (bound != qnnp_status_success) {
+      qnnp_log_error("failed to bind the tensors: device staging for host memory could not be allocated, or a tensor "
+          "lives on a different device than the operator");
+      return bound;
+    }
   }
 
   switch (op->ukernel_type) {
@@ -411,4 +418,75 @@ enum qnnp_status qnnp_setup_convolution2d_nhwc_q8(
     default:
       return qnnp_status_invalid_parameter;
   }
+}
+
+/* ---- public entry points: run the implementation inside the right device context ------------------
+ * create: the calling thread's selected device (qnnp_gfx950_set_device, default = the primary one) becomes the
+ * operator's device; setup: the operator's device. The previous HIP device of the thread is restored on return. */
+
+enum qnnp_status qnnp_create_convolution2d_nhwc_q8(
+    uint32_t input_padding_top,
+    uint32_t input_padding_right,
+    uint32_t input_padding_bottom,
+    uint32_t input_padding_left,
+    uint32_t kernel_height,
+    uint32_t kernel_width,
+    uint32_t subsampling_height,
+    uint32_t subsampling_width,
+    uint32_t dilation_height,
+    uint32_t dilation_width,
+    uint32_t groups,
+    size_t group_input_channels,
+    size_t group_output_channels,
+    uint8_t input_zero_point,
+    float input_scale,
+    uint8_t kernel_zero_point,
+    float kernel_scale,
+    const uint8_t* kernel,
+    const int32_t* bias,
+    uint8_t output_zero_point,
+    float output_scale,
+    uint8_t output_min,
+    uint8_t output_max,
+    uint32_t flags,
+    qnnp_operator_t* convolution_out)
+{
+  if (!qnnp_state.initialized) {
+    return qnnp_create_convolution2d_nhwc_q8_impl(input_padding_top, input_padding_right, input_padding_bottom, input_padding_left, kernel_height, kernel_width, subsampling_height, subsampling_width, dilation_height, dilation_width, groups, group_input_channels, group_output_channels, input_zero_point, input_scale, kernel_zero_point, kernel_scale, kernel, bias, output_zero_point, output_scale, output_min, output_max, flags, convolution_out);   /* logs and answers qnnp_status_uninitialized */
+  }
+  const int token = qnnp_hip_enter(qnnp_hip_device());
+  if (token < 0) {
+    return qnnp_status_unsupported_hardware;
+  }
+  const enum qnnp_status status = qnnp_create_convolution2d_nhwc_q8_impl(input_padding_top, input_padding_right, input_padding_bottom, input_padding_left, kernel_height, kernel_width, subsampling_height, subsampling_width, dilation_height, dilation_width, groups, group_input_channels, group_output_channels, input_zero_point, input_scale, kernel_zero_point, kernel_scale, kernel, bias, output_zero_point, output_scale, output_min, output_max, flags, convolution_out);
+  qnnp_hip_leave(token);
+  return status;
+}
+
+enum qnnp_status qnnp_setup_convolution2d_nhwc_q8(
+    qnnp_operator_t op,
+    size_t batch_size,
+    size_t input_height,
+    size_t input_width,
+    const uint8_t* input,
+    size_t input_pixel_stride,
+    uint8_t* output,
+    size_t output_pixel_stride,
+    pthreadpool_t threadpool)
+{
+  if (!qnnp_state.initialized || op == NULL) {
+    return qnnp_setup_convolution2d_nhwc_q8_impl(op, batch_size, input_height, input_width, input, input_pixel_stride, output, output_pixel_stride, threadpool);   /* answers qnnp_status_uninitialized / invalid_parameter */
+  }
+  const int token = qnnp_hip_enter(op->device);
+  if (token < 0) {
+    return qnnp_status_invalid_parameter;   /* not a live operator of this library instance */
+  }
+  const enum qnnp_status status = qnnp_setup_convolution2d_nhwc_q8_impl(op, batch_size, input_height, input_width, input, input_pixel_stride, output, output_pixel_stride, threadpool);
+  /* the implementation cleared setup_valid where it began to change the operator: a failed setup leaves it
+   * unrunnable instead of half updated (run answers invalid_parameter) */
+  if (status == qnnp_status_success) {
+    op->setup_valid = 1;
+  }
+  qnnp_hip_leave(token);
+  return status;
 }

@@ -97,7 +97,7 @@ void qnnp_debug_requant_fast_bits(
     uint32_t accumulator_bits, uint8_t* out, int* bounded_out)
 {
   const struct qnnp_hip_requant rq = qnnp_compute_requant(scale, zero_point, qmin, qmax);
-  /* exactly what make_requant_dev (hip/requant.cuh) hands the kernels: zero point folded into the addend when it
+  /* exactly what make_requant_dev (hip/requant.hip.h) hands the kernels: zero point folded into the addend when it
    * fits, clamp bounds in the output domain */
   struct qnnp_requant_fast f = qnnp_requant_fast_init(rq.multiplier, rq.shift);
   const int folded = qnnp_requant_fast_fold_zero_point(&f, (uint32_t) rq.output_zero_point);

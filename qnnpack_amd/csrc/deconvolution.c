@@ -53,7 +53,7 @@ static inline bool scale_is_valid(float scale)
   return scale > 0.0f && isnormal(scale);
 }
 
-enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8(
+static enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8_impl(
     uint32_t input_padding_top,
     uint32_t input_padding_right,
     uint32_t input_padding_bottom,
@@ -152,6 +152,7 @@ enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8(
 
   status = qnnp_status_out_of_memory;
   op = calloc(1, sizeof(struct qnnp_operator));
+  if (op != NULL) op->device = qnnp_hip_device();   /* the context this create runs in (entry point below) */
   if (op == NULL) {
     qnnp_log_error("failed to allocate %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
     goto error;
@@ -406,7 +407,7 @@ static enum qnnp_status upload_phase_table(struct qnnp_operator* op)
   return qnnp_status_success;
 }
 
-enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8(
+static enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8_impl(
     qnnp_operator_t op,
     size_t batch_size,
     size_t input_height,
@@ -459,6 +460,7 @@ enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8(
   }
 
   /* reference deconvolution.c:243-262 */
+  op->setup_valid = 0;   /* until every check, allocation and upload below has succeeded */
   op->batch_size = batch_size;
   op->input_height = input_height;
   op->input_width = input_width;
@@ -479,11 +481,15 @@ enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8(
 
   op->input_span = (batch_size * input_size - 1) * input_pixel_stride + in_channels;
   op->output_span = (batch_size * output_size - 1) * output_pixel_stride + out_channels;
-  if (qnnp_bind_endpoint(input, op->input_span, &op->input_on_device, &op->d_stage_in, &op->stage_in_capacity) != 0 ||
-      qnnp_bind_endpoint(output, op->output_span, &op->output_on_device, &op->d_stage_out, &op->stage_out_capacity) != 0) {
-    qnnp_log_error("failed to allocate device staging for host tensors (%zu + %zu bytes)",
-        op->input_span, op->output_span);
-    return qnnp_status_out_of_memory;
+  {
+    enum qnnp_status bound = qnnp_status_success;
+    if (bound == qnnp_status_success) bound = qnnp_bind_endpoint(input, op->input_span, &op->input_on_device, &op->d_stage_in, &op->stage_in_capacity);
+    if (bound == qnnp_status_success) bound = qnnp_bind_endpoint(output, op->output_span, &op->output_on_device, &op->d_stage_out, &op->stage_out_capacity);
+    if (bound != qnnp_status_success) {
+      qnnp_log_error("failed to bind the tensors: device staging for host memory could not be allocated, or a tensor "
+          "lives on a different device than the operator");
+      return bound;
+    }
   }
 
   op->variant = 1;   /* the offset-table kernel: the table, not the geometry, defines this operator */
@@ -590,4 +596,77 @@ enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8(
   op->offsets_in_w = input_width;
   op->offsets_in_stride = input_pixel_stride;
   return qnnp_status_success;
+}
+
+/* ---- public entry points: run the implementation inside the right device context ------------------
+ * create: the calling thread's selected device (qnnp_gfx950_set_device, default = the primary one) becomes the
+ * operator's device; setup: the operator's device. The previous HIP device of the thread is restored on return. */
+
+enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8(
+    uint32_t input_padding_top,
+    uint32_t input_padding_right,
+    uint32_t input_padding_bottom,
+    uint32_t input_padding_left,
+    uint32_t adjustment_height,
+    uint32_t adjustment_width,
+    uint32_t kernel_height,
+    uint32_t kernel_width,
+    uint32_t stride_height,
+    uint32_t stride_width,
+    uint32_t dilation_height,
+    uint32_t dilation_width,
+    uint32_t groups,
+    size_t group_input_channels,
+    size_t group_output_channels,
+    uint8_t input_zero_point,
+    float input_scale,
+    uint8_t kernel_zero_point,
+    float kernel_scale,
+    const uint8_t* kernel,
+    const int32_t* bias,
+    uint8_t output_zero_point,
+    float output_scale,
+    uint8_t output_min,
+    uint8_t output_max,
+    uint32_t flags,
+    qnnp_operator_t* deconvolution_out)
+{
+  if (!qnnp_state.initialized) {
+    return qnnp_create_deconvolution2d_nhwc_q8_impl(input_padding_top, input_padding_right, input_padding_bottom, input_padding_left, adjustment_height, adjustment_width, kernel_height, kernel_width, stride_height, stride_width, dilation_height, dilation_width, groups, group_input_channels, group_output_channels, input_zero_point, input_scale, kernel_zero_point, kernel_scale, kernel, bias, output_zero_point, output_scale, output_min, output_max, flags, deconvolution_out);   /* logs and answers qnnp_status_uninitialized */
+  }
+  const int token = qnnp_hip_enter(qnnp_hip_device());
+  if (token < 0) {
+    return qnnp_status_unsupported_hardware;
+  }
+  const enum qnnp_status status = qnnp_create_deconvolution2d_nhwc_q8_impl(input_padding_top, input_padding_right, input_padding_bottom, input_padding_left, adjustment_height, adjustment_width, kernel_height, kernel_width, stride_height, stride_width, dilation_height, dilation_width, groups, group_input_channels, group_output_channels, input_zero_point, input_scale, kernel_zero_point, kernel_scale, kernel, bias, output_zero_point, output_scale, output_min, output_max, flags, deconvolution_out);
+  qnnp_hip_leave(token);
+  return status;
+}
+
+enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8(
+    qnnp_operator_t op,
+    size_t batch_size,
+    size_t input_height,
+    size_t input_width,
+    const uint8_t* input,
+    size_t input_pixel_stride,
+    uint8_t* output,
+    size_t output_pixel_stride,
+    pthreadpool_t threadpool)
+{
+  if (!qnnp_state.initialized || op == NULL) {
+    return qnnp_setup_deconvolution2d_nhwc_q8_impl(op, batch_size, input_height, input_width, input, input_pixel_stride, output, output_pixel_stride, threadpool);   /* answers qnnp_status_uninitialized / invalid_parameter */
+  }
+  const int token = qnnp_hip_enter(op->device);
+  if (token < 0) {
+    return qnnp_status_invalid_parameter;   /* not a live operator of this library instance */
+  }
+  const enum qnnp_status status = qnnp_setup_deconvolution2d_nhwc_q8_impl(op, batch_size, input_height, input_width, input, input_pixel_stride, output, output_pixel_stride, threadpool);
+  /* the implementation cleared setup_valid where it began to change the operator: a failed setup leaves it
+   * unrunnable instead of half updated (run answers invalid_parameter) */
+  if (status == qnnp_status_success) {
+    op->setup_valid = 1;
+  }
+  qnnp_hip_leave(token);
+  return status;
 }

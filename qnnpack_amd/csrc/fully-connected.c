@@ -27,7 +27,7 @@ static inline bool scale_is_valid(float scale)
   return scale > 0.0f && isnormal(scale);
 }
 
-enum qnnp_status qnnp_create_fully_connected_nc_q8(
+static enum qnnp_status qnnp_create_fully_connected_nc_q8_impl(
     size_t input_channels,
     size_t output_channels,
     uint8_t input_zero_point,
@@ -95,6 +95,7 @@ enum qnnp_status qnnp_create_fully_connected_nc_q8(
 
   status = qnnp_status_out_of_memory;
   op = calloc(1, sizeof(struct qnnp_operator));
+  if (op != NULL) op->device = qnnp_hip_device();   /* the context this create runs in (entry point below) */
   if (op == NULL) {
     qnnp_log_error("failed to allocate %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
     goto error;
@@ -154,7 +155,7 @@ error:
   return status;
 }
 
-enum qnnp_status qnnp_setup_fully_connected_nc_q8(
+static enum qnnp_status qnnp_setup_fully_connected_nc_q8_impl(
     qnnp_operator_t op,
     size_t batch_size,
     const uint8_t* input,
@@ -187,6 +188,7 @@ enum qnnp_status qnnp_setup_fully_connected_nc_q8(
   }
 
   /* reference fully-connected.c:149-158: the batch becomes the row dimension */
+  op->setup_valid = 0;   /* until every check, allocation and upload below has succeeded */
   op->batch_size = 1;
   op->input_height = batch_size;
   op->input_width = 1;
@@ -199,22 +201,72 @@ enum qnnp_status qnnp_setup_fully_connected_nc_q8(
 
   op->input_span = (batch_size - 1) * input_stride + op->group_input_channels;
   op->output_span = (batch_size - 1) * output_stride + op->group_output_channels;
-  op->input_on_device = qnnp_hip_is_device_pointer(input);
-  op->output_on_device = qnnp_hip_is_device_pointer(output);
-  if (!op->input_on_device && op->stage_in_capacity < op->input_span) {
-    qnnp_hip_free(op->d_stage_in);
-    op->stage_in_capacity = 0;
-    op->d_stage_in = qnnp_hip_alloc(op->input_span);
-    if (op->d_stage_in == NULL) return qnnp_status_out_of_memory;
-    op->stage_in_capacity = op->input_span;
-  }
-  if (!op->output_on_device && op->stage_out_capacity < op->output_span) {
-    qnnp_hip_free(op->d_stage_out);
-    op->stage_out_capacity = 0;
-    op->d_stage_out = qnnp_hip_alloc(op->output_span);
-    if (op->d_stage_out == NULL) return qnnp_status_out_of_memory;
-    op->stage_out_capacity = op->output_span;
+  {
+    enum qnnp_status bound = qnnp_bind_endpoint(input, op->input_span, &op->input_on_device, &op->d_stage_in, &op->stage_in_capacity);
+    if (bound == qnnp_status_success) bound = qnnp_bind_endpoint(output, op->output_span, &op->output_on_device, &op->d_stage_out, &op->stage_out_capacity);
+    if (bound != qnnp_status_success) {
+      qnnp_log_error("failed to bind the tensors: device staging for host memory could not be allocated, or a tensor "
+          "lives on a different device than the operator");
+      return bound;
+    }
   }
   op->variant = qnnp_state.opt_gemm_kernel;
   return qnnp_status_success;
+}
+
+/* ---- public entry points: run the implementation inside the right device context ------------------
+ * create: the calling thread's selected device (qnnp_gfx950_set_device, default = the primary one) becomes the
+ * operator's device; setup: the operator's device. The previous HIP device of the thread is restored on return. */
+
+enum qnnp_status qnnp_create_fully_connected_nc_q8(
+    size_t input_channels,
+    size_t output_channels,
+    uint8_t input_zero_point,
+    float input_scale,
+    uint8_t kernel_zero_point,
+    float kernel_scale,
+    const uint8_t* kernel,
+    const int32_t* bias,
+    uint8_t output_zero_point,
+    float output_scale,
+    uint8_t output_min,
+    uint8_t output_max,
+    uint32_t flags,
+    qnnp_operator_t* fully_connected_out)
+{
+  if (!qnnp_state.initialized) {
+    return qnnp_create_fully_connected_nc_q8_impl(input_channels, output_channels, input_zero_point, input_scale, kernel_zero_point, kernel_scale, kernel, bias, output_zero_point, output_scale, output_min, output_max, flags, fully_connected_out);   /* logs and answers qnnp_status_uninitialized */
+  }
+  const int token = qnnp_hip_enter(qnnp_hip_device());
+  if (token < 0) {
+    return qnnp_status_unsupported_hardware;
+  }
+  const enum qnnp_status status = qnnp_create_fully_connected_nc_q8_impl(input_channels, output_channels, input_zero_point, input_scale, kernel_zero_point, kernel_scale, kernel, bias, output_zero_point, output_scale, output_min, output_max, flags, fully_connected_out);
+  qnnp_hip_leave(token);
+  return status;
+}
+
+enum qnnp_status qnnp_setup_fully_connected_nc_q8(
+    qnnp_operator_t op,
+    size_t batch_size,
+    const uint8_t* input,
+    size_t input_stride,
+    uint8_t* output,
+    size_t output_stride)
+{
+  if (!qnnp_state.initialized || op == NULL) {
+    return qnnp_setup_fully_connected_nc_q8_impl(op, batch_size, input, input_stride, output, output_stride);   /* answers qnnp_status_uninitialized / invalid_parameter */
+  }
+  const int token = qnnp_hip_enter(op->device);
+  if (token < 0) {
+    return qnnp_status_invalid_parameter;   /* not a live operator of this library instance */
+  }
+  const enum qnnp_status status = qnnp_setup_fully_connected_nc_q8_impl(op, batch_size, input, input_stride, output, output_stride);
+  /* the implementation cleared setup_valid where it began to change the operator: a failed setup leaves it
+   * unrunnable instead of half updated (run answers invalid_parameter) */
+  if (status == qnnp_status_success) {
+    op->setup_valid = 1;
+  }
+  qnnp_hip_leave(token);
+  return status;
 }

@@ -75,7 +75,7 @@ static struct qnnp_hip_fused_args fused_args(const struct qnnp_operator* op, con
   return a;
 }
 
-enum qnnp_status qnnp_gfx950_create_fused_block(
+static enum qnnp_status qnnp_gfx950_create_fused_block_impl(
     qnnp_operator_t expand, qnnp_operator_t depthwise, qnnp_operator_t project, qnnp_operator_t residual_add,
     qnnp_operator_t* fused_out)
 {
@@ -106,7 +106,12 @@ enum qnnp_status qnnp_gfx950_create_fused_block(
       return qnnp_status_unsupported_parameter;
     }
   }
+  if (project->device != depthwise->device || (expand != NULL && expand->device != depthwise->device)) {
+    qnnp_log_error("failed to create fused block: the operators live on different devices");
+    return qnnp_status_invalid_parameter;
+  }
   qnnp_operator_t op = calloc(1, sizeof(struct qnnp_operator));
+  if (op != NULL) op->device = depthwise->device;   /* it borrows their device images */
   if (op == NULL) {
     qnnp_log_error("failed to allocate %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
     return qnnp_status_out_of_memory;
@@ -121,7 +126,7 @@ enum qnnp_status qnnp_gfx950_create_fused_block(
   return qnnp_status_success;
 }
 
-enum qnnp_status qnnp_gfx950_setup_fused_block(
+static enum qnnp_status qnnp_gfx950_setup_fused_block_impl(
     qnnp_operator_t op, size_t batch_size, size_t input_height, size_t input_width,
     const uint8_t* input, size_t input_stride, uint8_t* output, size_t output_stride)
 {
@@ -143,6 +148,7 @@ enum qnnp_status qnnp_gfx950_setup_fused_block(
     return qnnp_status_invalid_parameter;
   }
   const size_t s = op->fused_depthwise->stride_height;
+  op->setup_valid = 0;   /* until every check, allocation and upload below has succeeded */
   op->batch_size = batch_size;
   op->input_height = input_height;
   op->input_width = input_width;
@@ -160,9 +166,15 @@ enum qnnp_status qnnp_gfx950_setup_fused_block(
   }
   op->input_span = (in_pixels - 1) * input_stride + cin;
   op->output_span = (out_pixels - 1) * output_stride + cout;
-  if (qnnp_bind_endpoint(input, op->input_span, &op->input_on_device, &op->d_stage_in, &op->stage_in_capacity) != 0 ||
-      qnnp_bind_endpoint(output, op->output_span, &op->output_on_device, &op->d_stage_out, &op->stage_out_capacity) != 0) {
-    return qnnp_status_out_of_memory;
+  {
+    enum qnnp_status bound = qnnp_status_success;
+    if (bound == qnnp_status_success) bound = qnnp_bind_endpoint(input, op->input_span, &op->input_on_device, &op->d_stage_in, &op->stage_in_capacity);
+    if (bound == qnnp_status_success) bound = qnnp_bind_endpoint(output, op->output_span, &op->output_on_device, &op->d_stage_out, &op->stage_out_capacity);
+    if (bound != qnnp_status_success) {
+      qnnp_log_error("failed to bind the tensors: device staging for host memory could not be allocated, or a tensor "
+          "lives on a different device than the operator");
+      return bound;
+    }
   }
   /* does the kernel take this block (LDS plan, channel multiples, alignment)? */
   const struct qnnp_hip_fused_args probe = fused_args(op, op->input_on_device ? input : op->d_stage_in,
@@ -180,4 +192,45 @@ int qnnp_fused_block_launch(struct qnnp_operator* op, const void* input, void* o
 {
   const struct qnnp_hip_fused_args args = fused_args(op, input, output);
   return qnnp_hip_fused_block_run(&args, &op->kernel_name);
+}
+
+/* ---- public entry points: run the implementation inside the right device context ------------------
+ * create: the calling thread's selected device (qnnp_gfx950_set_device, default = the primary one) becomes the
+ * operator's device; setup: the operator's device. The previous HIP device of the thread is restored on return. */
+
+enum qnnp_status qnnp_gfx950_create_fused_block(
+    qnnp_operator_t expand, qnnp_operator_t depthwise, qnnp_operator_t project, qnnp_operator_t residual_add,
+    qnnp_operator_t* fused_out)
+{
+  if (!qnnp_state.initialized) {
+    return qnnp_gfx950_create_fused_block_impl(expand, depthwise, project, residual_add, fused_out);   /* logs and answers qnnp_status_uninitialized */
+  }
+  const int token = qnnp_hip_enter(qnnp_hip_device());
+  if (token < 0) {
+    return qnnp_status_unsupported_hardware;
+  }
+  const enum qnnp_status status = qnnp_gfx950_create_fused_block_impl(expand, depthwise, project, residual_add, fused_out);
+  qnnp_hip_leave(token);
+  return status;
+}
+
+enum qnnp_status qnnp_gfx950_setup_fused_block(
+    qnnp_operator_t op, size_t batch_size, size_t input_height, size_t input_width,
+    const uint8_t* input, size_t input_stride, uint8_t* output, size_t output_stride)
+{
+  if (!qnnp_state.initialized || op == NULL) {
+    return qnnp_gfx950_setup_fused_block_impl(op, batch_size, input_height, input_width, input, input_stride, output, output_stride);   /* answers qnnp_status_uninitialized / invalid_parameter */
+  }
+  const int token = qnnp_hip_enter(op->device);
+  if (token < 0) {
+    return qnnp_status_invalid_parameter;   /* not a live operator of this library instance */
+  }
+  const enum qnnp_status status = qnnp_gfx950_setup_fused_block_impl(op, batch_size, input_height, input_width, input, input_stride, output, output_stride);
+  /* the implementation cleared setup_valid where it began to change the operator: a failed setup leaves it
+   * unrunnable instead of half updated (run answers invalid_parameter) */
+  if (status == qnnp_status_success) {
+    op->setup_valid = 1;
+  }
+  qnnp_hip_leave(token);
+  return status;
 }

@@ -1,5 +1,5 @@
 /*
- * add_math.cuh -- the quantized element-wise add, in registers (reference src/qnnpack/requantization.h:500-522,
+ * add_math.hip.h -- the quantized element-wise add, in registers (reference src/qnnpack/requantization.h:500-522,
  * qnnp_add_quantize). Shared by the stand-alone add kernel (q8pointwise.hip) and by epilogues that fuse a residual
  * add (q8fused.hip).
  */

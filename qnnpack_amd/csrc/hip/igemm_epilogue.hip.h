@@ -1,7 +1,7 @@
 /*
- * igemm_epilogue.cuh -- the fused output stage shared by the MFMA GEMM kernels:
+ * igemm_epilogue.hip.h -- the fused output stage shared by the MFMA GEMM kernels:
  * accumulator tile (+ folded bias + kernel-zero-point row term) -> Q31 requantize
- * (requant.cuh, bit-exact with reference src/qnnpack/requantization.h:464-480) ->
+ * (requant.hip.h, bit-exact with reference src/qnnpack/requantization.h:464-480) ->
  * uint8, 4 channels per dword -> global stores.
  *
  * One call handles one 32x32 MFMA accumulator tile of one wave. C/D layout of
@@ -22,9 +22,9 @@
 
 #include <stdint.h>
 
-#include "add_math.cuh"
+#include "add_math.hip.h"
 #include "igemm_params.h"
-#include "requant.cuh"
+#include "requant.hip.h"
 
 namespace qnnp {
 

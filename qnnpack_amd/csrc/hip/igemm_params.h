@@ -9,7 +9,7 @@
 #include <stdint.h>
 
 #include "qnnp_hip.h"
-#include "requant.cuh"
+#include "requant.hip.h"
 
 namespace qnnp {
 
@@ -58,7 +58,7 @@ struct IgemmParams {
   uint32_t output_stride;
   int32_t row_coeff;
   uint32_t izp_fill;       // input zero point replicated into 4 bytes
-  uint32_t store_mode;     // 2: 16-byte stores, 1: dword stores, 0: byte stores (igemm_epilogue.cuh)
+  uint32_t store_mode;     // 2: 16-byte stores, 1: dword stores, 0: byte stores (igemm_epilogue.hip.h)
   uint32_t cu_count;       // compute units of the bound device (persistent-grid sizing)
   unsigned long long* trace;  // measurement builds only (QNNP_ENABLE_ABLATION + env QNNP_GFX950_TRACE): cycle stamps
   const uint8_t* fill_table; // [256][16]: entry v = 16 bytes of value v (LDS-DMA padding sources)

@@ -1,9 +1,12 @@
 /*
- * mfma_probe.hip -- diagnostic behind qnnp_gfx950_mfma_probe(): the rate the whole chip sustains on a bare
+ * mfma_probe.hip -- qnnp_gfx950_mfma_probe(): the rate the whole chip sustains on a bare
  * v_mfma_i32_32x32x32_i8 loop (no LDS, no global traffic). bench.py reports it beside the GEMM roofline: on
  * MI355X the figure depends on the operand DATA (zero operands hold 2.4 GHz, random ones make the power
  * management drop the clock), so it is the practical ceiling the GEMM kernel's fraction should be read against.
  * The reference has no counterpart. Same loop as tools/ubench_mfma.hip.
+ *
+ * Measurement code: built into libqnnpack_gfx950_dbg.so, NOT into the product library. Self-contained -- it runs
+ * on the calling thread's current HIP device and default stream and needs no library state.
  */
 #include <hip/hip_runtime.h>
 
@@ -12,8 +15,6 @@
 #include <vector>
 
 #include "qnnp_hip.h"
-
-extern "C" void* qnnp_hip_get_stream(void);
 
 namespace {
 
@@ -47,9 +48,15 @@ __global__ __launch_bounds__(512) void mfma_probe_kernel(const v4i* in, int* out
 
 }  // namespace
 
-extern "C" int qnnp_hip_mfma_probe(int random_operands, int iters, int compute_units, float* tops_out)
+/* returns 0 on success, a negative QNNP_HIP_* code otherwise; *tops_out = TOP/s over all compute units */
+extern "C" int qnnp_gfx950_mfma_probe(int random_operands, int iters, float* tops_out)
 {
-  if (tops_out == nullptr || iters <= 0 || compute_units <= 0) return QNNP_HIP_EINVAL;
+  if (tops_out == nullptr || iters <= 0) return QNNP_HIP_EINVAL;
+  int device = 0;
+  hipDeviceProp_t props;
+  if (hipGetDevice(&device) != hipSuccess || hipGetDeviceProperties(&props, device) != hipSuccess) return QNNP_HIP_ENODEV;
+  const int compute_units = props.multiProcessorCount;
+  if (compute_units <= 0) return QNNP_HIP_ENODEV;
   std::vector<uint32_t> host(4096 * 4, 0u);
   if (random_operands) {
     uint32_t x = 0x9E3779B9u;
@@ -62,7 +69,7 @@ extern "C" int qnnp_hip_mfma_probe(int random_operands, int iters, int compute_u
     (void) hipFree(d_in);
     return QNNP_HIP_ENOMEM;
   }
-  hipStream_t stream = reinterpret_cast<hipStream_t>(qnnp_hip_get_stream());
+  hipStream_t stream = nullptr;
   hipEvent_t e0, e1;
   bool ok = hipMemcpy(d_in, host.data(), host.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
             hipEventCreate(&e0) == hipSuccess;

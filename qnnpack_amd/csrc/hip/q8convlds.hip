@@ -28,9 +28,10 @@
 
 #include <stdint.h>
 
-#include "igemm_epilogue.cuh"
+#include "igemm_epilogue.hip.h"
 #include "igemm_params.h"
-#include "requant.cuh"
+#include "per_device.h"
+#include "requant.hip.h"
 
 namespace qnnp {
 
@@ -321,13 +322,12 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
 template <int TN, bool PIPE, int ABL = 0>
 int launch_one(const IgemmParams& p, const ConvGeom& g, const Plan& pl, uint32_t batch, hipStream_t stream)
 {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
+  if (attr_once.first()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_lds_mfma_kernel<TN, PIPE, ABL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       (void) hipGetLastError();
     }
-    attr_set = true;
   }
   const uint32_t total_items = batch * pl.blocks_per_image;
   const uint32_t resident = p.cu_count * (kLdsLimit >= 2 * pl.lds_bytes ? 2u : 1u);

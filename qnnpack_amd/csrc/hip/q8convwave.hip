@@ -34,9 +34,10 @@
 
 #include <stdint.h>
 
-#include "igemm_epilogue.cuh"
+#include "igemm_epilogue.hip.h"
 #include "igemm_params.h"
-#include "requant.cuh"
+#include "per_device.h"
+#include "requant.hip.h"
 
 namespace qnnp {
 
@@ -311,13 +312,12 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
 template <int TN>
 int launch(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, uint32_t lds_bytes, hipStream_t stream)
 {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
+  if (attr_once.first()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_mfma_kernel<TN>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       (void) hipGetLastError();
     }
-    attr_set = true;
   }
   const uint32_t want = (a.units + kWaves - 1) / kWaves;
   const uint32_t grid = want < p.cu_count ? want : p.cu_count;

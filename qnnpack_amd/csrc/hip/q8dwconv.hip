@@ -37,10 +37,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-#include "igemm_epilogue.cuh"
+#include "igemm_epilogue.hip.h"
 #include "igemm_params.h"
 #include "qnnp_hip.h"
-#include "requant.cuh"
+#include "requant.hip.h"
 
 extern "C" void* qnnp_hip_get_stream(void);
 
@@ -73,7 +73,7 @@ struct DwParams {
   const int8_t* dwm_x;
   const int32_t* dwm_bias;
   uint32_t dwm_parts, c_pad32;
-  uint32_t store_mode;   // as igemm_epilogue.cuh: 2 = 16-byte stores, 1 = dword stores, 0 = byte stores
+  uint32_t store_mode;   // as igemm_epilogue.hip.h: 2 = 16-byte stores, 1 = dword stores, 0 = byte stores
   uint32_t abl;          // measurement builds only: bit 0 = no stores, bit 1 = no global loads (kernel F)
   unsigned long long* trace;   // measurement builds only (QNNP_ENABLE_ABLATION + env QNNP_GFX950_TRACE)
   qnnp::RequantDev rq;
@@ -1031,6 +1031,65 @@ int launch_lds(const DwParams& p, bool vec16, hipStream_t stream)
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
+enum : uint32_t { kPlanDirect = 1, kPlanLds33, kPlanLds55, kPlanRow, kPlanMfma, kPlanMfmaLds };
+
+// measurement knob, read once: LDS budget per workgroup of the LDS-tiled kernel in KiB
+uint32_t lds_budget()
+{
+  static const uint32_t budget = [] {
+    if (const char* env = getenv("QNNP_GFX950_DW_LDS_KB")) {
+      const int kb = atoi(env);
+      if (kb >= 4 && kb <= 64) return static_cast<uint32_t>(kb) * 1024u;
+    }
+    return kDwLdsBudgetDefault;
+  }();
+  return budget;
+}
+
+// Kernel choice and launch geometry for one (shape, variant, alignment); fills `p` and `plan`.
+int make_plan(DwParams& p, const struct qnnp_hip_dwconv_args* a, uintptr_t in_addr, uintptr_t out_addr,
+              struct qnnp_hip_dwconv_plan* plan)
+{
+  const bool k33 = p.KH == 3 && p.KW == 3;
+  const bool k55 = p.KH == 5 && p.KW == 5;
+  const bool aligned4 = p.in_stride % 4 == 0 && p.out_stride % 4 == 0 && in_addr % 4 == 0 && out_addr % 4 == 0;
+  p.store_mode = 0;
+  if (p.C % 16 == 0 && p.out_stride % 16 == 0 && out_addr % 16 == 0) p.store_mode = 2;
+  else if (p.C % 4 == 0 && p.out_stride % 4 == 0 && out_addr % 4 == 0) p.store_mode = 1;
+  plan->vec16 = 0;
+  plan->kernel = 0;
+  if (a->variant == 5) {
+    if (!plan_mfma_lds(p, a)) return QNNP_HIP_EINVAL;
+    plan->kernel = kPlanMfmaLds;
+  } else if (a->variant == 4) {
+    if (!plan_mfma(p, a)) return QNNP_HIP_EINVAL;
+    plan->kernel = kPlanMfma;
+  } else if (a->variant == 0 && k33 && p.OW >= 56 && p.C <= 96 && plan_mfma_lds(p, a)) {
+    // Large images with few channels (MobileNetV2 layers 2 and 5): the matrix-core kernel with the LDS-staged band
+    // measured 8-10 % ahead of the VALU kernels; everywhere else it is level or behind (same-box A/B).
+    plan->kernel = kPlanMfmaLds;
+  } else {
+    // Order of preference (same-box A/B over the MobileNetV2 layers: the LDS-tiled and the sliding-window
+    // kernel are within +-10 % of each other, LDS ahead on the small late layers): LDS-tiled, then the
+    // register sliding window (3x3 shapes whose band does not fit the LDS budget), then the direct kernel.
+    const bool use_lds = a->variant != 1 && a->variant != 3 && (k33 || k55) && aligned4 && plan_lds(p, lds_budget());
+    if (a->variant == 2 && !use_lds) return QNNP_HIP_EINVAL;
+    if (!use_lds && (a->variant == 0 || a->variant == 3) && k33 && aligned4 && plan_row(p)) {
+      plan->kernel = kPlanRow;
+    } else if (a->variant == 3) {
+      return QNNP_HIP_EINVAL;
+    } else if (use_lds) {
+      plan->vec16 = (p.CS % 16 == 0 && p.in_stride % 16 == 0 && in_addr % 16 == 0) ? 1u : 0u;
+      plan->kernel = k33 ? kPlanLds33 : kPlanLds55;
+    } else {
+      plan->kernel = kPlanDirect;
+    }
+  }
+  plan->CS = p.CS; plan->TOH = p.TOH; plan->IR = p.IR; plan->IC = p.IC; plan->PP = p.PP;
+  plan->bands = p.bands; plan->slabs = p.slabs; plan->store_mode = p.store_mode;
+  return QNNP_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const char** kernel_name)
@@ -1060,59 +1119,49 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
   if (const char* env = getenv("QNNP_DW_ABL")) p.abl = static_cast<uint32_t>(atoi(env));
 #endif
   {
-    int cus = 0;
-    p.cu_count = (qnnp_hip_device_info(nullptr, 0, &cus, nullptr, nullptr) == QNNP_HIP_OK && cus > 0) ? static_cast<uint32_t>(cus) : 256u;
+    const int cus = qnnp_hip_compute_units();
+    p.cu_count = cus > 0 ? static_cast<uint32_t>(cus) : 256u;
   }
 
   hipStream_t stream = reinterpret_cast<hipStream_t>(qnnp_hip_get_stream());
   const uintptr_t in_addr = reinterpret_cast<uintptr_t>(a->input);
   const uintptr_t out_addr = reinterpret_cast<uintptr_t>(a->output);
-
-  const bool k33 = p.KH == 3 && p.KW == 3;
-  const bool k55 = p.KH == 5 && p.KW == 5;
-  const bool aligned4 = p.in_stride % 4 == 0 && p.out_stride % 4 == 0 && in_addr % 4 == 0 && out_addr % 4 == 0;
-  uint32_t budget = kDwLdsBudgetDefault;
-  if (const char* env = getenv("QNNP_GFX950_DW_LDS_KB")) {   // tuning knob (measurement only)
-    const int kb = atoi(env);
-    if (kb >= 4 && kb <= 64) budget = static_cast<uint32_t>(kb) * 1024u;
-  }
   p.dwm_x = a->dwm_x; p.dwm_bias = a->dwm_bias; p.dwm_parts = a->dwm_parts; p.c_pad32 = a->c_pad32;
-  p.store_mode = 0;
-  if (p.C % 16 == 0 && p.out_stride % 16 == 0 && out_addr % 16 == 0) p.store_mode = 2;
-  else if (p.C % 4 == 0 && p.out_stride % 4 == 0 && out_addr % 4 == 0) p.store_mode = 1;
-  if (a->variant == 5) {
-    if (!plan_mfma_lds(p, a)) return QNNP_HIP_EINVAL;
-    if (kernel_name != nullptr) *kernel_name = "q8_dwconv_mfma_lds_3x3";
-    return launch_mfma_lds(p, stream);
-  }
-  if (a->variant == 4) {
-    if (!plan_mfma(p, a)) return QNNP_HIP_EINVAL;
-    if (kernel_name != nullptr) *kernel_name = "q8_dwconv_mfma_3x3";
-    return launch_mfma<3, 3>(p, stream);
-  }
-  // Large images with few channels (MobileNetV2 layers 2 and 5): the matrix-core kernel with the LDS-staged band
-  // measured 8-10 % ahead of the VALU kernels; everywhere else it is level or behind (same-box A/B).
-  if (a->variant == 0 && k33 && p.OW >= 56 && p.C <= 96 && plan_mfma_lds(p, a)) {
-    if (kernel_name != nullptr) *kernel_name = "q8_dwconv_mfma_lds_3x3";
-    return launch_mfma_lds(p, stream);
-  }
-  // Order of preference (same-box A/B over the MobileNetV2 layers: the LDS-tiled and the sliding-window
-  // kernel are within +-10 % of each other, LDS ahead on the small late layers): LDS-tiled, then the
-  // register sliding window (3x3 shapes whose band does not fit the LDS budget), then the direct kernel.
-  bool use_lds = a->variant != 1 && a->variant != 3 && (k33 || k55) && aligned4 && plan_lds(p, budget);
-  if (a->variant == 2 && !use_lds) return QNNP_HIP_EINVAL;
-  if (!use_lds && (a->variant == 0 || a->variant == 3) && k33 && aligned4 && plan_row(p)) {
-    if (kernel_name != nullptr) *kernel_name = "q8_dwconv_row_3x3";
-    return launch_row(p, stream);
-  }
-  if (a->variant == 3) return QNNP_HIP_EINVAL;
 
-  if (use_lds) {
-    const bool vec16 = p.CS % 16 == 0 && p.in_stride % 16 == 0 && in_addr % 16 == 0;
-    if (kernel_name != nullptr) *kernel_name = k33 ? "q8_dwconv_lds_3x3" : "q8_dwconv_lds_5x5";
-    return k33 ? launch_lds<3, 3>(p, vec16, stream) : launch_lds<5, 5>(p, vec16, stream);
+  // The plan (kernel choice + band / slab geometry) depends on the shapes fixed at setup, the variant and the
+  // pointers' alignment only: it is computed at the first run after a setup and kept with the operator.
+  const uint32_t key = 0x80000000u | (static_cast<uint32_t>(in_addr & 15u)) | (static_cast<uint32_t>(out_addr & 15u) << 4) |
+                       (static_cast<uint32_t>(a->variant & 0xFF) << 8) | ((a->batch & 0x7FFFu) << 16);
+  struct qnnp_hip_dwconv_plan local_plan;
+  struct qnnp_hip_dwconv_plan* plan = a->plan != nullptr ? a->plan : &local_plan;
+  if (a->plan == nullptr || plan->key != key) {
+    plan->key = 0;
+    const int rc = make_plan(p, a, in_addr, out_addr, plan);
+    if (rc != QNNP_HIP_OK) return rc;
+    plan->key = key;
+  } else {
+    p.CS = plan->CS; p.TOH = plan->TOH; p.IR = plan->IR; p.IC = plan->IC; p.PP = plan->PP;
+    p.bands = plan->bands; p.slabs = plan->slabs; p.store_mode = plan->store_mode;
   }
-
+  switch (plan->kernel) {
+    case kPlanMfmaLds:
+      if (kernel_name != nullptr) *kernel_name = "q8_dwconv_mfma_lds_3x3";
+      return launch_mfma_lds(p, stream);
+    case kPlanMfma:
+      if (kernel_name != nullptr) *kernel_name = "q8_dwconv_mfma_3x3";
+      return launch_mfma<3, 3>(p, stream);
+    case kPlanRow:
+      if (kernel_name != nullptr) *kernel_name = "q8_dwconv_row_3x3";
+      return launch_row(p, stream);
+    case kPlanLds33:
+      if (kernel_name != nullptr) *kernel_name = "q8_dwconv_lds_3x3";
+      return launch_lds<3, 3>(p, plan->vec16 != 0, stream);
+    case kPlanLds55:
+      if (kernel_name != nullptr) *kernel_name = "q8_dwconv_lds_5x5";
+      return launch_lds<5, 5>(p, plan->vec16 != 0, stream);
+    default:
+      break;
+  }
   if (kernel_name != nullptr) *kernel_name = "q8_dwconv_direct";
   const uint64_t total = static_cast<uint64_t>(p.batch) * p.OH * p.OW * p.C;
   uint64_t blocks = (total + 255) / 256;

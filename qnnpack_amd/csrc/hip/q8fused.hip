@@ -23,9 +23,10 @@
 
 #include <stdint.h>
 
-#include "igemm_epilogue.cuh"
+#include "igemm_epilogue.hip.h"
 #include "igemm_params.h"
-#include "requant.cuh"
+#include "per_device.h"
+#include "requant.hip.h"
 
 namespace qnnp {
 
@@ -417,19 +418,18 @@ extern "C" int qnnp_hip_fused_block_run(const struct qnnp_hip_fused_args* a, con
   p.add = a->add;
   if (p.kb3 > p.kblocks3 || (a->has_expand && p.kb1 > p.kblocks1)) return QNNP_HIP_EINVAL;
 
-  static bool attr_set = false;
-  if (!attr_set) {
+  static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
+  if (attr_once.first()) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_fused_block_kernel<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_fused_block_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
     (void) hipGetLastError();
-    attr_set = true;
   }
   const uint64_t total_tiles = static_cast<uint64_t>(a->batch) * p.tiles_x * p.tiles_y;
   if (total_tiles > 0x7FFFFFFFull) return QNNP_HIP_EINVAL;
-  int cus = 0;
-  if (qnnp_hip_device_info(nullptr, 0, &cus, nullptr, nullptr) != QNNP_HIP_OK || cus <= 0) cus = 256;
+  int cus = qnnp_hip_compute_units();
+  if (cus <= 0) cus = 256;
   uint32_t per_cu = kLdsLimit / lds_bytes;
   if (per_cu > 4u) per_cu = 4u;
   uint64_t blocks = static_cast<uint64_t>(cus) * per_cu;

@@ -44,9 +44,9 @@
 
 #include <type_traits>
 
-#include "igemm_epilogue.cuh"
+#include "igemm_epilogue.hip.h"
 #include "igemm_params.h"
-#include "requant.cuh"
+#include "requant.hip.h"
 
 namespace qnnp {
 
@@ -501,7 +501,7 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
   __syncthreads();
   QNNP_TRACE(p, blockIdx.x, 0, 3);
 
-  // ---- fused epilogue (igemm_epilogue.cuh); the requantization flavour is chosen once ----
+  // ---- fused epilogue (igemm_epilogue.hip.h); the requantization flavour is chosen once ----
   const uint32_t raw_to_centred = 128u * p.k_pad;      // sum(a') = sum(a) - 128 * k_pad
   requant_dispatch(p.rq, [&](auto shift0, auto full) {
     if (p.store_mode == 2) {

@@ -39,10 +39,10 @@
 
 #include <stdint.h>
 
-#include "igemm_epilogue.cuh"
+#include "igemm_epilogue.hip.h"
 #include "igemm_params.h"
 #include "qnnp_hip.h"
-#include "requant.cuh"
+#include "requant.hip.h"
 
 
 namespace {
@@ -373,7 +373,7 @@ void q8_igemm_mfma_kernel(const IgemmParams p_in)
     }
     __syncthreads();
 
-    // ---- fused epilogue (igemm_epilogue.cuh); the requantization flavour is chosen once per tile ----
+    // ---- fused epilogue (igemm_epilogue.hip.h); the requantization flavour is chosen once per tile ----
     if (p.store_mode == 2 && p.out_rows == nullptr) {
       // staged: requantized tile -> LDS (row-major image of the output) -> line-sized coalesced stores
       qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
@@ -536,8 +536,8 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   p.trace = static_cast<unsigned long long*>(qnnp_hip_trace_buffer());
 #endif
   {
-    int cus = 0;
-    p.cu_count = (qnnp_hip_device_info(nullptr, 0, &cus, nullptr, nullptr) == QNNP_HIP_OK && cus > 0) ? static_cast<uint32_t>(cus) : 256u;
+    const int cus = qnnp_hip_compute_units();
+    p.cu_count = cus > 0 ? static_cast<uint32_t>(cus) : 256u;
   }
 
   // widest activation vector the actual alignment allows (a vector never straddles a tap)

@@ -16,7 +16,7 @@
 
 #include <stdint.h>
 
-#include "add_math.cuh"
+#include "add_math.hip.h"
 #include "qnnp_hip.h"
 
 namespace qnnp {
@@ -153,18 +153,8 @@ inline uint32_t grid_for(uint64_t items, uint32_t cus)
 
 inline uint32_t device_cus()
 {
-  static uint32_t cus = 0;
-  if (cus == 0) {
-    int cu_count = 0, clock = 0;
-    size_t mem = 0;
-    char arch[32];
-    if (qnnp_hip_device_info(arch, sizeof(arch), &cu_count, &clock, &mem) == QNNP_HIP_OK && cu_count > 0) {
-      cus = static_cast<uint32_t>(cu_count);
-    } else {
-      cus = 256;
-    }
-  }
-  return cus;
+  const int cus = qnnp_hip_compute_units();   // of the active device context
+  return cus > 0 ? static_cast<uint32_t>(cus) : 256u;
 }
 
 inline bool aligned(const void* p, uintptr_t a) { return reinterpret_cast<uintptr_t>(p) % a == 0; }

@@ -17,7 +17,7 @@
  *     MFMA B-operand layout (lane l = row l%32, K half l/32), the loads of the next
  *     block being in flight while the current one is multiplied and requantized;
  *   - per 32-channel block: K/32 MFMAs against fragments read from LDS, the fused
- *     Q31 epilogue of igemm_epilogue.cuh, one 16-byte store per lane.
+ *     Q31 epilogue of igemm_epilogue.hip.h, one 16-byte store per lane.
  * Rows are independent, so there is no exchange between waves at all.
  *
  * Zero-point algebra as in pack.h; row sums over the RAW bytes with v_sad_u8 (K
@@ -29,9 +29,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-#include "igemm_epilogue.cuh"
+#include "igemm_epilogue.hip.h"
 #include "igemm_params.h"
-#include "requant.cuh"
+#include "per_device.h"
+#include "requant.hip.h"
 
 namespace qnnp {
 
@@ -578,11 +579,10 @@ bool convstream_c3_supported(const IgemmParams& p, uint32_t groups)
 int convstream_c3_launch(const IgemmParams& p, hipStream_t stream, const char** name)
 {
   const uint32_t lds_bytes = (p.n_pad / 32u) * 2u * 1024u + ((p.n_pad * 4u + 1023u) & ~1023u);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
+  if (attr_once.first()) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(q8_conv_stream_c3_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-    attr_set = true;
   }
   const uint32_t units = (p.rows + 31u) / 32u;
   uint32_t grid = p.cu_count * 4u;

@@ -40,26 +40,43 @@ struct qnnp_hip_requant {
                                  * reduction length), or 0 = unknown: lets the device pick a cheaper rounding sequence */
 };
 
-/* ---- runtime ---------------------------------------------------------- */
-int qnnp_hip_init(int device /* <0: current/env */);
+/* ---- runtime (runtime.hip) ----------------------------------------------
+ * One context per gfx950 device (stream, asynchrony flag, fill table, properties). qnnp_hip_init binds the
+ * PRIMARY device; qnnp_hip_bind adds others. Every call below acts on the calling thread's ACTIVE context:
+ * the one entered with qnnp_hip_enter (operators enter their own device), else the thread's selected device
+ * (qnnp_hip_select), else the primary. Thread-local: selection, active context, hipGraph capture. */
+int qnnp_hip_init(int device /* <0: the calling thread's current HIP device */);
+int qnnp_hip_bind(int device);           /* bind one more device after init (idempotent) */
 int qnnp_hip_shutdown(void);
-int qnnp_hip_device(void);
+int qnnp_hip_device_count(void);
+int qnnp_hip_select(int device);         /* the calling thread's library device from now on (must be bound) */
+int qnnp_hip_device(void);               /* active context's device ordinal, -1 if none */
+/* enter: make `device`'s context active for this thread and its HIP device current; returns a token (< 0: the
+ * device is not bound). leave(token) restores the previous context and the previous current HIP device. */
+int qnnp_hip_enter(int device);
+void qnnp_hip_leave(int token);
 int qnnp_hip_device_info(char* arch, size_t arch_len, int* cus, int* clock_khz, size_t* mem_bytes);
+int qnnp_hip_compute_units(void);
 void qnnp_hip_set_stream(void* stream);
-void* qnnp_hip_get_stream(void);
+void* qnnp_hip_get_stream(void);         /* the stream a launch of this thread goes to (its capture stream while recording) */
+void qnnp_hip_set_async(int async);
+int qnnp_hip_get_async(void);
 int qnnp_hip_stream_sync(void);
 /* device table [256][16]: entry v = sixteen bytes of value v (constant LDS-DMA sources) */
 const uint8_t* qnnp_hip_fill_table(void);
+#ifdef QNNP_ENABLE_ABLATION
 /* measurement builds: device buffer for in-kernel cycle stamps (NULL unless env QNNP_GFX950_TRACE is set) and its dump */
 void* qnnp_hip_trace_buffer(void);
 int qnnp_hip_trace_dump(unsigned long long* host, size_t count);
+#endif
 
 void* qnnp_hip_alloc(size_t bytes);
 void qnnp_hip_free(void* p);
+/* async = 0: complete on return and ordered behind the work already enqueued on the library stream */
 int qnnp_hip_h2d(void* dst, const void* src, size_t bytes, int async);
 int qnnp_hip_d2h(void* dst, const void* src, size_t bytes, int async);
 int qnnp_hip_memset(void* dst, int value, size_t bytes);
-/* 1 = device-accessible pointer on the bound device, 0 = host memory */
+/* 1 = memory of the active device (or managed), 0 = host memory, -1 = memory of another device */
 int qnnp_hip_is_device_pointer(const void* p);
 
 /* hipEvent-based timing on the library stream (for qnnp_gfx950_time_operator) */
@@ -68,16 +85,16 @@ int qnnp_hip_timer_start(void* timer);
 int qnnp_hip_timer_stop_ms(void* timer, float* ms);
 void qnnp_hip_timer_destroy(void* timer);
 
-/* diagnostic: sustained rate (TOP/s) of a bare v_mfma_i32_32x32x32_i8 loop over `compute_units` workgroups */
-int qnnp_hip_mfma_probe(int random_operands, int iters, int compute_units, float* tops_out);
-
-/* hipGraph capture of operator launches on the library stream (a private stream stands in for the default
+/* hipGraph capture of the calling thread's operator launches (a private stream stands in for the default
  * stream, which cannot be captured); replay = one submission, no per-launch gaps */
 int qnnp_hip_graph_capturing(void);
 int qnnp_hip_graph_begin(void);
 int qnnp_hip_graph_end(void** graph);
+int qnnp_hip_graph_device(void* graph);
 int qnnp_hip_graph_launch(void* graph);
 int qnnp_hip_graph_time(void* graph, int warmup, int iters, float* avg_ms);
+/* `samples` event-bracketed batches of `iters` replays; the median batch / iters */
+int qnnp_hip_graph_time_median(void* graph, int warmup, int iters, int samples, float* avg_ms);
 int qnnp_hip_graph_sync(void* graph);
 void qnnp_hip_graph_destroy(void* graph);
 
@@ -164,6 +181,15 @@ int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* args, const char** kern
  * (the reference's own folding, src/qnnpack/pack.h:146-159); padding taps read
  * a = input_zero_point.
  */
+/* Launch plan of a depthwise operator (kernel choice + band / slab geometry). It depends on what setup fixes, on the
+ * variant and on the tensors' alignment only, so the operator keeps it: computed at the first run after a setup
+ * (setup zeroes `key`), reused by every later run (the reference's run path plans nothing either, src/operator-run.c:647-710). */
+struct qnnp_hip_dwconv_plan {
+  uint32_t key;               /* 0 = not computed; else the (alignment, variant, batch) signature it is valid for */
+  uint32_t kernel;
+  uint32_t CS, TOH, IR, IC, PP, bands, slabs, store_mode, vec16;
+};
+
 struct qnnp_hip_dwconv_args {
   const uint8_t* input;
   uint8_t* output;
@@ -185,6 +211,7 @@ struct qnnp_hip_dwconv_args {
   uint32_t input_zero_point;
   struct qnnp_hip_requant rq;
   int variant;                /* 0 auto, 1 generic direct, 2 LDS-tiled, 3 register sliding window (3x3), 4 matrix-core (gather), 5 matrix-core (LDS band) */
+  struct qnnp_hip_dwconv_plan* plan;   /* optional plan cache owned by the caller (NULL: plan on every call) */
 };
 int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* args, const char** kernel_name);
 

@@ -1,5 +1,5 @@
 /*
- * requant.cuh -- the fused Q31 fixed-point down-convert, in registers.
+ * requant.hip.h -- the fused Q31 fixed-point down-convert, in registers.
  *
  * Bit-exact with qnnp_q31_requantize (reference src/qnnpack/requantization.h:464-480;
  * stand-alone spec src/requantization/q31-scalar.c:17-138), which every reference

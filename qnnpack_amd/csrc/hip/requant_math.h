@@ -1,6 +1,6 @@
 /*
  * requant_math.h -- the Q31 fixed-point down-convert as plain integer arithmetic,
- * written once and compiled both for the device (requant.cuh) and for the host
+ * written once and compiled both for the device (requant.hip.h) and for the host
  * (debug-hooks.c, so the CPU test tier can check it against the oracle over
  * hundreds of millions of accumulators without a GPU).
  *

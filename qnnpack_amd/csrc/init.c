@@ -22,7 +22,6 @@
 struct qnnp_state qnnp_state = {
   .initialized = false,
   .requested_device = -1,
-  .async = 0,
   .opt_gemm_kernel = 0,
   .opt_dwconv_kernel = 0,
   .opt_timing_graph = 1,
@@ -68,14 +67,26 @@ enum qnnp_status qnnp_deinitialize(void)
 
 /* ---- qnnpack_gfx950.h ---- */
 
+/* run `expr` (an int QNNP_HIP_* code or a value) inside the calling thread's selected device context */
+#define QNNP_WITH_SELECTED_DEVICE(token) \
+  const int token = qnnp_hip_enter(qnnp_hip_device())
+
 enum qnnp_status qnnp_gfx950_set_device(int device)
 {
   enum qnnp_status status = qnnp_status_success;
+  if (device < 0) {
+    return qnnp_status_invalid_parameter;
+  }
   pthread_mutex_lock(&init_lock);
-  if (qnnp_state.initialized || device < 0) {
-    status = qnnp_status_invalid_parameter;
+  if (!qnnp_state.initialized) {
+    qnnp_state.requested_device = device;          /* the primary device qnnp_initialize will bind */
   } else {
-    qnnp_state.requested_device = device;
+    /* after initialization: bind the device if this is its first use and make it the calling THREAD's device --
+     * operators created from this thread live there (one host thread per GPU drives a whole node) */
+    if (qnnp_hip_bind(device) != QNNP_HIP_OK || qnnp_hip_select(device) != QNNP_HIP_OK) {
+      qnnp_log_error("qnnp_gfx950_set_device: device %d is not a usable gfx950 GPU", device);
+      status = qnnp_status_invalid_parameter;
+    }
   }
   pthread_mutex_unlock(&init_lock);
   return status;
@@ -84,6 +95,11 @@ enum qnnp_status qnnp_gfx950_set_device(int device)
 int qnnp_gfx950_get_device(void)
 {
   return qnnp_state.initialized ? qnnp_hip_device() : -1;
+}
+
+int qnnp_gfx950_device_count(void)
+{
+  return qnnp_hip_device_count();
 }
 
 enum qnnp_status qnnp_gfx950_set_stream(void* hip_stream)
@@ -95,20 +111,27 @@ enum qnnp_status qnnp_gfx950_set_stream(void* hip_stream)
 
 enum qnnp_status qnnp_gfx950_set_async(int async)
 {
-  qnnp_state.async = async != 0;
+  if (!qnnp_state.initialized) return qnnp_status_uninitialized;
+  qnnp_hip_set_async(async);
   return qnnp_status_success;
 }
 
 enum qnnp_status qnnp_gfx950_synchronize(void)
 {
   if (!qnnp_state.initialized) return qnnp_status_uninitialized;
-  return qnnp_hip_stream_sync() == QNNP_HIP_OK ? qnnp_status_success : qnnp_status_unsupported_hardware;
+  QNNP_WITH_SELECTED_DEVICE(token);
+  const int rc = qnnp_hip_stream_sync();
+  qnnp_hip_leave(token);
+  return rc == QNNP_HIP_OK ? qnnp_status_success : qnnp_status_unsupported_hardware;
 }
 
 void* qnnp_gfx950_malloc(size_t bytes)
 {
   if (!qnnp_state.initialized) return NULL;
-  return qnnp_hip_alloc(bytes);
+  QNNP_WITH_SELECTED_DEVICE(token);
+  void* p = qnnp_hip_alloc(bytes);
+  qnnp_hip_leave(token);
+  return p;
 }
 
 void qnnp_gfx950_free(void* device_ptr)
@@ -119,22 +142,28 @@ void qnnp_gfx950_free(void* device_ptr)
 enum qnnp_status qnnp_gfx950_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes)
 {
   if (!qnnp_state.initialized) return qnnp_status_uninitialized;
-  return qnnp_hip_h2d(dst_device, src_host, bytes, 0) == QNNP_HIP_OK ?
-      qnnp_status_success : qnnp_status_invalid_parameter;
+  QNNP_WITH_SELECTED_DEVICE(token);
+  const int rc = qnnp_hip_h2d(dst_device, src_host, bytes, 0);
+  qnnp_hip_leave(token);
+  return rc == QNNP_HIP_OK ? qnnp_status_success : qnnp_status_invalid_parameter;
 }
 
 enum qnnp_status qnnp_gfx950_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes)
 {
   if (!qnnp_state.initialized) return qnnp_status_uninitialized;
-  return qnnp_hip_d2h(dst_host, src_device, bytes, 0) == QNNP_HIP_OK ?
-      qnnp_status_success : qnnp_status_invalid_parameter;
+  QNNP_WITH_SELECTED_DEVICE(token);
+  const int rc = qnnp_hip_d2h(dst_host, src_device, bytes, 0);
+  qnnp_hip_leave(token);
+  return rc == QNNP_HIP_OK ? qnnp_status_success : qnnp_status_invalid_parameter;
 }
 
 enum qnnp_status qnnp_gfx950_memset(void* dst_device, int value, size_t bytes)
 {
   if (!qnnp_state.initialized) return qnnp_status_uninitialized;
-  return qnnp_hip_memset(dst_device, value, bytes) == QNNP_HIP_OK ?
-      qnnp_status_success : qnnp_status_invalid_parameter;
+  QNNP_WITH_SELECTED_DEVICE(token);
+  const int rc = qnnp_hip_memset(dst_device, value, bytes);
+  qnnp_hip_leave(token);
+  return rc == QNNP_HIP_OK ? qnnp_status_success : qnnp_status_invalid_parameter;
 }
 
 enum qnnp_status qnnp_gfx950_set_option(const char* key, int value)

@@ -17,6 +17,9 @@ enum qnnp_status qnnp_delete_operator(qnnp_operator_t op)
   if (op == NULL) {
     return qnnp_status_invalid_parameter;
   }
+  /* the allocations belong to the operator's device (a negative token = the library was deinitialized: the
+   * runtime then frees by pointer on whatever device is current, which HIP accepts) */
+  const int token = qnnp_hip_enter(op->device);
   qnnp_hip_free(op->d_weights);
   qnnp_hip_free(op->d_bias);
   qnnp_hip_free(op->d_dwm_x);
@@ -33,5 +36,6 @@ enum qnnp_status qnnp_delete_operator(qnnp_operator_t op)
   qnnp_hip_free(op->d_stage_in2);
   qnnp_hip_free(op->d_stage_out);
   free(op);
+  qnnp_hip_leave(token);
   return qnnp_status_success;
 }

@@ -11,6 +11,11 @@
  * Like the reference, nothing is allocated and nothing is logged on this path
  * (device pointers). Host pointers given to setup are staged through device
  * scratch sized at setup.
+ *
+ * Threading: as in the reference (run contexts are stack-local, src/operator-run.c:783-795), distinct operators
+ * may be run from different threads at the same time. Nothing on this path is process-global mutable state: the
+ * operator names its device, the launch stream / asynchrony flag belong to that device's context, and a hipGraph
+ * capture belongs to the capturing thread (hip/runtime.hip).
  */
 #include <stddef.h>
 #include <stdint.h>
@@ -22,6 +27,8 @@
 #include "operator.h"
 #include "state.h"
 
+#define QNNP_TIMING_SAMPLES 5
+
 static enum qnnp_status status_from_hip(int rc)
 {
   switch (rc) {
@@ -32,21 +39,26 @@ static enum qnnp_status status_from_hip(int rc)
   }
 }
 
-/* Enqueue the operator's kernel on the library stream, reading `input` and
- * writing `output` (both device pointers). */
-int qnnp_bind_endpoint(const void* ptr, size_t span, int* on_device, void** stage, size_t* capacity)
+enum qnnp_status qnnp_bind_endpoint(const void* ptr, size_t span, int* on_device, void** stage, size_t* capacity)
 {
-  *on_device = qnnp_hip_is_device_pointer(ptr);
-  if (*on_device) return 0;
+  const int where = qnnp_hip_is_device_pointer(ptr);
+  if (where < 0) {
+    return qnnp_status_invalid_parameter;   /* memory of a GPU other than the operator's */
+  }
+  *on_device = where;
+  if (where) return qnnp_status_success;
   if (*capacity < span) {
     qnnp_hip_free(*stage);
     *capacity = 0;
     *stage = qnnp_hip_alloc(span);
-    if (*stage == NULL) return -1;
+    if (*stage == NULL) return qnnp_status_out_of_memory;
     *capacity = span;
   }
-  return 0;
+  return qnnp_status_success;
 }
+
+/* Enqueue the operator's kernel on the library stream of the active context, reading `input` and
+ * writing `output` (both device pointers). */
 
 static int launch(struct qnnp_operator* op, const void* input, const void* input2, void* output)
 {
@@ -83,6 +95,7 @@ static int launch(struct qnnp_operator* op, const void* input, const void* input
         .input_zero_point = op->input_zero_point,
         .rq = op->requant,
         .variant = op->variant,
+        .plan = &op->dw_plan,
       };
       return qnnp_hip_dwconv_run(&args, &op->kernel_name);
     }
@@ -242,21 +255,17 @@ static int launch(struct qnnp_operator* op, const void* input, const void* input
   }
 }
 
-enum qnnp_status qnnp_run_operator(qnnp_operator_t op, pthreadpool_t threadpool)
+static enum qnnp_status run_operator(qnnp_operator_t op)
 {
-  (void) threadpool;
-  if (op == NULL) {
-    return qnnp_status_invalid_parameter;
-  }
-  if (!qnnp_state.initialized) {
-    return qnnp_status_uninitialized;
+  if (!op->setup_valid) {
+    return qnnp_status_invalid_parameter;  /* run before setup, or after a setup that failed */
   }
   /* reference operator-run.c:642-644: nothing to do for an empty batch */
   if (op->batch_size == 0) {
     return qnnp_status_success;
   }
   if (op->input == NULL || op->output == NULL) {
-    return qnnp_status_invalid_parameter;  /* run before setup */
+    return qnnp_status_invalid_parameter;
   }
 
   const void* input = op->input;
@@ -304,31 +313,46 @@ enum qnnp_status qnnp_run_operator(qnnp_operator_t op, pthreadpool_t threadpool)
   if (capturing) {
     return qnnp_status_success;            /* recorded into the graph; nothing has run yet */
   }
-  if (staged || !qnnp_state.async) {
+  if (staged || !qnnp_hip_get_async()) {
     /* reference semantics: outputs are complete when run returns */
     return status_from_hip(qnnp_hip_stream_sync());
   }
   return qnnp_status_success;
 }
 
-/* ---- qnnpack_gfx950.h timing helpers ---------------------------------- */
-
-enum qnnp_status qnnp_gfx950_time_operator_rotating(
-    qnnp_operator_t op, size_t nsets, const void* const* inputs, void* const* outputs,
-    int warmup, int iters, float* avg_ms_out)
+enum qnnp_status qnnp_run_operator(qnnp_operator_t op, pthreadpool_t threadpool)
 {
-  if (op == NULL || avg_ms_out == NULL || iters <= 0 || nsets == 0 || inputs == NULL || outputs == NULL) {
+  (void) threadpool;
+  if (op == NULL) {
     return qnnp_status_invalid_parameter;
   }
   if (!qnnp_state.initialized) {
     return qnnp_status_uninitialized;
+  }
+  const int token = qnnp_hip_enter(op->device);
+  if (token < 0) {
+    return qnnp_status_invalid_parameter;
+  }
+  const enum qnnp_status status = run_operator(op);
+  qnnp_hip_leave(token);
+  return status;
+}
+
+/* ---- qnnpack_gfx950.h timing helpers ---------------------------------- */
+
+static enum qnnp_status time_operator_rotating(
+    qnnp_operator_t op, size_t nsets, const void* const* inputs, void* const* outputs,
+    int warmup, int iters, float* avg_ms_out)
+{
+  if (!op->setup_valid) {
+    return qnnp_status_invalid_parameter;
   }
   if (op->batch_size == 0) {
     *avg_ms_out = 0.0f;
     return qnnp_status_success;
   }
   for (size_t s = 0; s < nsets; s++) {
-    if (!qnnp_hip_is_device_pointer(inputs[s]) || !qnnp_hip_is_device_pointer(outputs[s])) {
+    if (qnnp_hip_is_device_pointer(inputs[s]) != 1 || qnnp_hip_is_device_pointer(outputs[s]) != 1) {
       return qnnp_status_invalid_parameter;
     }
   }
@@ -337,7 +361,9 @@ enum qnnp_status qnnp_gfx950_time_operator_rotating(
   }
   /* Preferred: record the `iters` launches into a hipGraph and time its replay -- one submission, so the
    * figure is kernel time, not the host's per-launch dispatch gap (5-8 us, as large as the small layers).
-   * Falls back to a plain launch loop if the capture is refused. */
+   * The replay is timed QNNP_TIMING_SAMPLES times, each sample its own event pair, and the MEDIAN sample is
+   * reported (one sample is at the mercy of the clock state of the moment). Falls back to a plain launch loop
+   * if the capture is refused. */
   if (qnnp_state.opt_timing_graph && !qnnp_hip_graph_capturing() && qnnp_hip_graph_begin() == QNNP_HIP_OK) {
     int rc = QNNP_HIP_OK;
     size_t gset = 0;
@@ -350,7 +376,7 @@ enum qnnp_status qnnp_gfx950_time_operator_rotating(
     if (rc == QNNP_HIP_OK && rc_end == QNNP_HIP_OK) {
       float ms = 0.0f;
       const int reps = warmup > 0 ? 1 : 0;
-      rc = qnnp_hip_graph_time(graph, reps, 1, &ms);
+      rc = qnnp_hip_graph_time_median(graph, reps, 1, QNNP_TIMING_SAMPLES, &ms);
       qnnp_hip_graph_destroy(graph);
       if (rc == QNNP_HIP_OK) {
         *avg_ms_out = ms / (float) iters;
@@ -385,6 +411,25 @@ enum qnnp_status qnnp_gfx950_time_operator_rotating(
   return status;
 }
 
+enum qnnp_status qnnp_gfx950_time_operator_rotating(
+    qnnp_operator_t op, size_t nsets, const void* const* inputs, void* const* outputs,
+    int warmup, int iters, float* avg_ms_out)
+{
+  if (op == NULL || avg_ms_out == NULL || iters <= 0 || nsets == 0 || inputs == NULL || outputs == NULL) {
+    return qnnp_status_invalid_parameter;
+  }
+  if (!qnnp_state.initialized) {
+    return qnnp_status_uninitialized;
+  }
+  const int token = qnnp_hip_enter(op->device);
+  if (token < 0) {
+    return qnnp_status_invalid_parameter;
+  }
+  const enum qnnp_status status = time_operator_rotating(op, nsets, inputs, outputs, warmup, iters, avg_ms_out);
+  qnnp_hip_leave(token);
+  return status;
+}
+
 enum qnnp_status qnnp_gfx950_time_operator(
     qnnp_operator_t op, int warmup, int iters, float* avg_ms_out)
 {
@@ -401,7 +446,12 @@ enum qnnp_status qnnp_gfx950_time_operator(
 enum qnnp_status qnnp_gfx950_graph_begin(void)
 {
   if (!qnnp_state.initialized) return qnnp_status_uninitialized;
-  return status_from_hip(qnnp_hip_graph_begin());
+  /* the calling thread records launches on its selected device until graph_end */
+  const int token = qnnp_hip_enter(qnnp_hip_device());
+  if (token < 0) return qnnp_status_unsupported_hardware;
+  const enum qnnp_status status = status_from_hip(qnnp_hip_graph_begin());
+  qnnp_hip_leave(token);
+  return status;
 }
 
 enum qnnp_status qnnp_gfx950_graph_end(void** graph_out)
@@ -416,13 +466,17 @@ enum qnnp_status qnnp_gfx950_graph_launch(void* graph)
   if (graph == NULL) return qnnp_status_invalid_parameter;
   const int rc = qnnp_hip_graph_launch(graph);
   if (rc != QNNP_HIP_OK) return status_from_hip(rc);
-  return qnnp_state.async ? qnnp_status_success : status_from_hip(qnnp_hip_graph_sync(graph));
+  const int token = qnnp_hip_enter(qnnp_hip_graph_device(graph));
+  const int async = token >= 0 ? qnnp_hip_get_async() : 0;
+  qnnp_hip_leave(token);
+  return async ? qnnp_status_success : status_from_hip(qnnp_hip_graph_sync(graph));
 }
 
 enum qnnp_status qnnp_gfx950_graph_time(void* graph, int warmup, int iters, float* avg_ms_out)
 {
   if (graph == NULL || avg_ms_out == NULL || iters <= 0) return qnnp_status_invalid_parameter;
-  return status_from_hip(qnnp_hip_graph_time(graph, warmup, iters, avg_ms_out));
+  /* QNNP_TIMING_SAMPLES event-bracketed batches of `iters` replays each; the median batch / iters */
+  return status_from_hip(qnnp_hip_graph_time_median(graph, warmup, iters, QNNP_TIMING_SAMPLES, avg_ms_out));
 }
 
 enum qnnp_status qnnp_gfx950_graph_synchronize(void* graph)
@@ -434,15 +488,4 @@ enum qnnp_status qnnp_gfx950_graph_synchronize(void* graph)
 void qnnp_gfx950_graph_destroy(void* graph)
 {
   qnnp_hip_graph_destroy(graph);
-}
-
-/* ---- qnnpack_gfx950.h diagnostics --------------------------------------- */
-
-enum qnnp_status qnnp_gfx950_mfma_probe(int random_operands, int iters, float* tops_out)
-{
-  if (tops_out == NULL || iters <= 0) return qnnp_status_invalid_parameter;
-  if (!qnnp_state.initialized) return qnnp_status_uninitialized;
-  int cus = 0;
-  if (qnnp_hip_device_info(NULL, 0, &cus, NULL, NULL) != QNNP_HIP_OK || cus <= 0) return qnnp_status_unsupported_hardware;
-  return status_from_hip(qnnp_hip_mfma_probe(random_operands, iters, cus, tops_out));
 }

@@ -11,6 +11,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <qnnpack.h>
+
 #include "hip/qnnp_hip.h"
 
 /* subset of reference enum qnnp_ukernel_type (src/qnnpack/operator.h:23-37) */
@@ -132,11 +134,18 @@ struct qnnp_operator {
 
   int variant;            /* kernel-variant option captured at setup */
   const char* kernel_name;
+
+  int device;             /* HIP ordinal of the GPU that owns every d_* allocation above: create runs on the calling
+                           * thread's selected device, setup / run / delete enter this one (runtime.hip) */
+  int setup_valid;        /* 1 after a successful setup; cleared where a setup starts to change the operator, so a
+                           * failed setup cannot be run against half-updated geometry / tables */
+  struct qnnp_hip_dwconv_plan dw_plan;   /* depthwise launch plan, computed at the first run after a setup */
 };
 
-/* Decide where a caller pointer lives and (re)size the device staging buffer a host pointer needs.
- * Returns 0 on success. (operator-run.c) */
-int qnnp_bind_endpoint(const void* ptr, size_t span, int* on_device, void** stage, size_t* capacity);
+/* Decide where a caller pointer lives and (re)size the device staging buffer a host pointer needs:
+ * success; out_of_memory (staging); invalid_parameter (device memory of a GPU other than the operator's).
+ * (operator-run.c) */
+enum qnnp_status qnnp_bind_endpoint(const void* ptr, size_t span, int* on_device, void** stage, size_t* capacity);
 
 /* fused-block.c */
 int qnnp_fused_block_launch(struct qnnp_operator* op, const void* input, void* output);

@@ -6,7 +6,7 @@
  * in [2^30, 2^31) and a right shift in [0, 31].
  *
  * The arithmetic that consumes these parameters (the normative rounding of
- * qnnp_q31_requantize, requantization.h:464-480) lives in hip/requant.cuh.
+ * qnnp_q31_requantize, requantization.h:464-480) lives in hip/requant.hip.h.
  */
 #pragma once
 

@@ -2,7 +2,10 @@
  * state.h -- process-wide library state. Role-equivalent to the reference's
  * global `qnnp_params` (src/qnnpack/params.h:520-538): there it is the per-ISA
  * microkernel table filled by init(); here it records that a gfx950 device is
- * bound plus the extension knobs of qnnpack_gfx950.h.
+ * bound plus the A/B knobs of qnnpack_gfx950.h, which are read at SETUP time only
+ * (an operator keeps the variant it was set up with). Everything the launch path
+ * needs -- stream, asynchrony, capture -- lives in the per-device contexts and
+ * thread-local state of hip/runtime.hip, not here.
  */
 #pragma once
 
@@ -10,8 +13,7 @@
 
 struct qnnp_state {
   bool initialized;
-  int requested_device;   /* -1: env / current */
-  int async;              /* 1: qnnp_run_operator only enqueues */
+  int requested_device;   /* primary device asked for before qnnp_initialize; -1: env / current */
   int opt_gemm_kernel;    /* 0 auto, 1 generic, 2 big-tile */
   int opt_dwconv_kernel;  /* 0 auto, 1 generic, 2 LDS-tiled */
   int opt_timing_graph;   /* 1: qnnp_gfx950_time_operator* replay a hipGraph of the launches (default) */

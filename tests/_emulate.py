@@ -46,7 +46,7 @@ def host_requant(L, scale, zp, qmin, qmax) -> Requant:
 
 
 def q31_requantize_np(acc: np.ndarray, rq: Requant) -> np.ndarray:
-    """hip/requant.cuh, vectorised in int64."""
+    """hip/requant.hip.h, vectorised in int64."""
     n = acc.astype(np.int64)
     p = n * int(rq.multiplier) + (1 << 30)
     q = ((p >> 31) + (1 << 31)) % (1 << 32) - (1 << 31)          # truncate to int32

@@ -22,6 +22,13 @@ def product():
 
 
 @pytest.fixture(scope="session")
+def debug_hooks(product):
+    """libqnnpack_gfx950_dbg.so: the create-time host logic exported for the CPU tier (not part of the product)."""
+    import qnnpack_amd
+    return qnnpack_amd.load_debug()
+
+
+@pytest.fixture(scope="session")
 def qnnp(product):
     """Product library bound to the GPU. Fails (never skips) when the device is unusable:
     a GPU-tier test passing without the HIP path would be a false parity claim."""

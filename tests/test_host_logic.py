@@ -16,8 +16,8 @@ SMALL_FC = [c for c in FC_CASES + EXTRA_FC_CASES if c.batch > 0 and c.batch * c.
 
 
 @pytest.fixture(scope="module")
-def hooks(product):
-    return em.bind_debug_hooks(product)
+def hooks(debug_hooks):
+    return em.bind_debug_hooks(debug_hooks)
 
 
 def test_requant_params_match_oracle(hooks):
@@ -91,10 +91,10 @@ def test_offset_table_semantics(hooks):
                                  (4 * 4 + 1) * 7, (4 * 4 + 2) * 7, (4 * 4 + 3) * 7, -1, -1, -1]
 
 
-def test_device_requantization_arithmetic_matches_oracle(product):
+def test_device_requantization_arithmetic_matches_oracle(debug_hooks):
     """hip/requant_math.h (the single-shift form the kernels evaluate) compiled for the host."""
     import ctypes
-    L = product.lib
+    L = debug_hooks.lib
     L.qnnp_debug_requant_fast.restype = None
     L.qnnp_debug_requant_fast.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_float, ctypes.c_uint8,
                                           ctypes.c_uint8, ctypes.c_uint8, ctypes.c_void_p]
@@ -115,11 +115,11 @@ def test_device_requantization_arithmetic_matches_oracle(product):
             assert np.array_equal(out, o1.q31_requantize(acc, scale, zp, qmin, qmax)), (scale, zp, qmin, qmax)
 
 
-def test_bounded_requantization_sequence_matches_oracle(product):
+def test_bounded_requantization_sequence_matches_oracle(debug_hooks):
     """hip/requant_math.h, qnnp_requant_scale_sn_bounded: the four-instruction rounding sequence the kernels use when
     the operator's accumulators are bounded at create time (|acc| < 2^bits, bits <= 30, 1 <= shift <= 20)."""
     import ctypes
-    L = product.lib
+    L = debug_hooks.lib
     fn = L.qnnp_debug_requant_fast_bits
     fn.restype = None
     fn.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_float, ctypes.c_uint8, ctypes.c_uint8, ctypes.c_uint8,
@@ -151,10 +151,10 @@ def test_bounded_requantization_sequence_matches_oracle(product):
         assert np.array_equal(out, o1.q31_requantize(acc, scale, 9, 0, 255)), (scale, bits)
 
 
-def test_accumulator_bound(product):
+def test_accumulator_bound(debug_hooks):
     """requantization.h, qnnp_accumulator_bits: |bias| + K * 255^2 < 2^bits, 0 when it does not fit 31 bits."""
     import ctypes
-    fn = product.lib.qnnp_debug_accumulator_bits
+    fn = debug_hooks.lib.qnnp_debug_accumulator_bits
     fn.restype = ctypes.c_uint32
     fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]
 
@@ -170,11 +170,11 @@ def test_accumulator_bound(product):
 
 
 @pytest.mark.parametrize("izp,kzp", [(127, 127), (0, 255), (255, 0), (3, 128), (128, 1)])
-def test_depthwise_matrix_core_weight_parts(product, izp, kzp):
+def test_depthwise_matrix_core_weight_parts(debug_hooks, izp, kzp):
     """qnnp_pack_dwconv_mfma (pack.h): int8 parts sum to w - kzp, the part count is minimal, and the folded bias
     makes  biasm + sum_t (a_t - 128) * x_t  ==  bias + sum_t (a_t - izp) * (w_t - kzp)  for every activation."""
     import ctypes
-    L = product.lib if hasattr(product, "lib") else product
+    L = debug_hooks.lib
     fn = L.qnnp_debug_pack_dwconv_mfma
     fn.restype = ctypes.c_uint32
     fn.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint8, ctypes.c_uint8,
