@@ -173,3 +173,44 @@ def test_c5_mobilenetv2_first_layer(qnnp):
         assert_bytes_equal(from_device(d_out), expected, "C5 first layer vs oracle")
     finally:
         qnnp.delete_operator(op)
+
+
+def test_c2_q8gemm_4096_cubed_full_output_vs_compiled_reference(qnnp):
+    """configs[1], every one of the 16.8 M output bytes: the compiled REFERENCE (oracle/_ref, its SSE2 q8gemm under
+    qnnp_fully_connected_nc_q8, all host threads) computes the same 4096^3 problem with bench.py's quantization
+    (bench/q8gemm.cc:103: zero points 127, scale 0.75, clamp [1, 254]) in well under a minute; the device output
+    must equal it byte for byte. Where the prebuilt reference did not travel, the oracle restatement (O1, pinned to it)
+    takes over on 512 rows so the test never silently does nothing."""
+    from oracle import ref
+    M = N = K = 4096
+    rng = np.random.default_rng(0xC2F011)
+    a = rng.integers(0, 256, size=(M, K), dtype=np.uint8)
+    w = rng.integers(0, 256, size=(N, K), dtype=np.uint8)
+    bias = rng.integers(-10000, 10001, size=N, dtype=np.int32)
+    op = qnnp.create_fully_connected_nc_q8(K, N, 127, 0.75, 127, 1.0, w, bias, 127, 1.0, 1, 254)
+    try:
+        d_a = to_device(a.reshape(-1))
+        d_c = to_device(np.full(M * N, FILL, np.uint8))
+        qnnp.setup_fully_connected_nc_q8(op, M, d_a, K, d_c, N)
+        qnnp.run_operator(op)
+        assert qnnp.operator_kernel(op) == "q8_gemm_mfma_256x256", qnnp.operator_kernel(op)
+        got = from_device(d_c).reshape(M, N)
+    finally:
+        qnnp.delete_operator(op)
+    if ref.available():
+        rlib = ref.lib()
+        want = np.full(M * N, FILL, np.uint8)
+        rop = rlib.create_fully_connected_nc_q8(K, N, 127, 0.75, 127, 1.0, w, bias, 127, 1.0, 1, 254)
+        pool = rlib.threadpool(16)
+        rlib.setup_fully_connected_nc_q8(rop, M, a.reshape(-1), K, want, N)
+        rlib.run_operator(rop, pool)
+        rlib.destroy_threadpool(pool)
+        rlib.delete_operator(rop)
+        assert_bytes_equal(got.reshape(-1), want, "4096^3 FULL output vs the compiled reference")
+    else:
+        rows = np.arange(0, M, 8)
+        o1.set_threads(8)
+        acc = o1.gemm_acc(np.ascontiguousarray(a[rows]), w, bias, 127, 127)
+        want = o1.requantize_rows(acc, np.float32(0.75), 127, 1, 254)
+        o1.set_threads(1)
+        assert_bytes_equal(got[rows].reshape(-1), want.reshape(-1), "4096^3 every 8th row vs oracle (no prebuilt reference here)")
