@@ -116,7 +116,8 @@ enum qnnp_status qnnp_gfx950_setup_fused_block(
  *                    8 = wave-per-8x8-block direct-convolution MFMA kernel (small windows, <= 64 channels, dense output)
  *   "dwconv_kernel": 0 = auto, 1 = generic direct kernel, 2 = LDS-tiled kernel, 3 = register sliding-window kernel (3x3),
  *                    4 = matrix-core kernel (diagonal MFMA operands; 3x3, channels % 16 == 0), tap operands gathered
- *                        from global memory, 5 = the same with the input band staged in LDS first
+ *                        from global memory, 5 = the same with the input band staged in LDS first,
+ *                    6 = column-sliding register window (3x3, stride 1 | 2): tap pairs shared between output rows
  *   "timing_graph":  1 (default) = qnnp_gfx950_time_operator* time a hipGraph replay of the launches (kernel
  *                    time without per-launch dispatch gaps); 0 = a plain back-to-back launch loop
  * Unknown key -> invalid_parameter. Kernel choices apply to operators set up afterwards. */

@@ -515,6 +515,298 @@ int launch_row(const DwParams& p, hipStream_t stream)
 }
 
 // --------------------------------------------------------------------------
+// Kernel G: column-sliding register window, 3x3, dilation 1, stride 1 or 2 (both axes), C % 4 == 0
+// --------------------------------------------------------------------------
+/*
+ * What bounds the depthwise kernels is VALU issue (PMC: 24.5 VALU instructions per output, 78 % VALU-active at a third
+ * of the HBM rate), and ten of those instructions are the tap arithmetic: five v_perm_b32 that pair two taps' bytes as
+ * int16 x 2 and five v_dot2_i32_i16. tools/ubench_valu.hip prices both at 3.2 cycles per wave-instruction (every
+ * 8-byte-encoded VALU op; the 4-byte VOP2 ones take 2.0), so the lever is the COUNT. This kernel shares the pairing:
+ *
+ *   a thread owns one 4-channel dword column j = ox * (C/4) + c/4 of the flattened output row and walks DOWN the output
+ *   rows of a segment. Per step it loads one new input row (stride 2: two) -- the three dwords at columns
+ *   ix0..ix0+2 -- and pairs
+ *       H[r] = (col0, col1) of input row r        (per channel: v_perm -> two int16)   used by the THREE output rows
+ *       Q[r] = (col2 @ r, col2 @ r+1)                                                  whose windows contain row r
+ *   so an output costs 2 x 4 new v_perm (stride 2: 3 x 4) instead of 5 x 4, and 5 x 4 v_dot2:
+ *       out(t) = sum_r H[t+r] . (w_r0, w_r1)  +  Q[t-1] . (0, w_02)  +  Q[t+1] . (w_12, w_22)        (stride 1)
+ *   Everything the window re-uses vertically stays in registers; the horizontal overlap (a dword is col0 / col1 / col2
+ *   of three neighbouring threads) is served by L1, and because consecutive lanes are consecutive dwords of the NHWC
+ *   row, every load and store instruction of a wave covers one contiguous run of memory (256 bytes for dense tensors).
+ *   No LDS, no barrier; the rows two steps ahead are in flight while a step computes.
+ * Padding: rows outside the image are wave-uniform (a wave = one image, one row segment) and replaced by the zero
+ * point without touching memory; columns outside the image exist only in the waves at the ends of a row (FIX flavour).
+ */
+constexpr int kColThreads = 256;
+
+template <int S, bool FIX>
+__device__ __forceinline__ void dwconv_col3x3_body(
+    const DwParams& p, const uint32_t n, const uint32_t oy0, const uint32_t oy1, const uint32_t ox, const uint32_t cg,
+    const bool ok0, const bool ok1, const bool ok2)
+{
+  // tap weights: W01[r] = (w_r0, w_r1) pairs, WQA = (0, w_02), WQB = (w_12, w_22); per channel of the group
+  uint32_t w01[3][4], wqa[4], wqb[4];
+  int32_t bias[4];
+  {
+    uint2 t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = *reinterpret_cast<const uint2*>(p.wadj + i * p.c_pad + cg);   // 4 x int16
+    auto lo16 = [](uint2 v, int c) -> uint32_t { return ((c < 2 ? v.x : v.y) >> ((c & 1) * 16)) & 0xFFFFu; };
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+      for (int r = 0; r < 3; r++) w01[r][c] = lo16(t[r * 3 + 0], c) | (lo16(t[r * 3 + 1], c) << 16);
+      wqa[c] = lo16(t[2], c) << 16;
+      wqb[c] = lo16(t[5], c) | (lo16(t[8], c) << 16);
+    }
+    const int4 bv = *reinterpret_cast<const int4*>(p.bias1 + cg);
+    bias[0] = bv.x; bias[1] = bv.y; bias[2] = bv.z; bias[3] = bv.w;
+  }
+
+  const uint32_t fill = p.izp * 0x01010101u;
+  const uint32_t row_bytes = p.W * p.in_stride;
+  // Buffer addressing: a descriptor over the whole tensor (built from kernel arguments only, so it stays in SGPRs),
+  // per lane a constant 32-bit byte offset inside a row, per row a SCALAR offset -- no vector address arithmetic in
+  // the loop. Invalid columns are clamped to column 0 (their value is replaced below).
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.input), 0, static_cast<int>(p.batch * p.H * row_bytes), 0x00020000);
+  const int32_t ix0 = static_cast<int32_t>(ox * S) - static_cast<int32_t>(p.pad_left);
+  uint32_t coff[3];
+  coff[0] = cg + (ok0 ? static_cast<uint32_t>(ix0) : 0u) * p.in_stride;
+  coff[1] = cg + (ok1 ? static_cast<uint32_t>(ix0 + 1) : 0u) * p.in_stride;
+  coff[2] = cg + (ok2 ? static_cast<uint32_t>(ix0 + 2) : 0u) * p.in_stride;
+  const uint32_t img_off = n * p.H * row_bytes;                     // wave-uniform
+  const int32_t iy_first = static_cast<int32_t>(oy0 * S) - static_cast<int32_t>(p.pad_top);
+
+  struct Row { uint32_t c[3]; };
+  // one input row: three dwords (wave-uniform row validity: no memory access for padding rows)
+  auto load_row = [&](int32_t iy) __attribute__((always_inline)) -> Row {
+    Row r;
+    if (iy >= 0 && iy < static_cast<int32_t>(p.H)) {
+      const uint32_t ro = img_off + static_cast<uint32_t>(iy) * row_bytes;      // scalar
+      r.c[0] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[0], ro, 0);
+      r.c[1] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[1], ro, 0);
+      r.c[2] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[2], ro, 0);
+      if constexpr (FIX) {
+        r.c[0] = ok0 ? r.c[0] : fill;
+        r.c[1] = ok1 ? r.c[1] : fill;
+        r.c[2] = ok2 ? r.c[2] : fill;
+      }
+    } else {
+      r.c[0] = r.c[1] = r.c[2] = fill;
+    }
+    return r;
+  };
+  struct Pair { uint32_t v[4]; };
+  // per channel c: (lo.byte c, hi.byte c) as two zero-extended int16
+  auto pair = [](uint32_t lo, uint32_t hi) __attribute__((always_inline)) -> Pair {
+    Pair q;
+    q.v[0] = __builtin_amdgcn_perm(hi, lo, 0x0c040c00u);
+    q.v[1] = __builtin_amdgcn_perm(hi, lo, 0x0c050c01u);
+    q.v[2] = __builtin_amdgcn_perm(hi, lo, 0x0c060c02u);
+    q.v[3] = __builtin_amdgcn_perm(hi, lo, 0x0c070c03u);
+    return q;
+  };
+  auto dot = [](const Pair& a, const uint32_t (&w)[4], int32_t (&acc)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      acc[c] = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a.v[c]), __builtin_bit_cast(v2s, w[c]), acc[c], false);
+    }
+  };
+  // first product of an output: the three-operand form takes the bias as its addend (the two-operand accumulate
+  // form the compiler prefers would need a copy of the bias per output first)
+  auto dot_first = [](const Pair& a, const uint32_t (&w)[4], const int32_t (&b)[4], int32_t (&acc)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(acc[c]) : "v"(a.v[c]), "v"(w[c]), "v"(b[c]));
+    }
+  };
+
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.output, 0, static_cast<int>(p.batch * p.OH * p.OW * p.out_stride), 0x00020000);
+  const uint32_t out_voff = ox * p.out_stride + cg;
+  uint32_t out_soff = (n * p.OH + oy0) * p.OW * p.out_stride;       // scalar, advances one output row per step
+  const uint32_t out_step = p.OW * p.out_stride;
+
+  qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
+    auto finish = [&](int32_t (&acc)[4]) __attribute__((always_inline)) {
+      const uint32_t packed = qnnp::q31_requantize_pack4<decltype(shift0)::value, decltype(full)::value>(
+          acc[0], acc[1], acc[2], acc[3], p.rq);
+      __builtin_amdgcn_raw_buffer_store_b32(packed, out_rsrc, out_voff, out_soff, 0);
+      out_soff += out_step;
+    };
+    const uint32_t steps = oy1 - oy0;
+    if constexpr (S == 1) {
+      // window rows of output t: t, t+1, t+2 (relative to iy_first). State entering step t:
+      //   HA = H[t], HB = H[t+1], QA = Q[t-1] (only its high half matters), QB = Q[t],
+      //   RP = row t+1 (its col2 is still needed), RC = row t+2, third row buffer = row t+3 (in flight).
+      // The step pairs row t+2, then re-uses RP for row t+4: two rows are always in flight. Roles rotate through
+      // the same registers with period three, so three steps are written out per trip and nothing is copied.
+      const Row r0 = load_row(iy_first);
+      Row b1 = load_row(iy_first + 1);
+      Row b2 = load_row(iy_first + 2);
+      Row b3 = load_row(iy_first + 3);
+      Pair h0 = pair(r0.c[0], r0.c[1]);
+      Pair h1 = pair(b1.c[0], b1.c[1]);
+      Pair qa = pair(r0.c[2], r0.c[2]);            // Q[-1] = (don't care, col2 @ 0)
+      Pair qb = pair(r0.c[2], b1.c[2]);            // Q[0]
+      Pair h2, qc;
+      uint32_t t = 0;
+#define QNNP_DW_COL_STEP(HA, HB, HC, QA, QB, QC, RP, RC)                             \
+      {                                                                             \
+        HC = pair(RC.c[0], RC.c[1]);                        /* H[t+2] */            \
+        QC = pair(RP.c[2], RC.c[2]);                        /* Q[t+1] */            \
+        RP = load_row(iy_first + static_cast<int32_t>(t) + 4);                      \
+        int32_t acc[4];                                                             \
+        dot_first(HA, w01[0], bias, acc);                                           \
+        dot(HB, w01[1], acc);                                                       \
+        dot(HC, w01[2], acc);                                                       \
+        dot(QA, wqa, acc);                                                          \
+        dot(QC, wqb, acc);                                                          \
+        finish(acc);                                                                \
+        t++;                                                                        \
+      }
+      while (t + 3 <= steps) {
+        QNNP_DW_COL_STEP(h0, h1, h2, qa, qb, qc, b1, b2)
+        QNNP_DW_COL_STEP(h1, h2, h0, qb, qc, qa, b2, b3)
+        QNNP_DW_COL_STEP(h2, h0, h1, qc, qa, qb, b3, b1)
+      }
+      if (t < steps) {
+        QNNP_DW_COL_STEP(h0, h1, h2, qa, qb, qc, b1, b2)
+        if (t < steps) {
+          QNNP_DW_COL_STEP(h1, h2, h0, qb, qc, qa, b2, b3)
+        }
+      }
+#undef QNNP_DW_COL_STEP
+    } else {
+      // stride 2: window rows of output t: 2t, 2t+1, 2t+2. State entering step t:
+      //   HA = H[2t], QA = (don't care, col2 @ 2t), (RA, RB) = rows 2t+1 / 2t+2, the other row pair = rows 2t+3 / 2t+4
+      //   (in flight). Period two: two steps per trip.
+      const Row r0 = load_row(iy_first);
+      Row a1 = load_row(iy_first + 1);
+      Row a2 = load_row(iy_first + 2);
+      Row c1 = load_row(iy_first + 3);
+      Row c2 = load_row(iy_first + 4);
+      Pair ha = pair(r0.c[0], r0.c[1]);
+      Pair qa = pair(r0.c[2], r0.c[2]);
+      Pair hb, qb;
+      uint32_t t = 0;
+#define QNNP_DW_COL_STEP2(HA, HC, QA, QC, RA, RB)                                   \
+      {                                                                             \
+        const Pair hmid = pair(RA.c[0], RA.c[1]);           /* H[2t+1] */           \
+        HC = pair(RB.c[0], RB.c[1]);                        /* H[2t+2] = H[2(t+1)] */ \
+        QC = pair(RA.c[2], RB.c[2]);                        /* (col2 @ 2t+1, col2 @ 2t+2) */ \
+        RA = load_row(iy_first + 2 * static_cast<int32_t>(t) + 5);                  \
+        RB = load_row(iy_first + 2 * static_cast<int32_t>(t) + 6);                  \
+        int32_t acc[4];                                                             \
+        dot_first(HA, w01[0], bias, acc);                                           \
+        dot(hmid, w01[1], acc);                                                     \
+        dot(HC, w01[2], acc);                                                       \
+        dot(QA, wqa, acc);                                                          \
+        dot(QC, wqb, acc);                                                          \
+        finish(acc);                                                                \
+        t++;                                                                        \
+      }
+      while (t + 2 <= steps) {
+        QNNP_DW_COL_STEP2(ha, hb, qa, qb, a1, a2)
+        QNNP_DW_COL_STEP2(hb, ha, qb, qa, c1, c2)
+      }
+      if (t < steps) {
+        QNNP_DW_COL_STEP2(ha, hb, qa, qb, a1, a2)
+      }
+#undef QNNP_DW_COL_STEP2
+    }
+  });
+}
+
+template <int S>
+__global__ __launch_bounds__(kColThreads)
+void q8_dwconv_col3x3_kernel(const DwParams p)
+{
+  // wave -> (image, row segment, 64-dword chunk of the flattened output row); `slabs` = row segments, `TOH` = rows
+  // per segment, `bands` = chunks per row here
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kColThreads / 64) + (threadIdx.x >> 6));
+  const uint32_t chunk = w % p.bands; w /= p.bands;
+  const uint32_t seg = w % p.slabs;
+  const uint32_t n = w / p.slabs;
+  if (n >= p.batch) return;
+  const uint32_t q4 = p.C >> 2;
+  const uint32_t cols = p.OW * q4;
+  // lanes past the end of the row repeat its last dword column: same loads, same results, same stores -- harmless
+  uint32_t j = chunk * 64u + lane;
+  if (j >= cols) j = cols - 1u;
+  const uint32_t ox = j / q4;
+  const uint32_t cg = (j - ox * q4) * 4u;
+  const uint32_t oy0 = seg * p.TOH;
+  const uint32_t oy1 = min(p.OH, oy0 + p.TOH);
+  const int32_t ix0 = static_cast<int32_t>(ox * S) - static_cast<int32_t>(p.pad_left);
+  const bool ok0 = ix0 >= 0 && ix0 < static_cast<int32_t>(p.W);
+  const bool ok1 = ix0 + 1 >= 0 && ix0 + 1 < static_cast<int32_t>(p.W);
+  const bool ok2 = ix0 + 2 >= 0 && ix0 + 2 < static_cast<int32_t>(p.W);
+  if (__builtin_amdgcn_ballot_w64(!(ok0 && ok1 && ok2)) != 0) {
+    dwconv_col3x3_body<S, true>(p, n, oy0, oy1, ox, cg, ok0, ok1, ok2);
+  } else {
+    dwconv_col3x3_body<S, false>(p, n, oy0, oy1, ox, cg, true, true, true);
+  }
+}
+
+// measurement knob, read once: output rows per segment of kernel G (0 = automatic)
+uint32_t col_rows_override()
+{
+  static const uint32_t rows = [] {
+    if (const char* env = getenv("QNNP_GFX950_DW_COL_ROWS")) {
+      const int v = atoi(env);
+      if (v >= 1 && v <= 4096) return static_cast<uint32_t>(v);
+    }
+    return 0u;
+  }();
+  return rows;
+}
+
+// geometry of kernel G: `bands` = 64-dword chunks per flattened output row, `slabs` = row segments, `TOH` = rows each
+bool plan_col(DwParams& p)
+{
+  if (p.C % 4 != 0 || p.KH != 3 || p.KW != 3 || p.dh != 1 || p.dw != 1) return false;
+  if (p.sh != p.sw || (p.sw != 1 && p.sw != 2)) return false;
+  // 32-bit byte offsets into both tensors
+  const uint64_t in_bytes = static_cast<uint64_t>(p.batch) * p.H * p.W * p.in_stride;
+  const uint64_t out_bytes = static_cast<uint64_t>(p.batch) * p.OH * p.OW * p.out_stride;
+  if (in_bytes >= (UINT64_C(1) << 31) || out_bytes >= (UINT64_C(1) << 32)) return false;
+  const uint32_t cols = p.OW * (p.C / 4);
+  const uint32_t chunks = (cols + 63u) / 64u;
+  // Row segments: each re-loads its halo (two rows at stride 1) and builds the first pairs again, so as few as
+  // still give every SIMD several waves' worth of work (the tail of the last round is what it buys back).
+  const uint64_t waves_per_seg = static_cast<uint64_t>(p.batch) * chunks;
+  const uint64_t target = static_cast<uint64_t>(p.cu_count) * 4u * 6u * 3u;      // ~3 rounds at 6 waves per SIMD
+  uint32_t segs = static_cast<uint32_t>((target + waves_per_seg - 1) / waves_per_seg);
+  const uint32_t min_rows = 7;
+  uint32_t max_segs = p.OH / min_rows;
+  if (max_segs < 1) max_segs = 1;
+  if (segs > max_segs) segs = max_segs;
+  if (segs < 1) segs = 1;
+  uint32_t toh = (p.OH + segs - 1) / segs;
+  if (const uint32_t forced = col_rows_override()) toh = forced < p.OH ? forced : p.OH;
+  p.TOH = toh;
+  p.slabs = (p.OH + toh - 1) / toh;
+  p.bands = chunks;
+  const uint64_t waves = static_cast<uint64_t>(p.batch) * p.slabs * chunks;
+  return waves < (UINT64_C(1) << 31);
+}
+
+int launch_col(const DwParams& p, hipStream_t stream)
+{
+  const uint64_t waves = static_cast<uint64_t>(p.batch) * p.slabs * p.bands;
+  const uint32_t blocks = static_cast<uint32_t>((waves + (kColThreads / 64) - 1) / (kColThreads / 64));
+  if (p.sw == 1) {
+    hipLaunchKernelGGL(q8_dwconv_col3x3_kernel<1>, dim3(blocks), dim3(kColThreads), 0, stream, p);
+  } else {
+    hipLaunchKernelGGL(q8_dwconv_col3x3_kernel<2>, dim3(blocks), dim3(kColThreads), 0, stream, p);
+  }
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+// --------------------------------------------------------------------------
 // Kernel D: matrix cores, 3x3, any stride / dilation, C % 16 == 0
 // --------------------------------------------------------------------------
 /*
@@ -1031,7 +1323,7 @@ int launch_lds(const DwParams& p, bool vec16, hipStream_t stream)
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
-enum : uint32_t { kPlanDirect = 1, kPlanLds33, kPlanLds55, kPlanRow, kPlanMfma, kPlanMfmaLds };
+enum : uint32_t { kPlanDirect = 1, kPlanLds33, kPlanLds55, kPlanRow, kPlanMfma, kPlanMfmaLds, kPlanCol };
 
 // measurement knob, read once: LDS budget per workgroup of the LDS-tiled kernel in KiB
 uint32_t lds_budget()
@@ -1058,15 +1350,24 @@ int make_plan(DwParams& p, const struct qnnp_hip_dwconv_args* a, uintptr_t in_ad
   else if (p.C % 4 == 0 && p.out_stride % 4 == 0 && out_addr % 4 == 0) p.store_mode = 1;
   plan->vec16 = 0;
   plan->kernel = 0;
-  if (a->variant == 5) {
+  if (a->variant == 6) {
+    if (!aligned4 || !plan_col(p)) return QNNP_HIP_EINVAL;
+    plan->kernel = kPlanCol;
+  } else if (a->variant == 5) {
     if (!plan_mfma_lds(p, a)) return QNNP_HIP_EINVAL;
     plan->kernel = kPlanMfmaLds;
   } else if (a->variant == 4) {
     if (!plan_mfma(p, a)) return QNNP_HIP_EINVAL;
     plan->kernel = kPlanMfma;
+  } else if (a->variant == 0 && k33 && aligned4 && !(p.sh == 2 && p.OH < 28) && plan_col(p)) {
+    // 3x3, dilation 1, stride 1 | 2: the column-sliding window (kernel G) -- 10-25 % ahead of the LDS-tiled and the
+    // matrix-core kernels on eight of the ten MobileNetV2 depthwise layers at batch 128 (same-box A/B,
+    // scripts/gpu_dwab.sh); the two short stride-2 images (28 -> 14, 14 -> 7 rows: 7-14 steps per wave against a
+    // fixed start-up) stay with the LDS-tiled kernel, 5-8 % ahead there.
+    plan->kernel = kPlanCol;
   } else if (a->variant == 0 && k33 && p.OW >= 56 && p.C <= 96 && plan_mfma_lds(p, a)) {
-    // Large images with few channels (MobileNetV2 layers 2 and 5): the matrix-core kernel with the LDS-staged band
-    // measured 8-10 % ahead of the VALU kernels; everywhere else it is level or behind (same-box A/B).
+    // (shapes kernel G declines, e.g. tensors beyond its 32-bit offsets) large images with few channels: the
+    // matrix-core kernel with the LDS-staged band
     plan->kernel = kPlanMfmaLds;
   } else {
     // Order of preference (same-box A/B over the MobileNetV2 layers: the LDS-tiled and the sliding-window
@@ -1153,6 +1454,9 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
     case kPlanRow:
       if (kernel_name != nullptr) *kernel_name = "q8_dwconv_row_3x3";
       return launch_row(p, stream);
+    case kPlanCol:
+      if (kernel_name != nullptr) *kernel_name = "q8_dwconv_col_3x3";
+      return launch_col(p, stream);
     case kPlanLds33:
       if (kernel_name != nullptr) *kernel_name = "q8_dwconv_lds_3x3";
       return launch_lds<3, 3>(p, plan->vec16 != 0, stream);

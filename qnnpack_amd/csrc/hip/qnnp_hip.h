@@ -210,7 +210,7 @@ struct qnnp_hip_dwconv_args {
   uint32_t input_stride, output_stride;
   uint32_t input_zero_point;
   struct qnnp_hip_requant rq;
-  int variant;                /* 0 auto, 1 generic direct, 2 LDS-tiled, 3 register sliding window (3x3), 4 matrix-core (gather), 5 matrix-core (LDS band) */
+  int variant;                /* 0 auto, 1 generic direct, 2 LDS-tiled, 3 register sliding window (3x3), 4 matrix-core (gather), 5 matrix-core (LDS band), 6 column-sliding window (3x3) */
   struct qnnp_hip_dwconv_plan* plan;   /* optional plan cache owned by the caller (NULL: plan on every call) */
 };
 int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* args, const char** kernel_name);

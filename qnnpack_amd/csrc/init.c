@@ -177,7 +177,7 @@ enum qnnp_status qnnp_gfx950_set_option(const char* key, int value)
     qnnp_state.opt_timing_graph = value;
     return qnnp_status_success;
   }
-  if (strcmp(key, "dwconv_kernel") == 0 && value >= 0 && value <= 5) {
+  if (strcmp(key, "dwconv_kernel") == 0 && value >= 0 && value <= 6) {
     qnnp_state.opt_dwconv_kernel = value;
     return qnnp_status_success;
   }

@@ -1,12 +1,10 @@
 #!/bin/bash
-# measurement only: A/B the depthwise kernels ($1, default "2 3 4") per sweep layer inside ONE call
-# (box-to-box variance is +-10 %)
-for rep in 1 2; do
-for k in ${1:-2 3 4}; do
-  echo -n "dw_kernel=$k:"
-  for l in 2 5 8 10 13 15 18 22 24 27; do
-    python bench.py --layer $l --dw-kernel $k 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(' L%d %.1f' % (d['layer'], d['ms']*1e3), end='')"
+# same-box A/B of depthwise kernel variants over the ten MobileNetV2 depthwise layers (sweep indices), batch 128
+# usage: gpurun -- bash scripts/gpu_dwab.sh <tag> "<variants>" ["<layers>"]
+TAG=${1:-dwab}; VARS=${2:-"0 6"}; LAYERS=${3:-"2 5 8 10 13 15 18 22 24 27"}
+OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+for L in $LAYERS; do
+  for V in $VARS; do
+    timeout 120 python bench.py --layer $L --dw-kernel $V --steps 20 --warmup 3 2>/dev/null | tail -n 1 | sed "s/^/v$V /" | tee -a $OUT/dwab.txt
   done
-  echo
-done
 done

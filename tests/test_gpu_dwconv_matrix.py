@@ -30,7 +30,7 @@ def dw(name, channels, width, height=1, **kw):
 def check(qnnp, case):
     expected, quant, out_hw = conv_expected(case)
     ran = []
-    for variant in (0, 1, 2, 3, 4, 5):
+    for variant in (0, 1, 2, 3, 4, 5, 6):
         qnnp.set_option("dwconv_kernel", variant)
         try:
             out, kname = conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)

@@ -35,6 +35,29 @@ __global__ void k(uint32_t* out, int iters, uint32_t seed)
         if (OP == 14) asm volatile("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(a[i]) : "v"(m));
         if (OP == 15) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(w[i]));
         if (OP == 16) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(m));
+        // ---- round 2: what a depthwise tap loop could be built from ----
+        if (OP == 17) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(a[(i + 1) & 7]));
+        if (OP == 18) asm volatile("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(m), "v"(a[(i + 1) & 7]));
+        if (OP == 19) asm volatile("v_dot4_i32_i8 %0, %1, %2, %0" : "+v"(a[i]) : "v"(m), "v"(a[(i + 1) & 7]));
+        if (OP == 20) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(a[i]) : "v"(m), "v"(a[(i + 1) & 7]));
+        if (OP == 21) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(w[i]) : "v"(w[(i + 1) & 7]));
+        if (OP == 22) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(a[(i + 1) & 7]));
+        if (OP == 23) asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(a[i]) : "v"(m));
+        if (OP == 24) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a[i]));
+        if (OP == 25) asm volatile("v_sad_u8 %0, %1, %2, %0" : "+v"(a[i]) : "v"(m), "v"(a[(i + 1) & 7]));
+        if (OP == 26) asm volatile("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(a[i]) : "v"(m), "v"(a[(i + 1) & 7]));
+        if (OP == 27) asm volatile("v_pk_mad_i16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(m), "v"(a[(i + 1) & 7]));
+        if (OP == 28) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+        if (OP == 29) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(m));
+        if (OP == 30) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(a[i]));
+        if (OP == 31) asm volatile("v_mul_u32_u24_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(a[i]) : "v"(m));
+        if (OP == 32) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "+v"(a[i]) : "v"(m));
+        if (OP == 33) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(a[(i + 1) & 7]));
+        if (OP == 34) asm volatile("v_pk_fma_f16 %0, %0, %1, %0" : "+v"(a[i]) : "v"(m));
+        if (OP == 35) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(m), "v"(a[(i + 1) & 7]));
+        if (OP == 36) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+        if (OP == 37) asm volatile("v_dot2c_i32_i16 %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(a[(i + 1) & 7]));
+        if (OP == 38) asm volatile("v_dot4c_i32_i8 %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(a[(i + 1) & 7]));
       }
     }
   }
@@ -86,5 +109,27 @@ int main()
   run<14>("v_pk_add_i16 clamp", d_out);
   run<15>("v_lshlrev_b64", d_out);
   run<16>("v_fma_f32", d_out);
+  run<22>("v_fmac_f32 (VOP2)", d_out);
+  run<36>("v_add_f32", d_out);
+  run<21>("v_pk_fma_f32", d_out);
+  run<34>("v_pk_fma_f16", d_out);
+  run<35>("v_dot2_f32_f16", d_out);
+  run<17>("v_perm_b32", d_out);
+  run<18>("v_dot2_i32_i16", d_out);
+  run<37>("v_dot2c_i32_i16", d_out);
+  run<19>("v_dot4_i32_i8", d_out);
+  run<38>("v_dot4c_i32_i8", d_out);
+  run<20>("v_dot4_u32_u8", d_out);
+  run<23>("v_cvt_f32_ubyte1", d_out);
+  run<24>("v_cvt_i32_f32", d_out);
+  run<25>("v_sad_u8", d_out);
+  run<26>("v_mad_i32_i24", d_out);
+  run<27>("v_pk_mad_i16", d_out);
+  run<28>("v_and_b32", d_out);
+  run<29>("v_lshl_add_u32", d_out);
+  run<30>("v_bfe_u32", d_out);
+  run<31>("v_mul_u32_u24_sdwa", d_out);
+  run<32>("v_add_u32_sdwa", d_out);
+  run<33>("v_med3_i32", d_out);
   return 0;
 }
