@@ -82,7 +82,8 @@ static_assert(kWN == 2 && kBK == 64, "row-sum split: each channel-wave owns one 
 // ABL: measurement-only ablation mask (builds with -DQNNP_ENABLE_ABLATION, env QNNP_GFX950_ABLATE);
 // 0 in the product. 1 = no requantization in the epilogue, 2 = no recentring / row sums,
 // 4 = no MFMA, 8 = no LDS-DMA after the prologue, 16 = no fragment reads after the first tile,
-// 32 = no per-tile wait + barrier.
+// 32 = no per-tile wait + barrier; 64 = experiment: static s_setprio 1 for the younger half of the workgroup
+// (waves 4-7) before the main loop (guide T5, static form).
 // WM = waves along rows: 4 -> 8 waves (two per SIMD), 64 x 128 outputs per wave, 12 fragment reads per 16 MFMAs;
 //                        2 -> 4 waves (one per SIMD, the whole register file), 128 x 128 outputs per wave,
 //                             16 fragment reads per 32 MFMAs.
@@ -473,6 +474,9 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 
   // (the prologue above staged tiles 0..2; tile 3 completes the ring)
   if (ktiles > 3) stage(3);
+  if constexpr ((ABL & 64) != 0) {
+    if (wave >= static_cast<uint32_t>(kWM * kWN / 2)) __builtin_amdgcn_s_setprio(1);
+  }
   uint32_t kt = 0;
   if (ktiles > 4) {
     iteration(std::false_type{}, std::true_type{}, std::true_type{}, 0u);
@@ -615,7 +619,8 @@ int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, co
         return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
     switch (abl) {
       case 0: break;
-      QNNP_ABL_CASE(1) QNNP_ABL_CASE(2) QNNP_ABL_CASE(4) QNNP_ABL_CASE(8) QNNP_ABL_CASE(16) QNNP_ABL_CASE(24) QNNP_ABL_CASE(26)
+      QNNP_ABL_CASE(1) QNNP_ABL_CASE(2) QNNP_ABL_CASE(3) QNNP_ABL_CASE(4) QNNP_ABL_CASE(8) QNNP_ABL_CASE(16) QNNP_ABL_CASE(24) QNNP_ABL_CASE(26)
+      QNNP_ABL_CASE(27) QNNP_ABL_CASE(64)
       default: break;
     }
 #undef QNNP_ABL_CASE
