@@ -1,5 +1,6 @@
 /*
- * q8convwave.hip -- direct convolution on the matrix cores, one WAVE per 8x8 block of output positions.
+ * q8convwave.hip -- direct convolution on the matrix cores, one WAVE per 8x8 block of output positions, input
+ * patches streamed by LDS-DMA two units ahead of the multiplies.
  *
  * Same operator and arithmetic as q8convlds.hip (replaces q8conv_ukernel_4x4c2__sse2,
  * src/q8conv/4x4c2-sse2.c:14-273, + compute_q8conv, src/operator-run.c:183-217, 837-842, + the indirection
@@ -7,26 +8,30 @@
  * input channels, <= 64 output channels, a small window (3x3 stride 1).
  *
  * Why a second kernel: in q8convlds.hip a workgroup's four waves walk the phases of an item together
- * (stage band | barrier | K loop | epilogue | barrier), and ablation shows the phases ADD UP -- removing the
- * stores, the staging or the LDS operand reads each shortens the kernel by its full cost -- because two
- * co-resident workgroups are all the overlap there is. Here nothing is shared but the weights:
- *   - ONE workgroup of 12 waves per CU; the packed weight image and the bias go to LDS once;
- *   - each wave owns a private LDS patch and processes UNITS = 8x8 output positions x all channels on its own,
- *     with no workgroup barrier after the weights: global -> registers (next unit's input patch, issued before
- *     the K loop of the current one) -> LDS patch (re-centred bytes a ^ 0x80, chunk-swizzled by patch row, plus
- *     per-pixel channel sums by v_sad_u8) -> K loop over (tap, 32-channel block) reading shifted B fragments
- *     from the patch and A fragments from the shared weights -> row term from the pixel sums -> Q31
- *     requantization into the (now free) patch as a 64 x n output image -> 16-byte stores of whole 8-position
- *     runs;
- *   - units are handed out inside the workgroup by an LDS counter, so a wave that waits (loads, store
- *     acknowledgements) never holds up another one, and three waves per SIMD fill each other's gaps.
- * MEASURED (configs[2], batch 128, same box, production builds): 41.9-42.6 us against 37.0-38.0 us for the
- * LDS-tiled kernel, so this kernel is OPT-IN ("gemm_kernel" = 8) and never selected automatically. In-kernel
- * stamps say why: a wave gets only ~2 units (6272 units over 3072 waves), so there is no steady state -- the
- * first two patches of every wave are 98 % of the input, requested at once (store_patch waits 3.4-4.5 k
- * cycles, the first load issue stalls 10 k), then the K loops run (480 cycles per K block per wave, the MFMA
- * pipe 80 % busy while three waves are in it), then the stores. Kept as the tested starting point for larger
- * batches / images, where units per wave grow.
+ * (stage band | barrier | K loop | epilogue | barrier). In-kernel stamps (tools/trace_dump.py 99): the K loop takes
+ * 10.4 k cycles per item for 2 x 72 MFMAs x 32 cycles = 4.6 k cycles of matrix-pipe work per SIMD -- 44 % busy,
+ * each (tap, channel block) step waits for its own LDS reads -- and staging, epilogue and the two barriers add
+ * 4 k more during which the pipe idles. Here nothing is shared but the weights, and every latency has something
+ * queued behind it:
+ *   - ONE workgroup of 8 waves per CU (two per SIMD); the packed weight image and the bias go to LDS once (LDS-DMA);
+ *   - each wave owns TWO private LDS patch buffers and processes UNITS = 8x8 output positions x all channels on its
+ *     own, no workgroup barrier after the weights. The input patch of the NEXT unit is gathered by LDS-DMA
+ *     (global_load_lds, 16 bytes per lane, no registers: per-lane source = pixel chunk or the zero-point line of
+ *     the fill table, destination lane-linear, chunk-swizzled by patch row on the SOURCE side) while the current
+ *     unit is multiplied; a counted vmcnt leaves it in flight;
+ *   - one pass over a landed patch re-centres its bytes in place (a ^ 0x80) and leaves per-pixel channel sums beside
+ *     it (v_sad_u8 + DPP), so that the K loop carries NOTHING but fragment reads and MFMAs: a wave issues roughly
+ *     one instruction per four cycles, i.e. eight per 32-cycle MFMA, and the first version of this loop -- sixteen
+ *     v_sad_u8, sixteen v_xor and the address arithmetic per eight MFMAs -- ran at half the matrix-pipe rate;
+ *   - K loop software-pipelined in registers: the fragments of tap t+1 (activations from the patch, weights from
+ *     the shared image) are read while the MFMAs of tap t issue; for the 3x3 / stride 1 / dilation 1 window every
+ *     fragment address is a per-unit register plus an immediate;
+ *   - the LDS-DMA instructions are inline asm: hipcc guards every LDS access behind a global_load_lds it knows of
+ *     with s_waitcnt vmcnt(0) (it cannot prove the two do not alias), which would drain the gather of the next patch
+ *     and wait for the previous unit's store acknowledgements several times per unit (see dma16);
+ *   - epilogue: row term, Q31 requantization into the (now free) patch buffer as a 64 x n output image, whole
+ *     8-position runs stored with 16-byte pieces (full 128-byte lines);
+ *   - units are handed out inside the workgroup by an LDS counter.
  * An 8x8 block needs a (7*s + (K-1)*d + 1)^2 patch: 10x10 pixels for 3x3/s1, 1.56x the block's own pixels,
  * re-read from L2 (HBM sees the input about once).
  */
@@ -46,9 +51,9 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int kWaves = 12;
+constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
-constexpr int kPatchVec = 7;            // 16-byte vectors of a unit's input patch per lane (<= 448 per patch)
+constexpr int kMaxDma = 8;              // 1 KiB LDS-DMA pieces per patch (<= 512 chunks of 16 bytes)
 constexpr uint32_t kFlip = 0x80808080u;
 constexpr uint32_t kLdsLimit = 160 * 1024;
 
@@ -58,9 +63,12 @@ struct WaveArgs {
   uint32_t tiles_x, tiles_y;
   uint32_t units;           // batch * tiles_y * tiles_x
   uint32_t w_bytes;         // packed weight image
-  uint32_t head_bytes;      // weights + bias + counter, 256-aligned: offset of the first wave region
-  uint32_t patch_bytes;     // per wave: patch / output image (the larger of the two), 256-aligned
-  uint32_t wave_bytes;      // per wave: patch_bytes + pixel sums
+  uint32_t head_bytes;      // weights + bias + counter, 1024-aligned: offset of the first wave region
+  uint32_t ndma;            // LDS-DMA pieces per patch
+  uint32_t patch_bytes;     // one patch buffer (256-aligned; the last DMA piece is lane-masked to the patch)
+  uint32_t stage_bytes;     // per wave: output staging image of 32 positions x n bytes
+  uint32_t pix_bytes;       // per wave: per-pixel channel sums of the current patch (int32)
+  uint32_t wave_bytes;      // per wave: 2 patch buffers + staging + pixel sums
 };
 
 inline bool make_args(const IgemmParams& p, const ConvGeom& g, uint32_t batch, WaveArgs* a, uint32_t* lds_bytes)
@@ -72,22 +80,60 @@ inline bool make_args(const IgemmParams& p, const ConvGeom& g, uint32_t batch, W
   a->tiles_y = (g.OH + 7u) / 8u;
   a->units = batch * a->tiles_x * a->tiles_y;
   a->w_bytes = p.n_pad * p.k_pad;
-  a->head_bytes = (a->w_bytes + p.n * 4u + 16u + 255u) & ~255u;
+  a->head_bytes = (a->w_bytes + p.n * 4u + 16u + 1023u) & ~1023u;
   const uint32_t patch = a->PH * a->PW * p.kc;
-  const uint32_t image = 64u * p.n;
-  a->patch_bytes = ((patch > image ? patch : image) + 255u) & ~255u;
-  a->wave_bytes = a->patch_bytes + ((a->PH * a->PW * 4u + 255u) & ~255u);
+  a->ndma = (patch + 1023u) / 1024u;
+  a->patch_bytes = (patch + 255u) & ~255u;
+  a->stage_bytes = 32u * p.n;
+  a->pix_bytes = (a->PH * a->PW * 4u + 255u) & ~255u;
+  a->wave_bytes = 2u * a->patch_bytes + a->stage_bytes + a->pix_bytes;
   *lds_bytes = a->head_bytes + kWaves * a->wave_bytes;
-  if (a->PH * a->PW * (p.kc >> 4) > static_cast<uint32_t>(kPatchVec) * 64u) return false;
-  if (a->PH * a->PW > 4096u) return false;   // inv_pw exactness
+  if (a->ndma > static_cast<uint32_t>(kMaxDma)) return false;
+  if (a->ndma * 64u > 4096u * (p.kc >> 4)) return false;   // inv_pw exactness: pixel index < 4096
+  if (a->w_bytes % 1024u != 0) return false;
   return *lds_bytes <= kLdsLimit;
 }
 
-template <int TN>
-__global__ __launch_bounds__(kThreads)
+// byte offset of an LDS pointer inside the workgroup's LDS allocation (what DS instructions and M0 address)
+__device__ __forceinline__ uint32_t lds_off(const void* p)
+{
+  return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) uint8_t*) p));
+}
+
+/* LDS-DMA, 16 bytes per lane: LDS destination = wave-uniform base (M0) + lane * 16, source address per lane.
+ * Issued as inline asm ON PURPOSE: with the builtin, hipcc (ROCm 7.2) remembers that a global_load_lds is in flight
+ * and puts s_waitcnt vmcnt(0) in front of every later LDS access it cannot prove disjoint -- inside this kernel's unit
+ * loop that is every ds_read / ds_write / LDS atomic, each draining the gather of the next patch (and waiting for
+ * the previous unit's store acknowledgements on the way). The asm form is invisible to that bookkeeping; the waits
+ * this kernel needs are the explicit s_waitcnt vmcnt in the unit loop, nothing else orders a ds_read behind a DMA
+ * (cdna_hip_programming.md section 5.7). M0 is restored: the compiler owns it. */
+__device__ __forceinline__ void dma16(const uint8_t* src, uint8_t* lds_wave_base)
+{
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_off(lds_wave_base));
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+
+// 16-byte / 4-byte LDS stores the compiler does not see as LDS accesses (see the header: no vmcnt(0) in front)
+__device__ __forceinline__ void ds_write16_raw(uint32_t off, uint4 v)
+{
+  typedef int raw_v4i __attribute__((ext_vector_type(4)));
+  const raw_v4i x = {static_cast<int>(v.x), static_cast<int>(v.y), static_cast<int>(v.z), static_cast<int>(v.w)};
+  asm volatile("ds_write_b128 %0, %1" :: "v"(off), "v"(x) : "memory");
+}
+__device__ __forceinline__ void ds_write4_raw(uint32_t off, int32_t v)
+{
+  asm volatile("ds_write_b32 %0, %1" :: "v"(off), "v"(v) : "memory");
+}
+
+// KS: 3 = 3x3 window, stride 1, dilation 1 (10x10 patch; every fragment address = per-unit register + immediate),
+//     0 = any geometry make_args accepts (addresses computed per tap)
+template <int TN, int CB, int KS>
+__global__ __launch_bounds__(kThreads, 2)
 void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveArgs a)
 {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [weights][bias][counter][12 x (patch | pixel sums)]
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [weights][bias][counter][8 x (2 x patch | staging)]
   uint8_t* w_lds = lds;
   int32_t* bias_lds = reinterpret_cast<int32_t*>(lds + a.w_bytes);
   uint32_t* counter = reinterpret_cast<uint32_t*>(lds + a.w_bytes + p.n * 4u);
@@ -95,125 +141,149 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  uint8_t* patch = lds + a.head_bytes + wave * a.wave_bytes;
-  int32_t* pix = reinterpret_cast<int32_t*>(patch + a.patch_bytes);
+  uint8_t* patch0 = lds + a.head_bytes + wave * a.wave_bytes;
+  uint8_t* stage = patch0 + 2u * a.patch_bytes;
+  int32_t* pix = reinterpret_cast<int32_t*>(stage + a.stage_bytes);
 
   // contiguous unit range of this workgroup (neighbouring blocks share halos in L2)
   const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * a.units / gridDim.x);
   const uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * a.units / gridDim.x);
 
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(p.packed_w);
-    uint4* dst = reinterpret_cast<uint4*>(w_lds);
-    for (uint32_t i = tid; i < (a.w_bytes >> 4); i += kThreads) dst[i] = src[i];
-    for (uint32_t i = tid; i < p.n; i += kThreads) bias_lds[i] = p.bias2[i];
-    if (tid == 0) *counter = lo + kWaves;
-  }
-  __syncthreads();          // the only workgroup barrier
-
-  const uint32_t cin = p.kc;                       // 32 or 64
-  const uint32_t log_cin = 31u - __builtin_clz(cin);
-  const uint32_t cpp = cin >> 4;                   // 16-byte chunks per pixel
-  const uint32_t log_cpp = log_cin - 4u;
+  constexpr uint32_t cin = CB * 32u;
+  constexpr uint32_t log_cin = CB == 1 ? 5u : (CB == 2 ? 6u : 7u);
+  constexpr uint32_t cpp = cin >> 4;               // 16-byte chunks per pixel
+  constexpr uint32_t log_cpp = log_cin - 4u;
   const uint32_t sh_log = g.sh >> 1;               // strides 1 / 2
   const uint32_t pvec = a.PH * a.PW * cpp;
   const uint32_t tiles = a.tiles_x * a.tiles_y;
-  const uint32_t raw_fill = (p.izp_fill & 0xFFu) * 0x01010101u;
+  const uint8_t* fill_line = p.fill_table + (p.izp_fill & 0xFFu) * 16u;   // sixteen bytes of the raw zero point
   const uint32_t khalf = lane >> 5;
 
-  // this lane's two output positions inside a unit (fixed): i = j*32 + (lane & 31) -> (i >> 3, i & 7)
-  uint32_t ty[2], tx[2], qbase[2];
+  // ---- LDS-DMA gather of the input patch of `unit` into `dst` (a.ndma pieces of 1 KiB) ----
+  // LDS image: [pixel q][cin bytes]; 16-byte slot s of pixel q holds chunk s ^ swz(row of q): the destination is
+  // lane-linear by construction, so the swizzle is applied to the SOURCE chunk (and again on the fragment reads).
+  // The gather pattern is the same for every unit: per piece u, this lane's patch pixel (py, px) and its byte offset
+  // from the patch's first pixel are fixed (kept in registers), only the patch origin moves.
+  uint32_t g_rel[kMaxDma], g_pyx[kMaxDma];
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const uint32_t i = j * 32u + (lane & 31u);
-    ty[j] = i >> 3;
-    tx[j] = i & 7u;
-    qbase[j] = ty[j] * g.sh * a.PW + tx[j] * g.sw;
+  for (int u = 0; u < kMaxDma; u++) {
+    const uint32_t v = lane + u * 64u;
+    const uint32_t s = v & (cpp - 1u);
+    const uint32_t q = v >> log_cpp;
+    const uint32_t py = (q * a.inv_pw) >> 16;
+    const uint32_t px = q - py * a.PW;
+    const uint32_t c = s ^ ((py >> sh_log) & (cpp - 1u));
+    g_rel[u] = (py * g.W + px) * p.input_stride + c * 16u;
+    g_pyx[u] = (py << 16) | px;
   }
-
-  uint4 st_val[kPatchVec];
-#pragma unroll
-  for (int u = 0; u < kPatchVec; u++) st_val[u] = make_uint4(0, 0, 0, 0);
-
-  // global -> registers: the input patch of unit `unit` (padding = the raw zero point)
-  auto load_patch = [&](uint32_t unit) __attribute__((always_inline)) {
+  auto dma_patch = [&](uint32_t unit, uint8_t* dst) __attribute__((always_inline)) {
     const uint32_t img = unit / tiles;
     const uint32_t r = unit - img * tiles;
     const uint32_t tyi = r / a.tiles_x;
     const uint32_t txi = r - tyi * a.tiles_x;
     const int32_t iy0 = static_cast<int32_t>(tyi * 8u * g.sh) - static_cast<int32_t>(g.pad_top);
     const int32_t ix0 = static_cast<int32_t>(txi * 8u * g.sw) - static_cast<int32_t>(g.pad_left);
-    const uint8_t* image = p.input + static_cast<uint64_t>(img) * p.image_stride;
+    // byte offset of the patch origin inside the tensor (may be "negative" for border units: wraps consistently in
+    // 64-bit arithmetic below, and is only dereferenced for in-bounds pixels)
+    const int64_t origin = static_cast<int64_t>(img) * static_cast<int64_t>(p.image_stride) +
+        (static_cast<int64_t>(iy0) * static_cast<int64_t>(g.W) + ix0) * static_cast<int64_t>(p.input_stride);
+    const uint8_t* base = p.input + origin;
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + static_cast<int32_t>(a.PH) <= static_cast<int32_t>(g.H) &&
+                          ix0 + static_cast<int32_t>(a.PW) <= static_cast<int32_t>(g.W);      // wave-uniform
 #pragma unroll
-    for (int u = 0; u < kPatchVec; u++) {
-      const uint32_t v = lane + u * 64u;
-      const uint32_t c = v & (cpp - 1u);
-      const uint32_t q = v >> log_cpp;
-      const uint32_t py = (q * a.inv_pw) >> 16;
-      const uint32_t px = q - py * a.PW;
-      const int32_t iy = iy0 + static_cast<int32_t>(py);
-      const int32_t ix = ix0 + static_cast<int32_t>(px);
-      const bool inb = v < pvec && iy >= 0 && iy < static_cast<int32_t>(g.H) && ix >= 0 && ix < static_cast<int32_t>(g.W);
-      st_val[u] = make_uint4(raw_fill, raw_fill, raw_fill, raw_fill);
-      if (inb) {
-        st_val[u] = *reinterpret_cast<const uint4*>(
-            image + (static_cast<uint64_t>(static_cast<uint32_t>(iy)) * g.W + static_cast<uint32_t>(ix)) * p.input_stride + c * 16u);
-      }
-    }
-  };
-  // registers -> LDS patch: re-centred bytes at the swizzled slot, per-pixel channel sums (of a') beside it
-  auto store_patch = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < kPatchVec; u++) {
-      const uint32_t v = lane + u * 64u;
-      const uint32_t c = v & (cpp - 1u);
-      const uint32_t q = v >> log_cpp;
-      const uint32_t py = (q * a.inv_pw) >> 16;
-      const uint32_t swz = (py >> sh_log) & (cpp - 1u);
-      uint4 x = st_val[u];
-      uint32_t sum = __builtin_amdgcn_sad_u8(x.x, 0u, 0u);
-      sum = __builtin_amdgcn_sad_u8(x.y, 0u, sum);
-      sum = __builtin_amdgcn_sad_u8(x.z, 0u, sum);
-      sum = __builtin_amdgcn_sad_u8(x.w, 0u, sum);
-      sum += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(sum), 0xB1, 0xF, 0xF, false));        // lane ^ 1
-      if (cpp > 2) sum += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(sum), 0x4E, 0xF, 0xF, false));   // lane ^ 2
-      if (v < pvec) {
-        x.x ^= kFlip; x.y ^= kFlip; x.z ^= kFlip; x.w ^= kFlip;
-        *reinterpret_cast<uint4*>(patch + (q << log_cin) + ((c ^ swz) << 4)) = x;
-        if (c == 0) pix[q] = static_cast<int32_t>(sum) - 128 * static_cast<int32_t>(cin);
+    for (int u = 0; u < kMaxDma; u++) {
+      if (static_cast<uint32_t>(u) < a.ndma) {
+        const uint32_t v = lane + u * 64u;
+        const uint8_t* src = base + g_rel[u];
+        if (!interior) {
+          const int32_t iy = iy0 + static_cast<int32_t>(g_pyx[u] >> 16);
+          const int32_t ix = ix0 + static_cast<int32_t>(g_pyx[u] & 0xFFFFu);
+          const bool inb = iy >= 0 && iy < static_cast<int32_t>(g.H) && ix >= 0 && ix < static_cast<int32_t>(g.W);
+          src = inb ? src : fill_line;
+        }
+        if (v < pvec) dma16(src, dst + u * 1024u);        // lanes past the patch write nothing (the buffer ends there)
       }
     }
   };
 
+  // ---- weights + bias + counter, once per workgroup; the first patch rides along ----
+  {
+    const uint32_t pieces = a.w_bytes >> 10;
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(p.packed_w) + lane * 16u;
+    for (uint32_t i = wave; i < pieces; i += kWaves) dma16(src + i * 1024u, w_lds + i * 1024u);
+    for (uint32_t i = tid; i < p.n; i += kThreads) bias_lds[i] = p.bias2[i];
+  }
+  uint32_t cur = lo + wave;
+  if (tid == 0) *counter = lo + kWaves;
+  if (cur < hi) dma_patch(cur, patch0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's weight pieces and its first patch have landed
+  __syncthreads();                                        // ... and everybody else's weights: the only workgroup barrier
+  // (Holding the second half of the workgroup back by half a unit, so that the two waves of a SIMD alternate between
+  //  multiplying and requantizing, was measured: s_sleep 0 / 56 / 110 -> 30.8 / 32.2 / 32.8 us on configs[2]. Not kept.)
+
+  // this lane's two output positions inside a unit (fixed): i = j*32 + (lane & 31) -> (i >> 3, i & 7)
+  uint32_t ty[2], rowbase[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const uint32_t i = j * 32u + (lane & 31u);
+    ty[j] = i >> 3;
+    rowbase[j] = (ty[j] * g.sh * a.PW + (i & 7u) * g.sw) << log_cin;
+  }
+
   const uint32_t kblocks = p.k_pad / 32;
-  const uint32_t cblocks = cin >> 5;
   const uint8_t* w_lane = w_lds + lane * 16;
   const uint32_t cpr = p.n >> 4;                   // 16-byte pieces per output position (2 or 4)
   const uint32_t log_cpr = 31u - __builtin_clz(cpr);
+  const uint32_t taps = g.KH * g.KW;
 
-
-  uint32_t cur = lo + wave;
-  if (cur < hi) load_patch(cur);
-
+  struct Frags {
+    v4i a[2][CB];
+    v4i w[TN][CB];
+  };
+  uint32_t buf = 0;
   uint32_t unit_no = 0;
   (void) unit_no;
 #define CW_STAMP(slot) do { if (wave == 0) { QNNP_TRACE(p, blockIdx.x, unit_no, slot); } } while (0)
   while (cur < hi) {
     CW_STAMP(0);
-    store_patch();                                  // (waits for the patch loads)
-    // next unit: claimed now so that its loads fly under this unit's K loop
-    uint32_t claimed = 0;
-    if (lane == 0) claimed = atomicAdd(counter, 1u);
-    const uint32_t nxt = __builtin_amdgcn_readfirstlane(claimed);
+    uint8_t* patch = patch0 + buf * a.patch_bytes;
+    // next unit: claimed now, its patch gathered into the other buffer while this unit is multiplied. (The patch of
+    // `cur` has landed: its gather was waited for after the K loop of the previous unit, or before the barrier.)
+    uint32_t nxt = hi;
+    {
+      uint32_t claimed = 0;
+      if (lane == 0) claimed = atomicAdd(counter, 1u);
+      nxt = __builtin_amdgcn_readfirstlane(claimed);
+    }
+    if (nxt < hi) dma_patch(nxt, patch0 + (buf ^ 1u) * a.patch_bytes);
     CW_STAMP(1);
-    if (nxt < hi) load_patch(nxt);
-    CW_STAMP(2);
-
     const uint32_t img = cur / tiles;
     const uint32_t r = cur - img * tiles;
     const uint32_t tyi = r / a.tiles_x;
     const uint32_t oy0 = tyi * 8u;
     const uint32_t ox0 = (r - tyi * a.tiles_x) * 8u;
+
+    // ---- the landed patch: re-centre the bytes in place, per-pixel channel sums (of a') beside it ----
+    {
+      const uint32_t patch_off = lds_off(patch);
+      const uint32_t pix_off = lds_off(pix);
+      for (uint32_t u = 0; u < a.ndma; u++) {
+        const uint32_t v = lane + u * 64u;
+        if (v < pvec) {                                  // whole pixels: pvec is a multiple of cpp
+          uint4 x = *reinterpret_cast<const uint4*>(patch + v * 16u);
+          uint32_t sum = __builtin_amdgcn_sad_u8(x.x, 0u, 0u);
+          sum = __builtin_amdgcn_sad_u8(x.y, 0u, sum);
+          sum = __builtin_amdgcn_sad_u8(x.z, 0u, sum);
+          sum = __builtin_amdgcn_sad_u8(x.w, 0u, sum);
+          sum += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(sum), 0xB1, 0xF, 0xF, false));        // lane ^ 1
+          if (cpp > 2) sum += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(sum), 0x4E, 0xF, 0xF, false));   // lane ^ 2
+          x.x ^= kFlip; x.y ^= kFlip; x.z ^= kFlip; x.w ^= kFlip;
+          ds_write16_raw(patch_off + v * 16u, x);
+          if ((v & (cpp - 1u)) == 0) ds_write4_raw(pix_off + (v >> log_cpp) * 4u, static_cast<int32_t>(sum) - 128 * static_cast<int32_t>(cin));
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
     // accumulators start at the folded bias
     v16i acc[2][TN];
@@ -231,97 +301,171 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
         }
       }
 
-    int32_t rs[2] = {0, 0};
-    uint32_t kb = 0, t = 0;
-    for (uint32_t ky = 0; ky < g.KH; ky++) {
-      for (uint32_t kx = 0; kx < g.KW; kx++, t++) {
-        const uint32_t tap_off = ky * g.dh * a.PW + kx * g.dw;       // wave-uniform
-        uint32_t abase[2], aswz[2];
+    auto mma = [&](const Frags& f) __attribute__((always_inline)) {
+#pragma unroll
+      for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int tn = 0; tn < TN; tn++)
+            acc[j][tn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[tn][cb], f.a[j][cb], acc[j][tn], 0, 0, 0);
+    };
+
+    if constexpr (KS == 3) {
+      // 3x3, stride 1, dilation 1: patch row pitch 10 pixels. Fragment address of (ky, kx, j, cb) =
+      //   patch + rowbase[j] + ky * 10 * cin + slot(ky, j, cb) * 16   [one register per (ky, j, cb)]   + kx * cin [immediate]
+      const uint8_t* abase[3][2][CB];
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-          const uint32_t q = qbase[j] + tap_off;
-          const uint32_t py = ty[j] * g.sh + ky * g.dh;
-          abase[j] = q << log_cin;
-          aswz[j] = (py >> sh_log) & (cpp - 1u);
-          if ((t & 1u) == khalf) rs[j] += pix[q];                    // this lane: every second tap; partner: the others
-        }
-        for (uint32_t cb = 0; cb < cblocks; cb++, kb++) {
-          v4i af[2];
+          const uint32_t swz = (ty[j] + ky) & (cpp - 1u);
 #pragma unroll
-          for (int j = 0; j < 2; j++) {
-            af[j] = *reinterpret_cast<const v4i*>(patch + abase[j] + ((((cb << 1) | khalf) ^ aswz[j]) << 4));
+          for (int cb = 0; cb < CB; cb++) {
+            abase[ky][j][cb] = patch + rowbase[j] + ky * 10 * cin + ((((cb << 1) | khalf) ^ swz) << 4);
           }
-          v4i wf[TN];
-#pragma unroll
-          for (int tn = 0; tn < TN; tn++) {
-            wf[tn] = *reinterpret_cast<const v4i*>(w_lane + (tn * kblocks + kb) * 1024);
-          }
-#pragma unroll
-          for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int tn = 0; tn < TN; tn++)
-              acc[j][tn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[tn], af[j], acc[j][tn], 0, 0, 0);
         }
+      auto read3 = [&](auto t_c, Frags& f) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_c)::value;
+        constexpr int ky = t / 3, kx = t % 3;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int cb = 0; cb < CB; cb++) f.a[j][cb] = *reinterpret_cast<const v4i*>(abase[ky][j][cb] + kx * cin);
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+          for (int cb = 0; cb < CB; cb++)
+            f.w[tn][cb] = *reinterpret_cast<const v4i*>(w_lane + (tn * kblocks + t * CB + cb) * 1024u);
+      };
+      Frags f0, f1;
+      read3(std::integral_constant<int, 0>{}, f0);
+      read3(std::integral_constant<int, 1>{}, f1); mma(f0);
+      read3(std::integral_constant<int, 2>{}, f0); mma(f1);
+      read3(std::integral_constant<int, 3>{}, f1); mma(f0);
+      read3(std::integral_constant<int, 4>{}, f0); mma(f1);
+      read3(std::integral_constant<int, 5>{}, f1); mma(f0);
+      read3(std::integral_constant<int, 6>{}, f0); mma(f1);
+      read3(std::integral_constant<int, 7>{}, f1); mma(f0);
+      read3(std::integral_constant<int, 8>{}, f0); mma(f1);
+      mma(f0);
+    } else {
+      // any window: addresses per tap
+      auto read_frags = [&](uint32_t t, uint32_t ky, uint32_t kx, Frags& f) __attribute__((always_inline)) {
+        const uint32_t tap_off = (ky * g.dh * a.PW + kx * g.dw) << log_cin;       // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const uint32_t swz = ((ty[j] * g.sh + ky * g.dh) >> sh_log) & (cpp - 1u);
+          const uint8_t* base = patch + rowbase[j] + tap_off;
+#pragma unroll
+          for (int cb = 0; cb < CB; cb++) {
+            f.a[j][cb] = *reinterpret_cast<const v4i*>(base + ((((cb << 1) | khalf) ^ swz) << 4));
+          }
+        }
+        const uint8_t* wt = w_lane + (t * CB) * 1024u;
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+          for (int cb = 0; cb < CB; cb++) {
+            f.w[tn][cb] = *reinterpret_cast<const v4i*>(wt + (tn * kblocks + cb) * 1024u);
+          }
+      };
+      // two taps per trip, two register sets: the reads of tap t+1 are issued before the multiplies of tap t
+      Frags f0, f1;
+      read_frags(0, 0, 0, f0);
+      uint32_t ky = 0, kx = 0;
+      auto advance = [&]() __attribute__((always_inline)) { if (++kx == g.KW) { kx = 0; ky++; } };
+      uint32_t t = 0;
+      while (t + 2 <= taps) {
+        advance();
+        read_frags(t + 1, ky, kx, f1);
+        mma(f0);
+        advance();
+        if (t + 2 < taps) read_frags(t + 2, ky, kx, f0);
+        mma(f1);
+        t += 2;
       }
+      if (t < taps) mma(f0);
     }
+    CW_STAMP(2);
+    // Everything this wave has in flight -- the gather of `nxt` and the output stores of the previous unit -- was
+    // issued before the K loop: by now it has landed, so this wait is (almost) free; it is what makes `nxt`'s patch
+    // safe to read at the top of the next iteration without waiting for THIS unit's stores.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-    CW_STAMP(3);
-    // ---- fused epilogue: row term, Q31 requantization into the patch (now an output image), 16-byte stores ----
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // patch reads done before it is overwritten
+    // ---- fused epilogue, 32 positions at a time: row term from the pixel sums, Q31 requantization into the staging
+    //      image, whole 4-row x 8-position runs stored with 16-byte pieces ----
+    uint8_t* out_img = p.output + static_cast<uint64_t>(img) * g.OH * g.OW * p.n;
+    const uint32_t stage_off = lds_off(stage);
     requant_dispatch(p.rq, [&](auto shift0, auto full) {
-      const int4 no_bias[4] = {};
 #pragma unroll
       for (int j = 0; j < 2; j++) {
-        int32_t s = rs[j];
-        s += __shfl_xor(s, 32);
+        // sum of a' over this position's window: the window's pixel sums
+        int32_t s = 0;
+        const int32_t* pq = pix + (ty[j] * g.sh * a.PW + ((j * 32u + (lane & 31u)) & 7u) * g.sw);
+        if constexpr (KS == 3) {
+#pragma unroll
+          for (int t = 0; t < 9; t++) s += pq[(t / 3) * 10 + (t % 3)];
+        } else {
+          for (uint32_t ky = 0; ky < g.KH; ky++)
+            for (uint32_t kx = 0; kx < g.KW; kx++) s += pq[ky * g.dh * a.PW + kx * g.dw];
+        }
         const int32_t rowterm = p.row_coeff * s;
-        uint8_t* img_row = patch + (j * 32u + (lane & 31u)) * p.n;
 #pragma unroll
         for (int tn = 0; tn < TN; tn++) {
-          igemm_stage_tile<decltype(shift0)::value, decltype(full)::value, false, 2>(
-              acc[j][tn], no_bias, rowterm, img_row, tn * 32, khalf, p);
+          // (igemm_stage_tile, with the LDS store as a raw ds_write: see the header)
+          uint32_t pk[4];
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {
+            pk[rg] = q31_requantize_pack4<decltype(shift0)::value, decltype(full)::value>(
+                acc[j][tn][rg * 4 + 0] + rowterm, acc[j][tn][rg * 4 + 1] + rowterm,
+                acc[j][tn][rg * 4 + 2] + rowterm, acc[j][tn][rg * 4 + 3] + rowterm, p.rq);
+          }
+          const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+          const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+          ds_write16_raw(stage_off + (lane & 31u) * p.n + tn * 32 + khalf * 16, make_uint4(s02[0], s02[1], s13[0], s13[1]));
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // image complete before it is read back
+        const uint32_t pieces = 32u * cpr;
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++) {
+          const uint32_t idx = lane + tt * 64u;
+          const uint32_t i = j * 32u + (idx >> log_cpr);
+          const uint32_t ch = idx & (cpr - 1u);
+          const uint32_t oy = oy0 + (i >> 3);
+          const uint32_t ox = ox0 + (i & 7u);
+          if (idx < pieces && oy < g.OH && ox < g.OW) {
+            *reinterpret_cast<uint4*>(out_img + (static_cast<uint64_t>(oy) * g.OW + ox) * p.n + ch * 16u) =
+                *reinterpret_cast<const uint4*>(stage + idx * 16u);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // read back before the next half overwrites it
       }
     });
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // image complete before it is read back
+    CW_STAMP(3);
     CW_STAMP(4);
-    {
-      const uint32_t pieces = 64u * cpr;
-      uint8_t* out_img = p.output + static_cast<uint64_t>(img) * g.OH * g.OW * p.n;
-#pragma unroll
-      for (int tt = 0; tt < 4; tt++) {
-        const uint32_t idx = lane + tt * 64u;
-        const uint32_t i = idx >> log_cpr;
-        const uint32_t ch = idx & (cpr - 1u);
-        const uint32_t oy = oy0 + (i >> 3);
-        const uint32_t ox = ox0 + (i & 7u);
-        if (idx < pieces && oy < g.OH && ox < g.OW) {
-          *reinterpret_cast<uint4*>(out_img + (static_cast<uint64_t>(oy) * g.OW + ox) * p.n + ch * 16u) =
-              *reinterpret_cast<const uint4*>(patch + idx * 16u);
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // read back before the next patch lands
     CW_STAMP(5);
     unit_no++;
     cur = nxt;
+    buf ^= 1u;
   }
 #undef CW_STAMP
 }
 
-template <int TN>
+template <int TN, int CB, int KS>
 int launch(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, uint32_t lds_bytes, hipStream_t stream)
 {
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
   if (attr_once.first()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_mfma_kernel<TN>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_mfma_kernel<TN, CB, KS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       (void) hipGetLastError();
     }
   }
   const uint32_t want = (a.units + kWaves - 1) / kWaves;
   const uint32_t grid = want < p.cu_count ? want : p.cu_count;
-  hipLaunchKernelGGL((q8_conv_wave_mfma_kernel<TN>), dim3(grid), dim3(kThreads), lds_bytes, stream, p, g, a);
+  hipLaunchKernelGGL((q8_conv_wave_mfma_kernel<TN, CB, KS>), dim3(grid), dim3(kThreads), lds_bytes, stream, p, g, a);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
@@ -329,7 +473,7 @@ int launch(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, uint32_t 
 
 bool convwave_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32_t vec, uint32_t batch)
 {
-  if (groups != 1 || vec != 16) return false;
+  if (groups != 1 || vec != 16 || p.fill_table == nullptr) return false;
   if (!(p.kc == 32 || p.kc == 64)) return false;
   if (!(p.n == 32 || p.n == 64) || p.n_pad != p.n || p.output_stride != p.n) return false;
   if (p.k_total != g.KH * g.KW * p.kc) return false;
@@ -345,7 +489,13 @@ int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hip
   uint32_t lds_bytes = 0;
   if (!make_args(p, g, batch, &a, &lds_bytes)) return QNNP_HIP_EINVAL;
   *name = "q8_conv_wave_mfma";
-  return p.n == 32 ? launch<1>(p, g, a, lds_bytes, stream) : launch<2>(p, g, a, lds_bytes, stream);
+  const bool k33 = g.KH == 3 && g.KW == 3 && g.sh == 1 && g.sw == 1 && g.dh == 1 && g.dw == 1;
+  if (p.kc == 32) {
+    if (k33) return p.n == 32 ? launch<1, 1, 3>(p, g, a, lds_bytes, stream) : launch<2, 1, 3>(p, g, a, lds_bytes, stream);
+    return p.n == 32 ? launch<1, 1, 0>(p, g, a, lds_bytes, stream) : launch<2, 1, 0>(p, g, a, lds_bytes, stream);
+  }
+  if (k33) return p.n == 32 ? launch<1, 2, 3>(p, g, a, lds_bytes, stream) : launch<2, 2, 3>(p, g, a, lds_bytes, stream);
+  return p.n == 32 ? launch<1, 2, 0>(p, g, a, lds_bytes, stream) : launch<2, 2, 0>(p, g, a, lds_bytes, stream);
 }
 
 }  // namespace qnnp

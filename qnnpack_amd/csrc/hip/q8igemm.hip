@@ -568,11 +568,13 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   geom.dh = a->dilation_height; geom.dw = a->dilation_width; geom.pad_top = a->pad_top; geom.pad_left = a->pad_left;
   const bool lds_ok = a->offsets != nullptr && !pad3 && a->rows_per_image > 0 &&
       a->output_stride % 16 == 0 && qnnp::convlds_supported(p, geom, a->groups, vec);
-  // Opt-in alternative for the small-window, <= 64-channel ones: one wave per 8x8 block of positions, no
-  // barriers (q8convwave.hip). Measured 12 % SLOWER than the LDS-tiled kernel on configs[2] (41.9 vs 37.2 us,
-  // same box), so it is never selected automatically.
-  const bool wave_ok = a->variant == 8 && a->offsets != nullptr && !pad3 && a->rows_per_image > 0 && p.store_mode == 2 &&
+  // 3x3 / stride 1 / dilation 1 windows with 32 or 64 channels in and out (BASELINE configs[2]): one wave per 8x8 block of
+  // positions, patches streamed by LDS-DMA, no barriers (q8convwave.hip) -- 31 us against 37.7 us for the LDS-tiled
+  // kernel on configs[2], same box. Other windows the wave kernel accepts run on it only when forced ("gemm_kernel" = 8).
+  const bool wave_shape = a->offsets != nullptr && !pad3 && a->rows_per_image > 0 && p.store_mode == 2 &&
       qnnp::convwave_supported(p, geom, a->groups, vec, a->rows / a->rows_per_image);
+  const bool wave_k33 = geom.KH == 3 && geom.KW == 3 && geom.sh == 1 && geom.sw == 1 && geom.dh == 1 && geom.dw == 1;
+  const bool wave_ok = wave_shape && (a->variant == 8 || (a->variant == 0 && wave_k33 && a->rows >= 16384u));
   if (a->variant == 8 && !wave_ok) return QNNP_HIP_EINVAL;
   if (wave_ok) {
     const int rc_wave = qnnp::convwave_launch(p, geom, a->rows / a->rows_per_image, stream, &name);

@@ -44,6 +44,7 @@ if layer_id == 0:
     print("start skew across blocks (cycles):", int(t[:, 0, 0].max() - t[:, 0, 0].min()), " end skew:", int(t[:, 0, 4].max() - t[:, 0, 4].min()))
     sys.exit(0)
 lib.set_option("dwconv_kernel", int(os.environ.get("DW_KERNEL", "0")))
+lib.set_option("gemm_kernel", int(os.environ.get("GEMM_KERNEL", "0")))
 H, W, KH, KW, S, D, G, GIC, GOC = (56, 56, 3, 3, 1, 1, 1, 64, 64) if layer_id == 99 else bench.MOBILENETV2[layer_id - 1]
 layer = bench.ConvLayer(lib, torch, batch, H, W, KH, KW, S, D, G, GIC, GOC, seed=1, min_bytes_between_reuse=512 << 20)
 for _ in range(3): lib.run_operator(layer.op)
