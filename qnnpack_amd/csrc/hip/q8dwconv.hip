@@ -579,24 +579,40 @@ __device__ __forceinline__ void dwconv_col3x3_body(
   const int32_t iy_first = static_cast<int32_t>(oy0 * S) - static_cast<int32_t>(p.pad_top);
 
   struct Row { uint32_t c[3]; };
-  // one input row: three dwords (wave-uniform row validity: no memory access for padding rows)
-  auto load_row = [&](int32_t iy) __attribute__((always_inline)) -> Row {
+  // One input row: three dwords. The loads are ALWAYS issued (a row outside the image is clamped to a valid one and
+  // its values replaced afterwards, wave-uniformly): a branch around the loads makes the number of outstanding
+  // operations path-dependent, and hipcc then falls back to s_waitcnt vmcnt(<3) right behind the newest loads --
+  // the rows "in flight" were waited for at once (measured: 17 of 45 us on MobileNetV2 layer 8).
+  // CHECK = false: the caller knows the row is inside the image (the steady state of a segment).
+  auto load_row = [&](auto check, int32_t iy) __attribute__((always_inline)) -> Row {
+    constexpr bool CHECK = decltype(check)::value;
     Row r;
-    if (iy >= 0 && iy < static_cast<int32_t>(p.H)) {
-      const uint32_t ro = img_off + static_cast<uint32_t>(iy) * row_bytes;      // scalar
-      r.c[0] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[0], ro, 0);
-      r.c[1] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[1], ro, 0);
-      r.c[2] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[2], ro, 0);
-      if constexpr (FIX) {
-        r.c[0] = ok0 ? r.c[0] : fill;
-        r.c[1] = ok1 ? r.c[1] : fill;
-        r.c[2] = ok2 ? r.c[2] : fill;
-      }
-    } else {
-      r.c[0] = r.c[1] = r.c[2] = fill;
+#ifdef QNNP_ENABLE_ABLATION
+    if (p.abl & 2u) { r.c[0] = coff[0] ^ static_cast<uint32_t>(iy); r.c[1] = coff[1]; r.c[2] = coff[2] + static_cast<uint32_t>(iy); return r; }
+#endif
+    bool row_ok = true;
+    if constexpr (CHECK) {
+      row_ok = iy >= 0 && iy < static_cast<int32_t>(p.H);
+      iy = iy < 0 ? 0 : (iy >= static_cast<int32_t>(p.H) ? static_cast<int32_t>(p.H) - 1 : iy);
+    }
+    const uint32_t ro = img_off + static_cast<uint32_t>(iy) * row_bytes;      // scalar
+    r.c[0] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[0], ro, 0);
+    r.c[1] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[1], ro, 0);
+    r.c[2] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[2], ro, 0);
+    if constexpr (FIX) {
+      r.c[0] = ok0 ? r.c[0] : fill;
+      r.c[1] = ok1 ? r.c[1] : fill;
+      r.c[2] = ok2 ? r.c[2] : fill;
+    }
+    if constexpr (CHECK) {
+      r.c[0] = row_ok ? r.c[0] : fill;
+      r.c[1] = row_ok ? r.c[1] : fill;
+      r.c[2] = row_ok ? r.c[2] : fill;
     }
     return r;
   };
+  constexpr std::true_type kChecked{};
+  constexpr std::false_type kInside{};
   struct Pair { uint32_t v[4]; };
   // per channel c: (lo.byte c, hi.byte c) as two zero-extended int16
   auto pair = [](uint32_t lo, uint32_t hi) __attribute__((always_inline)) -> Pair {
@@ -632,6 +648,9 @@ __device__ __forceinline__ void dwconv_col3x3_body(
     auto finish = [&](int32_t (&acc)[4]) __attribute__((always_inline)) {
       const uint32_t packed = qnnp::q31_requantize_pack4<decltype(shift0)::value, decltype(full)::value>(
           acc[0], acc[1], acc[2], acc[3], p.rq);
+#ifdef QNNP_ENABLE_ABLATION
+      if (p.abl & 1u) { asm volatile("" :: "v"(packed)); out_soff += out_step; return; }
+#endif
       __builtin_amdgcn_raw_buffer_store_b32(packed, out_rsrc, out_voff, out_soff, 0);
       out_soff += out_step;
     };
@@ -642,21 +661,24 @@ __device__ __forceinline__ void dwconv_col3x3_body(
       //   RP = row t+1 (its col2 is still needed), RC = row t+2, third row buffer = row t+3 (in flight).
       // The step pairs row t+2, then re-uses RP for row t+4: two rows are always in flight. Roles rotate through
       // the same registers with period three, so three steps are written out per trip and nothing is copied.
-      const Row r0 = load_row(iy_first);
-      Row b1 = load_row(iy_first + 1);
-      Row b2 = load_row(iy_first + 2);
-      Row b3 = load_row(iy_first + 3);
+      const Row r0 = load_row(kChecked, iy_first);
+      Row b1 = load_row(kChecked, iy_first + 1);
+      Row b2 = load_row(kChecked, iy_first + 2);
+      Row b3 = load_row(kChecked, iy_first + 3);
       Pair h0 = pair(r0.c[0], r0.c[1]);
       Pair h1 = pair(b1.c[0], b1.c[1]);
       Pair qa = pair(r0.c[2], r0.c[2]);            // Q[-1] = (don't care, col2 @ 0)
       Pair qb = pair(r0.c[2], b1.c[2]);            // Q[0]
       Pair h2, qc;
       uint32_t t = 0;
-#define QNNP_DW_COL_STEP(HA, HB, HC, QA, QB, QC, RP, RC)                             \
+      // steps whose prefetched row (iy_first + t + 4) is inside the image: t < t_inside
+      const int32_t inside = static_cast<int32_t>(p.H) - 4 - iy_first;
+      const uint32_t t_inside = inside <= 0 ? 0u : (static_cast<uint32_t>(inside) < steps ? static_cast<uint32_t>(inside) : steps);
+#define QNNP_DW_COL_STEP(CHECK, HA, HB, HC, QA, QB, QC, RP, RC)                      \
       {                                                                             \
         HC = pair(RC.c[0], RC.c[1]);                        /* H[t+2] */            \
         QC = pair(RP.c[2], RC.c[2]);                        /* Q[t+1] */            \
-        RP = load_row(iy_first + static_cast<int32_t>(t) + 4);                      \
+        RP = load_row(CHECK, iy_first + static_cast<int32_t>(t) + 4);               \
         int32_t acc[4];                                                             \
         dot_first(HA, w01[0], bias, acc);                                           \
         dot(HB, w01[1], acc);                                                       \
@@ -666,15 +688,18 @@ __device__ __forceinline__ void dwconv_col3x3_body(
         finish(acc);                                                                \
         t++;                                                                        \
       }
-      while (t + 3 <= steps) {
-        QNNP_DW_COL_STEP(h0, h1, h2, qa, qb, qc, b1, b2)
-        QNNP_DW_COL_STEP(h1, h2, h0, qb, qc, qa, b2, b3)
-        QNNP_DW_COL_STEP(h2, h0, h1, qc, qa, qb, b3, b1)
+      while (t + 3 <= t_inside) {                  // steady state: straight-line body, counted waits
+        QNNP_DW_COL_STEP(kInside, h0, h1, h2, qa, qb, qc, b1, b2)
+        QNNP_DW_COL_STEP(kInside, h1, h2, h0, qb, qc, qa, b2, b3)
+        QNNP_DW_COL_STEP(kInside, h2, h0, h1, qc, qa, qb, b3, b1)
       }
-      if (t < steps) {
-        QNNP_DW_COL_STEP(h0, h1, h2, qa, qb, qc, b1, b2)
+      while (t < steps) {                          // the last steps of a segment (and of the image: padding rows)
+        QNNP_DW_COL_STEP(kChecked, h0, h1, h2, qa, qb, qc, b1, b2)
         if (t < steps) {
-          QNNP_DW_COL_STEP(h1, h2, h0, qb, qc, qa, b2, b3)
+          QNNP_DW_COL_STEP(kChecked, h1, h2, h0, qb, qc, qa, b2, b3)
+          if (t < steps) {
+            QNNP_DW_COL_STEP(kChecked, h2, h0, h1, qc, qa, qb, b3, b1)
+          }
         }
       }
 #undef QNNP_DW_COL_STEP
@@ -682,22 +707,26 @@ __device__ __forceinline__ void dwconv_col3x3_body(
       // stride 2: window rows of output t: 2t, 2t+1, 2t+2. State entering step t:
       //   HA = H[2t], QA = (don't care, col2 @ 2t), (RA, RB) = rows 2t+1 / 2t+2, the other row pair = rows 2t+3 / 2t+4
       //   (in flight). Period two: two steps per trip.
-      const Row r0 = load_row(iy_first);
-      Row a1 = load_row(iy_first + 1);
-      Row a2 = load_row(iy_first + 2);
-      Row c1 = load_row(iy_first + 3);
-      Row c2 = load_row(iy_first + 4);
+      const Row r0 = load_row(kChecked, iy_first);
+      Row a1 = load_row(kChecked, iy_first + 1);
+      Row a2 = load_row(kChecked, iy_first + 2);
+      Row c1 = load_row(kChecked, iy_first + 3);
+      Row c2 = load_row(kChecked, iy_first + 4);
+      // steps whose prefetched rows (iy_first + 2t + 5, + 6) are inside the image: t < t_inside
+      const int32_t inside = (static_cast<int32_t>(p.H) - 5 - iy_first) / 2;
+      const uint32_t t_inside = (static_cast<int32_t>(p.H) - 5 - iy_first) <= 0 ? 0u :
+          (static_cast<uint32_t>(inside) < steps ? static_cast<uint32_t>(inside) : steps);
       Pair ha = pair(r0.c[0], r0.c[1]);
       Pair qa = pair(r0.c[2], r0.c[2]);
       Pair hb, qb;
       uint32_t t = 0;
-#define QNNP_DW_COL_STEP2(HA, HC, QA, QC, RA, RB)                                   \
+#define QNNP_DW_COL_STEP2(CHECK, HA, HC, QA, QC, RA, RB)                            \
       {                                                                             \
         const Pair hmid = pair(RA.c[0], RA.c[1]);           /* H[2t+1] */           \
         HC = pair(RB.c[0], RB.c[1]);                        /* H[2t+2] = H[2(t+1)] */ \
         QC = pair(RA.c[2], RB.c[2]);                        /* (col2 @ 2t+1, col2 @ 2t+2) */ \
-        RA = load_row(iy_first + 2 * static_cast<int32_t>(t) + 5);                  \
-        RB = load_row(iy_first + 2 * static_cast<int32_t>(t) + 6);                  \
+        RA = load_row(CHECK, iy_first + 2 * static_cast<int32_t>(t) + 5);           \
+        RB = load_row(CHECK, iy_first + 2 * static_cast<int32_t>(t) + 6);           \
         int32_t acc[4];                                                             \
         dot_first(HA, w01[0], bias, acc);                                           \
         dot(hmid, w01[1], acc);                                                     \
@@ -707,12 +736,15 @@ __device__ __forceinline__ void dwconv_col3x3_body(
         finish(acc);                                                                \
         t++;                                                                        \
       }
-      while (t + 2 <= steps) {
-        QNNP_DW_COL_STEP2(ha, hb, qa, qb, a1, a2)
-        QNNP_DW_COL_STEP2(hb, ha, qb, qa, c1, c2)
+      while (t + 2 <= t_inside) {
+        QNNP_DW_COL_STEP2(kInside, ha, hb, qa, qb, a1, a2)
+        QNNP_DW_COL_STEP2(kInside, hb, ha, qb, qa, c1, c2)
       }
-      if (t < steps) {
-        QNNP_DW_COL_STEP2(ha, hb, qa, qb, a1, a2)
+      while (t < steps) {
+        QNNP_DW_COL_STEP2(kChecked, ha, hb, qa, qb, a1, a2)
+        if (t < steps) {
+          QNNP_DW_COL_STEP2(kChecked, hb, ha, qb, qa, c1, c2)
+        }
       }
 #undef QNNP_DW_COL_STEP2
     }
@@ -778,7 +810,9 @@ bool plan_col(DwParams& p)
   // Row segments: each re-loads its halo (two rows at stride 1) and builds the first pairs again, so as few as
   // still give every SIMD several waves' worth of work (the tail of the last round is what it buys back).
   const uint64_t waves_per_seg = static_cast<uint64_t>(p.batch) * chunks;
-  const uint64_t target = static_cast<uint64_t>(p.cu_count) * 4u * 6u * 3u;      // ~3 rounds at 6 waves per SIMD
+  // (measured on the MobileNetV2 layers, batch 128: 1.3-2 rounds of waves beat 3-4 -- 35.6 against 39.6 us on
+  //  layer 8 -- now that the rows in flight are really in flight; shorter segments only add start-ups and halo rows)
+  const uint64_t target = static_cast<uint64_t>(p.cu_count) * 4u * 6u * 3u / 2u;  // ~1.5 rounds at 6 waves per SIMD
   uint32_t segs = static_cast<uint32_t>((target + waves_per_seg - 1) / waves_per_seg);
   const uint32_t min_rows = 7;
   uint32_t max_segs = p.OH / min_rows;
@@ -1359,11 +1393,10 @@ int make_plan(DwParams& p, const struct qnnp_hip_dwconv_args* a, uintptr_t in_ad
   } else if (a->variant == 4) {
     if (!plan_mfma(p, a)) return QNNP_HIP_EINVAL;
     plan->kernel = kPlanMfma;
-  } else if (a->variant == 0 && k33 && aligned4 && !(p.sh == 2 && p.OH < 28) && plan_col(p)) {
-    // 3x3, dilation 1, stride 1 | 2: the column-sliding window (kernel G) -- 10-25 % ahead of the LDS-tiled and the
-    // matrix-core kernels on eight of the ten MobileNetV2 depthwise layers at batch 128 (same-box A/B,
-    // scripts/gpu_dwab.sh); the two short stride-2 images (28 -> 14, 14 -> 7 rows: 7-14 steps per wave against a
-    // fixed start-up) stay with the LDS-tiled kernel, 5-8 % ahead there.
+  } else if (a->variant == 0 && k33 && aligned4 && plan_col(p)) {
+    // 3x3, dilation 1, stride 1 | 2: the column-sliding window (kernel G) -- 20-35 % ahead of the LDS-tiled and the
+    // matrix-core kernels on every one of the ten MobileNetV2 depthwise layers at batch 128 (same-box A/B,
+    // scripts/gpu_dwab.sh, profiles/r02/dwconv_kernel_ab_*.txt).
     plan->kernel = kPlanCol;
   } else if (a->variant == 0 && k33 && p.OW >= 56 && p.C <= 96 && plan_mfma_lds(p, a)) {
     // (shapes kernel G declines, e.g. tensors beyond its 32-bit offsets) large images with few channels: the

@@ -112,8 +112,8 @@ def test_c4_mobilenetv2_depthwise_layers(qnnp, h, s, c):
         qnnp.setup_convolution2d_nhwc_q8(op, batch, h, h, d_in, c, d_out, c)
         qnnp.run_operator(op)
         kname = qnnp.operator_kernel(op)
-        # the column-sliding window kernel, except the short stride-2 images (LDS-tiled kernel): q8dwconv.hip make_plan
-        assert kname == ("q8_dwconv_lds_3x3" if (s == 2 and h // s < 28) else "q8_dwconv_col_3x3"), kname
+        # the column-sliding window kernel (q8dwconv.hip make_plan)
+        assert kname == "q8_dwconv_col_3x3", kname
         assert_bytes_equal(from_device(d_out), expected, f"C4 depthwise {h}x{h} s{s} C{c} vs oracle")
     finally:
         qnnp.delete_operator(op)
