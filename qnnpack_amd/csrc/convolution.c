@@ -394,7 +394,9 @@ static enum qnnp_status qnnp_setup_convolution2d_nhwc_q8_impl(
       if (op->offsets_capacity < entries) {
         qnnp_hip_free(op->d_offsets);
         op->offsets_capacity = 0;
-        op->d_offsets = (int32_t*) qnnp_hip_alloc(sizeof(int32_t) * entries);
+        /* (+ 16 bytes: the 3-channel streaming kernel reads a lane's four consecutive entries with one 16-byte
+         *  load, which for the last pixel's second K block starts on its 9th entry and runs past the table) */
+        op->d_offsets = (int32_t*) qnnp_hip_alloc(sizeof(int32_t) * entries + 16);
         if (op->d_offsets == NULL) {
           free(host_table);
           qnnp_log_error("failed to allocate %zu bytes for the device offset table", sizeof(int32_t) * entries);

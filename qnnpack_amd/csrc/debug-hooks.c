@@ -115,6 +115,30 @@ void qnnp_debug_requant_fast_bits(
   }
 }
 
+/* the offset forms (hip/requant_math.h, qnnp_requant_fast_enable_offset) through the same path: what a kernel that
+ * hands over n + 2^31 evaluates. `kind_out`: 0 none (general form used), 1 shift-0 form, 2 bounded form */
+void qnnp_debug_requant_fast_offset(
+    size_t count, const int32_t* acc, float scale, uint8_t zero_point, uint8_t qmin, uint8_t qmax,
+    uint32_t accumulator_bits, uint8_t* out, int* kind_out)
+{
+  const struct qnnp_hip_requant rq = qnnp_compute_requant(scale, zero_point, qmin, qmax);
+  struct qnnp_requant_fast f = qnnp_requant_fast_init(rq.multiplier, rq.shift);
+  const int folded = qnnp_requant_fast_fold_zero_point(&f, (uint32_t) rq.output_zero_point);
+  (void) qnnp_requant_fast_enable_bounded(&f, (uint32_t) rq.output_zero_point, folded, accumulator_bits);
+  const uint32_t kind = qnnp_requant_fast_enable_offset(&f);
+  if (kind_out != NULL) *kind_out = (int) kind;
+  const int32_t zp_late = folded ? 0 : rq.output_zero_point;
+  int32_t lo = rq.output_min_less_zero_point + (folded ? rq.output_zero_point : 0);
+  const int32_t hi = rq.output_max_less_zero_point + (folded ? rq.output_zero_point : 0);
+  if (lo > hi) lo = hi;
+  for (size_t i = 0; i < count; i++) {
+    int32_t y = qnnp_requant_scale_via_offset(acc[i], f);
+    if (y < lo) y = lo;
+    if (y > hi) y = hi;
+    out[i] = (uint8_t) (y + zp_late);
+  }
+}
+
 void qnnp_debug_pack_igemm_w_slots(
     uint32_t groups, uint32_t n, uint32_t ks, uint32_t kc, uint32_t kc_slot, uint32_t n_pad, uint32_t k_pad,
     uint8_t izp, uint8_t kzp, const uint8_t* kernel, const int32_t* bias,

@@ -50,12 +50,12 @@ __device__ __forceinline__ void igemm_store_tile(
   for (int rg = 0; rg < 4; rg++) {
     int32_t v0 = acc[rg * 4 + 0], v1 = acc[rg * 4 + 1], v2 = acc[rg * 4 + 2], v3 = acc[rg * 4 + 3];
     if constexpr (PRE_BIASED == 0) {
-      v0 += rowterm + bias[rg].x;
-      v1 += rowterm + bias[rg].y;
-      v2 += rowterm + bias[rg].z;
-      v3 += rowterm + bias[rg].w;
+      v0 = add_wrap(v0, rowterm, bias[rg].x);    // (wrapping: the row term may carry the 2^31 offset, requant.hip.h)
+      v1 = add_wrap(v1, rowterm, bias[rg].y);
+      v2 = add_wrap(v2, rowterm, bias[rg].z);
+      v3 = add_wrap(v3, rowterm, bias[rg].w);
     } else if constexpr (PRE_BIASED == 2) {
-      v0 += rowterm; v1 += rowterm; v2 += rowterm; v3 += rowterm;
+      v0 = add_wrap(v0, rowterm); v1 = add_wrap(v1, rowterm); v2 = add_wrap(v2, rowterm); v3 = add_wrap(v3, rowterm);
     }
     if constexpr (NO_REQUANT) {
       pk[rg] = static_cast<uint32_t>(v0 ^ v1 ^ v2 ^ v3);   // measurement-only ablation
@@ -118,12 +118,12 @@ __device__ __forceinline__ void igemm_stage_tile_rq(
   for (int rg = 0; rg < 4; rg++) {
     int32_t v0 = acc[rg * 4 + 0], v1 = acc[rg * 4 + 1], v2 = acc[rg * 4 + 2], v3 = acc[rg * 4 + 3];
     if constexpr (PRE_BIASED == 0) {
-      v0 += rowterm + bias[rg].x;
-      v1 += rowterm + bias[rg].y;
-      v2 += rowterm + bias[rg].z;
-      v3 += rowterm + bias[rg].w;
+      v0 = add_wrap(v0, rowterm, bias[rg].x);    // (wrapping: the row term may carry the 2^31 offset, requant.hip.h)
+      v1 = add_wrap(v1, rowterm, bias[rg].y);
+      v2 = add_wrap(v2, rowterm, bias[rg].z);
+      v3 = add_wrap(v3, rowterm, bias[rg].w);
     } else if constexpr (PRE_BIASED == 2) {
-      v0 += rowterm; v1 += rowterm; v2 += rowterm; v3 += rowterm;
+      v0 = add_wrap(v0, rowterm); v1 = add_wrap(v1, rowterm); v2 = add_wrap(v2, rowterm); v3 = add_wrap(v3, rowterm);
     }
     if constexpr (NO_REQUANT) {
       pk[rg] = static_cast<uint32_t>(v0 ^ v1 ^ v2 ^ v3);

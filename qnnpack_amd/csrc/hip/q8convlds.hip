@@ -299,12 +299,13 @@ void q8_conv_lds_mfma_kernel(const IgemmParams p, const ConvGeom g, const uint32
 
   QNNP_TRACE(p, blockIdx.x, item_no, 3);
   // ---- fused epilogue ----
-  requant_dispatch(p.rq, [&](auto shift0, auto full) {
+  requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       int32_t s = rs[j];
       s += __shfl_xor(s, 32);                     // the two K halves of a position live in lanes l, l+32
-      const int32_t rowterm = p.row_coeff * s;
+      // (+ 2^31 for the offset rounding sequences, requant.hip.h)
+      const int32_t rowterm = with_rq_offset<decltype(shift0)::value>(p.row_coeff * s);
       uint8_t* out_row = p.output + (static_cast<uint64_t>(img) * ohw + pos[j]) * p.output_stride;
 #pragma unroll
       for (int tn = 0; tn < TN; tn++) {

@@ -398,7 +398,7 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
     //      image, whole 4-row x 8-position runs stored with 16-byte pieces ----
     uint8_t* out_img = p.output + static_cast<uint64_t>(img) * g.OH * g.OW * p.n;
     const uint32_t stage_off = lds_off(stage);
-    requant_dispatch(p.rq, [&](auto shift0, auto full) {
+    requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         // sum of a' over this position's window: the window's pixel sums
@@ -411,7 +411,8 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
           for (uint32_t ky = 0; ky < g.KH; ky++)
             for (uint32_t kx = 0; kx < g.KW; kx++) s += pq[ky * g.dh * a.PW + kx * g.dw];
         }
-        const int32_t rowterm = p.row_coeff * s;
+        // (+ 2^31 for the offset rounding sequences, requant.hip.h: free here)
+        const int32_t rowterm = with_rq_offset<decltype(shift0)::value>(p.row_coeff * s);
 #pragma unroll
         for (int tn = 0; tn < TN; tn++) {
           // (igemm_stage_tile, with the LDS store as a raw ds_write: see the header)
@@ -419,8 +420,8 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
 #pragma unroll
           for (int rg = 0; rg < 4; rg++) {
             pk[rg] = q31_requantize_pack4<decltype(shift0)::value, decltype(full)::value>(
-                acc[j][tn][rg * 4 + 0] + rowterm, acc[j][tn][rg * 4 + 1] + rowterm,
-                acc[j][tn][rg * 4 + 2] + rowterm, acc[j][tn][rg * 4 + 3] + rowterm, p.rq);
+                add_wrap(acc[j][tn][rg * 4 + 0], rowterm), add_wrap(acc[j][tn][rg * 4 + 1], rowterm),
+                add_wrap(acc[j][tn][rg * 4 + 2], rowterm), add_wrap(acc[j][tn][rg * 4 + 3], rowterm), p.rq);
           }
           const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
           const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);

@@ -278,7 +278,10 @@ void q8_dwconv_lds_kernel(const DwParams p)
   uint32_t base_off = (oyl * p.sh) * row_bytes + c4 * line_bytes + (ox * p.sw) * 4;
   const uint32_t d_base = (d_oy * p.sh) * row_bytes + (d_ox * p.sw) * 4;
   const uint32_t wrap_base = p.sh * row_bytes - (p.OW * p.sw) * 4;      // one row down, OW columns back
-  qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
+  qnnp::requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
+    // the offset rounding sequences (requant.hip.h) take accumulator + 2^31: folded into the bias, once per thread
+#pragma unroll
+    for (int c = 0; c < 4; c++) bias[c] = qnnp::with_rq_offset<decltype(shift0)::value>(bias[c]);
     for (uint32_t pos = slot; pos < npos; pos += nslots) {
       const uint8_t* base = tile + base_off;
       uint32_t in[TAPS];
@@ -413,7 +416,9 @@ void q8_dwconv_row3x3_kernel(const DwParams p)
     }
   };
 
-  qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
+  qnnp::requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) bias[c] = qnnp::with_rq_offset<decltype(shift0)::value>(bias[c]);
     // window columns kx = 0, 1, 2 of the current output plus the SW columns the NEXT output adds: those are
     // loaded one step ahead, so a load has a whole step of VALU work (and the other waves) to land
     uint32_t w0[3], w1[3], w2[3], n0[3], n1[3];
@@ -539,7 +544,7 @@ int launch_row(const DwParams& p, hipStream_t stream)
  */
 constexpr int kColThreads = 256;
 
-template <int S, bool FIX>
+template <int S, bool FIX, int SEQ, bool FULL>
 __device__ __forceinline__ void dwconv_col3x3_body(
     const DwParams& p, const uint32_t n, const uint32_t oy0, const uint32_t oy1, const uint32_t ox, const uint32_t cg,
     const bool ok0, const bool ok1, const bool ok2)
@@ -644,9 +649,12 @@ __device__ __forceinline__ void dwconv_col3x3_body(
   uint32_t out_soff = (n * p.OH + oy0) * p.OW * p.out_stride;       // scalar, advances one output row per step
   const uint32_t out_step = p.OW * p.out_stride;
 
-  qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
+  {
+    // the offset rounding sequences (requant.hip.h) take accumulator + 2^31: folded into the bias, once per thread
+#pragma unroll
+    for (int c = 0; c < 4; c++) bias[c] = qnnp::with_rq_offset<SEQ>(bias[c]);
     auto finish = [&](int32_t (&acc)[4]) __attribute__((always_inline)) {
-      const uint32_t packed = qnnp::q31_requantize_pack4<decltype(shift0)::value, decltype(full)::value>(
+      const uint32_t packed = qnnp::q31_requantize_pack4<SEQ, FULL>(
           acc[0], acc[1], acc[2], acc[3], p.rq);
 #ifdef QNNP_ENABLE_ABLATION
       if (p.abl & 1u) { asm volatile("" :: "v"(packed)); out_soff += out_step; return; }
@@ -748,10 +756,12 @@ __device__ __forceinline__ void dwconv_col3x3_body(
       }
 #undef QNNP_DW_COL_STEP2
     }
-  });
+  }
 }
 
-template <int S>
+/* SEQ / FULL: the requantization flavour (requant.hip.h), chosen on the host -- one kernel per flavour, so that the
+ * common one is not charged the registers of the rare ones (83 against 77 VGPRs: 5 instead of 6 waves per SIMD) */
+template <int S, int SEQ, bool FULL>
 __global__ __launch_bounds__(kColThreads)
 void q8_dwconv_col3x3_kernel(const DwParams p)
 {
@@ -777,9 +787,9 @@ void q8_dwconv_col3x3_kernel(const DwParams p)
   const bool ok1 = ix0 + 1 >= 0 && ix0 + 1 < static_cast<int32_t>(p.W);
   const bool ok2 = ix0 + 2 >= 0 && ix0 + 2 < static_cast<int32_t>(p.W);
   if (__builtin_amdgcn_ballot_w64(!(ok0 && ok1 && ok2)) != 0) {
-    dwconv_col3x3_body<S, true>(p, n, oy0, oy1, ox, cg, ok0, ok1, ok2);
+    dwconv_col3x3_body<S, true, SEQ, FULL>(p, n, oy0, oy1, ox, cg, ok0, ok1, ok2);
   } else {
-    dwconv_col3x3_body<S, false>(p, n, oy0, oy1, ox, cg, true, true, true);
+    dwconv_col3x3_body<S, false, SEQ, FULL>(p, n, oy0, oy1, ox, cg, true, true, true);
   }
 }
 
@@ -832,11 +842,15 @@ int launch_col(const DwParams& p, hipStream_t stream)
 {
   const uint64_t waves = static_cast<uint64_t>(p.batch) * p.slabs * p.bands;
   const uint32_t blocks = static_cast<uint32_t>((waves + (kColThreads / 64) - 1) / (kColThreads / 64));
-  if (p.sw == 1) {
-    hipLaunchKernelGGL(q8_dwconv_col3x3_kernel<1>, dim3(blocks), dim3(kColThreads), 0, stream, p);
-  } else {
-    hipLaunchKernelGGL(q8_dwconv_col3x3_kernel<2>, dim3(blocks), dim3(kColThreads), 0, stream, p);
-  }
+  qnnp::requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+    constexpr int kSeq = decltype(seq)::value;
+    constexpr bool kFull = decltype(full)::value;
+    if (p.sw == 1) {
+      hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<1, kSeq, kFull>), dim3(blocks), dim3(kColThreads), 0, stream, p);
+    } else {
+      hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<2, kSeq, kFull>), dim3(blocks), dim3(kColThreads), 0, stream, p);
+    }
+  });
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 

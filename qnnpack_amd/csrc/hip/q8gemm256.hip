@@ -507,7 +507,9 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 
   // ---- fused epilogue (igemm_epilogue.hip.h); the requantization flavour is chosen once ----
   const uint32_t raw_to_centred = 128u * p.k_pad;      // sum(a') = sum(a) - 128 * k_pad
-  requant_dispatch(p.rq, [&](auto shift0, auto full) {
+  requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
+    // (+ 2^31 for the offset rounding sequences, requant.hip.h: rides on the row term)
+    constexpr int kSeq = decltype(shift0)::value;
     if (p.store_mode == 2) {
       // 16-byte aligned rows: a wave's (kTM*32) x 128-byte sub-tile is requantized into a private image in the
       // (now idle) LDS ring and leaves as WHOLE 128-byte lines, eight rows per store instruction. Direct
@@ -522,8 +524,8 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 #pragma unroll
         for (int tm = 0; tm < kTM; tm++) {
           const uint32_t row = frag_row0 + tm * 32;
-          const int32_t rowterm = p.row_coeff *
-              static_cast<int32_t>(static_cast<uint32_t>(lds_rowsum[row]) + static_cast<uint32_t>(lds_rowsum[kBM + row]) - raw_to_centred);
+          const int32_t rowterm = with_rq_offset<kSeq>(p.row_coeff *
+              static_cast<int32_t>(static_cast<uint32_t>(lds_rowsum[row]) + static_cast<uint32_t>(lds_rowsum[kBM + row]) - raw_to_centred));
           igemm_stage_tile<decltype(shift0)::value, decltype(full)::value, (ABL & 1) != 0, 2>(
               acc[tm][tn], no_bias, rowterm, image + (tm * 32 + (lane & 31u)) * kPitch, tn * 32, frag_khalf, p);
         }
@@ -549,8 +551,8 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
       for (int tm = 0; tm < kTM; tm++) {
         const uint32_t row = frag_row0 + tm * 32;
         const uint32_t m = m_tile * kBM + row;
-        const int32_t rowterm = p.row_coeff *
-            static_cast<int32_t>(static_cast<uint32_t>(lds_rowsum[row]) + static_cast<uint32_t>(lds_rowsum[kBM + row]) - raw_to_centred);
+        const int32_t rowterm = with_rq_offset<kSeq>(p.row_coeff *
+            static_cast<int32_t>(static_cast<uint32_t>(lds_rowsum[row]) + static_cast<uint32_t>(lds_rowsum[kBM + row]) - raw_to_centred));
         uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride + static_cast<uint64_t>(g) * p.n;
 #pragma unroll
         for (int tn = 0; tn < kTN; tn++) {
@@ -565,8 +567,8 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 #pragma unroll
       for (int tm = 0; tm < kTM; tm++) {
         const uint32_t row = frag_row0 + tm * 32;
-        rowterm[tm] = p.row_coeff *
-            static_cast<int32_t>(static_cast<uint32_t>(lds_rowsum[row]) + static_cast<uint32_t>(lds_rowsum[kBM + row]) - raw_to_centred);
+        rowterm[tm] = with_rq_offset<kSeq>(p.row_coeff *
+            static_cast<int32_t>(static_cast<uint32_t>(lds_rowsum[row]) + static_cast<uint32_t>(lds_rowsum[kBM + row]) - raw_to_centred));
       }
 #pragma unroll
       for (int tn = 0; tn < kTN; tn++) {

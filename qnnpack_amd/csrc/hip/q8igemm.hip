@@ -376,11 +376,11 @@ void q8_igemm_mfma_kernel(const IgemmParams p_in)
     // ---- fused epilogue (igemm_epilogue.hip.h); the requantization flavour is chosen once per tile ----
     if (p.store_mode == 2 && p.out_rows == nullptr) {
       // staged: requantized tile -> LDS (row-major image of the output) -> line-sized coalesced stores
-      qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
+      qnnp::requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
 #pragma unroll
         for (int tm = 0; tm < TM; tm++) {
           const uint32_t row = frag_row0 + tm * 32;
-          const int32_t rowterm = p.row_coeff * lds_rowsum[row];
+          const int32_t rowterm = qnnp::with_rq_offset<decltype(shift0)::value>(p.row_coeff * lds_rowsum[row]);
 #pragma unroll
           for (int tn = 0; tn < TN; tn++) {
             if (nb0 + tn >= nblocks) continue;       // wave-uniform
@@ -399,12 +399,12 @@ void q8_igemm_mfma_kernel(const IgemmParams p_in)
           p.output + static_cast<uint64_t>(m0) * p.output_stride + static_cast<uint64_t>(g) * p.n + n0,
           p.output_stride, tid);
     } else {
-      qnnp::requant_dispatch(p.rq, [&](auto shift0, auto full) {
+      qnnp::requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
 #pragma unroll
         for (int tm = 0; tm < TM; tm++) {
           const uint32_t row = frag_row0 + tm * 32;
           const uint32_t m = m_tile * BM + row;
-          const int32_t rowterm = p.row_coeff * lds_rowsum[row];
+          const int32_t rowterm = qnnp::with_rq_offset<decltype(shift0)::value>(p.row_coeff * lds_rowsum[row]);
           uint64_t out_pixel = m;
           if (p.out_rows != nullptr && m < p.rows) {          // scattered rows (deconvolution phases)
             const uint32_t img_m = m / p.rows_per_image;

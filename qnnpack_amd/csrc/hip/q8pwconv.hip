@@ -50,7 +50,7 @@ constexpr uint32_t kMaxLds = 64 * 1024;     // weights + bias: two workgroups pe
  * only 8-byte aligned, e.g. 24 channels) */
 /* D2S: depth-to-space stores (igemm_params.h) -- a deconvolution whose kernel equals its stride is this pointwise
  * GEMM with stride_h*stride_w times the channels, each phase's block landing on its own output pixel. */
-template <int KB, int VEC, bool STAGED, bool D2S = false>
+template <int KB, int VEC, bool D2S = false>
 __global__ __launch_bounds__(kThreads, (KB <= 5) ? 4 : 2)
 void q8_pw_stream_mfma_kernel(const IgemmParams p)
 {
@@ -88,8 +88,6 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
   }
   const uint8_t* lds_w = lds + lane * 16;
   const int4* lds_bias4 = reinterpret_cast<const int4*>(lds + nblocks * KB * 1024);
-  // per-wave image of a unit's 32 x n output block (store_mode 3 only; the launcher sizes it)
-  uint8_t* stage = lds + nblocks * KB * 1024 + ((p.n_pad * 4u + 1023u) & ~1023u) + wave * (32u * p.n);
 
   // ---- which of this lane's 16-byte K pieces exist (only the last block can be short) ----
   const uint8_t* pad16 = p.fill_table + 0x80 * 16;        // 16 bytes of a' == 0
@@ -133,7 +131,7 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // weights + bias are in LDS (and the first rows landed)
   __syncthreads();
 
-  requant_dispatch(p.rq, [&](auto shift0, auto full) {
+  requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
     for (; unit < units; unit += unit_stride) {
       v4i a[KB];
 #pragma unroll
@@ -154,7 +152,8 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
         a[kb].w ^= static_cast<int>(kFlip);
       }
       rs += __shfl_xor(rs, 32);                           // the other K half of the same row
-      const int32_t rowterm = p.row_coeff * static_cast<int32_t>(rs - raw_to_centred);
+      // (+ 2^31 for the offset rounding sequences, requant.hip.h: the accumulators start from bias + this)
+      const int32_t rowterm = with_rq_offset<decltype(shift0)::value>(p.row_coeff * static_cast<int32_t>(rs - raw_to_centred));
 
       const uint32_t m = unit * 32u + row_in_block;
       uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride;
@@ -178,10 +177,10 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
       auto multiply = [&](uint32_t nb, v16i& acc) __attribute__((always_inline)) {
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
-          acc[rg * 4 + 0] = bias4[rg].x + rowterm;
-          acc[rg * 4 + 1] = bias4[rg].y + rowterm;
-          acc[rg * 4 + 2] = bias4[rg].z + rowterm;
-          acc[rg * 4 + 3] = bias4[rg].w + rowterm;
+          acc[rg * 4 + 0] = add_wrap(bias4[rg].x, rowterm);
+          acc[rg * 4 + 1] = add_wrap(bias4[rg].y, rowterm);
+          acc[rg * 4 + 2] = add_wrap(bias4[rg].z, rowterm);
+          acc[rg * 4 + 3] = add_wrap(bias4[rg].w, rowterm);
         }
         if (nb + 1 < nblocks) {
 #pragma unroll
@@ -195,31 +194,6 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
         }
       };
 
-      // Stores. A direct 16-byte store per lane writes 32 rows x 32 bytes per instruction: the L2 sees
-      // 32-byte partial-line writes, and that stream alone runs at 2.8 TB/s (55 us on the 16 -> 96 layer against
-      // 34 us for the same bytes stored contiguously -- ablation). With DENSE rows (stride == channels) the
-      // 32 x n block of a unit is one contiguous run of memory, so the wave drops its requantized 16-byte
-      // pieces into a private LDS image of it (ds_write_b128 in place of the global store) and copies the image
-      // out LINEARLY, 1 KiB per instruction: one ds_read_b128 + one global store per KiB extra.
-      if constexpr (STAGED) {
-        uint8_t* img = stage + row_in_block * p.n;
-        for (uint32_t nb = 0; nb < nblocks; nb++) {
-          v16i acc;
-          multiply(nb, acc);
-          // (every lane takes part in the half-wave exchange inside; n % 16 == 0: a lane's 16 channels exist or not)
-          igemm_stage_tile<decltype(shift0)::value, decltype(full)::value, false, true>(
-              acc, bias4, 0, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < p.n);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
-        const uint32_t rows_here = min(32u, p.rows - unit * 32u);
-        const uint32_t bytes = rows_here * p.n;
-        uint8_t* blk = p.output + static_cast<uint64_t>(unit) * 32u * p.n;
-        for (uint32_t o = lane * 16; o < bytes; o += 1024) {
-          *reinterpret_cast<uint4*>(blk + o) = *reinterpret_cast<const uint4*>(stage + o);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // read back before the next unit overwrites it
-        continue;
-      }
 #ifdef QNNP_ENABLE_ABLATION
       if (p.izp_fill & 4u) {                              // measurement: CONTIGUOUS stores only (dense rows assumed)
         uint8_t* blk = p.output + static_cast<uint64_t>(unit) * 32u * p.output_stride;
@@ -256,6 +230,210 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
   });
 }
 
+/* A wave's staged 32-row output block (LDS image `stage`) -> global memory. Dense rows and the whole N: the block
+ * is one contiguous run, 1 KiB per store instruction. Otherwise row chunks: the image has 2^log_cpr 16-byte pieces
+ * per row (pitch 16 << log_cpr), of which the first cw bytes exist; consecutive lanes take consecutive pieces of a
+ * row. c0 = first channel of the chunk. */
+__device__ __forceinline__ void stream_copy_out(
+    const uint8_t* stage, bool whole_dense, uint32_t log_cpr, uint32_t unit, uint32_t c0, uint32_t cw,
+    const IgemmParams& p, uint32_t lane)
+{
+  const uint32_t rows_here = min(32u, p.rows - unit * 32u);
+  if (whole_dense) {
+    const uint32_t bytes = rows_here * p.n;
+    uint8_t* blk = p.output + static_cast<uint64_t>(unit) * 32u * p.n;
+    for (uint32_t o = lane * 16; o < bytes; o += 2048) {
+      const uint4 v0 = *reinterpret_cast<const uint4*>(stage + o);
+      const bool two = o + 1024 < bytes;
+      const uint4 v1 = *reinterpret_cast<const uint4*>(stage + (two ? o + 1024 : o));
+      *reinterpret_cast<uint4*>(blk + o) = v0;
+      if (two) *reinterpret_cast<uint4*>(blk + o + 1024) = v1;
+    }
+  } else {
+    const uint32_t pieces = 32u << log_cpr;
+    uint8_t* blk = p.output + static_cast<uint64_t>(unit) * 32u * p.output_stride + c0;
+    for (uint32_t q = lane; q < pieces; q += 64) {
+      const uint32_t r = q >> log_cpr;
+      const uint32_t cb = (q - (r << log_cpr)) * 16u;
+      const uint4 v = *reinterpret_cast<const uint4*>(stage + q * 16u);
+      if (r < rows_here && cb < cw) {
+        *reinterpret_cast<uint4*>(blk + static_cast<uint64_t>(r) * p.output_stride + cb) = v;
+      }
+    }
+  }
+}
+
+/*
+ * Staged flavour: 16-byte aligned rows, n % 16 == 0 -- every MobileNet-style expand / project layer. Differences to
+ * the kernel above:
+ *   - N split: gridDim.y workgroup columns each own `nbp` of the 32-channel blocks (their weights only in LDS), so a
+ *     layer with few row blocks and many channels (14x14x96 -> 576: 784 row blocks) still fills the chip, and any N
+ *     fits (the whole-matrix kernel stops at 64 KiB of weights);
+ *   - a unit's requantized 32 x (nbp*32) block goes to a per-wave LDS image and leaves in row chunks of >= 64
+ *     contiguous bytes (whole contiguous 32-row blocks when rows are dense and N is not split): direct 16-byte
+ *     stores put 32-byte partial-line writes on the L2 (2.8 TB/s against 5+ for whole lines, ablation);
+ *   - the wave's instruction order is  loads(u+1) -> multiply / requantize(u) -> wait -> re-centre(u+1) ->
+ *     stores(u): the only vmcnt wait of the loop sits BEFORE the unit's stores, where everything outstanding
+ *     (the next rows, the previous unit's stores) has had a whole multiply phase to complete. hipcc counts loads
+ *     and stores in one counter and cannot count a run-time number of stores, so with the stores first it waited
+ *     for the stores it had just issued (vmcnt(0) at the loop end) -- a full store round trip per unit per wave.
+ *   - the loads are always issued (clamped unit index): a branch around them makes the outstanding count
+ *     path-dependent and costs the same vmcnt(0).
+ */
+template <int KB, int VEC>
+__global__ __launch_bounds__(kThreads, (KB <= 5) ? 4 : 2)
+void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const uint32_t log_cpr)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
+  const uint32_t row_in_block = lane & 31u;
+  const uint32_t khalf = lane >> 5;
+
+  const uint32_t nblocks = p.n_pad / 32;
+  const uint32_t kblocks = p.k_pad / 32;
+  const uint32_t nb0 = blockIdx.y * nbp;                  // this workgroup column's channel blocks
+  const uint32_t nbn = min(nbp, nblocks - nb0);
+  const uint32_t c0 = nb0 * 32u;                          // first channel
+  const uint32_t cw = min(p.n - c0, nbn * 32u);           // valid bytes per row of the chunk (n % 16 == 0)
+  const bool whole_dense = gridDim.y == 1 && p.output_stride == p.n;
+  const uint32_t pitch = whole_dense ? p.n : (16u << log_cpr);   // row pitch of the image
+
+  // ---- once per workgroup: the column's weight fragments and bias2 into LDS (LDS-DMA) ----
+  {
+    const uint32_t frags = nbn * KB;
+    for (uint32_t f = wave; f < frags; f += kWaves) {
+      const uint32_t nb = f / KB;
+      const uint32_t kb = f - nb * KB;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*) (p.packed_w + (static_cast<uint64_t>(nb0 + nb) * kblocks + kb) * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*) (lds + f * 1024), 16, 0, 0);
+    }
+    uint8_t* lds_bias = lds + nbp * KB * 1024;
+    const uint32_t bias_chunks = nbn * 8u;                // 16-byte pieces
+    for (uint32_t q0 = wave * 64; q0 < bias_chunks; q0 += kThreads) {
+      const uint32_t q = min(q0 + lane, bias_chunks - 1); // the tail lanes repeat the last piece (same bytes)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(p.bias2 + c0) + q * 16),
+          (__attribute__((address_space(3))) void*) (lds_bias + q0 * 16), 16, 0, 0);
+    }
+  }
+  const uint8_t* lds_w = lds + lane * 16;
+  const uint32_t bias_bytes = (nbp * 128u + 1023u) & ~1023u;
+  const int4* lds_bias4 = reinterpret_cast<const int4*>(lds + nbp * KB * 1024);
+  uint8_t* stage = lds + nbp * KB * 1024 + bias_bytes + wave * (32u * pitch);
+
+  const uint8_t* pad16 = p.fill_table + 0x80 * 16;        // 16 bytes of a' == 0
+  const uint32_t k_last = (KB - 1) * 32 + khalf * 16;
+  const bool last_lo_ok = k_last < p.k_total;
+  const bool last_hi_ok = k_last + 8 < p.k_total;
+
+  const uint32_t units = (p.rows + 31u) / 32u;
+  const uint32_t unit_stride = gridDim.x * kWaves;
+
+  auto load_rows = [&](uint32_t unit, v4i (&a)[KB]) __attribute__((always_inline)) {
+    uint32_t m = unit * 32u + row_in_block;
+    if (m >= p.rows) m = p.rows - 1;                      // clamped rows are never stored
+    const uint8_t* row = p.input + static_cast<uint64_t>(m) * p.input_stride + khalf * 16;
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+      const uint8_t* src = row + kb * 32;
+      if constexpr (VEC == 16) {
+        if (kb == KB - 1) src = last_lo_ok ? src : pad16;
+        a[kb] = *reinterpret_cast<const v4i*>(src);
+      } else {
+        const uint8_t* lo = src;
+        const uint8_t* hi = src + 8;
+        if (kb == KB - 1) {
+          lo = last_lo_ok ? lo : pad16;
+          hi = last_hi_ok ? hi : pad16;
+        }
+        const int2 vlo = *reinterpret_cast<const int2*>(lo);
+        const int2 vhi = *reinterpret_cast<const int2*>(hi);
+        a[kb] = v4i{vlo.x, vlo.y, vhi.x, vhi.y};
+      }
+    }
+  };
+  // raw bytes -> row sum, then re-centred at 128 in place
+  auto recentre = [&](v4i (&a)[KB]) __attribute__((always_inline)) -> uint32_t {
+    uint32_t rs = 0;
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+      rs = __builtin_amdgcn_sad_u8(a[kb].x, 0u, rs);
+      rs = __builtin_amdgcn_sad_u8(a[kb].y, 0u, rs);
+      rs = __builtin_amdgcn_sad_u8(a[kb].z, 0u, rs);
+      rs = __builtin_amdgcn_sad_u8(a[kb].w, 0u, rs);
+      a[kb].x ^= static_cast<int>(kFlip);
+      a[kb].y ^= static_cast<int>(kFlip);
+      a[kb].z ^= static_cast<int>(kFlip);
+      a[kb].w ^= static_cast<int>(kFlip);
+    }
+    rs += __shfl_xor(rs, 32);                             // the other K half of the same row
+    return rs;
+  };
+  const uint32_t raw_to_centred = 128u * 32u * KB;
+
+  uint32_t unit = blockIdx.x * kWaves + wave;
+  v4i a[KB];
+  load_rows(min(unit, units - 1u), a);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // weights + bias are in LDS (and the first rows landed)
+  __syncthreads();
+  if (unit >= units) return;
+
+  requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
+    uint32_t rs = recentre(a);
+    for (;;) {
+      const uint32_t next = unit + unit_stride;
+      v4i raw[KB];
+      load_rows(min(next, units - 1u), raw);              // always issued (the last one of a wave is wasted)
+      // (+ 2^31 for the offset rounding sequences, requant.hip.h: the accumulators start from bias + this)
+      const int32_t rowterm = with_rq_offset<decltype(shift0)::value>(p.row_coeff * static_cast<int32_t>(rs - raw_to_centred));
+      int4 bias4[4];
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[rg * 2 + khalf];
+      uint8_t* img = stage + row_in_block * pitch;
+      for (uint32_t nb = 0; nb < nbn; nb++) {
+        v16i acc;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          acc[rg * 4 + 0] = add_wrap(bias4[rg].x, rowterm);
+          acc[rg * 4 + 1] = add_wrap(bias4[rg].y, rowterm);
+          acc[rg * 4 + 2] = add_wrap(bias4[rg].z, rowterm);
+          acc[rg * 4 + 3] = add_wrap(bias4[rg].w, rowterm);
+        }
+        if (nb + 1 < nbn) {
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[(nb + 1) * 8 + rg * 2 + khalf];
+        }
+        const uint8_t* wf = lds_w + nb * (KB * 1024);
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) {
+          const v4i w = *reinterpret_cast<const v4i*>(wf + kb * 1024);
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a[kb], acc, 0, 0, 0);
+        }
+        // (every lane takes part in the half-wave exchange inside; a lane's 16 channels exist or not)
+        igemm_stage_tile<decltype(shift0)::value, decltype(full)::value, false, true>(
+            acc, bias4, 0, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < cw);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
+      // the next unit's rows: first use here, so the wait for them lands before this unit's stores
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < KB; kb++) a[kb] = raw[kb];
+      rs = recentre(a);
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef QNNP_ENABLE_ABLATION
+      if (p.izp_fill & 1u) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); if (next >= units) break; unit = next; continue; }
+#endif
+      stream_copy_out(stage, whole_dense, log_cpr, unit, c0, cw, p, lane);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // read back before the next unit overwrites it
+      if (next >= units) break;
+      unit = next;
+    }
+  });
+}
+
 /*
  * Second flavour for pointwise / fully-connected layers whose weights do NOT fit LDS (K up to ~1000 over few
  * rows: the late MobileNet layers, classifier heads): one WAVE = one 32-row x 32-channel output block, both
@@ -284,8 +462,10 @@ void q8_pw_stream_gw_kernel(const IgemmParams p)
   uint32_t m = rb * 32u + row_in_block;
   const bool row_ok = m < p.rows;
   if (!row_ok) m = p.rows - 1;
-  const uint8_t* row = p.input + static_cast<uint64_t>(m) * p.input_stride + khalf * 16;
-  const uint8_t* pad16 = p.fill_table + 0x80 * 16;          // 16 bytes of a' == 0
+  // (launcher: the input tensor is addressable with 32-bit offsets)
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.input), 0, static_cast<int>((p.rows - 1u) * p.input_stride + p.k_total), 0x00020000);
+  const uint32_t row_off = m * p.input_stride;
   const int8_t* wf = p.packed_w + static_cast<uint64_t>(nb) * kblocks * 1024 + lane * 16;
   const uint32_t kbt = (p.k_total + 31u) / 32u;
 
@@ -299,36 +479,147 @@ void q8_pw_stream_gw_kernel(const IgemmParams p)
 #pragma unroll
   for (int r = 0; r < 16; r++) acc[r] = 0;
   uint32_t rs = 0;
-  for (uint32_t kb0 = 0; kb0 < kbt; kb0 += kGwUnroll) {
-    v4i a[kGwUnroll], w[kGwUnroll];
+  // Two groups of kGwUnroll K blocks are in flight: group g+1 is issued before group g is multiplied (every load is
+  // unconditional -- clamped block index, padding source -- so hipcc counts the waits instead of draining). One
+  // group per round made the launch a chain of K/128 dependent L2 round trips.
+  // Activations come through a buffer descriptor: a piece beyond the row's K gets an out-of-range offset and reads
+  // as zeros -- nothing for the row sum, and its weights are zero -- without any branch or pointer select (a
+  // uniform "is this block there" branch around a load made hipcc copy the prefetched registers at the loop end,
+  // which waits for them).
+  auto load_group = [&](uint32_t kb0, v4i (&a)[kGwUnroll], v4i (&w)[kGwUnroll]) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < kGwUnroll; u++) {
       const uint32_t kb = kb0 + u;
-      const bool have = kb < kbt && kb * 32 + khalf * 16 < p.k_total;     // k_total % 16 == 0: whole piece or none
-      const uint8_t* src = have ? row + kb * 32 : pad16;
-      a[u] = *reinterpret_cast<const v4i*>(src);
-      const uint32_t kbc = kb < kbt ? kb : kbt - 1;                        // (clamped fragments meet a' == 0)
+      const uint32_t koff = kb * 32 + khalf * 16;                          // k_total % 16 == 0: whole piece or none
+      a[u] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, koff < p.k_total ? row_off + koff : 0xFFFFFFF0u, 0, 0));
+      const uint32_t kbc = min(kb, kbt - 1);                               // (clamped fragments meet zeros)
       w[u] = *reinterpret_cast<const v4i*>(wf + static_cast<uint64_t>(kbc) * 1024);
     }
+  };
+  auto multiply_group = [&](uint32_t kb0, v4i (&a)[kGwUnroll], const v4i (&w)[kGwUnroll]) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < kGwUnroll; u++) {
       rs = __builtin_amdgcn_sad_u8(a[u].x, 0u, rs);
       rs = __builtin_amdgcn_sad_u8(a[u].y, 0u, rs);
       rs = __builtin_amdgcn_sad_u8(a[u].z, 0u, rs);
       rs = __builtin_amdgcn_sad_u8(a[u].w, 0u, rs);
-      a[u].x ^= static_cast<int>(kFlip);
-      a[u].y ^= static_cast<int>(kFlip);
-      a[u].z ^= static_cast<int>(kFlip);
-      a[u].w ^= static_cast<int>(kFlip);
+      // a piece beyond K arrived as zeros and stays zero (a' == 0: the clamped weight fragment beside it is a real one)
+      const int flip = static_cast<int>((kb0 + u) * 32 + khalf * 16 < p.k_total ? kFlip : 0u);
+      a[u].x ^= flip;
+      a[u].y ^= flip;
+      a[u].z ^= flip;
+      a[u].w ^= flip;
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[u], a[u], acc, 0, 0, 0);
+    }
+  };
+  v4i a0[kGwUnroll], w0[kGwUnroll], a1[kGwUnroll], w1[kGwUnroll];
+  load_group(0, a0, w0);
+  for (uint32_t kb0 = 0; kb0 < kbt; kb0 += 2 * kGwUnroll) {
+    load_group(kb0 + kGwUnroll, a1, w1);
+    multiply_group(kb0, a0, w0);
+    load_group(kb0 + 2 * kGwUnroll, a0, w0);
+    multiply_group(kb0 + kGwUnroll, a1, w1);
+  }
+  rs += __shfl_xor(rs, 32);                                   // the other K half of the same row
+  // (pieces beyond K read as zeros: the raw sum is over the k_total real bytes)
+  const int32_t rowterm = p.row_coeff * static_cast<int32_t>(rs - 128u * p.k_total);
+  uint8_t* out_row = p.output + static_cast<uint64_t>(rb * 32u + row_in_block) * p.output_stride;
+  requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
+    igemm_store_tile<decltype(shift0)::value, decltype(full)::value>(
+        acc, bias4, with_rq_offset<decltype(shift0)::value>(rowterm), out_row, nb * 32, khalf, row_ok, p);
+  });
+}
+
+/*
+ * The same with the reduction SPLIT over the waves of a workgroup (one workgroup = one 32x32 output block): with one
+ * wave per block a K = 960 layer is a chain of 8 dependent (load 4 K blocks -> wait -> 4 MFMAs) rounds, ~1.2 us of
+ * L2 latency each, and the whole launch lasts exactly as long as that chain (10.6 us for 7x7x960 -> 320 at batch
+ * 128, which is 1 us of MFMA work). Here wave w takes K blocks w, w + 4, ... and issues up to eight blocks of loads
+ * (16 x 16 bytes per lane) before the first multiply; the partial accumulators and row sums of waves 1-3 meet wave
+ * 0's through LDS (12 KiB), and wave 0 requantizes and stores. int32 partial sums are exact, so the split is
+ * bit-invisible.
+ */
+template <int kGwkDepth>       // K blocks a wave has in flight: 4 or 8
+__global__ __launch_bounds__(kThreads, 4)
+void q8_pw_stream_gwk_kernel(const IgemmParams p)
+{
+  __shared__ __attribute__((aligned(16))) int32_t part[(kWaves - 1) * 17 * 64];   // [wave-1][register | row sum][lane]
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t row_in_block = lane & 31u;
+  const uint32_t khalf = lane >> 5;
+  const uint32_t nblocks = p.n_pad / 32;
+  const uint32_t kblocks = p.k_pad / 32;
+  const uint32_t unit = blockIdx.x;                         // channel block fastest: neighbours share the rows
+  const uint32_t rb = unit / nblocks;
+  const uint32_t nb = unit - rb * nblocks;
+
+  uint32_t m = rb * 32u + row_in_block;
+  const bool row_ok = m < p.rows;
+  if (!row_ok) m = p.rows - 1;
+  // (launcher: the input tensor is addressable with 32-bit offsets; pieces beyond K read as zeros, see the kernel above)
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.input), 0, static_cast<int>((p.rows - 1u) * p.input_stride + p.k_total), 0x00020000);
+  const uint32_t row_off = m * p.input_stride;
+  const int8_t* wf = p.packed_w + static_cast<uint64_t>(nb) * kblocks * 1024 + lane * 16;
+  const uint32_t kbt = (p.k_total + 31u) / 32u;
+
+  v16i acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0;
+  uint32_t rs = 0;
+  for (uint32_t kb0 = wave; kb0 < kbt; kb0 += kWaves * kGwkDepth) {
+    v4i a[kGwkDepth], w[kGwkDepth];
+#pragma unroll
+    for (int u = 0; u < kGwkDepth; u++) {
+      const uint32_t kb = kb0 + u * kWaves;
+      const uint32_t koff = kb * 32 + khalf * 16;                          // k_total % 16 == 0: whole piece or none
+      a[u] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, koff < p.k_total ? row_off + koff : 0xFFFFFFF0u, 0, 0));
+      const uint32_t kbc = min(kb, kbt - 1);                               // (clamped fragments meet zeros)
+      w[u] = *reinterpret_cast<const v4i*>(wf + static_cast<uint64_t>(kbc) * 1024);
+    }
+#pragma unroll
+    for (int u = 0; u < kGwkDepth; u++) {
+      rs = __builtin_amdgcn_sad_u8(a[u].x, 0u, rs);
+      rs = __builtin_amdgcn_sad_u8(a[u].y, 0u, rs);
+      rs = __builtin_amdgcn_sad_u8(a[u].z, 0u, rs);
+      rs = __builtin_amdgcn_sad_u8(a[u].w, 0u, rs);
+      // a piece beyond K arrived as zeros and stays zero (a' == 0: the clamped weight fragment beside it is a real one)
+      const int flip = static_cast<int>((kb0 + u * kWaves) * 32 + khalf * 16 < p.k_total ? kFlip : 0u);
+      a[u].x ^= flip;
+      a[u].y ^= flip;
+      a[u].z ^= flip;
+      a[u].w ^= flip;
       acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[u], a[u], acc, 0, 0, 0);
     }
   }
-  rs += __shfl_xor(rs, 32);                                   // the other K half of the same row
-  // every piece a lane read is either data or 0x80 padding: kGwUnroll-rounded blocks, 16 bytes each
-  const uint32_t pieces = ((kbt + kGwUnroll - 1) / kGwUnroll) * kGwUnroll * 2;
-  const int32_t rowterm = p.row_coeff * static_cast<int32_t>(rs - 128u * 16u * pieces);
+  // raw sums of the wave's K blocks; sum(a') = sum(a) - 128 * k_total once per row, below
+  int32_t rsc = static_cast<int32_t>(rs);
+  if (wave != 0) {
+    int32_t* mine = part + (wave - 1) * 17 * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; r++) mine[r * 64] = acc[r];
+    mine[16 * 64] = rsc;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 0; w < kWaves - 1; w++) {
+    const int32_t* other = part + w * 17 * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] += other[r * 64];
+    rsc += other[16 * 64];
+  }
+  rsc += __shfl_xor(rsc, 32);                                 // the other K half of the same row
+  rsc -= static_cast<int32_t>(128u * p.k_total);
+  int4 bias4[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) {
+    bias4[rg] = *reinterpret_cast<const int4*>(p.bias2 + nb * 32 + rg * 8 + khalf * 4);
+  }
   uint8_t* out_row = p.output + static_cast<uint64_t>(rb * 32u + row_in_block) * p.output_stride;
-  requant_dispatch(p.rq, [&](auto shift0, auto full) {
+  requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
+    const int32_t rowterm = with_rq_offset<decltype(shift0)::value>(p.row_coeff * rsc);
     igemm_store_tile<decltype(shift0)::value, decltype(full)::value>(
         acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p);
   });
@@ -433,7 +724,7 @@ void q8_conv_stream_c3_kernel(const IgemmParams p)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // weights + bias are in LDS
   __syncthreads();
 
-  requant_dispatch(p.rq, [&](auto shift0, auto full) {
+  requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
     for (; unit < units; unit += unit_stride) {
       v4i a[KB];
 #pragma unroll
@@ -456,7 +747,7 @@ void q8_conv_stream_c3_kernel(const IgemmParams p)
         a[kb].w ^= static_cast<int>(kFlip);
       }
       rs += __shfl_xor(rs, 32);
-      const int32_t rowterm = p.row_coeff * static_cast<int32_t>(rs - raw_to_centred);
+      const int32_t rowterm = with_rq_offset<decltype(shift0)::value>(p.row_coeff * static_cast<int32_t>(rs - raw_to_centred));
 
       const uint32_t m = unit * 32u + row_in_block;
       uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride;
@@ -468,10 +759,10 @@ void q8_conv_stream_c3_kernel(const IgemmParams p)
         v16i acc;
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
-          acc[rg * 4 + 0] = bias4[rg].x + rowterm;
-          acc[rg * 4 + 1] = bias4[rg].y + rowterm;
-          acc[rg * 4 + 2] = bias4[rg].z + rowterm;
-          acc[rg * 4 + 3] = bias4[rg].w + rowterm;
+          acc[rg * 4 + 0] = add_wrap(bias4[rg].x, rowterm);
+          acc[rg * 4 + 1] = add_wrap(bias4[rg].y, rowterm);
+          acc[rg * 4 + 2] = add_wrap(bias4[rg].z, rowterm);
+          acc[rg * 4 + 3] = add_wrap(bias4[rg].w, rowterm);
         }
         if (nb + 1 < nblocks) {
 #pragma unroll
@@ -490,17 +781,208 @@ void q8_conv_stream_c3_kernel(const IgemmParams p)
   });
 }
 
-template <int KB, int VEC, bool STAGED, bool D2S = false>
+/*
+ * The same gather for 16-byte aligned output rows (n % 16 == 0: every real first layer), built like the staged
+ * pointwise kernel: every load of the loop is issued unconditionally (buffer loads: 32-bit offsets, clamped unit
+ * index), the unit's block is requantized into a per-wave LDS image, and the one vmcnt wait sits between the
+ * multiply phase and the unit's stores. Per unit and lane: 8 table entries + 8 pixel dwords (two units / one unit
+ * ahead), ~4 vector instructions per tap -- the first version spent ~22 per tap on 64-bit addresses, per-load
+ * branches and the bytewise tail, and waited for its "prefetched" loads at once (vmcnt(0) behind them: the branch
+ * around each load made the outstanding count path-dependent).
+ * The last pixel of the tensor cannot be read as a dword: units that may touch the last image take a flavour of the
+ * gather that clamps the offset to the last whole dword and shifts (wave-uniform choice, both flavours issue the
+ * same loads).
+ */
+__global__ __launch_bounds__(kThreads, 4)
+void q8_conv_stream_c3s_kernel(const IgemmParams p, const uint32_t log_cpr)
+{
+  constexpr int KB = 2;                                    // k_pad == 64: up to 16 taps of 4-byte slots
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
+  const uint32_t row_in_block = lane & 31u;
+  const uint32_t khalf = lane >> 5;
+  const uint32_t nblocks = p.n_pad / 32;
+  const uint32_t kblocks = p.k_pad / 32;
+  const bool whole_dense = p.output_stride == p.n;
+  const uint32_t pitch = whole_dense ? p.n : (16u << log_cpr);
+  {
+    const uint32_t frags = nblocks * KB;
+    for (uint32_t f = wave; f < frags; f += kWaves) {
+      const uint32_t nb = f / KB;
+      const uint32_t kb = f - nb * KB;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*) (p.packed_w + (static_cast<uint64_t>(nb) * kblocks + kb) * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*) (lds + f * 1024), 16, 0, 0);
+    }
+    uint8_t* lds_bias = lds + frags * 1024;
+    const uint32_t bias_chunks = p.n_pad / 4;
+    for (uint32_t c0 = wave * 64; c0 < bias_chunks; c0 += kThreads) {
+      const uint32_t c = min(c0 + lane, bias_chunks - 1);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(p.bias2) + c * 16),
+          (__attribute__((address_space(3))) void*) (lds_bias + c0 * 16), 16, 0, 0);
+    }
+  }
+  const uint8_t* lds_w = lds + lane * 16;
+  const uint32_t bias_bytes = (p.n_pad * 4u + 1023u) & ~1023u;
+  const int4* lds_bias4 = reinterpret_cast<const int4*>(lds + nblocks * KB * 1024);
+  uint8_t* stage = lds + nblocks * KB * 1024 + bias_bytes + wave * (32u * pitch);
+
+  const uint32_t units = (p.rows + 31u) / 32u;
+  const uint32_t unit_stride = gridDim.x * kWaves;
+  const uint32_t raw_to_centred = 128u * 32u * KB;
+  const uint32_t in_bytes = static_cast<uint32_t>(p.input_end - p.input);          // (launcher: < 2^31)
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.input), 0, static_cast<int>(in_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t off_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int32_t*>(p.offsets), 0, static_cast<int>(p.rows_per_image * p.ks * 4u + 16u), 0x00020000);   // (+16: convolution.c allocates the slack)
+  // first output row (flattened) whose window may hold the tensor's last pixel: conservatively the last image
+  const uint32_t tail_first = p.rows - p.rows_per_image;
+
+  // what a slot that is not a pixel multiplies with: the padding pixel {izp, izp, izp, 0x80} for a tap of the
+  // kernel, a' == 0 for a slot beyond it (K padding)
+  uint32_t fill[KB * 4];
+  bool is_tap[KB * 4];
+#pragma unroll
+  for (int i = 0; i < KB * 4; i++) {
+    const uint32_t tap = (i >> 2) * 8 + khalf * 4 + (i & 3);       // kb*8 + khalf*4 + j
+    is_tap[i] = tap < p.ks;
+    fill[i] = is_tap[i] ? p.izp_fill : 0x80808080u;
+  }
+
+  struct Taps { int32_t off[KB * 4]; uint32_t img_off; };
+  // table entries of the lane's 8 slots; slots beyond the kernel read the neighbouring entries (or 0 beyond the
+  // table) and are replaced by `fill`
+  auto load_offsets = [&](uint32_t unit, Taps& t) __attribute__((always_inline)) {
+    uint32_t m = unit * 32u + row_in_block;
+    if (m >= p.rows) m = p.rows - 1;                       // clamped rows are never stored
+    const uint32_t img = m / p.rows_per_image;
+    const uint32_t pix = m - img * p.rows_per_image;
+    t.img_off = img * static_cast<uint32_t>(p.image_stride);
+    const uint32_t voff = pix * p.ks * 4u + khalf * 16u;
+    // one 16-byte load per K block (the lane's four consecutive entries): with a dword per load every instruction
+    // walked the same ~18 cache lines again (36 bytes between the pixels of neighbouring lanes)
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+      const v4i e = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(off_rsrc, voff + kb * 32, 0, 0));
+      t.off[kb * 4 + 0] = e.x; t.off[kb * 4 + 1] = e.y; t.off[kb * 4 + 2] = e.z; t.off[kb * 4 + 3] = e.w;
+    }
+  };
+  // pixel dwords of the slots: offsets < 0 (padding, K padding) read some other in-range dword or 0; replaced later
+  auto load_pixels = [&](auto tail_tag, const Taps& t, uint32_t (&x)[KB * 4]) __attribute__((always_inline)) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+#pragma unroll
+    for (int i = 0; i < KB * 4; i++) {
+      const uint32_t voff = t.img_off + static_cast<uint32_t>(t.off[i]);
+      if constexpr (TAIL) {
+        const uint32_t vc = min(voff, in_bytes - 4u);      // (negative offsets wrap to huge values: clamped too)
+        const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, vc, 0, 0);
+        x[i] = v >> (((voff - vc) & 3u) * 8u);
+      } else {
+        x[i] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, voff, 0, 0);
+      }
+    }
+  };
+  // slots -> MFMA operand (raw bytes), row sum, re-centred at 128
+  auto finish_rows = [&](const uint32_t (&x)[KB * 4], const Taps& t, v4i (&a)[KB]) __attribute__((always_inline)) -> uint32_t {
+    uint32_t rs = 0;
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+      uint32_t v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int i = kb * 4 + j;
+        const uint32_t pixel = (x[i] & 0x00FFFFFFu) | 0x80000000u;   // the slot's 4th byte is K padding: a' == 0
+        v[j] = (is_tap[i] && t.off[i] >= 0) ? pixel : fill[i];
+        rs = __builtin_amdgcn_sad_u8(v[j], 0u, rs);
+        v[j] ^= kFlip;
+      }
+      a[kb] = v4i{static_cast<int>(v[0]), static_cast<int>(v[1]), static_cast<int>(v[2]), static_cast<int>(v[3])};
+    }
+    rs += __shfl_xor(rs, 32);
+    return rs;
+  };
+  auto gather = [&](uint32_t unit, const Taps& t, uint32_t (&x)[KB * 4]) __attribute__((always_inline)) {
+    if (unit * 32u + 32u > tail_first) {                   // wave-uniform
+      load_pixels(std::true_type{}, t, x);
+    } else {
+      load_pixels(std::false_type{}, t, x);
+    }
+  };
+
+  uint32_t unit = blockIdx.x * kWaves + wave;
+  const uint32_t last = units - 1u;
+  Taps t_cur, t_next;
+  uint32_t x[KB * 4];
+  v4i a[KB];
+  load_offsets(min(unit, last), t_cur);
+  load_offsets(min(unit + unit_stride, last), t_next);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // weights + bias are in LDS, the table entries landed
+  gather(min(unit, last), t_cur, x);
+  __syncthreads();
+  if (unit >= units) return;
+
+  requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
+    uint32_t rs = finish_rows(x, t_cur, a);
+    for (;;) {
+      const uint32_t next = unit + unit_stride;
+      // pixels of the next unit (its table entries landed one iteration ago), table entries of the one after
+      gather(min(next, last), t_next, x);
+      Taps t_after;
+      load_offsets(min(next + unit_stride, last), t_after);
+
+      const int32_t rowterm = with_rq_offset<decltype(shift0)::value>(p.row_coeff * static_cast<int32_t>(rs - raw_to_centred));
+      int4 bias4[4];
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[rg * 2 + khalf];
+      uint8_t* img = stage + row_in_block * pitch;
+      for (uint32_t nb = 0; nb < nblocks; nb++) {
+        v16i acc;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          acc[rg * 4 + 0] = add_wrap(bias4[rg].x, rowterm);
+          acc[rg * 4 + 1] = add_wrap(bias4[rg].y, rowterm);
+          acc[rg * 4 + 2] = add_wrap(bias4[rg].z, rowterm);
+          acc[rg * 4 + 3] = add_wrap(bias4[rg].w, rowterm);
+        }
+        if (nb + 1 < nblocks) {
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[(nb + 1) * 8 + rg * 2 + khalf];
+        }
+        const uint8_t* wf = lds_w + nb * (KB * 1024);
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) {
+          const v4i w = *reinterpret_cast<const v4i*>(wf + kb * 1024);
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a[kb], acc, 0, 0, 0);
+        }
+        igemm_stage_tile<decltype(shift0)::value, decltype(full)::value, false, true>(
+            acc, bias4, 0, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < p.n);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
+      __builtin_amdgcn_sched_barrier(0);
+      rs = finish_rows(x, t_next, a);                            // first use of the loads: the wait lands here
+      t_next = t_after;
+      __builtin_amdgcn_sched_barrier(0);
+      stream_copy_out(stage, whole_dense, log_cpr, unit, 0u, p.n, p, lane);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // read back before the next unit overwrites it
+      if (next >= units) break;
+      unit = next;
+    }
+  });
+}
+
+template <int KB, int VEC, bool D2S = false>
 int launch_pw(const IgemmParams& p, uint32_t lds_bytes, hipStream_t stream)
 {
-  static int blocks_per_cu = 0;       // per instantiation; benign race (same value)
-  auto kernel = q8_pw_stream_mfma_kernel<KB, VEC, STAGED, D2S>;
-  if (blocks_per_cu == 0) {
+  auto kernel = q8_pw_stream_mfma_kernel<KB, VEC, D2S>;
+  static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
+  if (attr_once.first()) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-    blocks_per_cu = (KB <= 5) ? 4 : 2;
   }
   // LDS bounds the residency: kMaxLds -> 2 per CU, half of that -> 4
-  uint32_t per_cu = static_cast<uint32_t>(blocks_per_cu);
+  uint32_t per_cu = (KB <= 5) ? 4u : 2u;
   const uint32_t by_lds = lds_bytes > 0 ? (160u * 1024u) / lds_bytes : per_cu;
   if (by_lds < per_cu) per_cu = by_lds > 0 ? by_lds : 1u;
   const uint32_t units = (p.rows + 31u) / 32u;
@@ -521,32 +1003,135 @@ int launch_pw(const IgemmParams& p, uint32_t lds_bytes, hipStream_t stream)
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
-template <int VEC, bool STAGED>
+template <int VEC>
 int dispatch_kb(const IgemmParams& p, uint32_t kb, uint32_t lds_bytes, hipStream_t stream)
 {
   switch (kb) {
-    case 1: return launch_pw<1, VEC, STAGED>(p, lds_bytes, stream);
-    case 2: return launch_pw<2, VEC, STAGED>(p, lds_bytes, stream);
-    case 3: return launch_pw<3, VEC, STAGED>(p, lds_bytes, stream);
-    case 4: return launch_pw<4, VEC, STAGED>(p, lds_bytes, stream);
-    case 5: return launch_pw<5, VEC, STAGED>(p, lds_bytes, stream);
-    case 6: return launch_pw<6, VEC, STAGED>(p, lds_bytes, stream);
-    case 7: return launch_pw<7, VEC, STAGED>(p, lds_bytes, stream);
-    default: return launch_pw<8, VEC, STAGED>(p, lds_bytes, stream);
+    case 1: return launch_pw<1, VEC>(p, lds_bytes, stream);
+    case 2: return launch_pw<2, VEC>(p, lds_bytes, stream);
+    case 3: return launch_pw<3, VEC>(p, lds_bytes, stream);
+    case 4: return launch_pw<4, VEC>(p, lds_bytes, stream);
+    case 5: return launch_pw<5, VEC>(p, lds_bytes, stream);
+    case 6: return launch_pw<6, VEC>(p, lds_bytes, stream);
+    case 7: return launch_pw<7, VEC>(p, lds_bytes, stream);
+    default: return launch_pw<8, VEC>(p, lds_bytes, stream);
+  }
+}
+
+struct StagedPlan {
+  uint32_t nbp;        // channel blocks per workgroup column
+  uint32_t nsplit;     // workgroup columns
+  uint32_t log_cpr;    // log2(16-byte pieces per image row) of the chunked image
+  uint32_t lds_bytes;
+  uint32_t per_cu;     // resident workgroups per CU the launch is sized for
+};
+
+uint32_t staged_lds_bytes(uint32_t kb, uint32_t nbp, uint32_t pitch)
+{
+  return nbp * kb * 1024u + ((nbp * 128u + 1023u) & ~1023u) + kWaves * 32u * pitch;
+}
+
+/* How the staged kernel covers an N: whole rows per unit when that fills the chip (and fits), else columns of 2 / 4 /
+ * 8 channel blocks -- the widest that still gives every wave slot about two units. */
+bool plan_staged(const IgemmParams& p, uint32_t kb, StagedPlan* plan)
+{
+  if (p.store_mode != 2 || p.n % 16u != 0 || p.d2s_sh != 0) return false;
+  const uint32_t nblocks = p.n_pad / 32u;
+  const uint32_t units = (p.rows + 31u) / 32u;
+  const uint32_t base_per_cu = (kb <= 5) ? 4u : 2u;
+  const uint32_t slots = p.cu_count * base_per_cu * kWaves;
+  const bool dense = p.output_stride == p.n;
+  uint32_t log_whole = 1;                                       // chunked image of a whole row: pitch = 2^k * 16 >= n
+  while ((16u << log_whole) < nblocks * 32u) log_whole++;
+  const uint32_t whole_pitch = dense ? p.n : (16u << log_whole);
+  const uint32_t whole_lds = staged_lds_bytes(kb, nblocks, whole_pitch);
+  const bool whole_fits = whole_lds <= kMaxLds;
+  uint32_t nbp = 0;
+  if (whole_fits && (units >= slots || nblocks < 4u)) {
+    nbp = nblocks;
+  } else {
+    for (uint32_t cand = 8; cand >= 2; cand >>= 1) {
+      if (cand >= nblocks || staged_lds_bytes(kb, cand, cand * 32u) > kMaxLds) continue;
+      nbp = cand;
+      if (static_cast<uint64_t>(units) * ((nblocks + cand - 1) / cand) >= 2ull * slots) break;
+    }
+    if (nbp == 0) {
+      if (!whole_fits) return false;
+      nbp = nblocks;
+    }
+  }
+  plan->nbp = nbp;
+  plan->nsplit = (nblocks + nbp - 1) / nbp;
+  if (plan->nsplit == 1) {
+    plan->log_cpr = log_whole;
+    plan->lds_bytes = whole_lds;
+  } else {
+    uint32_t lg = 1;
+    while ((16u << lg) < nbp * 32u) lg++;
+    plan->log_cpr = lg;
+    plan->lds_bytes = staged_lds_bytes(kb, nbp, nbp * 32u);
+  }
+  uint32_t per_cu = base_per_cu;
+  const uint32_t by_lds = (160u * 1024u) / plan->lds_bytes;
+  if (by_lds < per_cu) per_cu = by_lds > 0 ? by_lds : 1u;
+  plan->per_cu = per_cu;
+  return true;
+}
+
+template <int KB, int VEC>
+int launch_pw_staged(const IgemmParams& p, const StagedPlan& plan, hipStream_t stream)
+{
+  auto kernel = q8_pw_stream_staged_kernel<KB, VEC>;
+  static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
+  if (attr_once.first()) {
+    (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+  }
+  const uint32_t units = (p.rows + 31u) / 32u;
+  uint32_t per_cu = plan.per_cu;
+#ifdef QNNP_ENABLE_ABLATION
+  if (const char* env = getenv("QNNP_PW_BLOCKS")) per_cu = static_cast<uint32_t>(atoi(env));
+#endif
+  // persistent workgroups: the resident set, spread over the columns
+  uint32_t gx = (p.cu_count * per_cu + plan.nsplit - 1) / plan.nsplit;
+  const uint32_t needed = (units + kWaves - 1) / kWaves;
+  if (gx > needed) gx = needed;
+#ifdef QNNP_ENABLE_ABLATION
+  IgemmParams pa = p;
+  pa.izp_fill = 0;
+  if (const char* env = getenv("QNNP_PW_ABL")) pa.izp_fill = static_cast<uint32_t>(atoi(env));
+  hipLaunchKernelGGL(kernel, dim3(gx, plan.nsplit), dim3(kThreads), plan.lds_bytes, stream, pa, plan.nbp, plan.log_cpr);
+#else
+  hipLaunchKernelGGL(kernel, dim3(gx, plan.nsplit), dim3(kThreads), plan.lds_bytes, stream, p, plan.nbp, plan.log_cpr);
+#endif
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+template <int VEC>
+int dispatch_kb_staged(const IgemmParams& p, uint32_t kb, const StagedPlan& plan, hipStream_t stream)
+{
+  switch (kb) {
+    case 1: return launch_pw_staged<1, VEC>(p, plan, stream);
+    case 2: return launch_pw_staged<2, VEC>(p, plan, stream);
+    case 3: return launch_pw_staged<3, VEC>(p, plan, stream);
+    case 4: return launch_pw_staged<4, VEC>(p, plan, stream);
+    case 5: return launch_pw_staged<5, VEC>(p, plan, stream);
+    case 6: return launch_pw_staged<6, VEC>(p, plan, stream);
+    case 7: return launch_pw_staged<7, VEC>(p, plan, stream);
+    default: return launch_pw_staged<8, VEC>(p, plan, stream);
   }
 }
 
 int dispatch_kb_d2s(const IgemmParams& p, uint32_t kb, uint32_t lds_bytes, hipStream_t stream)
 {
   switch (kb) {
-    case 1: return launch_pw<1, 16, false, true>(p, lds_bytes, stream);
-    case 2: return launch_pw<2, 16, false, true>(p, lds_bytes, stream);
-    case 3: return launch_pw<3, 16, false, true>(p, lds_bytes, stream);
-    case 4: return launch_pw<4, 16, false, true>(p, lds_bytes, stream);
-    case 5: return launch_pw<5, 16, false, true>(p, lds_bytes, stream);
-    case 6: return launch_pw<6, 16, false, true>(p, lds_bytes, stream);
-    case 7: return launch_pw<7, 16, false, true>(p, lds_bytes, stream);
-    default: return launch_pw<8, 16, false, true>(p, lds_bytes, stream);
+    case 1: return launch_pw<1, 16, true>(p, lds_bytes, stream);
+    case 2: return launch_pw<2, 16, true>(p, lds_bytes, stream);
+    case 3: return launch_pw<3, 16, true>(p, lds_bytes, stream);
+    case 4: return launch_pw<4, 16, true>(p, lds_bytes, stream);
+    case 5: return launch_pw<5, 16, true>(p, lds_bytes, stream);
+    case 6: return launch_pw<6, 16, true>(p, lds_bytes, stream);
+    case 7: return launch_pw<7, 16, true>(p, lds_bytes, stream);
+    default: return launch_pw<8, 16, true>(p, lds_bytes, stream);
   }
 }
 
@@ -565,7 +1150,9 @@ bool pwstream_supported(const IgemmParams& p, uint32_t groups, uint32_t vec)
   if (p.offsets != nullptr || groups != 1 || (vec != 16 && vec != 8)) return false;
   if (p.fill_table == nullptr || p.rows == 0 || p.k_total == 0 || p.k_total > 256u) return false;
   if (p.k_total % vec != 0) return false;
-  return pw_lds_bytes(p) <= kMaxLds;
+  if (pw_lds_bytes(p) <= kMaxLds) return true;
+  StagedPlan plan;
+  return plan_staged(p, (p.k_total + 31u) / 32u, &plan);     // any N, in workgroup columns
 }
 
 /* 3-channel-image flavour: offset-table convolution in 4-byte tap slots, at most 16 taps, one group */
@@ -579,6 +1166,30 @@ bool convstream_c3_supported(const IgemmParams& p, uint32_t groups)
 int convstream_c3_launch(const IgemmParams& p, hipStream_t stream, const char** name)
 {
   const uint32_t lds_bytes = (p.n_pad / 32u) * 2u * 1024u + ((p.n_pad * 4u + 1023u) & ~1023u);
+  // 16-byte aligned output rows, tensors addressable with 32-bit offsets: the staged flavour
+  const uint64_t in_bytes = static_cast<uint64_t>(p.input_end - p.input);
+  const uint64_t table_bytes = static_cast<uint64_t>(p.rows_per_image) * p.ks * 4u;
+  if (p.store_mode == 2 && p.n % 16u == 0 && in_bytes >= 4 && in_bytes < (UINT64_C(1) << 31) &&
+      table_bytes < (UINT64_C(1) << 31) && p.rows >= p.rows_per_image) {
+    uint32_t log_cpr = 1;
+    while ((16u << log_cpr) < p.n_pad) log_cpr++;
+    const uint32_t pitch = p.output_stride == p.n ? p.n : (16u << log_cpr);
+    const uint32_t staged_bytes = lds_bytes + kWaves * 32u * pitch;
+    if (staged_bytes <= kMaxLds) {
+      static qnnp::PerDeviceOnce attr_once_s;
+      if (attr_once_s.first()) {
+        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(q8_conv_stream_c3s_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+      }
+      const uint32_t units = (p.rows + 31u) / 32u;
+      uint32_t grid = p.cu_count * 4u;
+      const uint32_t needed = (units + kWaves - 1) / kWaves;
+      if (grid > needed) grid = needed;
+      *name = "q8_conv_stream_c3_mfma";
+      hipLaunchKernelGGL(q8_conv_stream_c3s_kernel, dim3(grid), dim3(kThreads), staged_bytes, stream, p, log_cpr);
+      return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+    }
+  }
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
   if (attr_once.first()) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(q8_conv_stream_c3_kernel),
@@ -599,12 +1210,30 @@ bool pwstream_gw_supported(const IgemmParams& p, uint32_t groups, uint32_t vec)
   if (p.offsets != nullptr || groups != 1 || vec != 16) return false;
   if (p.fill_table == nullptr || p.rows == 0 || p.k_total == 0 || p.k_total % 16 != 0) return false;
   const uint64_t units = static_cast<uint64_t>((p.rows + 31u) / 32u) * (p.n_pad / 32u);
-  return units < (UINT64_C(1) << 31);
+  const uint64_t in_bytes = static_cast<uint64_t>(p.rows - 1u) * p.input_stride + p.k_total;   // buffer addressing
+  return units < (UINT64_C(1) << 31) && in_bytes < (UINT64_C(1) << 31);
 }
 
 int pwstream_gw_launch(const IgemmParams& p, hipStream_t stream, const char** name)
 {
   const uint32_t units = ((p.rows + 31u) / 32u) * (p.n_pad / 32u);
+  // long reductions: K split over the four waves of a workgroup (one workgroup per block)
+  // (only when the blocks alone cannot fill the chip -- classifier heads: with ~2000 blocks the one-wave-per-block
+  //  kernel was 7-25 % faster, same box: the split costs three more waves' loads of the row block and a barrier)
+  bool split_k = p.k_total >= 256u && units <= 2u * p.cu_count;
+#ifdef QNNP_ENABLE_ABLATION
+  if (const char* env = getenv("QNNP_GW_SPLITK")) split_k = atoi(env) != 0;
+#endif
+  if (split_k) {
+    *name = "q8_pw_stream_gwk_mfma";
+    const uint32_t per_wave = ((p.k_total + 31u) / 32u + kWaves - 1) / kWaves;
+    if (per_wave <= 4) {
+      hipLaunchKernelGGL(q8_pw_stream_gwk_kernel<4>, dim3(units), dim3(kThreads), 0, stream, p);
+    } else {
+      hipLaunchKernelGGL(q8_pw_stream_gwk_kernel<8>, dim3(units), dim3(kThreads), 0, stream, p);
+    }
+    return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+  }
   *name = "q8_pw_stream_gw_mfma";
   hipLaunchKernelGGL(q8_pw_stream_gw_kernel, dim3((units + kWaves - 1) / kWaves), dim3(kThreads), 0, stream, p);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
@@ -612,30 +1241,22 @@ int pwstream_gw_launch(const IgemmParams& p, hipStream_t stream, const char** na
 
 int pwstream_launch(const IgemmParams& p0, uint32_t vec, hipStream_t stream, const char** name)
 {
-  IgemmParams p = p0;
+  const IgemmParams& p = p0;
   const uint32_t kb = (p.k_total + 31u) / 32u;
-  uint32_t lds_bytes = pw_lds_bytes(p);
-  // dense 16-byte-aligned rows wider than one 32-channel block: stage the unit's output block per wave and
-  // store it contiguously ("store_mode 3", private to this kernel), if the images fit beside the weights
-  const uint32_t stage_bytes = kWaves * 32u * p.n;
-  if (p.store_mode == 2 && p.output_stride == p.n && p.n > 32 && p.n <= 256 && lds_bytes + stage_bytes <= kMaxLds) {
-    p.store_mode = 3;
-    lds_bytes += stage_bytes;
-  }
+  const uint32_t lds_bytes = pw_lds_bytes(p);
   if (p.d2s_sh != 0) {
     if (vec != 16) return QNNP_HIP_EINVAL;
-    if (p.store_mode == 3) {
-      p.store_mode = 2;
-      lds_bytes -= stage_bytes;
-    }
     *name = "q8_pw_stream_d2s_mfma";
     return dispatch_kb_d2s(p, kb, lds_bytes, stream);
   }
   *name = "q8_pw_stream_mfma";
-  if (p.store_mode == 3) {
-    return vec == 16 ? dispatch_kb<16, true>(p, kb, lds_bytes, stream) : dispatch_kb<8, true>(p, kb, lds_bytes, stream);
+  // 16-byte aligned rows wider than one channel block: the staged flavour (whole-line stores, N in columns)
+  StagedPlan plan;
+  if (p.n > 32 && plan_staged(p, kb, &plan)) {
+    return vec == 16 ? dispatch_kb_staged<16>(p, kb, plan, stream) : dispatch_kb_staged<8>(p, kb, plan, stream);
   }
-  return vec == 16 ? dispatch_kb<16, false>(p, kb, lds_bytes, stream) : dispatch_kb<8, false>(p, kb, lds_bytes, stream);
+  if (lds_bytes > kMaxLds) return QNNP_HIP_EINVAL;
+  return vec == 16 ? dispatch_kb<16>(p, kb, lds_bytes, stream) : dispatch_kb<8>(p, kb, lds_bytes, stream);
 }
 
 }  // namespace qnnp

@@ -49,6 +49,7 @@ inline RequantDev make_requant_dev(const qnnp_hip_requant& rq)
   d.f = qnnp_requant_fast_init(rq.multiplier, rq.shift);
   const int folded = qnnp_requant_fast_fold_zero_point(&d.f, static_cast<uint32_t>(rq.output_zero_point));
   (void) qnnp_requant_fast_enable_bounded(&d.f, static_cast<uint32_t>(rq.output_zero_point), folded, rq.accumulator_bits);
+  (void) qnnp_requant_fast_enable_offset(&d.f);
   d.zp_late = folded ? 0 : rq.output_zero_point;
   // bounds in the domain of what the scale functions return: output domain when folded, output - zp otherwise
   // (the late addition comes AFTER the clamp: y + zp could wrap for |y| near 2^31)
@@ -82,13 +83,49 @@ __device__ __forceinline__ int32_t q31_requantize(int32_t n, const RequantDev& r
 constexpr int kRqShift0 = 1;     // shift == 0
 constexpr int kRqGeneral = 0;    // shift >= 1, any accumulator
 constexpr int kRqBounded = 2;    // shift >= 1, accumulators bounded at create time (requant_math.h)
+/* offset forms of the two above (requant_math.h): the kernel hands over n + 2^31 -- it adds rq_offset<SEQ>() to the
+ * bias / row term its accumulators start from -- and saves one (shift 0) or two (bounded) instructions per value.
+ * Only kernels that call requant_dispatch_ofs see them. */
+constexpr int kRqShift0Ofs = 3;
+constexpr int kRqBoundedOfs = 4;
+
+/* Two's-complement add. Accumulators that carry the 2^31 offset wrap around BY DESIGN, and a plain signed + lets the
+ * compiler assume they do not: it turned bias + INT32_MIN into bias | 0x80000000 (right only for bias >= 0). Every
+ * add on the way from the offset to q31_requantize_pack4 goes through this. */
+__device__ __forceinline__ int32_t add_wrap(int32_t a, int32_t b)
+{
+  return static_cast<int32_t>(static_cast<uint32_t>(a) + static_cast<uint32_t>(b));
+}
+__device__ __forceinline__ int32_t add_wrap(int32_t a, int32_t b, int32_t c)
+{
+  return static_cast<int32_t>(static_cast<uint32_t>(a) + static_cast<uint32_t>(b) + static_cast<uint32_t>(c));
+}
+
+/* what a kernel must have added to the accumulators it hands to q31_requantize_pack4<SEQ, ...> */
+template <int SEQ>
+__device__ __forceinline__ constexpr uint32_t rq_offset()
+{
+  return (SEQ == kRqShift0Ofs || SEQ == kRqBoundedOfs) ? QNNP_REQUANT_OFFSET : 0u;
+}
+/* x + rq_offset<SEQ>() (wrapping) */
+template <int SEQ>
+__device__ __forceinline__ int32_t with_rq_offset(int32_t x)
+{
+  return static_cast<int32_t>(static_cast<uint32_t>(x) + rq_offset<SEQ>());
+}
 
 template <int SHIFT0, bool FULL_RANGE>
 __device__ __forceinline__ uint32_t q31_requantize_pack4(
     int32_t n0, int32_t n1, int32_t n2, int32_t n3, const RequantDev& rq)
 {
   int32_t y0, y1, y2, y3;
-  if constexpr (SHIFT0 == kRqShift0) {
+  if constexpr (SHIFT0 == kRqShift0Ofs) {
+    y0 = qnnp_requant_scale_s0_ofs(n0, rq.f); y1 = qnnp_requant_scale_s0_ofs(n1, rq.f);
+    y2 = qnnp_requant_scale_s0_ofs(n2, rq.f); y3 = qnnp_requant_scale_s0_ofs(n3, rq.f);
+  } else if constexpr (SHIFT0 == kRqBoundedOfs) {
+    y0 = qnnp_requant_scale_sn_bounded_ofs(n0, rq.f); y1 = qnnp_requant_scale_sn_bounded_ofs(n1, rq.f);
+    y2 = qnnp_requant_scale_sn_bounded_ofs(n2, rq.f); y3 = qnnp_requant_scale_sn_bounded_ofs(n3, rq.f);
+  } else if constexpr (SHIFT0 == kRqShift0) {
     y0 = qnnp_requant_scale_s0(n0, rq.f); y1 = qnnp_requant_scale_s0(n1, rq.f);
     y2 = qnnp_requant_scale_s0(n2, rq.f); y3 = qnnp_requant_scale_s0(n3, rq.f);
   } else if constexpr (SHIFT0 == kRqBounded) {
@@ -129,6 +166,22 @@ __device__ __forceinline__ void requant_dispatch(const RequantDev& rq, F&& f)
     if (rq.full_range) f(Shift0{}, std::true_type{}); else f(Shift0{}, std::false_type{});
   } else if (rq.f.bounded && rq.full_range) {
     f(Bounded{}, std::true_type{});            // (the bounded form is instantiated for the common clamp only)
+  } else {
+    if (rq.full_range) f(General{}, std::true_type{}); else f(General{}, std::false_type{});
+  }
+}
+
+/* The same for kernels that fold rq_offset<SEQ>() into their accumulators: offset forms where they exist. */
+template <typename F>
+__host__ __device__ __forceinline__ void requant_dispatch_ofs(const RequantDev& rq, F&& f)   // (host: to pick a kernel instantiation)
+{
+  using Shift0Ofs = std::integral_constant<int, kRqShift0Ofs>;
+  using BoundedOfs = std::integral_constant<int, kRqBoundedOfs>;
+  using General = std::integral_constant<int, kRqGeneral>;
+  if (rq.f.shift == 0) {
+    if (rq.full_range) f(Shift0Ofs{}, std::true_type{}); else f(Shift0Ofs{}, std::false_type{});
+  } else if (rq.f.bounded && rq.full_range) {
+    f(BoundedOfs{}, std::true_type{});
   } else {
     if (rq.full_range) f(General{}, std::true_type{}); else f(General{}, std::false_type{});
   }

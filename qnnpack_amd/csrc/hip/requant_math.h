@@ -42,7 +42,13 @@ struct qnnp_requant_fast {
   uint32_t bounded_lo;         /* low / high word of the bounded form's addend (qnnp_requant_fast_enable_bounded) */
   uint32_t bounded_hi;
   uint32_t bounded;            /* 1: |accumulator| is known to be small enough for qnnp_requant_scale_sn_bounded */
+  /* offset forms (qnnp_requant_fast_enable_offset): the kernel hands over n + 2^31 as an UNSIGNED word */
+  uint64_t ofs_addend;         /* 64-bit addend of the unsigned multiply-add */
+  uint32_t ofs_multiplier;     /* 2M as an unsigned word */
+  uint32_t ofs_kind;           /* 0: none, 1: shift-0 form, 2: bounded shift >= 1 form */
 };
+
+#define QNNP_REQUANT_OFFSET UINT32_C(0x80000000)   /* what the offset forms expect added to the accumulator */
 
 QNNP_HD struct qnnp_requant_fast qnnp_requant_fast_init(int32_t multiplier, uint32_t shift)
 {
@@ -56,6 +62,9 @@ QNNP_HD struct qnnp_requant_fast qnnp_requant_fast_init(int32_t multiplier, uint
   f.bounded_lo = 0;
   f.bounded_hi = 0;
   f.bounded = 0;
+  f.ofs_addend = 0;
+  f.ofs_multiplier = 0;
+  f.ofs_kind = 0;
   return f;
 }
 
@@ -141,8 +150,61 @@ QNNP_HD int32_t qnnp_requant_scale_sn_bounded(int32_t n, const struct qnnp_requa
   return qnnp_asr32(r + qnnp_asr32(n, 31), f.shift);
 }
 
+/*
+ * Offset forms. Both forms above compute floor((n*2M + 2*addend) / 2^32) with a SIGNED 32x32+64 multiply-add, and 2M
+ * does not fit a signed operand -- hence the detour over 2M - 2^32 and the "+ n" afterwards. With the accumulator
+ * handed over as the unsigned word n' = n + 2^31 (a kernel folds the 2^31 into the bias / row term its accumulators
+ * start from, which costs nothing per value) the product n' * 2M is a plain UNSIGNED 32x32 -> 64 one:
+ *     n' * 2M + (2*addend - 2^31 * 2M)  ==  n*2M + 2*addend                 (mod 2^64; the true value fits 63 bits)
+ * so   s == 0          :  y = high32(n'*2M + C0)                             one v_mad_u64_u32
+ *      s >= 1, bounded :  y = (high32(n'*2M + C0 - 2^32) + (n' >> 31)) >> s  (n' >> 31 == (n >= 0) == 1 + (n >>arith 31))
+ * i.e. four instructions where the signed bounded form needs six. Same preconditions as the forms they replace.
+ * Call after the zero point was folded / the bounded form enabled. Returns the kind (0: not applicable).
+ */
+QNNP_HD uint32_t qnnp_requant_fast_enable_offset(struct qnnp_requant_fast* f)
+{
+  const uint64_t m2 = (uint64_t) (uint32_t) f->multiplier << 1;                  /* 2M in [2^31, 2^32) */
+  if (f->shift == 0) {
+    const uint64_t addend2 = ((((uint64_t) f->addend_hi << 32) | f->addend_lo)) << 1;
+    f->ofs_addend = addend2 - (m2 << 31);
+    f->ofs_kind = 1;
+  } else if (f->bounded) {
+    const uint64_t addend2 = ((uint64_t) f->bounded_hi << 32) | f->bounded_lo;
+    f->ofs_addend = addend2 - (m2 << 31) - (UINT64_C(1) << 32);
+    f->ofs_kind = 2;
+  } else {
+    f->ofs_kind = 0;
+    return 0;
+  }
+  f->ofs_multiplier = (uint32_t) m2;
+  return f->ofs_kind;
+}
+
+/* np = n + 2^31 (mod 2^32) */
+QNNP_HD int32_t qnnp_requant_scale_s0_ofs(uint32_t np, const struct qnnp_requant_fast f)
+{
+  const uint64_t t = (uint64_t) np * (uint64_t) f.ofs_multiplier + f.ofs_addend;
+  return (int32_t) (uint32_t) (t >> 32);
+}
+
+QNNP_HD int32_t qnnp_requant_scale_sn_bounded_ofs(uint32_t np, const struct qnnp_requant_fast f)
+{
+  const uint64_t t = (uint64_t) np * (uint64_t) f.ofs_multiplier + f.ofs_addend;
+  const int32_t r1 = (int32_t) (uint32_t) (t >> 32);
+  return qnnp_asr32(r1 + (int32_t) (np >> 31), f.shift);
+}
+
 QNNP_HD int32_t qnnp_requant_scale(int32_t n, const struct qnnp_requant_fast f)
 {
   if (f.shift == 0) return qnnp_requant_scale_s0(n, f);
   return f.bounded ? qnnp_requant_scale_sn_bounded(n, f) : qnnp_requant_scale_sn(n, f);
+}
+
+/* the same through the offset forms where they apply (what a kernel that opted into them evaluates) */
+QNNP_HD int32_t qnnp_requant_scale_via_offset(int32_t n, const struct qnnp_requant_fast f)
+{
+  const uint32_t np = (uint32_t) n + QNNP_REQUANT_OFFSET;
+  if (f.ofs_kind == 1) return qnnp_requant_scale_s0_ofs(np, f);
+  if (f.ofs_kind == 2) return qnnp_requant_scale_sn_bounded_ofs(np, f);
+  return qnnp_requant_scale(n, f);
 }

@@ -83,13 +83,38 @@ def test_pointwise_convolution(pw, case):
 
 @pytest.mark.parametrize("case", [FcCase("pw_bad_k", 64, 260, 16),       # K > 256
                                   FcCase("pw_bad_align", 64, 20, 16),    # rows only 4-byte aligned
-                                  FcCase("pw_bad_lds", 64, 256, 512)],   # weights exceed the LDS budget
+                                  FcCase("pw_bad_lds", 64, 256, 500)],   # weights exceed the LDS budget and the rows are
+                                                                         # not 16-byte aligned (no channel columns)
                          ids=lambda c: c.name)
 def test_unsupported_shapes_are_reported_not_silently_rerouted(pw, case):
     from qnnpack_amd import QnnpackError
     _, quant = fc_expected(case)
     with pytest.raises(QnnpackError):
         fc_run(pw, case, quant, to_device=to_device, from_device=from_device)
+
+
+# ---- channel columns (16-byte aligned rows): every workgroup column owns 2 / 4 / 8 channel blocks, any N fits ----
+@pytest.mark.parametrize("case", [
+    FcCase("pw_cols_n512_k256", 64, 256, 512),                       # the old LDS limit: 16 blocks x 8 KiB of weights
+    FcCase("pw_cols_n576_k96", 200, 96, 576),                        # MobileNetV2 14x14 expand shape, few rows
+    FcCase("pw_cols_n960_k160", 300, 160, 960),
+    FcCase("pw_cols_n272_ragged", 99, 48, 272),                      # 8.5 blocks: the last column is one half block
+    FcCase("pw_cols_n144_k24", 130, 24, 144),                        # 8-byte aligned input rows, 4.5 blocks
+    FcCase("pw_cols_strided", 130, 64, 320, input_stride=80, output_stride=352),
+    FcCase("pw_cols_clamp_zp", 70, 32, 192, izp=3, kzp=250, qmin=20, qmax=230),
+    FcCase("pw_cols_1row", 1, 32, 256),
+], ids=lambda c: c.name)
+def test_channel_columns(pw, case):
+    _fc(pw, case)
+
+
+@pytest.mark.parametrize("case", [
+    FcCase("pw_cols8_rows90000", 90000, 32, 544),                    # 17 blocks in columns of 8 (the last holds one)
+    FcCase("pw_cols4_rows100000", 100000, 32, 272),                  # 9 blocks in columns of 4
+    FcCase("pw_whole_rows140000", 140000, 16, 96),                   # enough rows: whole rows per unit, dense image
+], ids=lambda c: c.name)
+def test_channel_columns_chosen_by_row_count(pw, case):
+    _fc(pw, case)
 
 
 def test_auto_selection_takes_it_for_many_rows(qnnp):
@@ -100,8 +125,16 @@ def test_auto_selection_takes_it_for_many_rows(qnnp):
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 
 
-# ---- the global-operand flavour ("gemm_kernel" = 6): one wave per 32x32 block, any K ----
+# ---- the global-operand flavour ("gemm_kernel" = 6): one wave per 32x32 block, any K; from K = 256 on the reduction is
+#      split over the four waves of a workgroup (one workgroup per block) ----
 GW_KERNEL = "q8_pw_stream_gw_mfma"
+GWK_KERNEL = "q8_pw_stream_gwk_mfma"
+
+
+def _gw_name(k):
+    """(these cases have a handful of 32x32 blocks: from K = 256 on the reduction is split; with more than two blocks
+    per CU it is not -- test_gw_many_blocks_keep_one_wave_per_block)"""
+    return GWK_KERNEL if k >= 256 else GW_KERNEL
 
 
 @pytest.fixture()
@@ -114,7 +147,7 @@ def gw(qnnp):
 def _fc_gw(gw, case):
     expected, quant = fc_expected(case)
     out, kname = fc_run(gw, case, quant, to_device=to_device, from_device=from_device)
-    assert kname == GW_KERNEL, kname
+    assert kname == _gw_name(case.input_channels), kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 
 
@@ -123,7 +156,7 @@ def test_gw_row_edges(gw, m):
     _fc_gw(gw, FcCase(f"gw_m{m}", m, 384, 48))
 
 
-@pytest.mark.parametrize("k", [16, 32, 48, 112, 128, 144, 256, 272, 384, 576, 960, 1280])
+@pytest.mark.parametrize("k", [16, 32, 48, 112, 128, 144, 240, 256, 272, 384, 496, 512, 528, 576, 960, 1024, 1040, 1280, 2064])
 def test_gw_k_blocks_and_unroll_tails(gw, k):
     _fc_gw(gw, FcCase(f"gw_k{k}", 70, k, 40))
 
@@ -147,6 +180,14 @@ def test_gw_pointwise_convolution(gw):
     case = ConvCase("gw_1x1_960_160", (7, 7), gic=960, goc=160, batch=4)
     expected, quant, out_hw = conv_expected(case)
     out, kname = conv_run(gw, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == GWK_KERNEL, kname          # 35 blocks of K = 960: split over the waves
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+def test_gw_many_blocks_keep_one_wave_per_block(gw):
+    case = FcCase("gw_many_blocks", 6272, 576, 160)          # 196 x 5 blocks > 2 per CU
+    expected, quant = fc_expected(case)
+    out, kname = fc_run(gw, case, quant, to_device=to_device, from_device=from_device)
     assert kname == GW_KERNEL, kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 

@@ -151,6 +151,54 @@ def test_bounded_requantization_sequence_matches_oracle(debug_hooks):
         assert np.array_equal(out, o1.q31_requantize(acc, scale, 9, 0, 255)), (scale, bits)
 
 
+def test_offset_requantization_forms_match_oracle(debug_hooks):
+    """hip/requant_math.h, qnnp_requant_scale_{s0,sn_bounded}_ofs: the unsigned multiply-add forms the streaming kernels
+    evaluate on accumulators that carry + 2^31 (one instruction for shift 0, four for the bounded shift >= 1 form)."""
+    import ctypes
+    L = debug_hooks.lib
+    fn = L.qnnp_debug_requant_fast_offset
+    fn.restype = None
+    fn.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_float, ctypes.c_uint8, ctypes.c_uint8, ctypes.c_uint8,
+                   ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    rng = np.random.default_rng(13)
+    clamps = [(0, 0, 255), (127, 0, 255), (255, 0, 255), (100, 128, 255), (7, 5, 9)]
+    # shift 0 (scales in [0.5, 1)): every accumulator, bound irrelevant
+    acc = rng.integers(-2**31, 2**31, size=1 << 20).astype(np.int32)
+    acc[:8] = [-2**31, 2**31 - 1, 0, -1, 1, -2**30, 2**30, -2**31 + 1]
+    for scale in [0.5, 0.50000006, 0.6180339, 0.75, 0.99, float.fromhex("0x1.FFFFFCp-1"), float.fromhex("0x1.FFFFFEp-1")]:
+        for zp, qmin, qmax in clamps:
+            out = np.empty(acc.size, np.uint8)
+            kind = ctypes.c_int(-1)
+            fn(acc.size, acc.ctypes.data, np.float32(scale), zp, qmin, qmax, 0, out.ctypes.data, ctypes.byref(kind))
+            assert kind.value == 1, scale
+            assert np.array_equal(out, o1.q31_requantize(acc, scale, zp, qmin, qmax)), (scale, zp, qmin, qmax)
+    # bounded shift >= 1
+    for bits in (30, 27, 20, 12):
+        lim = 2 ** bits
+        acc = rng.integers(-lim + 1, lim, size=1 << 19).astype(np.int32)
+        acc[:6] = [-lim + 1, lim - 1, 0, -1, 1, -(lim // 2)]
+        ties = []
+        for s in range(1, 21):
+            for k in range(-12, 13):
+                ties += [v for v in ((k << s) + (1 << (s - 1)) + d for d in (-1, 0, 1)) if -lim < v < lim]
+        acc[6:6 + len(ties)] = np.array(ties, dtype=np.int64).astype(np.int32)
+        for scale in [0.49999997, 0.25, 0.3, 1 / 255.0, 0.0031, 2.0 ** -12, 1.7e-5, 2.0 ** -20, 1.9e-6]:
+            for zp, qmin, qmax in clamps:
+                out = np.empty(acc.size, np.uint8)
+                kind = ctypes.c_int(-1)
+                fn(acc.size, acc.ctypes.data, np.float32(scale), zp, qmin, qmax, bits, out.ctypes.data, ctypes.byref(kind))
+                assert kind.value == 2, (scale, bits)
+                assert np.array_equal(out, o1.q31_requantize(acc, scale, zp, qmin, qmax)), (bits, scale, zp, qmin, qmax)
+    # no offset form: shift >= 1 without a bound -> the general sequence answers, still exact
+    acc = rng.integers(-2**31, 2**31, size=1 << 14).astype(np.int32)
+    out = np.empty(acc.size, np.uint8)
+    for scale, bits in [(0.25, 0), (0.25, 31), (2.0 ** -22, 20)]:
+        kind = ctypes.c_int(-1)
+        fn(acc.size, acc.ctypes.data, np.float32(scale), 9, 0, 255, bits, out.ctypes.data, ctypes.byref(kind))
+        assert kind.value == 0, (scale, bits)
+        assert np.array_equal(out, o1.q31_requantize(acc, scale, 9, 0, 255)), (scale, bits)
+
+
 def test_accumulator_bound(debug_hooks):
     """requantization.h, qnnp_accumulator_bits: |bias| + K * 255^2 < 2^bits, 0 when it does not fit 31 bits."""
     import ctypes
