@@ -822,8 +822,16 @@ bool plan_col(DwParams& p)
   const uint64_t waves_per_seg = static_cast<uint64_t>(p.batch) * chunks;
   // (measured on the MobileNetV2 layers, batch 128: 1.3-2 rounds of waves beat 3-4 -- 35.6 against 39.6 us on
   //  layer 8 -- now that the rows in flight are really in flight; shorter segments only add start-ups and halo rows)
-  const uint64_t target = static_cast<uint64_t>(p.cu_count) * 4u * 6u * 3u / 2u;  // ~1.5 rounds at 6 waves per SIMD
+  const uint64_t slots = static_cast<uint64_t>(p.cu_count) * 4u * 6u;               // 6 waves per SIMD
+  const uint64_t target = slots * 3u / 2u;                                         // ~1.5 rounds
   uint32_t segs = static_cast<uint32_t>((target + waves_per_seg - 1) / waves_per_seg);
+  // Stride 1 with enough columns to give every SIMD a few waves: at most ONE round (28x28x192, batch 128: two
+  // segments 15.2 us, four 16.6; 14x14x576: one 12.5, two 14.3 -- a second, partly filled round costs more than it
+  // hides; the stride-2 layers are HBM-bound and keep the deeper queue)
+  if (p.sw == 1 && waves_per_seg * 5u >= slots * 2u) {
+    const uint32_t one_round = static_cast<uint32_t>(slots / waves_per_seg);
+    segs = one_round < 1u ? 1u : one_round;
+  }
   const uint32_t min_rows = 7;
   uint32_t max_segs = p.OH / min_rows;
   if (max_segs < 1) max_segs = 1;

@@ -280,8 +280,16 @@ __device__ __forceinline__ void stream_copy_out(
  *   - the loads are always issued (clamped unit index): a branch around them makes the outstanding count
  *     path-dependent and costs the same vmcnt(0).
  */
-template <int KB, int VEC>
-__global__ __launch_bounds__(kThreads, (KB <= 5) ? 4 : 2)
+/* resident workgroups per CU (= waves per SIMD) the staged kernel is compiled for, i.e. what its register need
+ * allows (72 / 80 / 90 / 96 / 104 / 114 / 124 / 134 VGPRs for 1..8 K blocks, per requantization flavour). A wave of
+ * this kernel spends most of a unit's time waiting -- the next rows, the previous unit's store acknowledgements --
+ * and residency is what hides that. */
+constexpr int staged_waves(int kb) { return kb <= 1 ? 7 : (kb == 2 ? 6 : (kb <= 4 ? 5 : (kb <= 7 ? 4 : 3))); }
+
+/* SEQ / FULL: the requantization flavour (requant.hip.h), chosen on the host -- one kernel per flavour, so that the
+ * common ones are not charged the registers of the rare ones */
+template <int KB, int VEC, int SEQ, bool FULL>
+__global__ __launch_bounds__(kThreads, staged_waves(KB))
 void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const uint32_t log_cpr)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -381,7 +389,12 @@ void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const u
   __syncthreads();
   if (unit >= units) return;
 
-  requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
+  {
+    using shift0_t = std::integral_constant<int, SEQ>;
+    using full_t = std::integral_constant<bool, FULL>;
+    const shift0_t shift0{};
+    const full_t full{};
+    (void) shift0; (void) full;
     uint32_t rs = recentre(a);
     for (;;) {
       const uint32_t next = unit + unit_stride;
@@ -431,7 +444,7 @@ void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const u
       if (next >= units) break;
       unit = next;
     }
-  });
+  }
 }
 
 /*
@@ -793,7 +806,8 @@ void q8_conv_stream_c3_kernel(const IgemmParams p)
  * gather that clamps the offset to the last whole dword and shifts (wave-uniform choice, both flavours issue the
  * same loads).
  */
-__global__ __launch_bounds__(kThreads, 4)
+template <int SEQ, bool FULL>       // the requantization flavour, chosen on the host (as the staged pointwise kernel)
+__global__ __launch_bounds__(kThreads, 5)
 void q8_conv_stream_c3s_kernel(const IgemmParams p, const uint32_t log_cpr)
 {
   constexpr int KB = 2;                                    // k_pad == 64: up to 16 taps of 4-byte slots
@@ -924,7 +938,10 @@ void q8_conv_stream_c3s_kernel(const IgemmParams p, const uint32_t log_cpr)
   __syncthreads();
   if (unit >= units) return;
 
-  requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
+  {
+    const std::integral_constant<int, SEQ> shift0{};
+    const std::integral_constant<bool, FULL> full{};
+    (void) shift0; (void) full;
     uint32_t rs = finish_rows(x, t_cur, a);
     for (;;) {
       const uint32_t next = unit + unit_stride;
@@ -970,7 +987,7 @@ void q8_conv_stream_c3s_kernel(const IgemmParams p, const uint32_t log_cpr)
       if (next >= units) break;
       unit = next;
     }
-  });
+  }
 }
 
 template <int KB, int VEC, bool D2S = false>
@@ -1038,7 +1055,7 @@ bool plan_staged(const IgemmParams& p, uint32_t kb, StagedPlan* plan)
   if (p.store_mode != 2 || p.n % 16u != 0 || p.d2s_sh != 0) return false;
   const uint32_t nblocks = p.n_pad / 32u;
   const uint32_t units = (p.rows + 31u) / 32u;
-  const uint32_t base_per_cu = (kb <= 5) ? 4u : 2u;
+  const uint32_t base_per_cu = static_cast<uint32_t>(staged_waves(static_cast<int>(kb)));
   const uint32_t slots = p.cu_count * base_per_cu * kWaves;
   const bool dense = p.output_stride == p.n;
   uint32_t log_whole = 1;                                       // chunked image of a whole row: pitch = 2^k * 16 >= n
@@ -1078,10 +1095,10 @@ bool plan_staged(const IgemmParams& p, uint32_t kb, StagedPlan* plan)
   return true;
 }
 
-template <int KB, int VEC>
-int launch_pw_staged(const IgemmParams& p, const StagedPlan& plan, hipStream_t stream)
+template <int KB, int VEC, int SEQ, bool FULL>
+int launch_pw_staged_as(const IgemmParams& p, const StagedPlan& plan, hipStream_t stream)
 {
-  auto kernel = q8_pw_stream_staged_kernel<KB, VEC>;
+  auto kernel = q8_pw_stream_staged_kernel<KB, VEC, SEQ, FULL>;
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
   if (attr_once.first()) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
@@ -1104,6 +1121,16 @@ int launch_pw_staged(const IgemmParams& p, const StagedPlan& plan, hipStream_t s
   hipLaunchKernelGGL(kernel, dim3(gx, plan.nsplit), dim3(kThreads), plan.lds_bytes, stream, p, plan.nbp, plan.log_cpr);
 #endif
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+template <int KB, int VEC>
+int launch_pw_staged(const IgemmParams& p, const StagedPlan& plan, hipStream_t stream)
+{
+  int rc = QNNP_HIP_EINVAL;
+  requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+    rc = launch_pw_staged_as<KB, VEC, decltype(seq)::value, decltype(full)::value>(p, plan, stream);
+  });
+  return rc;
 }
 
 template <int VEC>
@@ -1176,17 +1203,22 @@ int convstream_c3_launch(const IgemmParams& p, hipStream_t stream, const char** 
     const uint32_t pitch = p.output_stride == p.n ? p.n : (16u << log_cpr);
     const uint32_t staged_bytes = lds_bytes + kWaves * 32u * pitch;
     if (staged_bytes <= kMaxLds) {
-      static qnnp::PerDeviceOnce attr_once_s;
-      if (attr_once_s.first()) {
-        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(q8_conv_stream_c3s_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-      }
       const uint32_t units = (p.rows + 31u) / 32u;
-      uint32_t grid = p.cu_count * 4u;
+      uint32_t per_cu = 5;                                   // what the kernel's registers allow
+      const uint32_t by_lds = (160u * 1024u) / staged_bytes;
+      if (by_lds < per_cu) per_cu = by_lds > 0 ? by_lds : 1u;
+      uint32_t grid = p.cu_count * per_cu;
       const uint32_t needed = (units + kWaves - 1) / kWaves;
       if (grid > needed) grid = needed;
       *name = "q8_conv_stream_c3_mfma";
-      hipLaunchKernelGGL(q8_conv_stream_c3s_kernel, dim3(grid), dim3(kThreads), staged_bytes, stream, p, log_cpr);
+      requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+        auto kernel = q8_conv_stream_c3s_kernel<decltype(seq)::value, decltype(full)::value>;
+        static qnnp::PerDeviceOnce attr_once_s;   // (one per instantiation of this lambda body)
+        if (attr_once_s.first()) {
+          (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+        }
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), staged_bytes, stream, p, log_cpr);
+      });
       return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
     }
   }
