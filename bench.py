@@ -22,8 +22,8 @@ Secondary numbers travel in the same JSON line under "extra" (not separate bench
   * "next_rows": the operators SURVEY.md section 8f ranks after the hot path (deconvolution, add, pooling).
 
 The timed region is EXACTLY K steps between barriers (wall clock, max over ranks -> `value`), bracketed on the
-launch stream by HIP events as well (-> "roofline", same launches). It directly follows >= 250 ms of the same GEMM
-replayed as a hipGraph (five batches, median reported as roofline.sustained_launch_ms), so the chip is in its
+launch stream by HIP events as well (-> "roofline", same launches). It directly follows >= 1 s of the same GEMM
+replayed as a hipGraph (five batches of >= 200 ms, median reported as roofline.sustained_launch_ms), so the chip is in its
 sustained clock / power state, not in a boost burst. "cpu_baseline" times the reference's own SSE2 path (oracle/_ref, built from
 the reference sources) on this box's host cores on a bounded sample -- rank 0, N = 1 only.
 Inputs are synthetic uniform-random uint8 already resident in HBM when the timed region starts.
@@ -429,12 +429,12 @@ def main():
         lib.run_operator(op)
     torch.cuda.synchronize()
     # Sustained state first: the same GEMM replayed as a hipGraph of 64 launches, five event-bracketed batches of
-    # >= 50 ms each (median reported). The K timed steps follow at once, so they run at the sustained clock.
+    # >= 200 ms each (median reported). The K timed steps follow at once, so they run at the sustained clock.
     lib.graph_begin()
     for _ in range(64):
         lib.run_operator(op)
     graph = lib.graph_end()
-    sustained_ms = lib.graph_time(graph, 1, 12) / 64.0          # 5 batches x 12 replays x 64 launches
+    sustained_ms = lib.graph_time(graph, 1, 48) / 64.0          # 5 batches x 48 replays x 64 launches
     lib.graph_destroy(graph)
     stream = torch.cuda.current_stream()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # the launch stream IS torch's current stream (set_stream above)
@@ -469,7 +469,7 @@ def main():
                 "timed_as": "HIP events around the K timed steps (the launches `value` is computed from)",
                 "sustained_launch_ms": round(sustained_ms, 5),
                 "sustained_tops": round(gemm_ops / (sustained_ms * 1e-3) / 1e12, 2),
-                "sustained_as": "median of 5 batches of 12 replays of a 64-launch hipGraph (>= 50 ms per batch), run right before the timed steps"}
+                "sustained_as": "median of 5 batches of 48 replays of a 64-launch hipGraph (>= 200 ms per batch, 1 s in all), run right before the timed steps"}
     if rank == 0:
         # the bare-MFMA rate of this very chip, measured in this process: with random operands the power
         # management holds a lower clock, so this -- not the nominal peak -- is what a kernel can reach at best
@@ -480,6 +480,24 @@ def main():
             roofline["frac_of_mfma_only_random"] = round(achieved / roofline["mfma_only_random_operands"], 4)
         except Exception as exc:  # noqa: BLE001
             print(f"# mfma probe failed: {exc}", file=sys.stderr)
+        # the vendor library on the same problem, same box, same minute (torch._int_mm -> hipBLASLt: int8 x int8 ->
+        # int32, random operands, NO uint8 re-centring / row sums / requantization): a yardstick, not a baseline
+        try:
+            va = torch.randint(-128, 128, (M, K), dtype=torch.int8, device="cuda")
+            vb = torch.randint(-128, 128, (N, K), dtype=torch.int8, device="cuda").t()
+            for _ in range(5):
+                torch._int_mm(va, vb)
+            torch.cuda.synchronize()
+            ve0, ve1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ve0.record()
+            for _ in range(300):
+                torch._int_mm(va, vb)
+            ve1.record()
+            torch.cuda.synchronize()
+            roofline["vendor_int8_gemm_no_epilogue_tops"] = round(gemm_ops / (ve0.elapsed_time(ve1) * 1e-3 / 300) / 1e12, 1)
+            del va, vb
+        except Exception as exc:  # noqa: BLE001
+            print(f"# vendor int8 GEMM probe failed: {exc}", file=sys.stderr)
     lib.delete_operator(op)
     del a, c
 
