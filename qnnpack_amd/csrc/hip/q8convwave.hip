@@ -51,7 +51,7 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int kWaves = 8;
+constexpr int kWaves = 9;
 constexpr int kThreads = kWaves * 64;
 constexpr int kMaxDma = 8;              // 1 KiB LDS-DMA pieces per patch (<= 512 chunks of 16 bytes)
 constexpr uint32_t kFlip = 0x80808080u;
@@ -62,6 +62,8 @@ struct WaveArgs {
   uint32_t inv_pw;          // ceil(65536 / PW): q / PW == (q * inv_pw) >> 16 for the small q used here
   uint32_t tiles_x, tiles_y;
   uint32_t units;           // batch * tiles_y * tiles_x
+  uint32_t inv_tiles;       // ceil(2^32 / (tiles_x * tiles_y)), 0 when the divisor is 1: unit / tiles = mulhi(unit, inv_tiles)
+  uint32_t inv_tiles_x;     // the same for tiles_x (both exact while units * divisor < 2^32: make_args checks)
   uint32_t w_bytes;         // packed weight image
   uint32_t head_bytes;      // weights + bias + counter, 1024-aligned: offset of the first wave region
   uint32_t ndma;            // LDS-DMA pieces per patch
@@ -79,6 +81,13 @@ inline bool make_args(const IgemmParams& p, const ConvGeom& g, uint32_t batch, W
   a->tiles_x = (g.OW + 7u) / 8u;
   a->tiles_y = (g.OH + 7u) / 8u;
   a->units = batch * a->tiles_x * a->tiles_y;
+  {
+    // q = floor(n * M / 2^32) with M = ceil(2^32 / d) is exact while n * d < 2^32 (error term n*e/(d*2^32) < 1/d)
+    const uint64_t tiles = static_cast<uint64_t>(a->tiles_x) * a->tiles_y;
+    if (static_cast<uint64_t>(batch) * tiles * tiles >= (UINT64_C(1) << 32)) return false;
+    a->inv_tiles = tiles > 1 ? static_cast<uint32_t>(((UINT64_C(1) << 32) + tiles - 1) / tiles) : 0u;
+    a->inv_tiles_x = a->tiles_x > 1 ? static_cast<uint32_t>(((UINT64_C(1) << 32) + a->tiles_x - 1) / a->tiles_x) : 0u;
+  }
   a->w_bytes = p.n_pad * p.k_pad;
   a->head_bytes = (a->w_bytes + p.n * 4u + 16u + 1023u) & ~1023u;
   const uint32_t patch = a->PH * a->PW * p.kc;
@@ -86,7 +95,10 @@ inline bool make_args(const IgemmParams& p, const ConvGeom& g, uint32_t batch, W
   a->patch_bytes = (patch + 255u) & ~255u;
   a->stage_bytes = 32u * p.n;
   a->pix_bytes = (a->PH * a->PW * 4u + 255u) & ~255u;
-  a->wave_bytes = 2u * a->patch_bytes + a->stage_bytes + a->pix_bytes;
+  // (the staging image lives in the patch buffer of the unit just multiplied: its K loop is over, only its pixel sums
+  //  are still needed and they have their own region)
+  a->wave_bytes = 2u * a->patch_bytes + a->pix_bytes;
+  if (a->stage_bytes > a->patch_bytes) return false;
   *lds_bytes = a->head_bytes + kWaves * a->wave_bytes;
   if (a->ndma > static_cast<uint32_t>(kMaxDma)) return false;
   if (a->ndma * 64u > 4096u * (p.kc >> 4)) return false;   // inv_pw exactness: pixel index < 4096
@@ -127,9 +139,17 @@ __device__ __forceinline__ void ds_write4_raw(uint32_t off, int32_t v)
   asm volatile("ds_write_b32 %0, %1" :: "v"(off), "v"(v) : "memory");
 }
 
+// n / d through the host-made reciprocal (WaveArgs): one scalar multiply instead of the ~40-instruction sequence hipcc
+// emits for a division by a run-time value -- four of those per unit sat on every wave's critical path
+__device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t inv)
+{
+  return inv != 0u ? __umulhi(n, inv) : n;
+}
+
 // KS: 3 = 3x3 window, stride 1, dilation 1 (10x10 patch; every fragment address = per-unit register + immediate),
 //     0 = any geometry make_args accepts (addresses computed per tap)
-template <int TN, int CB, int KS>
+// SEQ / FULL: the requantization flavour (requant.hip.h), chosen on the host: one kernel per flavour
+template <int TN, int CB, int KS, int SEQ, bool FULL>
 __global__ __launch_bounds__(kThreads, 2)
 void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveArgs a)
 {
@@ -142,8 +162,7 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint8_t* patch0 = lds + a.head_bytes + wave * a.wave_bytes;
-  uint8_t* stage = patch0 + 2u * a.patch_bytes;
-  int32_t* pix = reinterpret_cast<int32_t*>(stage + a.stage_bytes);
+  int32_t* pix = reinterpret_cast<int32_t*>(patch0 + 2u * a.patch_bytes);
 
   // contiguous unit range of this workgroup (neighbouring blocks share halos in L2)
   const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * a.units / gridDim.x);
@@ -177,9 +196,9 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
     g_pyx[u] = (py << 16) | px;
   }
   auto dma_patch = [&](uint32_t unit, uint8_t* dst) __attribute__((always_inline)) {
-    const uint32_t img = unit / tiles;
+    const uint32_t img = div_magic(unit, a.inv_tiles);
     const uint32_t r = unit - img * tiles;
-    const uint32_t tyi = r / a.tiles_x;
+    const uint32_t tyi = div_magic(r, a.inv_tiles_x);
     const uint32_t txi = r - tyi * a.tiles_x;
     const int32_t iy0 = static_cast<int32_t>(tyi * 8u * g.sh) - static_cast<int32_t>(g.pad_top);
     const int32_t ix0 = static_cast<int32_t>(txi * 8u * g.sw) - static_cast<int32_t>(g.pad_left);
@@ -247,8 +266,11 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
   while (cur < hi) {
     CW_STAMP(0);
     uint8_t* patch = patch0 + buf * a.patch_bytes;
+    uint8_t* stage = patch;                  // (after the K loop, see make_args)
     // next unit: claimed now, its patch gathered into the other buffer while this unit is multiplied. (The patch of
     // `cur` has landed: its gather was waited for after the K loop of the previous unit, or before the barrier.)
+    // (Claiming one unit further ahead, so that the LDS atomic's round trip leaves the critical path, measured
+    //  SLOWER -- 28.9 against 27.8 us: a busy wave then sits on a unit an idle one could have taken in the last round.)
     uint32_t nxt = hi;
     {
       uint32_t claimed = 0;
@@ -257,33 +279,48 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
     }
     if (nxt < hi) dma_patch(nxt, patch0 + (buf ^ 1u) * a.patch_bytes);
     CW_STAMP(1);
-    const uint32_t img = cur / tiles;
+    const uint32_t img = div_magic(cur, a.inv_tiles);
     const uint32_t r = cur - img * tiles;
-    const uint32_t tyi = r / a.tiles_x;
+    const uint32_t tyi = div_magic(r, a.inv_tiles_x);
     const uint32_t oy0 = tyi * 8u;
     const uint32_t ox0 = (r - tyi * a.tiles_x) * 8u;
 
     // ---- the landed patch: re-centre the bytes in place, per-pixel channel sums (of a') beside it ----
+    // Software-pipelined by one piece: one piece per trip (read -> wait -> compute -> write, the raw writes being
+    // memory barriers to the compiler) cost an LDS round trip per piece, 2.4 k cycles per unit (stamps).
     {
       const uint32_t patch_off = lds_off(patch);
       const uint32_t pix_off = lds_off(pix);
-      for (uint32_t u = 0; u < a.ndma; u++) {
+      // (two pieces per trip, the read of the next piece issued before a piece is processed: two pieces live)
+      auto read_piece = [&](uint32_t u) __attribute__((always_inline)) -> uint4 {
         const uint32_t v = lane + u * 64u;
-        if (v < pvec) {                                  // whole pixels: pvec is a multiple of cpp
-          uint4 x = *reinterpret_cast<const uint4*>(patch + v * 16u);
+        return *reinterpret_cast<const uint4*>(patch + min(v, pvec - 1u) * 16u);    // (past the patch: its last chunk, unused)
+      };
+      auto fix_piece = [&](uint32_t u, const uint4& x) __attribute__((always_inline)) {
+        const uint32_t v = lane + u * 64u;
+        if (u < a.ndma && v < pvec) {                                // whole pixels: pvec is a multiple of cpp
           uint32_t sum = __builtin_amdgcn_sad_u8(x.x, 0u, 0u);
           sum = __builtin_amdgcn_sad_u8(x.y, 0u, sum);
           sum = __builtin_amdgcn_sad_u8(x.z, 0u, sum);
           sum = __builtin_amdgcn_sad_u8(x.w, 0u, sum);
           sum += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(sum), 0xB1, 0xF, 0xF, false));        // lane ^ 1
           if (cpp > 2) sum += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(sum), 0x4E, 0xF, 0xF, false));   // lane ^ 2
-          x.x ^= kFlip; x.y ^= kFlip; x.z ^= kFlip; x.w ^= kFlip;
-          ds_write16_raw(patch_off + v * 16u, x);
+          uint4 y = x;
+          y.x ^= kFlip; y.y ^= kFlip; y.z ^= kFlip; y.w ^= kFlip;
+          ds_write16_raw(patch_off + v * 16u, y);
           if ((v & (cpp - 1u)) == 0) ds_write4_raw(pix_off + (v >> log_cpp) * 4u, static_cast<int32_t>(sum) - 128 * static_cast<int32_t>(cin));
         }
+      };
+      uint4 xa = read_piece(0);
+      for (uint32_t u = 0; u < a.ndma; u += 2) {
+        const uint4 xb = read_piece(u + 1);
+        fix_piece(u, xa);
+        xa = read_piece(u + 2);
+        fix_piece(u + 1, xb);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    CW_STAMP(2);
 
     // accumulators start at the folded bias
     v16i acc[2][TN];
@@ -387,18 +424,22 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
       }
       if (t < taps) mma(f0);
     }
-    CW_STAMP(2);
+    CW_STAMP(3);
     // Everything this wave has in flight -- the gather of `nxt` and the output stores of the previous unit -- was
     // issued before the K loop: by now it has landed, so this wait is (almost) free; it is what makes `nxt`'s patch
     // safe to read at the top of the next iteration without waiting for THIS unit's stores.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    CW_STAMP(4);
 
     // ---- fused epilogue, 32 positions at a time: row term from the pixel sums, Q31 requantization into the staging
     //      image, whole 4-row x 8-position runs stored with 16-byte pieces ----
     uint8_t* out_img = p.output + static_cast<uint64_t>(img) * g.OH * g.OW * p.n;
     const uint32_t stage_off = lds_off(stage);
-    requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
+    {
+      const std::integral_constant<int, SEQ> shift0{};
+      const std::integral_constant<bool, FULL> full{};
+      (void) shift0; (void) full;
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         // sum of a' over this position's window: the window's pixel sums
@@ -443,9 +484,7 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // read back before the next half overwrites it
       }
-    });
-    CW_STAMP(3);
-    CW_STAMP(4);
+    }
     CW_STAMP(5);
     unit_no++;
     cur = nxt;
@@ -454,20 +493,30 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
 #undef CW_STAMP
 }
 
-template <int TN, int CB, int KS>
-int launch(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, uint32_t lds_bytes, hipStream_t stream)
+template <int TN, int CB, int KS, int SEQ, bool FULL>
+int launch_as(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, uint32_t lds_bytes, hipStream_t stream)
 {
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
   if (attr_once.first()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_mfma_kernel<TN, CB, KS>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_mfma_kernel<TN, CB, KS, SEQ, FULL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       (void) hipGetLastError();
     }
   }
   const uint32_t want = (a.units + kWaves - 1) / kWaves;
   const uint32_t grid = want < p.cu_count ? want : p.cu_count;
-  hipLaunchKernelGGL((q8_conv_wave_mfma_kernel<TN, CB, KS>), dim3(grid), dim3(kThreads), lds_bytes, stream, p, g, a);
+  hipLaunchKernelGGL((q8_conv_wave_mfma_kernel<TN, CB, KS, SEQ, FULL>), dim3(grid), dim3(kThreads), lds_bytes, stream, p, g, a);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+template <int TN, int CB, int KS>
+int launch(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, uint32_t lds_bytes, hipStream_t stream)
+{
+  int rc = QNNP_HIP_EINVAL;
+  requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+    rc = launch_as<TN, CB, KS, decltype(seq)::value, decltype(full)::value>(p, g, a, lds_bytes, stream);
+  });
+  return rc;
 }
 
 }  // namespace
