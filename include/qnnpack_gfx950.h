@@ -113,7 +113,9 @@ enum qnnp_status qnnp_gfx950_setup_fused_block(
  *                    5 = barrier-free streaming kernel for short-K pointwise / fully-connected layers,
  *                    6 = its global-operand flavour (one wave per 32x32 block; small problems with long K),
  *                    7 = its 3-channel-image convolution flavour (first layers; in-register tap gather),
- *                    8 = wave-per-8x8-block direct-convolution MFMA kernel (small windows, <= 64 channels, dense output)
+ *                    8 = wave-per-8x8-block direct-convolution MFMA kernel (small windows, <= 64 channels, dense output),
+ *                    9 = long-K flavour of the streaming kernel (256 < K <= 1024, 16-byte aligned rows both sides:
+ *                        a channel column's weights in LDS, every K block of a unit's rows in flight at once)
  *   "dwconv_kernel": 0 = auto, 1 = generic direct kernel, 2 = LDS-tiled kernel, 3 = register sliding-window kernel (3x3),
  *                    4 = matrix-core kernel (diagonal MFMA operands; 3x3, channels % 16 == 0), tap operands gathered
  *                        from global memory, 5 = the same with the input band staged in LDS first,

@@ -93,6 +93,8 @@ bool pwstream_supported(const IgemmParams& p, uint32_t groups, uint32_t vec);
 int pwstream_launch(const IgemmParams& p, uint32_t vec, hipStream_t stream, const char** name);
 bool convstream_c3_supported(const IgemmParams& p, uint32_t groups);
 int convstream_c3_launch(const IgemmParams& p, hipStream_t stream, const char** name);
+bool pwstream_longk_supported(const IgemmParams& p, uint32_t groups, uint32_t vec);
+int pwstream_longk_launch(const IgemmParams& p, hipStream_t stream, const char** name);
 bool pwstream_gw_supported(const IgemmParams& p, uint32_t groups, uint32_t vec);
 int pwstream_gw_launch(const IgemmParams& p, hipStream_t stream, const char** name);
 

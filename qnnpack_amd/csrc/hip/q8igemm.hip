@@ -604,6 +604,21 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
     if (kernel_name != nullptr) *kernel_name = name;
     return rc_pw;
   }
+  // Long reductions over few rows with 16-byte aligned rows on both sides: weights of a channel column in LDS, every
+  // K block of a unit's rows in flight at once ("gemm_kernel" = 9 forces it).
+  const bool lk_ok = !pad3 && qnnp::pwstream_longk_supported(p, a->groups, vec);
+  if (a->variant == 9 && !lk_ok) return QNNP_HIP_EINVAL;
+  // (auto where it measured ahead, batch 128 MobileNetV2: the 14x14 project layers -- 784 row blocks, K = 384 / 576:
+  //  8.6 against 10.1 us, 10.8 against 13.0 -- and 7x7x320 -> 1280 with its 40 channel blocks, 11.1 against 12.5 on
+  //  the tiled kernel; with ~200 row blocks and few channel blocks the one-wave-per-block kernel below keeps the lead:
+  //  7x7x960 -> 160 11.1 against 6.6 us)
+  const uint32_t lk_units = (a->rows + 31u) / 32u;
+  const bool lk_auto = a->rows <= 65536u && (lk_units >= 512u || a->n_pad >= 512u);
+  if (lk_ok && (a->variant == 9 || (a->variant == 0 && lk_auto))) {
+    const int rc_lk = qnnp::pwstream_longk_launch(p, stream, &name);
+    if (kernel_name != nullptr) *kernel_name = name;
+    return rc_lk;
+  }
   // Small problems with a long reduction (late MobileNet layers, classifier heads): one wave per 32x32 block,
   // operands from L2 -- the tiled kernels would launch fewer workgroups than there are CUs.
   const bool gw_ok = !pad3 && qnnp::pwstream_gw_supported(p, a->groups, vec);

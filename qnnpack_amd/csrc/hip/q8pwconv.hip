@@ -448,6 +448,146 @@ void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const u
 }
 
 /*
+ * Long reductions (256 < K <= 1024) on the same scheme: the late MobileNet project layers (14x14x384 -> 96,
+ * 7x7x960 -> 320 ...). A wave has about one unit there, so there is no next unit to prefetch; instead ALL the K
+ * blocks of the unit's rows are requested at once (up to 32 x 16 bytes per lane in flight) and the column's weights sit
+ * in LDS (up to 96 KiB per workgroup). The one-wave-per-32x32-block kernel below fetches both operands from L2 in
+ * groups of four K blocks: a chain of dependent round trips as long as the reduction.
+ * KBMAX: register budget in K blocks (12 / 20 / 32); the real count is a run-time value, blocks beyond it are skipped.
+ */
+constexpr uint32_t kMaxLdsLongK = 96 * 1024;
+constexpr int longk_waves(int kbmax) { return kbmax <= 12 ? 4 : (kbmax <= 20 ? 3 : 2); }
+
+template <int KBMAX, int SEQ, bool FULL>
+__global__ __launch_bounds__(kThreads, longk_waves(KBMAX))
+void q8_pw_stream_longk_kernel(const IgemmParams p, const uint32_t nbp, const uint32_t log_cpr)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
+  const uint32_t row_in_block = lane & 31u;
+  const uint32_t khalf = lane >> 5;
+
+  const uint32_t nblocks = p.n_pad / 32;
+  const uint32_t kblocks = p.k_pad / 32;
+  const uint32_t kbn = (p.k_total + 31u) / 32u;           // K blocks with data (<= KBMAX)
+  const uint32_t nb0 = blockIdx.y * nbp;
+  const uint32_t nbn = min(nbp, nblocks - nb0);
+  const uint32_t c0 = nb0 * 32u;
+  const uint32_t cw = min(p.n - c0, nbn * 32u);
+  const bool whole_dense = gridDim.y == 1 && p.output_stride == p.n;
+  const uint32_t pitch = whole_dense ? p.n : (16u << log_cpr);
+  {
+    const uint32_t frags = nbn * kbn;
+    for (uint32_t f = wave; f < frags; f += kWaves) {
+      const uint32_t nb = f / kbn;
+      const uint32_t kb = f - nb * kbn;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*) (p.packed_w + (static_cast<uint64_t>(nb0 + nb) * kblocks + kb) * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*) (lds + f * 1024), 16, 0, 0);
+    }
+    uint8_t* lds_bias = lds + nbp * kbn * 1024;
+    const uint32_t bias_chunks = nbn * 8u;
+    for (uint32_t q0 = wave * 64; q0 < bias_chunks; q0 += kThreads) {
+      const uint32_t q = min(q0 + lane, bias_chunks - 1);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(p.bias2 + c0) + q * 16),
+          (__attribute__((address_space(3))) void*) (lds_bias + q0 * 16), 16, 0, 0);
+    }
+  }
+  const uint8_t* lds_w = lds + lane * 16;
+  const uint32_t bias_bytes = (nbp * 128u + 1023u) & ~1023u;
+  const int4* lds_bias4 = reinterpret_cast<const int4*>(lds + nbp * kbn * 1024);
+  uint8_t* stage = lds + nbp * kbn * 1024 + bias_bytes + wave * (32u * pitch);
+  const uint8_t* pad16 = p.fill_table + 0x80 * 16;        // 16 bytes of a' == 0
+  const uint32_t units = (p.rows + 31u) / 32u;
+  const uint32_t unit_stride = gridDim.x * kWaves;
+  const uint32_t raw_to_centred = 128u * 32u * kbn;
+
+  // every K block of the unit's rows at once; a piece beyond K (only in the last block) reads the a' == 0 line
+  auto load_rows = [&](uint32_t unit, v4i (&a)[KBMAX]) __attribute__((always_inline)) {
+    uint32_t m = unit * 32u + row_in_block;
+    if (m >= p.rows) m = p.rows - 1;
+    const uint8_t* row = p.input + static_cast<uint64_t>(m) * p.input_stride + khalf * 16;
+#pragma unroll
+    for (int kb = 0; kb < KBMAX; kb++) {
+      if (static_cast<uint32_t>(kb) < kbn) {
+        const uint8_t* src = (kb * 32u + khalf * 16u < p.k_total) ? row + kb * 32 : pad16;
+        a[kb] = *reinterpret_cast<const v4i*>(src);
+      }
+    }
+  };
+  auto recentre = [&](v4i (&a)[KBMAX]) __attribute__((always_inline)) -> uint32_t {
+    uint32_t rs = 0;
+#pragma unroll
+    for (int kb = 0; kb < KBMAX; kb++) {
+      if (static_cast<uint32_t>(kb) < kbn) {
+        rs = __builtin_amdgcn_sad_u8(a[kb].x, 0u, rs);
+        rs = __builtin_amdgcn_sad_u8(a[kb].y, 0u, rs);
+        rs = __builtin_amdgcn_sad_u8(a[kb].z, 0u, rs);
+        rs = __builtin_amdgcn_sad_u8(a[kb].w, 0u, rs);
+        a[kb].x ^= static_cast<int>(kFlip);
+        a[kb].y ^= static_cast<int>(kFlip);
+        a[kb].z ^= static_cast<int>(kFlip);
+        a[kb].w ^= static_cast<int>(kFlip);
+      }
+    }
+    rs += __shfl_xor(rs, 32);
+    return rs;
+  };
+
+  uint32_t unit = blockIdx.x * kWaves + wave;
+  v4i a[KBMAX];
+  load_rows(min(unit, units - 1u), a);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // weights + bias are in LDS (and the first rows landed)
+  __syncthreads();
+  if (unit >= units) return;
+
+  const std::integral_constant<int, SEQ> shift0{};
+  const std::integral_constant<bool, FULL> full{};
+  (void) shift0; (void) full;
+  for (;;) {
+    const uint32_t rs = recentre(a);
+    const int32_t rowterm = with_rq_offset<SEQ>(p.row_coeff * static_cast<int32_t>(rs - raw_to_centred));
+    int4 bias4[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[rg * 2 + khalf];
+    uint8_t* img = stage + row_in_block * pitch;
+    for (uint32_t nb = 0; nb < nbn; nb++) {
+      v16i acc;
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        acc[rg * 4 + 0] = add_wrap(bias4[rg].x, rowterm);
+        acc[rg * 4 + 1] = add_wrap(bias4[rg].y, rowterm);
+        acc[rg * 4 + 2] = add_wrap(bias4[rg].z, rowterm);
+        acc[rg * 4 + 3] = add_wrap(bias4[rg].w, rowterm);
+      }
+      if (nb + 1 < nbn) {
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[(nb + 1) * 8 + rg * 2 + khalf];
+      }
+      const uint8_t* wf = lds_w + nb * (kbn * 1024);
+#pragma unroll
+      for (int kb = 0; kb < KBMAX; kb++) {
+        if (static_cast<uint32_t>(kb) < kbn) {
+          const v4i w = *reinterpret_cast<const v4i*>(wf + kb * 1024);
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a[kb], acc, 0, 0, 0);
+        }
+      }
+      igemm_stage_tile<SEQ, FULL, false, true>(acc, bias4, 0, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < cw);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
+    stream_copy_out(stage, whole_dense, log_cpr, unit, c0, cw, p, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // read back before the next unit overwrites it
+    const uint32_t next = unit + unit_stride;
+    if (next >= units) break;
+    unit = next;
+    load_rows(unit, a);
+  }
+}
+
+/*
  * Second flavour for pointwise / fully-connected layers whose weights do NOT fit LDS (K up to ~1000 over few
  * rows: the late MobileNet layers, classifier heads): one WAVE = one 32-row x 32-channel output block, both
  * MFMA operands straight from global memory / L2 (activations: 16 B per lane in B-operand layout; weights: one
@@ -1148,6 +1288,82 @@ int dispatch_kb_staged(const IgemmParams& p, uint32_t kb, const StagedPlan& plan
   }
 }
 
+/* plan for the long-K flavour: like plan_staged with the run-time K block count and its own LDS limit */
+bool plan_longk(const IgemmParams& p, StagedPlan* plan, int* kbmax)
+{
+  if (p.store_mode != 2 || p.n % 16u != 0 || p.d2s_sh != 0 || p.k_total % 16u != 0) return false;
+  const uint32_t kb = (p.k_total + 31u) / 32u;
+  if (kb <= 8 || kb > 32) return false;
+  *kbmax = kb <= 12 ? 12 : (kb <= 20 ? 20 : 32);
+  const uint32_t nblocks = p.n_pad / 32u;
+  const uint32_t units = (p.rows + 31u) / 32u;
+  const uint32_t base_per_cu = static_cast<uint32_t>(longk_waves(*kbmax));
+  const uint32_t slots = p.cu_count * base_per_cu * kWaves;
+  const bool dense = p.output_stride == p.n;
+  uint32_t log_whole = 1;
+  while ((16u << log_whole) < nblocks * 32u) log_whole++;
+  const uint32_t whole_pitch = dense ? p.n : (16u << log_whole);
+  const uint32_t whole_lds = staged_lds_bytes(kb, nblocks, whole_pitch);
+  const bool whole_fits = whole_lds <= kMaxLdsLongK;
+  uint32_t nbp = 0;
+  if (whole_fits && (units >= slots || nblocks < 4u)) {
+    nbp = nblocks;
+  } else {
+    // (columns of a single block measured worse: 7x7x960 -> 320 12.7 -> 14.3 us)
+    for (uint32_t cand = 8; cand >= 2; cand >>= 1) {
+      if (cand >= nblocks || staged_lds_bytes(kb, cand, cand * 32u) > kMaxLdsLongK) continue;
+      nbp = cand;
+      if (static_cast<uint64_t>(units) * ((nblocks + cand - 1) / cand) >= slots) break;
+    }
+    if (nbp == 0) {
+      if (!whole_fits) return false;
+      nbp = nblocks;
+    }
+  }
+  plan->nbp = nbp;
+  plan->nsplit = (nblocks + nbp - 1) / nbp;
+  if (plan->nsplit == 1) {
+    plan->log_cpr = log_whole;
+    plan->lds_bytes = whole_lds;
+  } else {
+    uint32_t lg = 1;
+    while ((16u << lg) < nbp * 32u) lg++;
+    plan->log_cpr = lg;
+    plan->lds_bytes = staged_lds_bytes(kb, nbp, nbp * 32u);
+  }
+  uint32_t per_cu = base_per_cu;
+  const uint32_t by_lds = (160u * 1024u) / plan->lds_bytes;
+  if (by_lds < per_cu) per_cu = by_lds > 0 ? by_lds : 1u;
+  plan->per_cu = per_cu;
+  return true;
+}
+
+template <int KBMAX, int SEQ, bool FULL>
+int launch_longk_as(const IgemmParams& p, const StagedPlan& plan, hipStream_t stream)
+{
+  auto kernel = q8_pw_stream_longk_kernel<KBMAX, SEQ, FULL>;
+  static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
+  if (attr_once.first()) {
+    (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsLongK);
+  }
+  const uint32_t units = (p.rows + 31u) / 32u;
+  uint32_t gx = (p.cu_count * plan.per_cu + plan.nsplit - 1) / plan.nsplit;
+  const uint32_t needed = (units + kWaves - 1) / kWaves;
+  if (gx > needed) gx = needed;
+  hipLaunchKernelGGL(kernel, dim3(gx, plan.nsplit), dim3(kThreads), plan.lds_bytes, stream, p, plan.nbp, plan.log_cpr);
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+template <int KBMAX>
+int launch_longk(const IgemmParams& p, const StagedPlan& plan, hipStream_t stream)
+{
+  int rc = QNNP_HIP_EINVAL;
+  requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+    rc = launch_longk_as<KBMAX, decltype(seq)::value, decltype(full)::value>(p, plan, stream);
+  });
+  return rc;
+}
+
 int dispatch_kb_d2s(const IgemmParams& p, uint32_t kb, uint32_t lds_bytes, hipStream_t stream)
 {
   switch (kb) {
@@ -1234,6 +1450,29 @@ int convstream_c3_launch(const IgemmParams& p, hipStream_t stream, const char** 
   *name = "q8_conv_stream_c3_mfma";
   hipLaunchKernelGGL(q8_conv_stream_c3_kernel, dim3(grid), dim3(kThreads), lds_bytes, stream, p);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+/* long-K staged flavour: pointwise / fully-connected form, one group, 16-byte aligned rows both sides, 256 < K <= 1024 */
+bool pwstream_longk_supported(const IgemmParams& p, uint32_t groups, uint32_t vec)
+{
+  if (p.offsets != nullptr || groups != 1 || vec != 16) return false;
+  if (p.fill_table == nullptr || p.rows == 0 || p.k_total <= 256u) return false;
+  StagedPlan plan;
+  int kbmax = 0;
+  return plan_longk(p, &plan, &kbmax);
+}
+
+int pwstream_longk_launch(const IgemmParams& p, hipStream_t stream, const char** name)
+{
+  StagedPlan plan;
+  int kbmax = 0;
+  if (!plan_longk(p, &plan, &kbmax)) return QNNP_HIP_EINVAL;
+  *name = "q8_pw_stream_longk_mfma";
+  switch (kbmax) {
+    case 12: return launch_longk<12>(p, plan, stream);
+    case 20: return launch_longk<20>(p, plan, stream);
+    default: return launch_longk<32>(p, plan, stream);
+  }
 }
 
 /* global-weights flavour: pointwise / fully-connected form, one group, 16-byte aligned rows, any K and N */

@@ -1,11 +1,12 @@
 #!/bin/bash
-# scratch experiments of the moment (same box): gpurun -- bash scripts/gpu_exp.sh <tag>
 TAG=${1:-exp}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-cp qnnpack_amd/libqnnpack_gfx950.so /tmp/keep.so
-layer() { timeout 120 python bench.py --layer $1 --steps 20 --warmup 3 2>/dev/null | tail -n 1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$2', d['layer'], d['kernel'], round(d['ms']*1000,1), 'us', d['gbs'])" | tee -a $OUT/exp.txt; }
-cp tmp_libs/abl.so qnnpack_amd/libqnnpack_gfx950.so
-for Y in 3 4 7 12 17 21 26 11 14 16; do
-  layer $Y auto
-  for B in 2 3 4 5 6 7 8; do QNNP_PW_BLOCKS=$B layer $Y blocks$B; done
-done
-cp /tmp/keep.so qnnpack_amd/libqnnpack_gfx950.so
+
+
+timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -n 15
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -n 1 > $OUT/bench.json
+python - <<PY
+import json
+d=json.loads(open("$OUT/bench.json").read()); e=d["extra"]; s=e["mobilenetv2_sweep"]
+print(d["value"], "sweep", s["images_per_s"], "net", e["mobilenetv2_network"]["images_per_s"])
+print(" ".join(f"{r['layer']}:{r['ms']*1000:.1f}" for r in s["layers"]))
+PY

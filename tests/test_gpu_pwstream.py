@@ -198,3 +198,68 @@ def test_gw_unsupported_alignment_is_reported(gw):
     _, quant = fc_expected(case)
     with pytest.raises(QnnpackError):
         fc_run(gw, case, quant, to_device=to_device, from_device=from_device)
+
+
+# ---- the long-K staged flavour ("gemm_kernel" = 9): 256 < K <= 1024, 16-byte aligned rows on both sides ----
+LONGK_KERNEL = "q8_pw_stream_longk_mfma"
+
+
+@pytest.fixture()
+def longk(qnnp):
+    qnnp.set_option("gemm_kernel", 9)
+    yield qnnp
+    qnnp.set_option("gemm_kernel", 0)
+
+
+def _fc_longk(lib, case):
+    expected, quant = fc_expected(case)
+    out, kname = fc_run(lib, case, quant, to_device=to_device, from_device=from_device)
+    assert kname == LONGK_KERNEL, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("k", [272, 288, 304, 320, 384, 400, 576, 624, 640, 656, 960, 1008, 1024])
+def test_longk_k_blocks_across_the_three_register_budgets(longk, k):
+    """9..12 K blocks run in the 12-block kernel, 13..20 in the 20-block one, 21..32 in the 32-block one; K % 32 = 16
+    leaves half of the last block to the a' == 0 line."""
+    _fc_longk(longk, FcCase(f"lk_k{k}", 70, k, 48))
+
+
+@pytest.mark.parametrize("m", [1, 31, 32, 33, 100, 1000])
+def test_longk_row_edges(longk, m):
+    _fc_longk(longk, FcCase(f"lk_m{m}", m, 384, 96))
+
+
+@pytest.mark.parametrize("case", [
+    FcCase("lk_n16", 50, 320, 16),
+    FcCase("lk_n96_whole", 90, 384, 96),                              # three blocks: whole rows per unit
+    FcCase("lk_n160_columns", 90, 576, 160),                          # five blocks in columns of two (the last of one)
+    FcCase("lk_n320_columns", 64, 960, 320),
+    FcCase("lk_n1280_columns", 40, 320, 1280),                        # MobileNetV2 layer 30's shape
+    FcCase("lk_n272_ragged", 45, 400, 272),                           # 8.5 blocks
+    FcCase("lk_strided", 130, 304, 80, input_stride=320, output_stride=96),
+    FcCase("lk_clamp_zp", 70, 512, 64, izp=3, kzp=250, qmin=20, qmax=230),
+    FcCase("lk_zp_extremes", 70, 448, 64, izp=255, kzp=0),
+], ids=lambda c: c.name)
+def test_longk_channel_layouts_and_quantization(longk, case):
+    _fc_longk(longk, case)
+
+
+def test_longk_pointwise_convolution_and_auto_selection(qnnp):
+    """14x14x384 -> 96 at a batch that gives 784 row blocks: chosen automatically (MobileNetV2 layer 20)."""
+    case = ConvCase("lk_1x1_384_96", (14, 14), gic=384, goc=96, batch=128)
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == LONGK_KERNEL, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("case", [FcCase("lk_bad_short_k", 64, 256, 64),      # K <= 256 belongs to the short-K kernels
+                                  FcCase("lk_bad_k", 64, 1040, 64),           # K > 1024
+                                  FcCase("lk_bad_out_align", 64, 384, 72)],   # output rows not 16-byte aligned
+                         ids=lambda c: c.name)
+def test_longk_unsupported_shapes_are_reported(longk, case):
+    from qnnpack_amd import QnnpackError
+    _, quant = fc_expected(case)
+    with pytest.raises(QnnpackError):
+        fc_run(longk, case, quant, to_device=to_device, from_device=from_device)
