@@ -493,6 +493,297 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
 #undef CW_STAMP
 }
 
+/*
+ * 3x3 / stride 1 / dilation 1 with the patch going through REGISTERS instead of LDS-DMA. Stamps on the kernel above
+ * put the issue of a patch's seven LDS-DMA pieces at 1.7-2.4 k cycles per unit -- 250+ cycles each on a CU this busy,
+ * wherever they are placed (between the taps of the K loop they lengthen it by the same 2 k) -- and the fix-up pass
+ * reads the landed patch back from LDS only to re-centre it. Here the next unit's patch is fetched with plain 16-byte
+ * global loads issued between the K loop and the epilogue (28 registers, held while the epilogue works), and the
+ * fix-up pass of that unit re-centres them on their way INTO the (single) patch buffer: no LDS-DMA, no read-back, half
+ * the patch LDS -- twelve waves per workgroup, three per SIMD. The epilogue's four stores are unconditional buffer
+ * stores (positions outside the image get an out-of-range offset), so the wait for the fetched patch is a counted
+ * vmcnt that does not cover them.
+ */
+constexpr int kRegWaves = 12;
+constexpr int kRegThreads = kRegWaves * 64;
+
+inline uint32_t reg_lds_bytes(const WaveArgs& a) { return a.head_bytes + kRegWaves * (a.patch_bytes + a.pix_bytes); }
+
+template <int TN, int CB, int SEQ, bool FULL>
+__global__ __launch_bounds__(kRegThreads, 3)
+void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [weights][bias][counter][12 x (patch | pixel sums)]
+  constexpr int NP = CB == 1 ? 4 : 7;              // 1 KiB pieces of the 10x10-pixel patch
+  uint8_t* w_lds = lds;
+  int32_t* bias_lds = reinterpret_cast<int32_t*>(lds + a.w_bytes);
+  uint32_t* counter = reinterpret_cast<uint32_t*>(lds + a.w_bytes + p.n * 4u);
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint8_t* patch = lds + a.head_bytes + wave * (a.patch_bytes + a.pix_bytes);
+  uint8_t* stage = patch;                          // the staging image lives in the patch once its K loop is over
+  int32_t* pix = reinterpret_cast<int32_t*>(patch + a.patch_bytes);
+
+  const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * a.units / gridDim.x);
+  const uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * a.units / gridDim.x);
+
+  constexpr uint32_t cin = CB * 32u;
+  constexpr uint32_t log_cin = CB == 1 ? 5u : 6u;
+  constexpr uint32_t cpp = cin >> 4;               // 16-byte chunks per pixel
+  constexpr uint32_t log_cpp = log_cin - 4u;
+  const uint32_t pvec = 100u * cpp;                // chunks of the patch
+  const uint32_t tiles = a.tiles_x * a.tiles_y;
+  const uint8_t* fill_line = p.fill_table + (p.izp_fill & 0xFFu) * 16u;   // sixteen bytes of the raw zero point
+  const uint32_t khalf = lane >> 5;
+
+  // ---- fetch of a unit's patch: NP x 16 bytes per lane, chunk v = lane + 64 u -> pixel v / cpp (10 per row), source
+  //      chunk (v % cpp) ^ swz(row); pixels outside the image read the zero-point line; chunks past the patch re-read
+  //      its last one (never written to LDS). Every load is unconditional.
+  uint32_t lane_now = lane;      // refreshed through an empty asm once per unit: keeps the per-piece address values from
+                                 // being hoisted out of the unit loop and held in registers across the K loop
+  struct Raw { v4i x[NP]; };
+  auto fetch_patch = [&](uint32_t unit, Raw& r) __attribute__((always_inline)) {
+    const uint32_t img = div_magic(unit, a.inv_tiles);
+    const uint32_t rr = unit - img * tiles;
+    const uint32_t tyi = div_magic(rr, a.inv_tiles_x);
+    const uint32_t txi = rr - tyi * a.tiles_x;
+    const int32_t iy0 = static_cast<int32_t>(tyi * 8u) - static_cast<int32_t>(g.pad_top);
+    const int32_t ix0 = static_cast<int32_t>(txi * 8u) - static_cast<int32_t>(g.pad_left);
+    const int64_t origin = static_cast<int64_t>(img) * static_cast<int64_t>(p.image_stride) +
+        (static_cast<int64_t>(iy0) * static_cast<int64_t>(g.W) + ix0) * static_cast<int64_t>(p.input_stride);
+    const uint8_t* base = p.input + origin;
+#pragma unroll
+    for (int u = 0; u < NP; u++) {
+      const uint32_t v = min(lane_now + u * 64u, pvec - 1u);
+      const uint32_t s = v & (cpp - 1u);
+      const uint32_t q = v >> log_cpp;
+      const uint32_t py = (q * 6554u) >> 16;                 // q / 10 for q < 100
+      const uint32_t px = q - py * 10u;
+      const uint32_t c = s ^ (py & (cpp - 1u));
+      const int32_t iy = iy0 + static_cast<int32_t>(py);
+      const int32_t ix = ix0 + static_cast<int32_t>(px);
+      const bool inb = iy >= 0 && iy < static_cast<int32_t>(g.H) && ix >= 0 && ix < static_cast<int32_t>(g.W);
+      const uint8_t* src = inb ? base + ((py * g.W + px) * p.input_stride + c * 16u) : fill_line;
+      r.x[u] = *reinterpret_cast<const v4i*>(src);
+    }
+  };
+
+  // ---- weights + bias + counter, once per workgroup ----
+  {
+    const uint32_t pieces = a.w_bytes >> 10;
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(p.packed_w) + lane * 16u;
+    for (uint32_t i = wave; i < pieces; i += kRegWaves) dma16(src + i * 1024u, w_lds + i * 1024u);
+    for (uint32_t i = tid; i < p.n; i += kRegThreads) bias_lds[i] = p.bias2[i];
+  }
+  uint32_t cur = lo + wave;
+  if (tid == 0) *counter = lo + kRegWaves;
+  Raw raw;
+  fetch_patch(min(cur, a.units - 1u), raw);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's weight pieces have landed (and its first patch)
+  __syncthreads();
+
+  uint32_t ty[2], rowbase[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const uint32_t i = j * 32u + (lane & 31u);
+    ty[j] = i >> 3;
+    rowbase[j] = (ty[j] * 10u + (i & 7u)) << log_cin;
+  }
+  const uint32_t kblocks = p.k_pad / 32;
+  const uint8_t* w_lane = w_lds + lane * 16;
+  const uint32_t cpr = p.n >> 4;                   // 16-byte pieces per output position (2 or 4)
+  const uint32_t log_cpr = 31u - __builtin_clz(cpr);
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.output, 0, static_cast<int>(a.units / tiles * g.OH * g.OW * p.n), 0x00020000);   // (launcher: < 2^31)
+
+  struct Frags {
+    v4i a[2][CB];
+    v4i w[TN][CB];
+  };
+  // Four stores to nowhere (out-of-range offset: the hardware drops them). hipcc sizes the vmcnt waits of the fix-up
+  // pass for the smaller of the counts outstanding on the two ways into the loop; coming from here that was "7 loads",
+  // from the loop's end "7 loads + 4 stores", so the waits came out as vmcnt(6..0) and covered the previous unit's
+  // stores. With the same sequence on both ways in they are vmcnt(10..4).
+  // (distinct offsets and a constant payload: identical stores are merged, a fetched register as payload is a wait)
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const v4i nothing = {0, 0, 0, 0};
+    __builtin_amdgcn_raw_buffer_store_b128(
+        __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, nothing), out_rsrc,
+        0xFFFFFF00u + static_cast<uint32_t>(i) * 16u, 0, 0);
+  }
+  while (cur < hi) {
+    asm volatile("" : "+v"(lane_now));
+    uint32_t claimed = 0;
+    if (lane == 0) claimed = atomicAdd(counter, 1u);        // the unit after this one (read after the K loop)
+    const uint32_t img = div_magic(cur, a.inv_tiles);
+    const uint32_t r = cur - img * tiles;
+    const uint32_t tyi = div_magic(r, a.inv_tiles_x);
+    const uint32_t oy0 = tyi * 8u;
+    const uint32_t ox0 = (r - tyi * a.tiles_x) * 8u;
+
+    // ---- the fetched patch: re-centred into LDS, per-pixel channel sums (of a') beside it ----
+    {
+      const uint32_t patch_off = lds_off(patch);
+      const uint32_t pix_off = lds_off(pix);
+#pragma unroll
+      for (int u = 0; u < NP; u++) {
+        const uint32_t v = lane + u * 64u;
+        if (v < pvec) {                                    // whole pixels: pvec is a multiple of cpp
+          const v4i x = raw.x[u];
+          uint32_t sum = __builtin_amdgcn_sad_u8(x.x, 0u, 0u);
+          sum = __builtin_amdgcn_sad_u8(x.y, 0u, sum);
+          sum = __builtin_amdgcn_sad_u8(x.z, 0u, sum);
+          sum = __builtin_amdgcn_sad_u8(x.w, 0u, sum);
+          sum += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(sum), 0xB1, 0xF, 0xF, false));        // lane ^ 1
+          if (cpp > 2) sum += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(sum), 0x4E, 0xF, 0xF, false));   // lane ^ 2
+          ds_write16_raw(patch_off + v * 16u, make_uint4(x.x ^ kFlip, x.y ^ kFlip, x.z ^ kFlip, x.w ^ kFlip));
+          if ((v & (cpp - 1u)) == 0) ds_write4_raw(pix_off + (v >> log_cpp) * 4u, static_cast<int32_t>(sum) - 128 * static_cast<int32_t>(cin));
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // accumulators start at the folded bias
+    v16i acc[2][TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const v4i b = *reinterpret_cast<const v4i*>(bias_lds + tn * 32 + rg * 8 + khalf * 4);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          acc[j][tn][rg * 4 + 0] = b.x;
+          acc[j][tn][rg * 4 + 1] = b.y;
+          acc[j][tn][rg * 4 + 2] = b.z;
+          acc[j][tn][rg * 4 + 3] = b.w;
+        }
+      }
+    auto mma = [&](const Frags& f) __attribute__((always_inline)) {
+#pragma unroll
+      for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int tn = 0; tn < TN; tn++)
+            acc[j][tn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[tn][cb], f.a[j][cb], acc[j][tn], 0, 0, 0);
+    };
+    {
+      const uint8_t* abase[3][2][CB];
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const uint32_t swz = (ty[j] + ky) & (cpp - 1u);
+#pragma unroll
+          for (int cb = 0; cb < CB; cb++) {
+            abase[ky][j][cb] = patch + rowbase[j] + ky * 10 * cin + ((((cb << 1) | khalf) ^ swz) << 4);
+          }
+        }
+      auto read3 = [&](auto t_c, Frags& f) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_c)::value;
+        constexpr int ky = t / 3, kx = t % 3;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int cb = 0; cb < CB; cb++) f.a[j][cb] = *reinterpret_cast<const v4i*>(abase[ky][j][cb] + kx * cin);
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+          for (int cb = 0; cb < CB; cb++)
+            f.w[tn][cb] = *reinterpret_cast<const v4i*>(w_lane + (tn * kblocks + t * CB + cb) * 1024u);
+      };
+      Frags f0, f1;
+      read3(std::integral_constant<int, 0>{}, f0);
+      read3(std::integral_constant<int, 1>{}, f1); mma(f0);
+      read3(std::integral_constant<int, 2>{}, f0); mma(f1);
+      read3(std::integral_constant<int, 3>{}, f1); mma(f0);
+      read3(std::integral_constant<int, 4>{}, f0); mma(f1);
+      read3(std::integral_constant<int, 5>{}, f1); mma(f0);
+      read3(std::integral_constant<int, 6>{}, f0); mma(f1);
+      read3(std::integral_constant<int, 7>{}, f1); mma(f0);
+      read3(std::integral_constant<int, 8>{}, f0); mma(f1);
+      mma(f0);
+    }
+
+    // ---- next unit (claimed at the top: the atomic's round trip is long over): its patch is requested now and lands
+    //      under the epilogue ----
+    const uint32_t nxt = __builtin_amdgcn_readfirstlane(claimed);
+    fetch_patch(min(nxt, a.units - 1u), raw);               // (past the range: some valid unit, unused)
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- fused epilogue, 32 positions at a time (as the kernel above), stores through the buffer descriptor ----
+    const uint32_t out_img = img * g.OH * g.OW * p.n;
+    const uint32_t stage_off = lds_off(stage);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      int32_t s = 0;
+      const int32_t* pq = pix + (ty[j] * 10u + ((j * 32u + (lane & 31u)) & 7u));
+#pragma unroll
+      for (int t = 0; t < 9; t++) s += pq[(t / 3) * 10 + (t % 3)];
+      const int32_t rowterm = with_rq_offset<SEQ>(p.row_coeff * s);
+#pragma unroll
+      for (int tn = 0; tn < TN; tn++) {
+        uint32_t pk[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          pk[rg] = q31_requantize_pack4<SEQ, FULL>(
+              add_wrap(acc[j][tn][rg * 4 + 0], rowterm), add_wrap(acc[j][tn][rg * 4 + 1], rowterm),
+              add_wrap(acc[j][tn][rg * 4 + 2], rowterm), add_wrap(acc[j][tn][rg * 4 + 3], rowterm), p.rq);
+        }
+        const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+        ds_write16_raw(stage_off + (lane & 31u) * p.n + tn * 32 + khalf * 16, make_uint4(s02[0], s02[1], s13[0], s13[1]));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // image complete before it is read back
+      const uint32_t pieces = 32u * cpr;
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++) {
+        const uint32_t idx = lane + tt * 64u;
+        const uint32_t i = j * 32u + (idx >> log_cpr);
+        const uint32_t ch = idx & (cpr - 1u);
+        const uint32_t oy = oy0 + (i >> 3);
+        const uint32_t ox = ox0 + (i & 7u);
+        const bool ok = idx < pieces && oy < g.OH && ox < g.OW;
+        const v4i v = *reinterpret_cast<const v4i*>(stage + min(idx, pieces - 1u) * 16u);
+        __builtin_amdgcn_raw_buffer_store_b128(
+            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc,
+            ok ? out_img + (oy * g.OW + ox) * p.n + ch * 16u : 0xFFFFFFF0u, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // read back before the next half overwrites it
+    }
+    cur = nxt;
+  }
+}
+
+template <int TN, int CB, int SEQ, bool FULL>
+int launch_reg_as(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hipStream_t stream)
+{
+  static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
+  if (attr_once.first()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_reg_kernel<TN, CB, SEQ, FULL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      (void) hipGetLastError();
+    }
+  }
+  const uint32_t want = (a.units + kRegWaves - 1) / kRegWaves;
+  const uint32_t grid = want < p.cu_count ? want : p.cu_count;
+  hipLaunchKernelGGL((q8_conv_wave_reg_kernel<TN, CB, SEQ, FULL>), dim3(grid), dim3(kRegThreads), reg_lds_bytes(a), stream, p, g, a);
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+template <int TN, int CB>
+int launch_reg(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hipStream_t stream)
+{
+  int rc = QNNP_HIP_EINVAL;
+  requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+    rc = launch_reg_as<TN, CB, decltype(seq)::value, decltype(full)::value>(p, g, a, stream);
+  });
+  return rc;
+}
+
 template <int TN, int CB, int KS, int SEQ, bool FULL>
 int launch_as(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, uint32_t lds_bytes, hipStream_t stream)
 {
@@ -540,6 +831,16 @@ int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hip
   if (!make_args(p, g, batch, &a, &lds_bytes)) return QNNP_HIP_EINVAL;
   *name = "q8_conv_wave_mfma";
   const bool k33 = g.KH == 3 && g.KW == 3 && g.sh == 1 && g.sw == 1 && g.dh == 1 && g.dw == 1;
+  // 3x3 / stride 1: the register-path kernel when its LDS fits and the output is addressable with 32-bit offsets
+  const uint64_t out_bytes = static_cast<uint64_t>(batch) * g.OH * g.OW * p.n;
+  bool reg_path = k33 && reg_lds_bytes(a) <= kLdsLimit && out_bytes < (UINT64_C(1) << 31);
+#ifdef QNNP_ENABLE_ABLATION
+  if (const char* env = getenv("QNNP_CONV_REG")) reg_path = reg_path && atoi(env) != 0;
+#endif
+  if (reg_path) {
+    if (p.kc == 32) return p.n == 32 ? launch_reg<1, 1>(p, g, a, stream) : launch_reg<2, 1>(p, g, a, stream);
+    return p.n == 32 ? launch_reg<1, 2>(p, g, a, stream) : launch_reg<2, 2>(p, g, a, stream);
+  }
   if (p.kc == 32) {
     if (k33) return p.n == 32 ? launch<1, 1, 3>(p, g, a, lds_bytes, stream) : launch<2, 1, 3>(p, g, a, lds_bytes, stream);
     return p.n == 32 ? launch<1, 1, 0>(p, g, a, lds_bytes, stream) : launch<2, 1, 0>(p, g, a, lds_bytes, stream);
