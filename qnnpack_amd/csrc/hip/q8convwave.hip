@@ -544,30 +544,37 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
   uint32_t lane_now = lane;      // refreshed through an empty asm once per unit: keeps the per-piece address values from
                                  // being hoisted out of the unit loop and held in registers across the K loop
   struct Raw { v4i x[NP]; };
-  auto fetch_patch = [&](uint32_t unit, Raw& r) __attribute__((always_inline)) {
+  struct Src { const uint8_t* base; int32_t iy0, ix0; };
+  auto patch_source = [&](uint32_t unit) __attribute__((always_inline)) -> Src {
     const uint32_t img = div_magic(unit, a.inv_tiles);
     const uint32_t rr = unit - img * tiles;
     const uint32_t tyi = div_magic(rr, a.inv_tiles_x);
     const uint32_t txi = rr - tyi * a.tiles_x;
-    const int32_t iy0 = static_cast<int32_t>(tyi * 8u) - static_cast<int32_t>(g.pad_top);
-    const int32_t ix0 = static_cast<int32_t>(txi * 8u) - static_cast<int32_t>(g.pad_left);
+    Src sc;
+    sc.iy0 = static_cast<int32_t>(tyi * 8u) - static_cast<int32_t>(g.pad_top);
+    sc.ix0 = static_cast<int32_t>(txi * 8u) - static_cast<int32_t>(g.pad_left);
     const int64_t origin = static_cast<int64_t>(img) * static_cast<int64_t>(p.image_stride) +
-        (static_cast<int64_t>(iy0) * static_cast<int64_t>(g.W) + ix0) * static_cast<int64_t>(p.input_stride);
-    const uint8_t* base = p.input + origin;
+        (static_cast<int64_t>(sc.iy0) * static_cast<int64_t>(g.W) + sc.ix0) * static_cast<int64_t>(p.input_stride);
+    sc.base = p.input + origin;
+    return sc;
+  };
+  auto fetch_piece = [&](const Src& sc, int u, Raw& r) __attribute__((always_inline)) {
+    const uint32_t v = min(lane_now + u * 64u, pvec - 1u);
+    const uint32_t s = v & (cpp - 1u);
+    const uint32_t q = v >> log_cpp;
+    const uint32_t py = (q * 6554u) >> 16;                 // q / 10 for q < 100
+    const uint32_t px = q - py * 10u;
+    const uint32_t c = s ^ (py & (cpp - 1u));
+    const int32_t iy = sc.iy0 + static_cast<int32_t>(py);
+    const int32_t ix = sc.ix0 + static_cast<int32_t>(px);
+    const bool inb = iy >= 0 && iy < static_cast<int32_t>(g.H) && ix >= 0 && ix < static_cast<int32_t>(g.W);
+    const uint8_t* src = inb ? sc.base + ((py * g.W + px) * p.input_stride + c * 16u) : fill_line;
+    r.x[u] = *reinterpret_cast<const v4i*>(src);
+  };
+  auto fetch_patch = [&](uint32_t unit, Raw& r) __attribute__((always_inline)) {
+    const Src sc = patch_source(unit);
 #pragma unroll
-    for (int u = 0; u < NP; u++) {
-      const uint32_t v = min(lane_now + u * 64u, pvec - 1u);
-      const uint32_t s = v & (cpp - 1u);
-      const uint32_t q = v >> log_cpp;
-      const uint32_t py = (q * 6554u) >> 16;                 // q / 10 for q < 100
-      const uint32_t px = q - py * 10u;
-      const uint32_t c = s ^ (py & (cpp - 1u));
-      const int32_t iy = iy0 + static_cast<int32_t>(py);
-      const int32_t ix = ix0 + static_cast<int32_t>(px);
-      const bool inb = iy >= 0 && iy < static_cast<int32_t>(g.H) && ix >= 0 && ix < static_cast<int32_t>(g.W);
-      const uint8_t* src = inb ? base + ((py * g.W + px) * p.input_stride + c * 16u) : fill_line;
-      r.x[u] = *reinterpret_cast<const v4i*>(src);
-    }
+    for (int u = 0; u < NP; u++) fetch_piece(sc, u, r);
   };
 
   // ---- weights + bias + counter, once per workgroup ----
@@ -614,7 +621,11 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
         __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, nothing), out_rsrc,
         0xFFFFFF00u + static_cast<uint32_t>(i) * 16u, 0, 0);
   }
+  uint32_t unit_no = 0;
+  (void) unit_no;
+#define CR_STAMP(slot) do { if (wave == 0) { QNNP_TRACE(p, blockIdx.x, unit_no, slot); } } while (0)
   while (cur < hi) {
+    CR_STAMP(0);
     asm volatile("" : "+v"(lane_now));
     uint32_t claimed = 0;
     if (lane == 0) claimed = atomicAdd(counter, 1u);        // the unit after this one (read after the K loop)
@@ -630,7 +641,7 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
       const uint32_t pix_off = lds_off(pix);
 #pragma unroll
       for (int u = 0; u < NP; u++) {
-        const uint32_t v = lane + u * 64u;
+        const uint32_t v = lane_now + u * 64u;             // (lane_now: recomputed per unit, not held across the K loop)
         if (v < pvec) {                                    // whole pixels: pvec is a multiple of cpp
           const v4i x = raw.x[u];
           uint32_t sum = __builtin_amdgcn_sad_u8(x.x, 0u, 0u);
@@ -645,6 +656,10 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    CR_STAMP(1);
+    // next unit (claimed at the top: the atomic's round trip passed under the fix-up); past the range: some valid unit
+    const uint32_t nxt = __builtin_amdgcn_readfirstlane(claimed);
+    const Src nsrc = patch_source(min(nxt, a.units - 1u));
 
     // accumulators start at the folded bias
     v16i acc[2][TN];
@@ -695,24 +710,26 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
           for (int cb = 0; cb < CB; cb++)
             f.w[tn][cb] = *reinterpret_cast<const v4i*>(w_lane + (tn * kblocks + t * CB + cb) * 1024u);
       };
+      // the next unit's patch is requested piece by piece between the taps: twelve waves asking for their seven
+      // pieces at the same moment queued on the CU's address unit for 1.4-2.9 k cycles (stamps); behind a tap's
+      // eight queued MFMAs the wait for the address unit costs nothing
+      auto piece = [&](int u) __attribute__((always_inline)) { if (u < NP) fetch_piece(nsrc, u, raw); };
       Frags f0, f1;
       read3(std::integral_constant<int, 0>{}, f0);
       read3(std::integral_constant<int, 1>{}, f1); mma(f0);
-      read3(std::integral_constant<int, 2>{}, f0); mma(f1);
-      read3(std::integral_constant<int, 3>{}, f1); mma(f0);
-      read3(std::integral_constant<int, 4>{}, f0); mma(f1);
-      read3(std::integral_constant<int, 5>{}, f1); mma(f0);
-      read3(std::integral_constant<int, 6>{}, f0); mma(f1);
-      read3(std::integral_constant<int, 7>{}, f1); mma(f0);
-      read3(std::integral_constant<int, 8>{}, f0); mma(f1);
+      read3(std::integral_constant<int, 2>{}, f0); mma(f1); piece(0);
+      read3(std::integral_constant<int, 3>{}, f1); mma(f0); piece(1);
+      read3(std::integral_constant<int, 4>{}, f0); mma(f1); piece(2);
+      read3(std::integral_constant<int, 5>{}, f1); mma(f0); piece(3);
+      read3(std::integral_constant<int, 6>{}, f0); mma(f1); piece(4);
+      read3(std::integral_constant<int, 7>{}, f1); mma(f0); piece(5);
+      read3(std::integral_constant<int, 8>{}, f0); mma(f1); piece(6);
       mma(f0);
     }
-
-    // ---- next unit (claimed at the top: the atomic's round trip is long over): its patch is requested now and lands
-    //      under the epilogue ----
-    const uint32_t nxt = __builtin_amdgcn_readfirstlane(claimed);
-    fetch_patch(min(nxt, a.units - 1u), raw);               // (past the range: some valid unit, unused)
+    CR_STAMP(2);
+    CR_STAMP(3);
     __builtin_amdgcn_sched_barrier(0);
+    CR_STAMP(4);
 
     // ---- fused epilogue, 32 positions at a time (as the kernel above), stores through the buffer descriptor ----
     const uint32_t out_img = img * g.OH * g.OW * p.n;
@@ -754,8 +771,11 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // read back before the next half overwrites it
     }
+    CR_STAMP(5);
+    unit_no++;
     cur = nxt;
   }
+#undef CR_STAMP
 }
 
 template <int TN, int CB, int SEQ, bool FULL>
