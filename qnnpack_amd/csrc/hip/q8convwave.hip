@@ -504,17 +504,45 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
  * stores (positions outside the image get an out-of-range offset), so the wait for the fetched patch is a counted
  * vmcnt that does not cover them.
  */
-constexpr int kRegWaves = 12;
-constexpr int kRegThreads = kRegWaves * 64;
+/* TM: 32-position groups per unit -- 2: 8x8 positions (10x10-pixel patch), twelve waves per workgroup; 1: 4 rows x 8
+ * positions (6x10 patch), sixteen waves. The small unit reads half again as many fragments per MFMA, but it halves
+ * what the last, partly filled round of units costs: with 24.5 units of 8x8 per CU and twelve waves that round --
+ * one unit on every other CU -- was a quarter of the launch. */
+template <int TM> constexpr int reg_waves() { return TM == 2 ? 12 : 16; }
 
-inline uint32_t reg_lds_bytes(const WaveArgs& a) { return a.head_bytes + kRegWaves * (a.patch_bytes + a.pix_bytes); }
+/* the unit geometry of the register-path kernel (its own tiling of the output in TM x 4 rows) */
+template <int TM>
+inline WaveArgs reg_args(const WaveArgs& a0, const IgemmParams& p, const ConvGeom& g, uint32_t batch, bool* ok)
+{
+  WaveArgs a = a0;
+  a.PH = TM * 4u + 2u;
+  a.PW = 10u;
+  a.tiles_x = (g.OW + 7u) / 8u;
+  a.tiles_y = (g.OH + TM * 4u - 1u) / (TM * 4u);
+  a.units = batch * a.tiles_x * a.tiles_y;
+  const uint64_t tiles = static_cast<uint64_t>(a.tiles_x) * a.tiles_y;
+  *ok = static_cast<uint64_t>(batch) * tiles * tiles < (UINT64_C(1) << 32);
+  a.inv_tiles = tiles > 1 ? static_cast<uint32_t>(((UINT64_C(1) << 32) + tiles - 1) / tiles) : 0u;
+  a.inv_tiles_x = a.tiles_x > 1 ? static_cast<uint32_t>(((UINT64_C(1) << 32) + a.tiles_x - 1) / a.tiles_x) : 0u;
+  const uint32_t patch = a.PH * a.PW * p.kc;
+  a.patch_bytes = (patch + 255u) & ~255u;
+  a.pix_bytes = (a.PH * a.PW * 4u + 255u) & ~255u;
+  if (a.stage_bytes > a.patch_bytes) *ok = false;
+  return a;
+}
 
-template <int TN, int CB, int SEQ, bool FULL>
-__global__ __launch_bounds__(kRegThreads, 3)
+template <int TM>
+inline uint32_t reg_lds_bytes(const WaveArgs& a) { return a.head_bytes + reg_waves<TM>() * (a.patch_bytes + a.pix_bytes); }
+
+template <int TM, int TN, int CB, int SEQ, bool FULL>
+__global__ __launch_bounds__(reg_waves<TM>() * 64, reg_waves<TM>() / 4)
 void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveArgs a)
 {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [weights][bias][counter][12 x (patch | pixel sums)]
-  constexpr int NP = CB == 1 ? 4 : 7;              // 1 KiB pieces of the 10x10-pixel patch
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [weights][bias][counter][waves x (patch | pixel sums)]
+  constexpr int kRegWaves = reg_waves<TM>();
+  constexpr int kRegThreads = kRegWaves * 64;
+  constexpr uint32_t kPR = TM * 4u + 2u;           // patch rows (10 columns)
+  constexpr int NP = (kPR * 10u * CB * 2u + 63u) / 64u;   // 1 KiB pieces of the patch
   uint8_t* w_lds = lds;
   int32_t* bias_lds = reinterpret_cast<int32_t*>(lds + a.w_bytes);
   uint32_t* counter = reinterpret_cast<uint32_t*>(lds + a.w_bytes + p.n * 4u);
@@ -522,6 +550,7 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave == 0) { QNNP_TRACE(p, blockIdx.x, 3, 0); }       // (measurement builds: kernel entry)
   uint8_t* patch = lds + a.head_bytes + wave * (a.patch_bytes + a.pix_bytes);
   uint8_t* stage = patch;                          // the staging image lives in the patch once its K loop is over
   int32_t* pix = reinterpret_cast<int32_t*>(patch + a.patch_bytes);
@@ -533,7 +562,7 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
   constexpr uint32_t log_cin = CB == 1 ? 5u : 6u;
   constexpr uint32_t cpp = cin >> 4;               // 16-byte chunks per pixel
   constexpr uint32_t log_cpp = log_cin - 4u;
-  const uint32_t pvec = 100u * cpp;                // chunks of the patch
+  const uint32_t pvec = kPR * 10u * cpp;           // chunks of the patch
   const uint32_t tiles = a.tiles_x * a.tiles_y;
   const uint8_t* fill_line = p.fill_table + (p.izp_fill & 0xFFu) * 16u;   // sixteen bytes of the raw zero point
   const uint32_t khalf = lane >> 5;
@@ -551,7 +580,7 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
     const uint32_t tyi = div_magic(rr, a.inv_tiles_x);
     const uint32_t txi = rr - tyi * a.tiles_x;
     Src sc;
-    sc.iy0 = static_cast<int32_t>(tyi * 8u) - static_cast<int32_t>(g.pad_top);
+    sc.iy0 = static_cast<int32_t>(tyi * (TM * 4u)) - static_cast<int32_t>(g.pad_top);
     sc.ix0 = static_cast<int32_t>(txi * 8u) - static_cast<int32_t>(g.pad_left);
     const int64_t origin = static_cast<int64_t>(img) * static_cast<int64_t>(p.image_stride) +
         (static_cast<int64_t>(sc.iy0) * static_cast<int64_t>(g.W) + sc.ix0) * static_cast<int64_t>(p.input_stride);
@@ -577,23 +606,26 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
     for (int u = 0; u < NP; u++) fetch_piece(sc, u, r);
   };
 
-  // ---- weights + bias + counter, once per workgroup ----
+  // ---- the first patch (requested first: its HBM round trip is the longest thing in the prologue -- 6.5 k cycles from
+  //      kernel entry to "everything landed" by the stamps), then weights + bias + counter, once per workgroup ----
+  uint32_t cur = lo + wave;
+  Raw raw;
+  fetch_patch(min(cur, a.units - 1u), raw);
   {
     const uint32_t pieces = a.w_bytes >> 10;
     const uint8_t* src = reinterpret_cast<const uint8_t*>(p.packed_w) + lane * 16u;
     for (uint32_t i = wave; i < pieces; i += kRegWaves) dma16(src + i * 1024u, w_lds + i * 1024u);
     for (uint32_t i = tid; i < p.n; i += kRegThreads) bias_lds[i] = p.bias2[i];
   }
-  uint32_t cur = lo + wave;
   if (tid == 0) *counter = lo + kRegWaves;
-  Raw raw;
-  fetch_patch(min(cur, a.units - 1u), raw);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's weight pieces have landed (and its first patch)
+  if (wave == 0) { QNNP_TRACE(p, blockIdx.x, 3, 1); }
   __syncthreads();
+  if (wave == 0) { QNNP_TRACE(p, blockIdx.x, 3, 2); }
 
-  uint32_t ty[2], rowbase[2];
+  uint32_t ty[TM], rowbase[TM];
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
+  for (int j = 0; j < TM; j++) {
     const uint32_t i = j * 32u + (lane & 31u);
     ty[j] = i >> 3;
     rowbase[j] = (ty[j] * 10u + (i & 7u)) << log_cin;
@@ -606,7 +638,7 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
       p.output, 0, static_cast<int>(a.units / tiles * g.OH * g.OW * p.n), 0x00020000);   // (launcher: < 2^31)
 
   struct Frags {
-    v4i a[2][CB];
+    v4i a[TM][CB];
     v4i w[TN][CB];
   };
   // Four stores to nowhere (out-of-range offset: the hardware drops them). hipcc sizes the vmcnt waits of the fix-up
@@ -615,7 +647,7 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
   // stores. With the same sequence on both ways in they are vmcnt(10..4).
   // (distinct offsets and a constant payload: identical stores are merged, a fetched register as payload is a wait)
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < 2 * TM; i++) {
     const v4i nothing = {0, 0, 0, 0};
     __builtin_amdgcn_raw_buffer_store_b128(
         __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, nothing), out_rsrc,
@@ -632,7 +664,7 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
     const uint32_t img = div_magic(cur, a.inv_tiles);
     const uint32_t r = cur - img * tiles;
     const uint32_t tyi = div_magic(r, a.inv_tiles_x);
-    const uint32_t oy0 = tyi * 8u;
+    const uint32_t oy0 = tyi * (TM * 4u);
     const uint32_t ox0 = (r - tyi * a.tiles_x) * 8u;
 
     // ---- the fetched patch: re-centred into LDS, per-pixel channel sums (of a') beside it ----
@@ -662,14 +694,14 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
     const Src nsrc = patch_source(min(nxt, a.units - 1u));
 
     // accumulators start at the folded bias
-    v16i acc[2][TN];
+    v16i acc[TM][TN];
 #pragma unroll
     for (int tn = 0; tn < TN; tn++)
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
         const v4i b = *reinterpret_cast<const v4i*>(bias_lds + tn * 32 + rg * 8 + khalf * 4);
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < TM; j++) {
           acc[j][tn][rg * 4 + 0] = b.x;
           acc[j][tn][rg * 4 + 1] = b.y;
           acc[j][tn][rg * 4 + 2] = b.z;
@@ -680,17 +712,17 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
 #pragma unroll
       for (int cb = 0; cb < CB; cb++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < TM; j++)
 #pragma unroll
           for (int tn = 0; tn < TN; tn++)
             acc[j][tn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[tn][cb], f.a[j][cb], acc[j][tn], 0, 0, 0);
     };
     {
-      const uint8_t* abase[3][2][CB];
+      const uint8_t* abase[3][TM][CB];
 #pragma unroll
       for (int ky = 0; ky < 3; ky++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < TM; j++) {
           const uint32_t swz = (ty[j] + ky) & (cpp - 1u);
 #pragma unroll
           for (int cb = 0; cb < CB; cb++) {
@@ -701,7 +733,7 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
         constexpr int t = decltype(t_c)::value;
         constexpr int ky = t / 3, kx = t % 3;
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < TM; j++)
 #pragma unroll
           for (int cb = 0; cb < CB; cb++) f.a[j][cb] = *reinterpret_cast<const v4i*>(abase[ky][j][cb] + kx * cin);
 #pragma unroll
@@ -735,7 +767,7 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
     const uint32_t out_img = img * g.OH * g.OW * p.n;
     const uint32_t stage_off = lds_off(stage);
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < TM; j++) {
       int32_t s = 0;
       const int32_t* pq = pix + (ty[j] * 10u + ((j * 32u + (lane & 31u)) & 7u));
 #pragma unroll
@@ -776,30 +808,33 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
     cur = nxt;
   }
 #undef CR_STAMP
+  if (wave == 0) { QNNP_TRACE(p, blockIdx.x, 3, 3); QNNP_TRACE(p, blockIdx.x, 3, 4); QNNP_TRACE(p, blockIdx.x, 3, 5); }
 }
 
-template <int TN, int CB, int SEQ, bool FULL>
+template <int TM, int TN, int CB, int SEQ, bool FULL>
 int launch_reg_as(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hipStream_t stream)
 {
+  constexpr int kRegWaves = reg_waves<TM>();
+  constexpr int kRegThreads = kRegWaves * 64;
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
   if (attr_once.first()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_reg_kernel<TN, CB, SEQ, FULL>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_reg_kernel<TM, TN, CB, SEQ, FULL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       (void) hipGetLastError();
     }
   }
   const uint32_t want = (a.units + kRegWaves - 1) / kRegWaves;
   const uint32_t grid = want < p.cu_count ? want : p.cu_count;
-  hipLaunchKernelGGL((q8_conv_wave_reg_kernel<TN, CB, SEQ, FULL>), dim3(grid), dim3(kRegThreads), reg_lds_bytes(a), stream, p, g, a);
+  hipLaunchKernelGGL((q8_conv_wave_reg_kernel<TM, TN, CB, SEQ, FULL>), dim3(grid), dim3(kRegThreads), reg_lds_bytes<TM>(a), stream, p, g, a);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
-template <int TN, int CB>
+template <int TM, int TN, int CB>
 int launch_reg(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hipStream_t stream)
 {
   int rc = QNNP_HIP_EINVAL;
   requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
-    rc = launch_reg_as<TN, CB, decltype(seq)::value, decltype(full)::value>(p, g, a, stream);
+    rc = launch_reg_as<TM, TN, CB, decltype(seq)::value, decltype(full)::value>(p, g, a, stream);
   });
   return rc;
 }
@@ -853,13 +888,25 @@ int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hip
   const bool k33 = g.KH == 3 && g.KW == 3 && g.sh == 1 && g.sw == 1 && g.dh == 1 && g.dw == 1;
   // 3x3 / stride 1: the register-path kernel when its LDS fits and the output is addressable with 32-bit offsets
   const uint64_t out_bytes = static_cast<uint64_t>(batch) * g.OH * g.OW * p.n;
-  bool reg_path = k33 && reg_lds_bytes(a) <= kLdsLimit && out_bytes < (UINT64_C(1) << 31);
+  if (k33 && out_bytes < (UINT64_C(1) << 31)) {
+    int tm = 1;                                    // 4x8-position units (see reg_waves)
 #ifdef QNNP_ENABLE_ABLATION
-  if (const char* env = getenv("QNNP_CONV_REG")) reg_path = reg_path && atoi(env) != 0;
+    if (const char* env = getenv("QNNP_CONV_REG")) tm = atoi(env);       // 0: LDS-DMA kernel, 1 / 2: unit size
 #endif
-  if (reg_path) {
-    if (p.kc == 32) return p.n == 32 ? launch_reg<1, 1>(p, g, a, stream) : launch_reg<2, 1>(p, g, a, stream);
-    return p.n == 32 ? launch_reg<1, 2>(p, g, a, stream) : launch_reg<2, 2>(p, g, a, stream);
+    bool ok = false;
+    if (tm == 1) {
+      const WaveArgs ar = reg_args<1>(a, p, g, batch, &ok);
+      if (ok && reg_lds_bytes<1>(ar) <= kLdsLimit) {
+        if (p.kc == 32) return p.n == 32 ? launch_reg<1, 1, 1>(p, g, ar, stream) : launch_reg<1, 2, 1>(p, g, ar, stream);
+        return p.n == 32 ? launch_reg<1, 1, 2>(p, g, ar, stream) : launch_reg<1, 2, 2>(p, g, ar, stream);
+      }
+    } else if (tm == 2) {
+      const WaveArgs ar = reg_args<2>(a, p, g, batch, &ok);
+      if (ok && reg_lds_bytes<2>(ar) <= kLdsLimit) {
+        if (p.kc == 32) return p.n == 32 ? launch_reg<2, 1, 1>(p, g, ar, stream) : launch_reg<2, 2, 1>(p, g, ar, stream);
+        return p.n == 32 ? launch_reg<2, 1, 2>(p, g, ar, stream) : launch_reg<2, 2, 2>(p, g, ar, stream);
+      }
+    }
   }
   if (p.kc == 32) {
     if (k33) return p.n == 32 ? launch<1, 1, 3>(p, g, a, lds_bytes, stream) : launch<2, 1, 3>(p, g, a, lds_bytes, stream);
