@@ -900,13 +900,16 @@ int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hip
         if (p.kc == 32) return p.n == 32 ? launch_reg<1, 1, 1>(p, g, ar, stream) : launch_reg<1, 2, 1>(p, g, ar, stream);
         return p.n == 32 ? launch_reg<1, 1, 2>(p, g, ar, stream) : launch_reg<1, 2, 2>(p, g, ar, stream);
       }
-    } else if (tm == 2) {
+    }
+#ifdef QNNP_ENABLE_ABLATION
+    else if (tm == 2) {                              // (measurement builds only: the 8x8-position flavour)
       const WaveArgs ar = reg_args<2>(a, p, g, batch, &ok);
       if (ok && reg_lds_bytes<2>(ar) <= kLdsLimit) {
         if (p.kc == 32) return p.n == 32 ? launch_reg<2, 1, 1>(p, g, ar, stream) : launch_reg<2, 2, 1>(p, g, ar, stream);
         return p.n == 32 ? launch_reg<2, 1, 2>(p, g, ar, stream) : launch_reg<2, 2, 2>(p, g, ar, stream);
       }
     }
+#endif
   }
   if (p.kc == 32) {
     if (k33) return p.n == 32 ? launch<1, 1, 3>(p, g, a, lds_bytes, stream) : launch<2, 1, 3>(p, g, a, lds_bytes, stream);
