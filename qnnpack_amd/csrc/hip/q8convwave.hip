@@ -540,7 +540,6 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [weights][bias][counter][waves x (patch | pixel sums)]
   constexpr int kRegWaves = reg_waves<TM>();
-  constexpr int kRegThreads = kRegWaves * 64;
   constexpr uint32_t kPR = TM * 4u + 2u;           // patch rows (10 columns)
   constexpr int NP = (kPR * 10u * CB * 2u + 63u) / 64u;   // 1 KiB pieces of the patch
   uint8_t* w_lds = lds;
@@ -606,22 +605,44 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
     for (int u = 0; u < NP; u++) fetch_piece(sc, u, r);
   };
 
-  // ---- the first patch (requested first: its HBM round trip is the longest thing in the prologue -- 6.5 k cycles from
-  //      kernel entry to "everything landed" by the stamps), then weights + bias + counter, once per workgroup ----
+  // ---- the first patch is requested first (its HBM round trip is the longest thing in the prologue: 6.5 k cycles from
+  //      kernel entry to "everything landed" by the stamps), then weights + bias + counter, once per workgroup. The
+  //      wait for the weights and the workgroup's only barrier sit AFTER the first unit's fix-up pass, which needs
+  //      the patch only. ----
   uint32_t cur = lo + wave;
   Raw raw;
   fetch_patch(min(cur, a.units - 1u), raw);
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.output, 0, static_cast<int>(a.units / tiles * g.OH * g.OW * p.n), 0x00020000);   // (launcher: < 2^31)
+  // Stores to nowhere (out-of-range offset: the hardware drops them), as many as a unit's epilogue issues. hipcc sizes
+  // the vmcnt waits of the fix-up pass for the smaller of the counts outstanding on the two ways into the loop; coming
+  // from here that was "NP loads", from the loop's end "NP loads + 2 TM stores", so the waits came out as
+  // vmcnt(NP-1..0) and covered the previous unit's stores. With the same sequence on both ways in they are counted
+  // past the stores. (Distinct offsets and a constant payload: identical stores are merged, a fetched register as
+  // payload is a wait. They come BEFORE the weight pieces, which the compiler does not see: its counts then never
+  // reach into them.)
+#pragma unroll
+  for (int i = 0; i < 2 * TM; i++) {
+    const v4i nothing = {0, 0, 0, 0};
+    __builtin_amdgcn_raw_buffer_store_b128(
+        __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, nothing), out_rsrc,
+        0xFFFFFF00u + static_cast<uint32_t>(i) * 16u, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   {
     const uint32_t pieces = a.w_bytes >> 10;
     const uint8_t* src = reinterpret_cast<const uint8_t*>(p.packed_w) + lane * 16u;
     for (uint32_t i = wave; i < pieces; i += kRegWaves) dma16(src + i * 1024u, w_lds + i * 1024u);
-    for (uint32_t i = tid; i < p.n; i += kRegThreads) bias_lds[i] = p.bias2[i];
+    // (the bias the same way, 16 bytes per lane of one wave: a load + LDS store would put a compiler-made vmcnt(0)
+    //  -- patch, weights and all -- in front of the first unit)
+    if (wave == kRegWaves - 1 && lane < p.n / 4u) {
+      dma16(reinterpret_cast<const uint8_t*>(p.bias2) + lane * 16u, reinterpret_cast<uint8_t*>(bias_lds));
+    }
   }
-  if (tid == 0) *counter = lo + kRegWaves;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's weight pieces have landed (and its first patch)
-  if (wave == 0) { QNNP_TRACE(p, blockIdx.x, 3, 1); }
-  __syncthreads();
-  if (wave == 0) { QNNP_TRACE(p, blockIdx.x, 3, 2); }
+  // (a wave's first TWO units are fixed -- lo + wave and lo + waves + wave -- so that its first claim on the counter
+  //  comes after the barrier that publishes it)
+  if (tid == 0) *counter = lo + 2u * kRegWaves;
+  bool weights_pending = true;                            // (wave-uniform)
 
   uint32_t ty[TM], rowbase[TM];
 #pragma unroll
@@ -634,33 +655,21 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
   const uint8_t* w_lane = w_lds + lane * 16;
   const uint32_t cpr = p.n >> 4;                   // 16-byte pieces per output position (2 or 4)
   const uint32_t log_cpr = 31u - __builtin_clz(cpr);
-  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      p.output, 0, static_cast<int>(a.units / tiles * g.OH * g.OW * p.n), 0x00020000);   // (launcher: < 2^31)
-
   struct Frags {
     v4i a[TM][CB];
     v4i w[TN][CB];
   };
-  // Four stores to nowhere (out-of-range offset: the hardware drops them). hipcc sizes the vmcnt waits of the fix-up
-  // pass for the smaller of the counts outstanding on the two ways into the loop; coming from here that was "7 loads",
-  // from the loop's end "7 loads + 4 stores", so the waits came out as vmcnt(6..0) and covered the previous unit's
-  // stores. With the same sequence on both ways in they are vmcnt(10..4).
-  // (distinct offsets and a constant payload: identical stores are merged, a fetched register as payload is a wait)
-#pragma unroll
-  for (int i = 0; i < 2 * TM; i++) {
-    const v4i nothing = {0, 0, 0, 0};
-    __builtin_amdgcn_raw_buffer_store_b128(
-        __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, nothing), out_rsrc,
-        0xFFFFFF00u + static_cast<uint32_t>(i) * 16u, 0, 0);
-  }
   uint32_t unit_no = 0;
   (void) unit_no;
 #define CR_STAMP(slot) do { if (wave == 0) { QNNP_TRACE(p, blockIdx.x, unit_no, slot); } } while (0)
   while (cur < hi) {
     CR_STAMP(0);
     asm volatile("" : "+v"(lane_now));
-    uint32_t claimed = 0;
-    if (lane == 0) claimed = atomicAdd(counter, 1u);        // the unit after this one (read after the K loop)
+    uint32_t claimed = cur + kRegWaves;                     // first unit: the next one is fixed (see above)
+    if (!weights_pending) {
+      claimed = 0;
+      if (lane == 0) claimed = atomicAdd(counter, 1u);      // the unit after this one (read before the K loop)
+    }
     const uint32_t img = div_magic(cur, a.inv_tiles);
     const uint32_t r = cur - img * tiles;
     const uint32_t tyi = div_magic(r, a.inv_tiles_x);
@@ -688,6 +697,11 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (weights_pending) {                                  // first unit only: the weights, for everybody
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      weights_pending = false;
+    }
     CR_STAMP(1);
     // next unit (claimed at the top: the atomic's round trip passed under the fix-up); past the range: some valid unit
     const uint32_t nxt = __builtin_amdgcn_readfirstlane(claimed);
@@ -808,6 +822,10 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
     cur = nxt;
   }
 #undef CR_STAMP
+  if (weights_pending) {                                    // a wave without a unit still owes the barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   if (wave == 0) { QNNP_TRACE(p, blockIdx.x, 3, 3); QNNP_TRACE(p, blockIdx.x, 3, 4); QNNP_TRACE(p, blockIdx.x, 3, 5); }
 }
 
