@@ -544,7 +544,7 @@ int launch_row(const DwParams& p, hipStream_t stream)
  */
 constexpr int kColThreads = 256;
 
-template <int S, bool FIX, int SEQ, bool FULL>
+template <int S, bool FIX, int SEQ, bool FULL, bool DEEP>
 __device__ __forceinline__ void dwconv_col3x3_body(
     const DwParams& p, const uint32_t n, const uint32_t oy0, const uint32_t oy1, const uint32_t ox, const uint32_t cg,
     const bool ok0, const bool ok1, const bool ok2)
@@ -663,7 +663,66 @@ __device__ __forceinline__ void dwconv_col3x3_body(
       out_soff += out_step;
     };
     const uint32_t steps = oy1 - oy0;
-    if constexpr (S == 1) {
+    if constexpr (S == 1 && DEEP) {
+      // The same walk with FOUR rows in flight instead of two: six row buffers (row r lives in buffer r % 6), the pair
+      // registers keep their period of three, so six steps are written out per trip. PMC on the two-rows-ahead loop
+      // (MobileNetV2 layers 8 / 13, batch 128): waves parked on s_waitcnt for 60 / 50 % of their lifetime, VALU busy
+      // 59 / 50 % -- a step of 4-5 waves sharing a SIMD takes ~850 cycles, two of them are less than an HBM round trip.
+      // State entering step t: HA = H[t], HB = H[t+1], QA = Q[t-1], QB = Q[t], RP = row t+1, RC = row t+2,
+      // RL = the buffer of row t (dead: both its pairs are built), reloaded with row t+6.
+      Row r0 = load_row(kChecked, iy_first);
+      Row r1 = load_row(kChecked, iy_first + 1);
+      Row r2 = load_row(kChecked, iy_first + 2);
+      Row r3 = load_row(kChecked, iy_first + 3);
+      Row r4 = load_row(kChecked, iy_first + 4);
+      Row r5 = load_row(kChecked, iy_first + 5);
+      Pair h0 = pair(r0.c[0], r0.c[1]);
+      Pair h1 = pair(r1.c[0], r1.c[1]);
+      Pair qa = pair(r0.c[2], r0.c[2]);            // Q[-1] = (don't care, col2 @ 0)
+      Pair qb = pair(r0.c[2], r1.c[2]);            // Q[0]
+      Pair h2, qc;
+      uint32_t t = 0;
+      // steps whose prefetched row (iy_first + t + 6) is inside the image: t < t_inside
+      const int32_t inside = static_cast<int32_t>(p.H) - 6 - iy_first;
+      const uint32_t t_inside = inside <= 0 ? 0u : (static_cast<uint32_t>(inside) < steps ? static_cast<uint32_t>(inside) : steps);
+#define QNNP_DW_COL_STEP6(CHECK, HA, HB, HC, QA, QB, QC, RP, RC, RL)                 \
+      {                                                                             \
+        HC = pair(RC.c[0], RC.c[1]);                        /* H[t+2] */            \
+        QC = pair(RP.c[2], RC.c[2]);                        /* Q[t+1] */            \
+        RL = load_row(CHECK, iy_first + static_cast<int32_t>(t) + 6);               \
+        __builtin_amdgcn_sched_barrier(0);   /* (left alone the scheduler sinks the loads towards their uses) */ \
+        int32_t acc[4];                                                             \
+        dot_first(HA, w01[0], bias, acc);                                           \
+        dot(HB, w01[1], acc);                                                       \
+        dot(HC, w01[2], acc);                                                       \
+        dot(QA, wqa, acc);                                                          \
+        dot(QC, wqb, acc);                                                          \
+        finish(acc);                                                                \
+        t++;                                                                        \
+      }
+      while (t + 6 <= t_inside) {                  // steady state: straight-line body, counted waits
+        QNNP_DW_COL_STEP6(kInside, h0, h1, h2, qa, qb, qc, r1, r2, r0)
+        QNNP_DW_COL_STEP6(kInside, h1, h2, h0, qb, qc, qa, r2, r3, r1)
+        QNNP_DW_COL_STEP6(kInside, h2, h0, h1, qc, qa, qb, r3, r4, r2)
+        QNNP_DW_COL_STEP6(kInside, h0, h1, h2, qa, qb, qc, r4, r5, r3)
+        QNNP_DW_COL_STEP6(kInside, h1, h2, h0, qb, qc, qa, r5, r0, r4)
+        QNNP_DW_COL_STEP6(kInside, h2, h0, h1, qc, qa, qb, r0, r1, r5)
+      }
+      while (t < steps) {                          // the last steps of a segment (and of the image: padding rows)
+        QNNP_DW_COL_STEP6(kChecked, h0, h1, h2, qa, qb, qc, r1, r2, r0)
+        if (t >= steps) break;
+        QNNP_DW_COL_STEP6(kChecked, h1, h2, h0, qb, qc, qa, r2, r3, r1)
+        if (t >= steps) break;
+        QNNP_DW_COL_STEP6(kChecked, h2, h0, h1, qc, qa, qb, r3, r4, r2)
+        if (t >= steps) break;
+        QNNP_DW_COL_STEP6(kChecked, h0, h1, h2, qa, qb, qc, r4, r5, r3)
+        if (t >= steps) break;
+        QNNP_DW_COL_STEP6(kChecked, h1, h2, h0, qb, qc, qa, r5, r0, r4)
+        if (t >= steps) break;
+        QNNP_DW_COL_STEP6(kChecked, h2, h0, h1, qc, qa, qb, r0, r1, r5)
+      }
+#undef QNNP_DW_COL_STEP6
+    } else if constexpr (S == 1) {
       // window rows of output t: t, t+1, t+2 (relative to iy_first). State entering step t:
       //   HA = H[t], HB = H[t+1], QA = Q[t-1] (only its high half matters), QB = Q[t],
       //   RP = row t+1 (its col2 is still needed), RC = row t+2, third row buffer = row t+3 (in flight).
@@ -761,7 +820,7 @@ __device__ __forceinline__ void dwconv_col3x3_body(
 
 /* SEQ / FULL: the requantization flavour (requant.hip.h), chosen on the host -- one kernel per flavour, so that the
  * common one is not charged the registers of the rare ones (83 against 77 VGPRs: 5 instead of 6 waves per SIMD) */
-template <int S, int SEQ, bool FULL>
+template <int S, int SEQ, bool FULL, bool DEEP>
 __global__ __launch_bounds__(kColThreads)
 void q8_dwconv_col3x3_kernel(const DwParams p)
 {
@@ -787,9 +846,9 @@ void q8_dwconv_col3x3_kernel(const DwParams p)
   const bool ok1 = ix0 + 1 >= 0 && ix0 + 1 < static_cast<int32_t>(p.W);
   const bool ok2 = ix0 + 2 >= 0 && ix0 + 2 < static_cast<int32_t>(p.W);
   if (__builtin_amdgcn_ballot_w64(!(ok0 && ok1 && ok2)) != 0) {
-    dwconv_col3x3_body<S, true, SEQ, FULL>(p, n, oy0, oy1, ox, cg, ok0, ok1, ok2);
+    dwconv_col3x3_body<S, true, SEQ, FULL, DEEP>(p, n, oy0, oy1, ox, cg, ok0, ok1, ok2);
   } else {
-    dwconv_col3x3_body<S, false, SEQ, FULL>(p, n, oy0, oy1, ox, cg, true, true, true);
+    dwconv_col3x3_body<S, false, SEQ, FULL, DEEP>(p, n, oy0, oy1, ox, cg, true, true, true);
   }
 }
 
@@ -822,7 +881,8 @@ bool plan_col(DwParams& p)
   const uint64_t waves_per_seg = static_cast<uint64_t>(p.batch) * chunks;
   // (measured on the MobileNetV2 layers, batch 128: 1.3-2 rounds of waves beat 3-4 -- 35.6 against 39.6 us on
   //  layer 8 -- now that the rows in flight are really in flight; shorter segments only add start-ups and halo rows)
-  const uint64_t slots = static_cast<uint64_t>(p.cu_count) * 4u * 6u;               // 6 waves per SIMD
+  // resident waves: 6 per SIMD for the stride-2 kernel (79 VGPRs), 5 for the stride-1 one (four rows in flight: 82)
+  const uint64_t slots = static_cast<uint64_t>(p.cu_count) * 4u * (p.sw == 1 ? 5u : 6u);
   const uint64_t target = slots * 3u / 2u;                                         // ~1.5 rounds
   uint32_t segs = static_cast<uint32_t>((target + waves_per_seg - 1) / waves_per_seg);
   // Stride 1 with enough columns to give every SIMD a few waves: at most ONE round (28x28x192, batch 128: two
@@ -854,9 +914,19 @@ int launch_col(const DwParams& p, hipStream_t stream)
     constexpr int kSeq = decltype(seq)::value;
     constexpr bool kFull = decltype(full)::value;
     if (p.sw == 1) {
-      hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<1, kSeq, kFull>), dim3(blocks), dim3(kColThreads), 0, stream, p);
+      // four rows in flight (see the kernel) when a segment is long enough to use them: 112x112x32 30.7 -> 29.1 us,
+      // 56x56x144 33.4 -> 32.3, 14-row segments level, 7x7x960 8.25 -> 8.55 with its six-row start-up
+      bool deep = p.TOH >= 12u;
+#ifdef QNNP_ENABLE_ABLATION
+      if (const char* env = getenv("QNNP_GFX950_DW_COL_DEEP")) deep = atoi(env) != 0;
+#endif
+      if (deep) {
+        hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<1, kSeq, kFull, true>), dim3(blocks), dim3(kColThreads), 0, stream, p);
+      } else {
+        hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<1, kSeq, kFull, false>), dim3(blocks), dim3(kColThreads), 0, stream, p);
+      }
     } else {
-      hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<2, kSeq, kFull>), dim3(blocks), dim3(kColThreads), 0, stream, p);
+      hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<2, kSeq, kFull, false>), dim3(blocks), dim3(kColThreads), 0, stream, p);
     }
   });
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
