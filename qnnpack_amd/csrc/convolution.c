@@ -178,6 +178,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
     qnnp_pack_dwconv_w(groups, c_pad, kernel_height, kernel_width,
         input_zero_point, kernel_zero_point, kernel, bias, (int16_t*) host_weights, host_bias);
     op->c_pad = c_pad;
+    op->dw_wrange = qnnp_dwconv_weight_range((const int16_t*) host_weights, kernel_size * c_pad);
     op->d_weights = qnnp_hip_alloc(w_bytes);
     op->d_bias = (int32_t*) qnnp_hip_alloc(b_bytes);
     if (op->d_weights == NULL || op->d_bias == NULL ||
@@ -185,6 +186,22 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
         qnnp_hip_h2d(op->d_bias, host_bias, b_bytes, 0) != QNNP_HIP_OK) {
       qnnp_log_error("failed to place %zu bytes of packed depthwise weights on the device", w_bytes + b_bytes);
       goto error;
+    }
+    /* 3x3 with weights in int8 range: the register image of the int8 dot-product walk (pack.h) */
+    if (kernel_height == 3 && kernel_width == 3 && op->dw_wrange != 0) {
+      const size_t q_bytes = sizeof(uint32_t) * 4 * c_pad;
+      uint32_t* host_q = (uint32_t*) malloc(q_bytes);
+      int ok = host_q != NULL;
+      if (ok) {
+        qnnp_pack_dwconv_dot4(c_pad, op->dw_wrange, (const int16_t*) host_weights, host_bias, host_q);
+        op->d_dw_dot4 = qnnp_hip_alloc(q_bytes);
+        ok = op->d_dw_dot4 != NULL && qnnp_hip_h2d(op->d_dw_dot4, host_q, q_bytes, 0) == QNNP_HIP_OK;
+      }
+      free(host_q);
+      if (!ok) {
+        qnnp_log_error("failed to place %zu bytes of depthwise dot-product weights on the device", q_bytes);
+        goto error;
+      }
     }
     /* second image: int8 weight parts + folded bias for the matrix-core depthwise kernel */
     {

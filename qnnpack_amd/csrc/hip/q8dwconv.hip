@@ -73,6 +73,10 @@ struct DwParams {
   const int8_t* dwm_x;
   const int32_t* dwm_bias;
   uint32_t dwm_parts, c_pad32;
+  uint32_t wrange;       // qnnp_dwconv_weight_range of wadj (pack.h): 1 / 2 = the int8 dot-product flavour of kernel G applies
+  const uint32_t* dot4;  // [4][c_pad] register image of that flavour (pack.h qnnp_pack_dwconv_dot4), or null
+  uint32_t xcd_ranges;   // kernel G: 1 = contiguous ranges of the work per XCD (launch_col)
+  uint32_t inv_bands, inv_slabs, inv_q4;   // kernel G: ceil(2^32 / d) of its three divisors (0 when d == 1), launch_col
   uint32_t store_mode;   // as igemm_epilogue.hip.h: 2 = 16-byte stores, 1 = dword stores, 0 = byte stores
   uint32_t abl;          // measurement builds only: bit 0 = no stores, bit 1 = no global loads (kernel F)
   unsigned long long* trace;   // measurement builds only (QNNP_ENABLE_ABLATION + env QNNP_GFX950_TRACE)
@@ -544,32 +548,67 @@ int launch_row(const DwParams& p, hipStream_t stream)
  */
 constexpr int kColThreads = 256;
 
-template <int S, bool FIX, int SEQ, bool FULL, bool DEEP>
+template <int S, bool FIX, int SEQ, bool FULL, bool DEEP, bool QUAD>
 __device__ __forceinline__ void dwconv_col3x3_body(
     const DwParams& p, const uint32_t n, const uint32_t oy0, const uint32_t oy1, const uint32_t ox, const uint32_t cg,
     const bool ok0, const bool ok1, const bool ok2)
 {
   // tap weights: W01[r] = (w_r0, w_r1) pairs, WQA = (0, w_02), WQB = (w_12, w_22); per channel of the group
   uint32_t w01[3][4], wqa[4], wqb[4];
+  // QUAD flavour: W4[r] = (x_r0, x_r1, x_r2, 0) as int8, x = +-(w - kzp) (see the step below)
+  uint32_t w4[3][4];
+  const uint32_t kx = p.wrange == 2u ? 0x7f7f7f7fu : 0x80808080u;    // wave-uniform
   int32_t bias[4];
-  {
-    uint2 t[9];
+  // The tap weights and the bias are REQUESTED here; the int8 walk moves them to their registers only after the first
+  // input rows have been requested too (unpack_weights()): traced on MobileNetV2 layer 8, a wave spent 5.3k cycles
+  // until its weights were in registers and another 2.9k until its first rows had arrived -- one round trip behind
+  // the other.
+  uint2 tw[9];
+  int4 bv;
+  uint4 wv[3];
+  if constexpr (QUAD) {
+    // host-made register image: W4[r] for the thread's four channels, and the bias that goes with a ^ kx
 #pragma unroll
-    for (int i = 0; i < 9; i++) t[i] = *reinterpret_cast<const uint2*>(p.wadj + i * p.c_pad + cg);   // 4 x int16
+    for (int r = 0; r < 3; r++) wv[r] = *reinterpret_cast<const uint4*>(p.dot4 + r * p.c_pad + cg);
+    bv = *reinterpret_cast<const int4*>(p.dot4 + 3u * p.c_pad + cg);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; i++) tw[i] = *reinterpret_cast<const uint2*>(p.wadj + i * p.c_pad + cg);   // 4 x int16
+    bv = *reinterpret_cast<const int4*>(p.bias1 + cg);
+  }
+  auto unpack_weights = [&]() __attribute__((always_inline)) {
+    if constexpr (QUAD) __builtin_amdgcn_sched_barrier(0);             // behind the row loads issued so far
     auto lo16 = [](uint2 v, int c) -> uint32_t { return ((c < 2 ? v.x : v.y) >> ((c & 1) * 16)) & 0xFFFFu; };
+    bias[0] = bv.x; bias[1] = bv.y; bias[2] = bv.z; bias[3] = bv.w;
+    if constexpr (QUAD) {
+#pragma unroll
+      for (int r = 0; r < 3; r++) { w4[r][0] = wv[r].x; w4[r][1] = wv[r].y; w4[r][2] = wv[r].z; w4[r][3] = wv[r].w; }
+    }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
+      if constexpr (!QUAD) {
 #pragma unroll
-      for (int r = 0; r < 3; r++) w01[r][c] = lo16(t[r * 3 + 0], c) | (lo16(t[r * 3 + 1], c) << 16);
-      wqa[c] = lo16(t[2], c) << 16;
-      wqb[c] = lo16(t[5], c) | (lo16(t[8], c) << 16);
+        for (int r = 0; r < 3; r++) w01[r][c] = lo16(tw[r * 3 + 0], c) | (lo16(tw[r * 3 + 1], c) << 16);
+        wqa[c] = lo16(tw[2], c) << 16;
+        wqb[c] = lo16(tw[5], c) | (lo16(tw[8], c) << 16);
+      }
+      // the offset rounding sequences (requant.hip.h) take accumulator + 2^31: folded into the bias, once per thread
+      bias[c] = qnnp::with_rq_offset<SEQ>(bias[c]);
     }
-    const int4 bv = *reinterpret_cast<const int4*>(p.bias1 + cg);
-    bias[0] = bv.x; bias[1] = bv.y; bias[2] = bv.z; bias[3] = bv.w;
-  }
-
+  };
+  // (the pair walks unpack at once: with the raw taps live across the first row requests they need 93-98 VGPRs
+  //  instead of 79-82, a wave per SIMD less, and the stride-2 layers measured no better for the overlap)
+  if constexpr (!QUAD) unpack_weights();
+  QNNP_DW_TRACE(p, 1);
   const uint32_t fill = p.izp * 0x01010101u;
   const uint32_t row_bytes = p.W * p.in_stride;
+#ifdef QNNP_ENABLE_ABLATION
+  // measurement knobs that leave the instruction stream alone: bit 2 = every step re-reads the segment's first row
+  // (loads served by L1 / L2), bit 3 = every step stores to the segment's first output row (writes combine in L2)
+  const uint32_t row_adv = (p.abl & 4u) ? 0u : row_bytes;
+#else
+  const uint32_t row_adv = row_bytes;
+#endif
   // Buffer addressing: a descriptor over the whole tensor (built from kernel arguments only, so it stays in SGPRs),
   // per lane a constant 32-bit byte offset inside a row, per row a SCALAR offset -- no vector address arithmetic in
   // the loop. Invalid columns are clamped to column 0 (their value is replaced below).
@@ -592,15 +631,12 @@ __device__ __forceinline__ void dwconv_col3x3_body(
   auto load_row = [&](auto check, int32_t iy) __attribute__((always_inline)) -> Row {
     constexpr bool CHECK = decltype(check)::value;
     Row r;
-#ifdef QNNP_ENABLE_ABLATION
-    if (p.abl & 2u) { r.c[0] = coff[0] ^ static_cast<uint32_t>(iy); r.c[1] = coff[1]; r.c[2] = coff[2] + static_cast<uint32_t>(iy); return r; }
-#endif
     bool row_ok = true;
     if constexpr (CHECK) {
       row_ok = iy >= 0 && iy < static_cast<int32_t>(p.H);
       iy = iy < 0 ? 0 : (iy >= static_cast<int32_t>(p.H) ? static_cast<int32_t>(p.H) - 1 : iy);
     }
-    const uint32_t ro = img_off + static_cast<uint32_t>(iy) * row_bytes;      // scalar
+    const uint32_t ro = img_off + static_cast<uint32_t>(iy) * row_adv;        // scalar
     r.c[0] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[0], ro, 0);
     r.c[1] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[1], ro, 0);
     r.c[2] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[2], ro, 0);
@@ -634,6 +670,31 @@ __device__ __forceinline__ void dwconv_col3x3_body(
       acc[c] = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a.v[c]), __builtin_bit_cast(v2s, w[c]), acc[c], false);
     }
   };
+  // QUAD flavour: per channel c the bytes (col0, col1, col2, 0) of one input row, re-centred to int8
+  struct Quad { uint32_t v[4]; };
+  auto quad = [kx](const Row& r) __attribute__((always_inline)) -> Quad {
+    const uint32_t d0 = r.c[0] ^ kx, d1 = r.c[1] ^ kx, d2 = r.c[2] ^ kx;
+    const uint32_t lo = __builtin_amdgcn_perm(d1, d0, 0x05010400u);      // (d0.b0, d1.b0, d0.b1, d1.b1)
+    const uint32_t hi = __builtin_amdgcn_perm(d1, d0, 0x07030602u);      // (d0.b2, d1.b2, d0.b3, d1.b3)
+    Quad q;
+    q.v[0] = __builtin_amdgcn_perm(d2, lo, 0x0c040100u);
+    q.v[1] = __builtin_amdgcn_perm(d2, lo, 0x0c050302u);
+    q.v[2] = __builtin_amdgcn_perm(d2, hi, 0x0c060100u);
+    q.v[3] = __builtin_amdgcn_perm(d2, hi, 0x0c070302u);
+    return q;
+  };
+  auto dot4 = [](const Quad& a, const uint32_t (&w)[4], int32_t (&acc)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      acc[c] = __builtin_amdgcn_sdot4(static_cast<int32_t>(a.v[c]), static_cast<int32_t>(w[c]), acc[c], false);
+    }
+  };
+  auto dot4_first = [](const Quad& a, const uint32_t (&w)[4], const int32_t (&b)[4], int32_t (&acc)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(acc[c]) : "v"(a.v[c]), "v"(w[c]), "v"(b[c]));
+    }
+  };
   // first product of an output: the three-operand form takes the bias as its addend (the two-operand accumulate
   // form the compiler prefers would need a copy of the bias per output first)
   auto dot_first = [](const Pair& a, const uint32_t (&w)[4], const int32_t (&b)[4], int32_t (&acc)[4]) __attribute__((always_inline)) {
@@ -647,23 +708,102 @@ __device__ __forceinline__ void dwconv_col3x3_body(
       p.output, 0, static_cast<int>(p.batch * p.OH * p.OW * p.out_stride), 0x00020000);
   const uint32_t out_voff = ox * p.out_stride + cg;
   uint32_t out_soff = (n * p.OH + oy0) * p.OW * p.out_stride;       // scalar, advances one output row per step
+#ifdef QNNP_ENABLE_ABLATION
+  const uint32_t out_step = (p.abl & 8u) ? 0u : p.OW * p.out_stride;
+#else
   const uint32_t out_step = p.OW * p.out_stride;
+#endif
 
   {
-    // the offset rounding sequences (requant.hip.h) take accumulator + 2^31: folded into the bias, once per thread
-#pragma unroll
-    for (int c = 0; c < 4; c++) bias[c] = qnnp::with_rq_offset<SEQ>(bias[c]);
     auto finish = [&](int32_t (&acc)[4]) __attribute__((always_inline)) {
       const uint32_t packed = qnnp::q31_requantize_pack4<SEQ, FULL>(
           acc[0], acc[1], acc[2], acc[3], p.rq);
-#ifdef QNNP_ENABLE_ABLATION
-      if (p.abl & 1u) { asm volatile("" :: "v"(packed)); out_soff += out_step; return; }
-#endif
       __builtin_amdgcn_raw_buffer_store_b32(packed, out_rsrc, out_voff, out_soff, 0);
       out_soff += out_step;
     };
     const uint32_t steps = oy1 - oy0;
-    if constexpr (S == 1 && DEEP) {
+    if constexpr (S == 1 && QUAD) {
+      // The int8 dot-product flavour (weights whose x = w - kzp, or -x, fit int8: DwParams::wrange). An input row is
+      // transposed ONCE into per-channel quads T[r] = (col0, col1, col2, 0) -- two v_perm over (col0, col1), four that
+      // append col2 -- and serves the three output rows whose windows contain it:
+      //     out(t) = T[t] . W4[0] + T[t+1] . W4[1] + T[t+2] . W4[2]               (v_dot4_i32_i8, 3 per channel)
+      // i.e. 6 v_perm + 3 v_xor + 12 dot products per output dword against 8 v_perm + 20 v_dot2 of the pair walk.
+      // a' = a ^ 0x80 = a - 128 pairs with x, a' = a ^ 0x7f = 127 - a with -x; the difference to sum a * x is a
+      // constant per channel, folded into the bias above. A row buffer is dead as soon as its quad is built, so
+      // NBUF buffers keep NBUF rows in flight: row r lives in buffer r % NBUF, T[.] rotate with period three.
+      constexpr int NBUF = DEEP ? 6 : 3;
+      Row r0 = load_row(kChecked, iy_first);
+      Row r1 = load_row(kChecked, iy_first + 1);
+      Row r2 = load_row(kChecked, iy_first + 2);
+      Row r3, r4, r5;
+      if constexpr (DEEP) {
+        r3 = load_row(kChecked, iy_first + 3);
+        r4 = load_row(kChecked, iy_first + 4);
+        r5 = load_row(kChecked, iy_first + 5);
+      }
+      unpack_weights();
+      Quad q0 = quad(r0);
+      r0 = load_row(kChecked, iy_first + NBUF);
+      Quad q1 = quad(r1);
+      r1 = load_row(kChecked, iy_first + NBUF + 1);
+      Quad q2;
+      uint32_t t = 0;
+      QNNP_DW_TRACE(p, 2);
+      // steps whose prefetched row (iy_first + t + 2 + NBUF) is inside the image: t < t_inside
+      const int32_t inside = static_cast<int32_t>(p.H) - (2 + NBUF) - iy_first;
+      const uint32_t t_inside = inside <= 0 ? 0u : (static_cast<uint32_t>(inside) < steps ? static_cast<uint32_t>(inside) : steps);
+#define QNNP_DW_COL_STEPQ(CHECK, TA, TB, TC, RC)                                      \
+      {                                                                             \
+        TC = quad(RC);                                      /* T[t+2] */            \
+        RC = load_row(CHECK, iy_first + static_cast<int32_t>(t) + 2 + NBUF);        \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+        int32_t acc[4];                                                             \
+        dot4_first(TA, w4[0], bias, acc);                                           \
+        dot4(TB, w4[1], acc);                                                       \
+        dot4(TC, w4[2], acc);                                                       \
+        finish(acc);                                                                \
+        t++;                                                                        \
+      }
+      if constexpr (DEEP) {
+        while (t + 6 <= t_inside) {                // steady state: straight-line body, counted waits
+          QNNP_DW_COL_STEPQ(kInside, q0, q1, q2, r2)
+          QNNP_DW_COL_STEPQ(kInside, q1, q2, q0, r3)
+          QNNP_DW_COL_STEPQ(kInside, q2, q0, q1, r4)
+          QNNP_DW_COL_STEPQ(kInside, q0, q1, q2, r5)
+          QNNP_DW_COL_STEPQ(kInside, q1, q2, q0, r0)
+          QNNP_DW_COL_STEPQ(kInside, q2, q0, q1, r1)
+        }
+        QNNP_DW_TRACE(p, 3);
+        while (t < steps) {                        // the last steps of a segment (and of the image: padding rows)
+          QNNP_DW_COL_STEPQ(kChecked, q0, q1, q2, r2)
+          if (t >= steps) break;
+          QNNP_DW_COL_STEPQ(kChecked, q1, q2, q0, r3)
+          if (t >= steps) break;
+          QNNP_DW_COL_STEPQ(kChecked, q2, q0, q1, r4)
+          if (t >= steps) break;
+          QNNP_DW_COL_STEPQ(kChecked, q0, q1, q2, r5)
+          if (t >= steps) break;
+          QNNP_DW_COL_STEPQ(kChecked, q1, q2, q0, r0)
+          if (t >= steps) break;
+          QNNP_DW_COL_STEPQ(kChecked, q2, q0, q1, r1)
+        }
+      } else {
+        while (t + 3 <= t_inside) {
+          QNNP_DW_COL_STEPQ(kInside, q0, q1, q2, r2)
+          QNNP_DW_COL_STEPQ(kInside, q1, q2, q0, r0)
+          QNNP_DW_COL_STEPQ(kInside, q2, q0, q1, r1)
+        }
+        while (t < steps) {
+          QNNP_DW_COL_STEPQ(kChecked, q0, q1, q2, r2)
+          if (t >= steps) break;
+          QNNP_DW_COL_STEPQ(kChecked, q1, q2, q0, r0)
+          if (t >= steps) break;
+          QNNP_DW_COL_STEPQ(kChecked, q2, q0, q1, r1)
+        }
+      }
+      QNNP_DW_TRACE(p, 4);
+#undef QNNP_DW_COL_STEPQ
+    } else if constexpr (S == 1 && DEEP) {
       // The same walk with FOUR rows in flight instead of two: six row buffers (row r lives in buffer r % 6), the pair
       // registers keep their period of three, so six steps are written out per trip. PMC on the two-rows-ahead loop
       // (MobileNetV2 layers 8 / 13, batch 128): waves parked on s_waitcnt for 60 / 50 % of their lifetime, VALU busy
@@ -820,24 +960,43 @@ __device__ __forceinline__ void dwconv_col3x3_body(
 
 /* SEQ / FULL: the requantization flavour (requant.hip.h), chosen on the host -- one kernel per flavour, so that the
  * common one is not charged the registers of the rare ones (83 against 77 VGPRs: 5 instead of 6 waves per SIMD) */
-template <int S, int SEQ, bool FULL, bool DEEP>
+template <int S, int SEQ, bool FULL, bool DEEP, bool QUAD>
 __global__ __launch_bounds__(kColThreads)
 void q8_dwconv_col3x3_kernel(const DwParams p)
 {
   // wave -> (image, row segment, 64-dword chunk of the flattened output row); `slabs` = row segments, `TOH` = rows
   // per segment, `bands` = chunks per row here
   const uint32_t lane = threadIdx.x & 63u;
-  uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kColThreads / 64) + (threadIdx.x >> 6));
-  const uint32_t chunk = w % p.bands; w /= p.bands;
-  const uint32_t seg = w % p.slabs;
-  const uint32_t n = w / p.slabs;
+  QNNP_DW_TRACE(p, 0);
+#ifdef QNNP_ENABLE_ABLATION
+  if (p.trace != nullptr && threadIdx.x == 0 && blockIdx.x < 4096) p.trace[(blockIdx.x * 4 + 3) * 8 + 0] = wall_clock64();
+#endif
+  // Workgroup b runs on XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup dispatch"; a speed assumption only). For
+  // tensors that more or less live in the caches (launch_col: <= 96 MiB in + out) every XCD takes a CONTIGUOUS range of
+  // the flattened (image, segment, chunk) space, so that the halo pixels either side of a chunk are found in that XCD's
+  // L2 by the neighbouring workgroups: same box, batch 128, 28x28x192 s2 8.8 -> 8.2 us, 14x14x576 s2 7.1 -> 6.9,
+  // 56x56x144 s2 19.3 -> 18.9. The big HBM-streaming layers keep the round-robin order, where the eight XCDs sweep
+  // neighbouring addresses at the same time: 112x112x96 s2 41.9 -> 43.8 us with the ranges, 112x112x32 +0.3.
+  uint32_t b = blockIdx.x;
+  if (p.xcd_ranges != 0u) {
+    const uint32_t q = gridDim.x >> 3, r = gridDim.x & 7u, xcd = b & 7u;
+    b = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (b >> 3);
+  }
+  uint32_t w = __builtin_amdgcn_readfirstlane(b * (kColThreads / 64) + (threadIdx.x >> 6));
+  // (divisions by run-time values through host-made reciprocals: ~40 instructions each otherwise, on every wave's way
+  //  to its first load; exact while dividend * divisor < 2^32, which plan_col checks)
+  auto div_by = [](uint32_t x, uint32_t inv) __attribute__((always_inline)) { return inv != 0u ? __umulhi(x, inv) : x; };
+  const uint32_t wb = div_by(w, p.inv_bands);
+  const uint32_t chunk = w - wb * p.bands;
+  const uint32_t n = div_by(wb, p.inv_slabs);
+  const uint32_t seg = wb - n * p.slabs;
   if (n >= p.batch) return;
   const uint32_t q4 = p.C >> 2;
   const uint32_t cols = p.OW * q4;
   // lanes past the end of the row repeat its last dword column: same loads, same results, same stores -- harmless
   uint32_t j = chunk * 64u + lane;
   if (j >= cols) j = cols - 1u;
-  const uint32_t ox = j / q4;
+  const uint32_t ox = div_by(j, p.inv_q4);
   const uint32_t cg = (j - ox * q4) * 4u;
   const uint32_t oy0 = seg * p.TOH;
   const uint32_t oy1 = min(p.OH, oy0 + p.TOH);
@@ -846,10 +1005,14 @@ void q8_dwconv_col3x3_kernel(const DwParams p)
   const bool ok1 = ix0 + 1 >= 0 && ix0 + 1 < static_cast<int32_t>(p.W);
   const bool ok2 = ix0 + 2 >= 0 && ix0 + 2 < static_cast<int32_t>(p.W);
   if (__builtin_amdgcn_ballot_w64(!(ok0 && ok1 && ok2)) != 0) {
-    dwconv_col3x3_body<S, true, SEQ, FULL, DEEP>(p, n, oy0, oy1, ox, cg, ok0, ok1, ok2);
+    dwconv_col3x3_body<S, true, SEQ, FULL, DEEP, QUAD>(p, n, oy0, oy1, ox, cg, ok0, ok1, ok2);
   } else {
-    dwconv_col3x3_body<S, false, SEQ, FULL, DEEP>(p, n, oy0, oy1, ox, cg, true, true, true);
+    dwconv_col3x3_body<S, false, SEQ, FULL, DEEP, QUAD>(p, n, oy0, oy1, ox, cg, true, true, true);
   }
+  QNNP_DW_TRACE(p, 5);
+#ifdef QNNP_ENABLE_ABLATION
+  if (p.trace != nullptr && threadIdx.x == 0 && blockIdx.x < 4096) p.trace[(blockIdx.x * 4 + 3) * 8 + 1] = wall_clock64();
+#endif
 }
 
 // measurement knob, read once: output rows per segment of kernel G (0 = automatic)
@@ -903,11 +1066,32 @@ bool plan_col(DwParams& p)
   p.slabs = (p.OH + toh - 1) / toh;
   p.bands = chunks;
   const uint64_t waves = static_cast<uint64_t>(p.batch) * p.slabs * chunks;
+  // (the kernel divides wave and column indices through 32-bit reciprocals: exact while dividend * divisor < 2^32)
+  const uint64_t dmax = chunks > p.slabs ? chunks : p.slabs;
+  if ((waves + 8u * (kColThreads / 64)) * dmax >= (UINT64_C(1) << 32)) return false;
+  if (static_cast<uint64_t>(cols) * (p.C / 4) >= (UINT64_C(1) << 32)) return false;
   return waves < (UINT64_C(1) << 31);
 }
 
-int launch_col(const DwParams& p, hipStream_t stream)
+// stride 1 with weights in int8 range (DwParams::wrange): the v_dot4_i32_i8 flavour of kernel G
+bool col_uses_dot4(const DwParams& p)
 {
+  bool quad = p.sw == 1u && (p.wrange == 1u || p.wrange == 2u) && p.dot4 != nullptr;
+#ifdef QNNP_ENABLE_ABLATION
+  if (const char* env = getenv("QNNP_GFX950_DW_COL_QUAD")) quad = quad && atoi(env) != 0;
+#endif
+  return quad;
+}
+
+int launch_col(const DwParams& geometry, hipStream_t stream)
+{
+  DwParams p = geometry;
+  auto reciprocal = [](uint32_t d) { return d > 1u ? static_cast<uint32_t>(((UINT64_C(1) << 32) + d - 1u) / d) : 0u; };
+  p.inv_bands = reciprocal(p.bands);
+  p.inv_slabs = reciprocal(p.slabs);
+  p.inv_q4 = reciprocal(p.C / 4u);
+  p.xcd_ranges = (static_cast<uint64_t>(p.batch) * p.H * p.W * p.in_stride +
+                  static_cast<uint64_t>(p.batch) * p.OH * p.OW * p.out_stride) <= (UINT64_C(96) << 20) ? 1u : 0u;
   const uint64_t waves = static_cast<uint64_t>(p.batch) * p.slabs * p.bands;
   const uint32_t blocks = static_cast<uint32_t>((waves + (kColThreads / 64) - 1) / (kColThreads / 64));
   qnnp::requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
@@ -920,13 +1104,18 @@ int launch_col(const DwParams& p, hipStream_t stream)
 #ifdef QNNP_ENABLE_ABLATION
       if (const char* env = getenv("QNNP_GFX950_DW_COL_DEEP")) deep = atoi(env) != 0;
 #endif
-      if (deep) {
-        hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<1, kSeq, kFull, true>), dim3(blocks), dim3(kColThreads), 0, stream, p);
+      const bool quad = col_uses_dot4(p);
+      if (quad && deep) {
+        hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<1, kSeq, kFull, true, true>), dim3(blocks), dim3(kColThreads), 0, stream, p);
+      } else if (quad) {
+        hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<1, kSeq, kFull, false, true>), dim3(blocks), dim3(kColThreads), 0, stream, p);
+      } else if (deep) {
+        hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<1, kSeq, kFull, true, false>), dim3(blocks), dim3(kColThreads), 0, stream, p);
       } else {
-        hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<1, kSeq, kFull, false>), dim3(blocks), dim3(kColThreads), 0, stream, p);
+        hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<1, kSeq, kFull, false, false>), dim3(blocks), dim3(kColThreads), 0, stream, p);
       }
     } else {
-      hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<2, kSeq, kFull, false>), dim3(blocks), dim3(kColThreads), 0, stream, p);
+      hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<2, kSeq, kFull, false, false>), dim3(blocks), dim3(kColThreads), 0, stream, p);
     }
   });
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
@@ -1553,6 +1742,10 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
   const uintptr_t in_addr = reinterpret_cast<uintptr_t>(a->input);
   const uintptr_t out_addr = reinterpret_cast<uintptr_t>(a->output);
   p.dwm_x = a->dwm_x; p.dwm_bias = a->dwm_bias; p.dwm_parts = a->dwm_parts; p.c_pad32 = a->c_pad32;
+  p.wrange = a->w_range;
+  p.dot4 = a->dot4;
+  p.inv_bands = p.inv_slabs = p.inv_q4 = 0;
+  p.xcd_ranges = 0;
 
   // The plan (kernel choice + band / slab geometry) depends on the shapes fixed at setup, the variant and the
   // pointers' alignment only: it is computed at the first run after a setup and kept with the operator.
@@ -1580,7 +1773,7 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
       if (kernel_name != nullptr) *kernel_name = "q8_dwconv_row_3x3";
       return launch_row(p, stream);
     case kPlanCol:
-      if (kernel_name != nullptr) *kernel_name = "q8_dwconv_col_3x3";
+      if (kernel_name != nullptr) *kernel_name = col_uses_dot4(p) ? "q8_dwconv_col_3x3_dot4" : "q8_dwconv_col_3x3";
       return launch_col(p, stream);
     case kPlanLds33:
       if (kernel_name != nullptr) *kernel_name = "q8_dwconv_lds_3x3";

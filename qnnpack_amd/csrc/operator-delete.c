@@ -24,6 +24,7 @@ enum qnnp_status qnnp_delete_operator(qnnp_operator_t op)
   qnnp_hip_free(op->d_bias);
   qnnp_hip_free(op->d_dwm_x);
   qnnp_hip_free(op->d_dwm_bias);
+  qnnp_hip_free(op->d_dw_dot4);
   qnnp_hip_free(op->d_offsets);
   qnnp_hip_free(op->d_phase_table);
   for (uint32_t i = 0; i < op->deconv_phases && i < QNNP_MAX_DECONV_PHASES; i++) {

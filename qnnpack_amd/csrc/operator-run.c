@@ -74,6 +74,8 @@ static int launch(struct qnnp_operator* op, const void* input, const void* input
         .dwm_x = (const int8_t*) op->d_dwm_x,
         .dwm_bias = op->d_dwm_bias,
         .dwm_parts = op->dwm_parts,
+        .w_range = op->dw_wrange,
+        .dot4 = (const uint32_t*) op->d_dw_dot4,
         .c_pad32 = op->c_pad32,
         .batch = (uint32_t) op->batch_size,
         .input_height = (uint32_t) op->input_height,

@@ -151,6 +151,51 @@ static inline void qnnp_pack_dwconv_w(
 }
 
 /*
+ * Range class of a depthwise weight image x = w - kzp (int16, as packed above) for the int8 dot-product flavour of the
+ * 3x3 column kernel: 1 = every x fits int8 as it is (kzp == 128 with full-range weights, i.e. what PyTorch's
+ * symmetric qint8 weights become), 2 = every -x does (kzp == 127, the zero point of the reference's benchmarks,
+ * bench/convolution.cc:71-74), 0 = neither (the int16 pair kernel serves those).
+ */
+static inline uint32_t qnnp_dwconv_weight_range(const int16_t* wadj, size_t count)
+{
+  int32_t lo = 0, hi = 0;
+  for (size_t i = 0; i < count; i++) {
+    const int32_t x = wadj[i];
+    if (x < lo) lo = x;
+    if (x > hi) hi = x;
+  }
+  if (lo >= -128 && hi <= 127) return 1;
+  if (lo >= -127 && hi <= 128) return 2;
+  return 0;
+}
+
+/*
+ * Third image, 3x3 depthwise operators whose range class is 1 or 2: the tap weights exactly as the int8 dot-product
+ * walk of the column kernel keeps them in registers -- image[r][c] = (x_r0, x_r1, x_r2, 0) as int8, x = w - kzp
+ * (class 1) or kzp - w (class 2) -- followed by image[3][c] = bias1[c] + (128 | 127) * sum_taps (w - kzp), the bias
+ * that goes with activations re-centred as a ^ 0x80 (= a - 128) or a ^ 0x7f (= 127 - a). Four 16-byte loads per
+ * thread instead of ten loads and ~100 unpacking instructions.
+ */
+static inline void qnnp_pack_dwconv_dot4(
+    uint32_t c_pad, uint32_t range, const int16_t* wadj /* [9][c_pad] */, const int32_t* bias1 /* [c_pad] */,
+    uint32_t* image /* [4][c_pad] */)
+{
+  for (uint32_t c = 0; c < c_pad; c++) {
+    uint32_t xsum = 0;
+    for (uint32_t r = 0; r < 3; r++) {
+      uint32_t q = 0;
+      for (uint32_t k = 0; k < 3; k++) {
+        const uint32_t x = (uint32_t) (int32_t) wadj[(size_t) (r * 3 + k) * c_pad + c];
+        xsum += x;
+        q |= ((range == 2 ? 0u - x : x) & 0xFFu) << (8 * k);
+      }
+      image[(size_t) r * c_pad + c] = q;
+    }
+    image[(size_t) 3 * c_pad + c] = (uint32_t) bias1[c] + (range == 2 ? 127u : 128u) * xsum;
+  }
+}
+
+/*
  * depthwise image for the MFMA kernel (q8dwconv.hip, kernel D): the signed tap weights
  *     x[t][c] = w[c][t] - kzp   in [-255, 255]
  * do not fit int8, so they are split into up to three int8 parts x = x0 + x1 + x2

@@ -2,7 +2,12 @@
 forced with "dwconv_kernel" = 6, against the scalar oracle: strides 1 and 2, every padding combination the
 reference's tests use (test/convolution.cc depthwise_3x3*), images smaller than a window, row segments (several
 waves walking one image), rows whose dword count is not a multiple of the wave width, pixel strides, batch, zero
-points, clamps, and every requantization flavour (shift 0, bounded / general shift >= 1, folded / late zero point)."""
+points, clamps, and every requantization flavour (shift 0, bounded / general shift >= 1, folded / late zero point).
+Stride 1 has two tap arithmetics chosen per operator from the weights' range (pack.h qnnp_dwconv_weight_range): the
+int8 dot-product walk when w - kzp (kzp = 128) or kzp - w (kzp = 127, the cases' default) fits int8, the int16 pair
+walk otherwise; every case runs under all three."""
+import dataclasses
+
 import numpy as np
 import pytest
 
@@ -58,22 +63,62 @@ def col(qnnp):
     qnnp.set_option("dwconv_kernel", 0)
 
 
+def _expected_name(case, kernel):
+    x = kernel.astype(np.int32) - case.kzp
+    fits = (x.min() >= -128 and x.max() <= 127) or (x.min() >= -127 and x.max() <= 128)
+    return "q8_dwconv_col_3x3_dot4" if fits and case.subsampling == (1, 1) else "q8_dwconv_col_3x3"
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
 def test_col_kernel_matches_oracle(col, case):
     inp, kernel, bias = conv_tensors(case)
     expected, quant, out_hw = conv_expected(case, inp, kernel, bias)
     out, kname = conv_run(col, case, quant, out_hw, inp, kernel, bias, to_device, from_device)
-    assert kname == "q8_dwconv_col_3x3", kname
+    assert kname == _expected_name(case, kernel), kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+STRIDE1 = [c for c in CASES if c.subsampling == (1, 1) and c.kzp == 127]
+
+
+@pytest.mark.parametrize("kzp", [128, 100], ids=lambda v: f"kzp{v}")
+@pytest.mark.parametrize("case", STRIDE1, ids=lambda c: c.name)
+def test_col_kernel_other_weight_ranges(col, case, kzp):
+    """kzp 128: w - kzp fits int8 as it is (dot-product walk, plain weights); kzp 100: neither sign fits (pair walk)"""
+    case = dataclasses.replace(case, kzp=kzp)
+    inp, kernel, bias = conv_tensors(case)
+    kernel[0, 0, 0, 0, 0], kernel[-1, 0, 2, 2, 0] = 0, 255          # the full range, whatever the seed drew
+    expected, quant, out_hw = conv_expected(case, inp, kernel, bias)
+    out, kname = conv_run(col, case, quant, out_hw, inp, kernel, bias, to_device, from_device)
+    assert kname == ("q8_dwconv_col_3x3_dot4" if kzp == 128 else "q8_dwconv_col_3x3"), kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}, kzp {kzp}]")
+
+
+@pytest.mark.parametrize("lo,hi,kzp,name", [
+    (40, 200, 100, "q8_dwconv_col_3x3_dot4"),      # x in [-60, 100]
+    (0, 129, 1, "q8_dwconv_col_3x3_dot4"),         # x in [-1, 128]: only the negated weights fit
+    (0, 130, 1, "q8_dwconv_col_3x3"),              # x up to 129: neither
+    (3, 3, 3, "q8_dwconv_col_3x3_dot4"),           # all-zero x
+])
+def test_col_kernel_flavour_follows_the_weights(col, lo, hi, kzp, name):
+    case = dataclasses.replace(_dw("g_range", (17, 15), 40, batch=2), kzp=kzp)
+    inp, kernel, bias = conv_tensors(case)
+    kernel = (lo + kernel.astype(np.int32) % (hi - lo + 1)).astype(np.uint8)
+    kernel[0, 0, 0, 0, 0], kernel[-1, 0, 2, 2, 0] = lo, hi
+    expected, quant, out_hw = conv_expected(case, inp, kernel, bias)
+    out, kname = conv_run(col, case, quant, out_hw, inp, kernel, bias, to_device, from_device)
+    assert kname == name, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [weights {lo}..{hi}, kzp {kzp}]")
 
 
 @pytest.mark.parametrize("scale,zp,qmin,qmax", [
     (0.5, 127, 0, 255), (0.75, 3, 0, 255), (0.0125, 127, 0, 255), (0.0125, 0, 10, 240), (2.0 ** -9, 255, 0, 255),
     (0.3, 128, 128, 255), (float.fromhex("0x1.FFFFFEp-1"), 200, 0, 255), (2.0 ** -24, 17, 0, 255)],
     ids=lambda v: str(v))
-def test_col_kernel_requantization_flavours(col, scale, zp, qmin, qmax):
-    """the fused epilogue is chosen per operator (requant_dispatch): drive each branch through this kernel"""
-    case = _dw("g_rq", (19, 18), 48, batch=2)
+@pytest.mark.parametrize("kzp", [127, 77], ids=lambda v: f"kzp{v}")
+def test_col_kernel_requantization_flavours(col, scale, zp, qmin, qmax, kzp):
+    """the fused epilogue is chosen per operator (requant_dispatch): drive each branch through both walks"""
+    case = dataclasses.replace(_dw("g_rq", (19, 18), 48, batch=2), kzp=kzp)
     inp, kernel, bias = conv_tensors(case)
     shape = o1.conv_shape(case.batch, 19, 18, case.padding, (3, 3), (1, 1), (1, 1), 48, 1, 1, 48)
     acc = o1.conv2d_acc(shape, inp, kernel, bias, case.izp, case.kzp)
@@ -84,8 +129,8 @@ def test_col_kernel_requantization_flavours(col, scale, zp, qmin, qmax):
         d_in, d_out = to_device(inp), to_device(np.full(expected.size, FILL, np.uint8))
         col.setup_convolution2d_nhwc_q8(op, case.batch, 19, 18, d_in, 48, d_out, 48)
         col.run_operator(op)
-        assert col.operator_kernel(op) == "q8_dwconv_col_3x3"
-        assert_bytes_equal(from_device(d_out), expected, f"col kernel, requantization scale {scale} zp {zp} [{qmin}, {qmax}]")
+        assert col.operator_kernel(op) == _expected_name(case, kernel)
+        assert_bytes_equal(from_device(d_out), expected, f"col kernel (kzp {kzp}), requantization scale {scale} zp {zp} [{qmin}, {qmax}]")
     finally:
         col.delete_operator(op)
 

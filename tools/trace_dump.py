@@ -65,3 +65,11 @@ for item in range(4):
 first = t[:, 0, 0]; last = t[:, :, 5].max(axis=1)
 ok = first > 0
 print("span first-start..last-end (cycles): min start", int(first[ok].min()), " max end", int(last[ok].max()), " span", int(last[ok].max() - first[ok].min()))
+w = t[:, 3, :2] * 10   # ns (100 MHz wall clock), kernel G: item 3 = [start, end] of wave 0 of each workgroup
+okw = w[:, 0] > 0
+if okw.sum():
+    w = w[okw]; base = w[:, 0].min()
+    life = w[:, 1] - w[:, 0]
+    print(f"wall: {okw.sum()} workgroups; starts 0..{int(w[:,0].max()-base)} ns (median {int(np.median(w[:,0])-base)}); ends {int(w[:,1].min()-base)}..{int(w[:,1].max()-base)} ns; "
+          f"lifetime min/median/max {int(life.min())}/{int(np.median(life))}/{int(life.max())} ns")
+    cyc = (t[okw][:, 0, 5] - t[okw][:, 0, 0]); print("shader clock during the kernel: %.2f GHz" % (cyc.mean() / life.mean()))
