@@ -42,6 +42,18 @@ uint32_t qnnp_debug_pack_dwconv_mfma(
   return qnnp_pack_dwconv_mfma(channels, c_pad32, kh, kw, izp, kzp, kernel, bias, xparts, biasm);
 }
 
+/* range class of the depthwise weights (0 / 1 / 2) and, for classes 1 and 2, the register image of the int8
+ * dot-product walk of the 3x3 column kernel (pack.h); `image` holds 4 * c_pad words */
+uint32_t qnnp_debug_pack_dwconv_dot4(
+    uint32_t channels, uint32_t c_pad, uint8_t izp, uint8_t kzp, const uint8_t* kernel, const int32_t* bias,
+    int16_t* wadj /* [9][c_pad] scratch */, int32_t* bias1 /* [c_pad] scratch */, uint32_t* image)
+{
+  qnnp_pack_dwconv_w(channels, c_pad, 3, 3, izp, kzp, kernel, bias, wadj, bias1);
+  const uint32_t range = qnnp_dwconv_weight_range(wadj, (size_t) 9 * c_pad);
+  if (range != 0) qnnp_pack_dwconv_dot4(c_pad, range, wadj, bias1, image);
+  return range;
+}
+
 void qnnp_debug_conv2d_offsets(
     size_t input_height, size_t input_width, size_t input_pixel_stride,
     size_t output_height, size_t output_width,

@@ -246,3 +246,44 @@ def test_depthwise_matrix_core_weight_parts(debug_hooks, izp, kzp):
     lhs = (biasm[:C].astype(np.int64) + ((a - 128) * x).sum(axis=0)) & 0xFFFFFFFF
     rhs = (bias.astype(np.int64) + ((a - izp) * x).sum(axis=0)) & 0xFFFFFFFF
     assert np.array_equal(lhs, rhs)
+
+
+@pytest.mark.parametrize("izp,kzp,lo,hi,expect", [
+    (127, 127, 0, 255, 2), (3, 128, 0, 255, 1), (255, 100, 40, 200, 1), (0, 1, 0, 129, 2), (9, 1, 0, 130, 0),
+    (127, 126, 0, 255, 0), (127, 129, 0, 255, 0), (200, 77, 77, 77, 1)])
+def test_depthwise_dot4_register_image(debug_hooks, izp, kzp, lo, hi, expect):
+    """qnnp_dwconv_weight_range / qnnp_pack_dwconv_dot4 (pack.h): the class is 1 when every w - kzp fits int8, 2 when
+    every kzp - w does, else 0; for classes 1 / 2 the image makes
+        image[3][c] + sum_rows dot4(int8(a ^ kx), image[r][c])  ==  bias + sum_t (a_t - izp) * (w_t - kzp)
+    with kx = 0x80 (class 1) or 0x7f (class 2), for every activation -- the identity the kernel's walk relies on."""
+    import ctypes
+    L = debug_hooks.lib
+    fn = L.qnnp_debug_pack_dwconv_dot4
+    fn.restype = ctypes.c_uint32
+    fn.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint8, ctypes.c_uint8] + [ctypes.c_void_p] * 5
+    rng = np.random.default_rng(izp * 256 + kzp + hi)
+    C, c_pad = 24, 32
+    kernel = rng.integers(lo, hi + 1, size=(C, 9)).astype(np.uint8)
+    kernel[0, 0], kernel[C - 1, 8] = lo, hi
+    bias = rng.integers(-2**31, 2**31, size=C).astype(np.int32)
+    wadj = np.empty(9 * c_pad, np.int16); bias1 = np.empty(c_pad, np.int32)
+    image = np.full(4 * c_pad, 0x5A5A5A5A, np.uint32)
+    got = fn(C, c_pad, izp, kzp, kernel.ctypes.data, bias.ctypes.data, wadj.ctypes.data, bias1.ctypes.data, image.ctypes.data)
+    assert got == expect
+    if expect == 0:
+        assert (image == 0x5A5A5A5A).all()
+        return
+    image = image.reshape(4, c_pad)
+    w8 = image[:3].view(np.int8).reshape(3, c_pad, 4).astype(np.int64)       # [row][channel][col0, col1, col2, 0]
+    assert not w8[:, :, 3].any()
+    assert not image[:3, C:].any(), "padding channels multiply to zero"
+    x = kernel.astype(np.int64) - kzp
+    sign = 1 if expect == 1 else -1
+    assert np.array_equal(w8[:, :C, :3].transpose(1, 0, 2).reshape(C, 9), sign * x)
+    a = rng.integers(0, 256, size=(C, 9), dtype=np.uint8)
+    a[0], a[1] = 0, 255
+    kx = 0x80 if expect == 1 else 0x7F
+    a8 = (a ^ kx).view(np.int8).astype(np.int64)
+    lhs = (image[3, :C].astype(np.int64) + (a8 * (sign * x)).sum(axis=1)) & 0xFFFFFFFF
+    rhs = (bias.astype(np.int64) + ((a.astype(np.int64) - izp) * x).sum(axis=1)) & 0xFFFFFFFF
+    assert np.array_equal(lhs, rhs)
