@@ -23,3 +23,5 @@ for f in $(find $OUT/prof_all -name "*kernel_stats*.csv" | head -1); do cut -c1-
 echo "== PMC: HBM-side traffic of one depthwise layer (MobileNetV2 layer 8, 56x56x144) and of the pointwise layer 4"
 bash scripts/gpu_pmc_layer2.sh $TAG dw8_traffic 8 TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum
 bash scripts/gpu_pmc_layer2.sh $TAG pw4_traffic 4 TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum
+echo "== PMC: VALU instruction count and activity of the depthwise layer 8 kernel"
+bash scripts/gpu_pmc_layer2.sh $TAG dw8_valu 8 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_ANY | tee $OUT/pmc_dw8_valu.txt
