@@ -460,7 +460,7 @@ void q8_conv_wave_mfma_kernel(const IgemmParams p, const ConvGeom g, const WaveA
           uint32_t pk[4];
 #pragma unroll
           for (int rg = 0; rg < 4; rg++) {
-            pk[rg] = q31_requantize_pack4<decltype(shift0)::value, decltype(full)::value>(
+            pk[rg] = q31_requantize_pack4<decltype(shift0)::value, decltype(full)::value, false>(
                 add_wrap(acc[j][tn][rg * 4 + 0], rowterm), add_wrap(acc[j][tn][rg * 4 + 1], rowterm),
                 add_wrap(acc[j][tn][rg * 4 + 2], rowterm), add_wrap(acc[j][tn][rg * 4 + 3], rowterm), p.rq);
           }
@@ -792,7 +792,7 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
         uint32_t pk[4];
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
-          pk[rg] = q31_requantize_pack4<SEQ, FULL>(
+          pk[rg] = q31_requantize_pack4<SEQ, FULL, false>(
               add_wrap(acc[j][tn][rg * 4 + 0], rowterm), add_wrap(acc[j][tn][rg * 4 + 1], rowterm),
               add_wrap(acc[j][tn][rg * 4 + 2], rowterm), add_wrap(acc[j][tn][rg * 4 + 3], rowterm), p.rq);
         }

@@ -114,17 +114,41 @@ __device__ __forceinline__ int32_t with_rq_offset(int32_t x)
   return static_cast<int32_t>(static_cast<uint32_t>(x) + rq_offset<SEQ>());
 }
 
-template <int SHIFT0, bool FULL_RANGE>
+/* hi32(np * multiplier + addend) of the offset forms (requant_math.h qnnp_requant_scale_s0_ofs). A VOP3 instruction
+ * reads ONE scalar operand on gfx9, and with both constants in SGPRs hipcc keeps the multiplier there and re-copies
+ * the 64-bit addend into a VGPR pair in front of every v_mad_u64_u32 (16 v_mov_b64 per 32x32 output tile and lane in
+ * the streaming kernels). The callers therefore hand the multiplier over in a VGPR (`mult_v`: made by an opaque asm,
+ * so it is neither rematerialised nor moved back), which leaves the addend as the scalar operand. */
+__device__ __forceinline__ uint32_t requant_mad_hi(uint32_t np, uint32_t mult_v, uint64_t addend)
+{
+  return static_cast<uint32_t>((static_cast<uint64_t>(np) * mult_v + addend) >> 32);
+}
+
+/* VMULT = false: leave the operand placement to the compiler (the wave-per-block 3x3 convolution measured 25.3 -> 26.6
+ * us with the multiplier pinned to a VGPR, the streaming kernels gain: sweep +1 %, same box) */
+template <int SHIFT0, bool FULL_RANGE, bool VMULT = true>
 __device__ __forceinline__ uint32_t q31_requantize_pack4(
     int32_t n0, int32_t n1, int32_t n2, int32_t n3, const RequantDev& rq)
 {
   int32_t y0, y1, y2, y3;
-  if constexpr (SHIFT0 == kRqShift0Ofs) {
-    y0 = qnnp_requant_scale_s0_ofs(n0, rq.f); y1 = qnnp_requant_scale_s0_ofs(n1, rq.f);
-    y2 = qnnp_requant_scale_s0_ofs(n2, rq.f); y3 = qnnp_requant_scale_s0_ofs(n3, rq.f);
-  } else if constexpr (SHIFT0 == kRqBoundedOfs) {
-    y0 = qnnp_requant_scale_sn_bounded_ofs(n0, rq.f); y1 = qnnp_requant_scale_sn_bounded_ofs(n1, rq.f);
-    y2 = qnnp_requant_scale_sn_bounded_ofs(n2, rq.f); y3 = qnnp_requant_scale_sn_bounded_ofs(n3, rq.f);
+  if constexpr (SHIFT0 == kRqShift0Ofs || SHIFT0 == kRqBoundedOfs) {
+    uint32_t mult_v = rq.f.ofs_multiplier;
+    if constexpr (VMULT) asm("" : "+v"(mult_v));
+    const uint64_t addend = rq.f.ofs_addend;
+    const uint32_t r0 = requant_mad_hi(static_cast<uint32_t>(n0), mult_v, addend);
+    const uint32_t r1 = requant_mad_hi(static_cast<uint32_t>(n1), mult_v, addend);
+    const uint32_t r2 = requant_mad_hi(static_cast<uint32_t>(n2), mult_v, addend);
+    const uint32_t r3 = requant_mad_hi(static_cast<uint32_t>(n3), mult_v, addend);
+    if constexpr (SHIFT0 == kRqShift0Ofs) {
+      y0 = static_cast<int32_t>(r0); y1 = static_cast<int32_t>(r1); y2 = static_cast<int32_t>(r2); y3 = static_cast<int32_t>(r3);
+    } else {
+      // (qnnp_requant_scale_sn_bounded_ofs: the sign of n rides in bit 31 of np)
+      const uint32_t sh = rq.f.shift;
+      y0 = qnnp_asr32(static_cast<int32_t>(r0 + (static_cast<uint32_t>(n0) >> 31)), sh);
+      y1 = qnnp_asr32(static_cast<int32_t>(r1 + (static_cast<uint32_t>(n1) >> 31)), sh);
+      y2 = qnnp_asr32(static_cast<int32_t>(r2 + (static_cast<uint32_t>(n2) >> 31)), sh);
+      y3 = qnnp_asr32(static_cast<int32_t>(r3 + (static_cast<uint32_t>(n3) >> 31)), sh);
+    }
   } else if constexpr (SHIFT0 == kRqShift0) {
     y0 = qnnp_requant_scale_s0(n0, rq.f); y1 = qnnp_requant_scale_s0(n1, rq.f);
     y2 = qnnp_requant_scale_s0(n2, rq.f); y3 = qnnp_requant_scale_s0(n3, rq.f);
