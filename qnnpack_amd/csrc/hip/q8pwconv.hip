@@ -172,19 +172,11 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
 
       // accumulators start at bias + row term (the MFMA adds into them): two VALU adds per value saved
       int4 bias4[4];
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[rg * 2 + khalf];
       auto multiply = [&](uint32_t nb, v16i& acc) __attribute__((always_inline)) {
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
-          acc[rg * 4 + 0] = add_wrap(bias4[rg].x, rowterm);
-          acc[rg * 4 + 1] = add_wrap(bias4[rg].y, rowterm);
-          acc[rg * 4 + 2] = add_wrap(bias4[rg].z, rowterm);
-          acc[rg * 4 + 3] = add_wrap(bias4[rg].w, rowterm);
-        }
-        if (nb + 1 < nblocks) {
-#pragma unroll
-          for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[(nb + 1) * 8 + rg * 2 + khalf];
+          acc[rg * 4 + 0] = bias4[rg].x; acc[rg * 4 + 1] = bias4[rg].y;
+          acc[rg * 4 + 2] = bias4[rg].z; acc[rg * 4 + 3] = bias4[rg].w;
         }
         const uint8_t* wf = lds_w + nb * (KB * 1024);
 #pragma unroll
@@ -206,6 +198,9 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
 #endif
       for (uint32_t nb = 0; nb < nblocks; nb++) {
         v16i acc;
+        // (read per block, beside the weight fragment: carried over from the previous trip it cost 16 v_mov_b64 per block)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[nb * 8 + rg * 2 + khalf];
 #ifdef QNNP_ENABLE_ABLATION
         if (p.izp_fill & 2u) {                            // measurement: stores only (no multiply, no requantization)
           const uint32_t c = nb * 32 + khalf * 16;
@@ -219,12 +214,12 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
           const uint32_t py = phase / p.d2s_sw;
           const uint32_t px = phase - py * p.d2s_sw;
           uint8_t* phase_row = out_row + (static_cast<uint64_t>(py) * (p.d2s_in_w * p.d2s_sw) + px) * p.output_stride;
-          igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, true>(
-              acc, bias4, 0, phase_row, (nb - phase * p.d2s_nbpp) * 32, khalf, row_ok, p);
+          igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 2>(
+              acc, bias4, rowterm, phase_row, (nb - phase * p.d2s_nbpp) * 32, khalf, row_ok, p);
           continue;
         }
-        igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, true>(
-            acc, bias4, 0, out_row, nb * 32, khalf, row_ok, p);
+        igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 2>(
+            acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p);
       }
     }
   });
@@ -402,22 +397,17 @@ void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const u
       load_rows(min(next, units - 1u), raw);              // always issued (the last one of a wave is wasted)
       // (+ 2^31 for the offset rounding sequences, requant.hip.h: the accumulators start from bias + this)
       const int32_t rowterm = with_rq_offset<decltype(shift0)::value>(p.row_coeff * static_cast<int32_t>(rs - raw_to_centred));
-      int4 bias4[4];
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[rg * 2 + khalf];
       uint8_t* img = stage + row_in_block * pitch;
       for (uint32_t nb = 0; nb < nbn; nb++) {
         v16i acc;
+        // (read per block, beside the weight fragment: carried over from the previous trip it cost 16 v_mov_b64 per block)
+        int4 bias4[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[nb * 8 + rg * 2 + khalf];
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
-          acc[rg * 4 + 0] = add_wrap(bias4[rg].x, rowterm);
-          acc[rg * 4 + 1] = add_wrap(bias4[rg].y, rowterm);
-          acc[rg * 4 + 2] = add_wrap(bias4[rg].z, rowterm);
-          acc[rg * 4 + 3] = add_wrap(bias4[rg].w, rowterm);
-        }
-        if (nb + 1 < nbn) {
-#pragma unroll
-          for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[(nb + 1) * 8 + rg * 2 + khalf];
+          acc[rg * 4 + 0] = bias4[rg].x; acc[rg * 4 + 1] = bias4[rg].y;
+          acc[rg * 4 + 2] = bias4[rg].z; acc[rg * 4 + 3] = bias4[rg].w;
         }
         const uint8_t* wf = lds_w + nb * (KB * 1024);
 #pragma unroll
@@ -426,8 +416,8 @@ void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const u
           acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a[kb], acc, 0, 0, 0);
         }
         // (every lane takes part in the half-wave exchange inside; a lane's 16 channels exist or not)
-        igemm_stage_tile<decltype(shift0)::value, decltype(full)::value, false, true>(
-            acc, bias4, 0, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < cw);
+        igemm_stage_tile<decltype(shift0)::value, decltype(full)::value, false, 2>(
+            acc, bias4, rowterm, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < cw);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
       // the next unit's rows: first use here, so the wait for them lands before this unit's stores
@@ -550,22 +540,17 @@ void q8_pw_stream_longk_kernel(const IgemmParams p, const uint32_t nbp, const ui
   for (;;) {
     const uint32_t rs = recentre(a);
     const int32_t rowterm = with_rq_offset<SEQ>(p.row_coeff * static_cast<int32_t>(rs - raw_to_centred));
-    int4 bias4[4];
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[rg * 2 + khalf];
     uint8_t* img = stage + row_in_block * pitch;
     for (uint32_t nb = 0; nb < nbn; nb++) {
       v16i acc;
+      // (read per block, beside the weight fragment: carried over from the previous trip it cost 16 v_mov_b64 per block)
+      int4 bias4[4];
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[nb * 8 + rg * 2 + khalf];
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
-        acc[rg * 4 + 0] = add_wrap(bias4[rg].x, rowterm);
-        acc[rg * 4 + 1] = add_wrap(bias4[rg].y, rowterm);
-        acc[rg * 4 + 2] = add_wrap(bias4[rg].z, rowterm);
-        acc[rg * 4 + 3] = add_wrap(bias4[rg].w, rowterm);
-      }
-      if (nb + 1 < nbn) {
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[(nb + 1) * 8 + rg * 2 + khalf];
+        acc[rg * 4 + 0] = bias4[rg].x; acc[rg * 4 + 1] = bias4[rg].y;
+        acc[rg * 4 + 2] = bias4[rg].z; acc[rg * 4 + 3] = bias4[rg].w;
       }
       const uint8_t* wf = lds_w + nb * (kbn * 1024);
 #pragma unroll
@@ -575,7 +560,7 @@ void q8_pw_stream_longk_kernel(const IgemmParams p, const uint32_t nbp, const ui
           acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a[kb], acc, 0, 0, 0);
         }
       }
-      igemm_stage_tile<SEQ, FULL, false, true>(acc, bias4, 0, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < cw);
+      igemm_stage_tile<SEQ, FULL, false, 2>(acc, bias4, rowterm, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < cw);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
     stream_copy_out(stage, whole_dense, log_cpr, unit, c0, cw, p, lane);
@@ -905,21 +890,16 @@ void q8_conv_stream_c3_kernel(const IgemmParams p)
       const uint32_t m = unit * 32u + row_in_block;
       uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride;
       const bool row_ok = m < p.rows;
-      int4 bias4[4];
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[rg * 2 + khalf];
       for (uint32_t nb = 0; nb < nblocks; nb++) {
         v16i acc;
+        // (read per block, beside the weight fragment: carried over from the previous trip it cost 16 v_mov_b64 per block)
+        int4 bias4[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[nb * 8 + rg * 2 + khalf];
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
-          acc[rg * 4 + 0] = add_wrap(bias4[rg].x, rowterm);
-          acc[rg * 4 + 1] = add_wrap(bias4[rg].y, rowterm);
-          acc[rg * 4 + 2] = add_wrap(bias4[rg].z, rowterm);
-          acc[rg * 4 + 3] = add_wrap(bias4[rg].w, rowterm);
-        }
-        if (nb + 1 < nblocks) {
-#pragma unroll
-          for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[(nb + 1) * 8 + rg * 2 + khalf];
+          acc[rg * 4 + 0] = bias4[rg].x; acc[rg * 4 + 1] = bias4[rg].y;
+          acc[rg * 4 + 2] = bias4[rg].z; acc[rg * 4 + 3] = bias4[rg].w;
         }
         const uint8_t* wf = lds_w + nb * (KB * 1024);
 #pragma unroll
@@ -927,8 +907,8 @@ void q8_conv_stream_c3_kernel(const IgemmParams p)
           const v4i w = *reinterpret_cast<const v4i*>(wf + kb * 1024);
           acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a[kb], acc, 0, 0, 0);
         }
-        igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, true>(
-            acc, bias4, 0, out_row, nb * 32, khalf, row_ok, p);
+        igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 2>(
+            acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p);
       }
     }
   });
@@ -1091,22 +1071,17 @@ void q8_conv_stream_c3s_kernel(const IgemmParams p, const uint32_t log_cpr)
       load_offsets(min(next + unit_stride, last), t_after);
 
       const int32_t rowterm = with_rq_offset<decltype(shift0)::value>(p.row_coeff * static_cast<int32_t>(rs - raw_to_centred));
-      int4 bias4[4];
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[rg * 2 + khalf];
       uint8_t* img = stage + row_in_block * pitch;
       for (uint32_t nb = 0; nb < nblocks; nb++) {
         v16i acc;
+        // (read per block, beside the weight fragment: carried over from the previous trip it cost 16 v_mov_b64 per block)
+        int4 bias4[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[nb * 8 + rg * 2 + khalf];
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
-          acc[rg * 4 + 0] = add_wrap(bias4[rg].x, rowterm);
-          acc[rg * 4 + 1] = add_wrap(bias4[rg].y, rowterm);
-          acc[rg * 4 + 2] = add_wrap(bias4[rg].z, rowterm);
-          acc[rg * 4 + 3] = add_wrap(bias4[rg].w, rowterm);
-        }
-        if (nb + 1 < nblocks) {
-#pragma unroll
-          for (int rg = 0; rg < 4; rg++) bias4[rg] = lds_bias4[(nb + 1) * 8 + rg * 2 + khalf];
+          acc[rg * 4 + 0] = bias4[rg].x; acc[rg * 4 + 1] = bias4[rg].y;
+          acc[rg * 4 + 2] = bias4[rg].z; acc[rg * 4 + 3] = bias4[rg].w;
         }
         const uint8_t* wf = lds_w + nb * (KB * 1024);
 #pragma unroll
@@ -1114,8 +1089,8 @@ void q8_conv_stream_c3s_kernel(const IgemmParams p, const uint32_t log_cpr)
           const v4i w = *reinterpret_cast<const v4i*>(wf + kb * 1024);
           acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a[kb], acc, 0, 0, 0);
         }
-        igemm_stage_tile<decltype(shift0)::value, decltype(full)::value, false, true>(
-            acc, bias4, 0, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < p.n);
+        igemm_stage_tile<decltype(shift0)::value, decltype(full)::value, false, 2>(
+            acc, bias4, rowterm, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < p.n);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
       __builtin_amdgcn_sched_barrier(0);
