@@ -276,7 +276,9 @@ __device__ __forceinline__ void stream_copy_out(
  *     path-dependent and costs the same vmcnt(0).
  */
 /* resident workgroups per CU (= waves per SIMD) the staged kernel is compiled for, i.e. what its register need
- * allows (72 / 80 / 90 / 96 / 104 / 114 / 124 / 134 VGPRs for 1..8 K blocks, per requantization flavour). A wave of
+ * allows (54 / 66 / 74 / 79 / 88 / 98 / 107 / 118 VGPRs for 1..8 K blocks, per requantization flavour, since the bias
+ * is no longer carried from block to block; 72 ... 134 before -- one more resident wave per SIMD, which the
+ * registers would now allow, measured level or slightly behind: layer 3 17.2 -> 17.7 us, layer 21 9.9 -> 10.7). A wave of
  * this kernel spends most of a unit's time waiting -- the next rows, the previous unit's store acknowledgements --
  * and residency is what hides that. */
 constexpr int staged_waves(int kb) { return kb <= 1 ? 7 : (kb == 2 ? 6 : (kb <= 4 ? 5 : (kb <= 7 ? 4 : 3))); }
