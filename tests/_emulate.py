@@ -206,3 +206,56 @@ def emulate_dwconv(L, case, inp, kernel, bias, rq, oh, ow, fill=0xA5):
                 m = (n * oh + oy) * ow + ox
                 out[m * case.out_stride: m * case.out_stride + C] = q31_requantize_np(wrap32(acc), rq)
     return out
+
+
+def emulate_dwconv_dot4(L, case, inp, kernel, bias, rq, oh, ow, fill=0xA5):
+    """Replay of the int8 dot-product walk of the 3x3 stride-1 column kernel (q8dwconv.hip, QUAD flavour) from the HOST
+    image it consumes (pack.h qnnp_pack_dwconv_dot4): per input row the quad T = (col0, col1, col2, 0) of bytes
+    re-centred with kx (padding pixels read the input zero point and are re-centred like any other), an output is
+    image[3] + T[t] . W4[0] + T[t+1] . W4[1] + T[t+2] . W4[2] in int8 x int8 products. Returns None when the weights'
+    range class is 0 (the kernel then takes the int16 pair walk)."""
+    import ctypes
+    C = case.groups
+    assert case.kernel_size == (3, 3) and case.subsampling == (1, 1) and case.dilation == (1, 1)
+    c_pad = round_up(C, 16)
+    kernel = np.ascontiguousarray(kernel.reshape(C, 9), dtype=np.uint8)
+    bias = np.ascontiguousarray(bias, dtype=np.int32)
+    wadj = np.empty(9 * c_pad, dtype=np.int16)
+    bias1 = np.empty(c_pad, dtype=np.int32)
+    image = np.zeros(4 * c_pad, dtype=np.uint32)
+    fn = L.qnnp_debug_pack_dwconv_dot4
+    fn.restype = ctypes.c_uint32
+    fn.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint8, ctypes.c_uint8] + [ctypes.c_void_p] * 5
+    rng_class = fn(C, c_pad, case.izp, case.kzp, kernel.ctypes.data, bias.ctypes.data, wadj.ctypes.data,
+                   bias1.ctypes.data, image.ctypes.data)
+    if rng_class == 0:
+        return None
+    image = image.reshape(4, c_pad)
+    w4 = image[:3].view(np.int8).reshape(3, c_pad, 4).astype(np.int64)[:, :C, :]      # [row][channel][col]
+    bias4 = image[3, :C].astype(np.int64)
+    kx = 0x80 if rng_class == 1 else 0x7F
+    H, W = case.input_size
+    rows = case.batch * oh * ow
+    out = np.full((rows - 1) * case.out_stride + C, fill, dtype=np.uint8)
+    ch = np.arange(C)
+
+    def quad(n, iy, ox):            # [channel][4] int8 values of input row iy, columns ox - pad_left .. + 2, and a zero
+        t = np.zeros((C, 4), dtype=np.int64)
+        for k in range(3):
+            ix = ox + k - case.padding[3]
+            if 0 <= iy < H and 0 <= ix < W:
+                a = inp[((n * H + iy) * W + ix) * case.in_stride + ch]
+            else:
+                a = np.full(C, case.izp, dtype=np.uint8)
+            t[:, k] = (a ^ kx).astype(np.uint8).view(np.int8)
+        return t
+
+    for n in range(case.batch):
+        for ox in range(ow):
+            for oy in range(oh):
+                acc = bias4.copy()
+                for r in range(3):
+                    acc += (quad(n, oy + r - case.padding[0], ox) * w4[r]).sum(axis=1)
+                m = (n * oh + oy) * ow + ox
+                out[m * case.out_stride: m * case.out_stride + C] = q31_requantize_np(wrap32(acc), rq)
+    return out

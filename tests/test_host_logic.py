@@ -287,3 +287,24 @@ def test_depthwise_dot4_register_image(debug_hooks, izp, kzp, lo, hi, expect):
     lhs = (image[3, :C].astype(np.int64) + (a8 * (sign * x)).sum(axis=1)) & 0xFFFFFFFF
     rhs = (bias.astype(np.int64) + ((a.astype(np.int64) - izp) * x).sum(axis=1)) & 0xFFFFFFFF
     assert np.array_equal(lhs, rhs)
+
+
+@pytest.mark.parametrize("kzp", [127, 128, 100])
+@pytest.mark.parametrize("shape", [((6, 7), 8, (1, 1, 1, 1)), ((5, 5), 20, (0, 0, 0, 0)), ((4, 9), 12, (2, 1, 0, 2))],
+                         ids=["6x7c8", "5x5c20_nopad", "4x9c12_asym"])
+def test_depthwise_dot4_walk_replay(hooks, shape, kzp):
+    """the arithmetic of the int8 dot-product depthwise walk, replayed from the host image, equals the oracle --
+    padding rows and columns included; kzp 100 with full-range weights has no int8 form and must say so"""
+    import dataclasses
+    from _cases import ConvCase
+    (hw, c, padding) = shape
+    case = ConvCase(f"dot4_{hw[0]}x{hw[1]}_c{c}_k{kzp}", hw, (3, 3), padding, groups=c, gic=1, goc=1, batch=2, izp=93, kzp=kzp)
+    inp, kernel, bias = conv_tensors(case)
+    kernel[0, 0, 0, 0, 0], kernel[-1, 0, 2, 2, 0] = 0, 255
+    expected, (oscale, ozp), (oh, ow) = conv_expected(case, inp, kernel, bias)
+    rq = em.host_requant(hooks, np.float32(1.0) / oscale, ozp, case.qmin, case.qmax)
+    out = em.emulate_dwconv_dot4(hooks, case, inp, kernel, bias, rq, oh, ow)
+    if kzp == 100:
+        assert out is None
+    else:
+        assert_bytes_equal(out, expected, f"dot-product walk replay vs oracle [{case.name}]")
