@@ -1044,7 +1044,10 @@ bool plan_col(DwParams& p)
   const uint64_t waves_per_seg = static_cast<uint64_t>(p.batch) * chunks;
   // (measured on the MobileNetV2 layers, batch 128: 1.3-2 rounds of waves beat 3-4 -- 35.6 against 39.6 us on
   //  layer 8 -- now that the rows in flight are really in flight; shorter segments only add start-ups and halo rows)
-  // resident waves: 6 per SIMD for the stride-2 kernel (79 VGPRs), 5 for the stride-1 one (four rows in flight: 82)
+  // wave slots the segment count is sized for: 6 per SIMD at stride 2, 5 at stride 1 (what the 79- and 82-VGPR kernels
+  // of the time allowed; today's 70-72 VGPRs would admit 7, but a rows-per-segment sweep of the present kernels --
+  // QNNP_GFX950_DW_COL_ROWS, same box -- found this choice at or within 3 % of the best on all ten MobileNetV2 layers:
+  // more, shorter segments pay the ~8k-cycle start-up of a wave again)
   const uint64_t slots = static_cast<uint64_t>(p.cu_count) * 4u * (p.sw == 1 ? 5u : 6u);
   const uint64_t target = slots * 3u / 2u;                                         // ~1.5 rounds
   uint32_t segs = static_cast<uint32_t>((target + waves_per_seg - 1) / waves_per_seg);
