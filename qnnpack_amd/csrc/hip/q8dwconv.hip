@@ -969,7 +969,12 @@ void q8_dwconv_col3x3_kernel(const DwParams p)
   const uint32_t lane = threadIdx.x & 63u;
   QNNP_DW_TRACE(p, 0);
 #ifdef QNNP_ENABLE_ABLATION
-  if (p.trace != nullptr && threadIdx.x == 0 && blockIdx.x < 4096) p.trace[(blockIdx.x * 4 + 3) * 8 + 0] = wall_clock64();
+  if (p.trace != nullptr && threadIdx.x == 0 && blockIdx.x < 4096) {
+    p.trace[(blockIdx.x * 4 + 3) * 8 + 0] = wall_clock64();
+    // where the workgroup's wave 0 runs: HW_REG_HW_ID (wave 3:0, SIMD 5:4, CU 11:8, SH 12, SE 15:13) and HW_REG_XCC_ID
+    p.trace[(blockIdx.x * 4 + 2) * 8 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    p.trace[(blockIdx.x * 4 + 2) * 8 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
 #endif
   // Workgroup b runs on XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup dispatch"; a speed assumption only). For
   // tensors that more or less live in the caches (launch_col: <= 96 MiB in + out) every XCD takes a CONTIGUOUS range of

@@ -73,3 +73,22 @@ if okw.sum():
     print(f"wall: {okw.sum()} workgroups; starts 0..{int(w[:,0].max()-base)} ns (median {int(np.median(w[:,0])-base)}); ends {int(w[:,1].min()-base)}..{int(w[:,1].max()-base)} ns; "
           f"lifetime min/median/max {int(life.min())}/{int(np.median(life))}/{int(life.max())} ns")
     cyc = (t[okw][:, 0, 5] - t[okw][:, 0, 0]); print("shader clock during the kernel: %.2f GHz" % (cyc.mean() / life.mean()))
+    hw = t[okw][:, 2, 0]; xcc = t[okw][:, 2, 1] & 0xF
+    if hw.any():
+        import collections
+        cu_key = (xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xF)      # (XCC, SE, SH, CU)
+        per_cu = collections.Counter(cu_key.tolist())
+        hist = collections.Counter(per_cu.values())
+        print("workgroups per CU -> number of CUs:", dict(sorted(hist.items())), " distinct CUs:", len(per_cu))
+        n_on_cu = np.array([per_cu[k] for k in cu_key.tolist()])
+        for k in sorted(hist):
+            sel = n_on_cu == k
+            print(f"  CUs holding {k} workgroups: lifetime min/median/max {int(life[sel].min())}/{int(np.median(life[sel]))}/{int(life[sel].max())} ns, last end {int((w[sel][:,1]-base).max())} ns")
+        # inside one CU: lifetimes in start order (does the oldest wave finish first?)
+        ranks = collections.defaultdict(list)
+        for key in per_cu:
+            idx = np.where(cu_key == key)[0]
+            order = idx[np.argsort(w[idx, 0])]
+            for r, i in enumerate(order): ranks[r].append(life[i])
+        print("  mean lifetime by arrival order on the CU:", {r: int(np.mean(v)) for r, v in sorted(ranks.items())})
+        print("  xcc of block b == b % 8 for", int((xcc == (np.where(okw)[0] % 8)).sum()), "of", int(okw.sum()), "blocks")
