@@ -4,7 +4,7 @@ TAG=$1; NAME=$2; LAYER=$3; shift 3
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$NAME -o pmc -- python $REPO/bench.py --layer $LAYER --dw-kernel ${DWK:-0} > $OUT/pmc_$NAME.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$NAME -o pmc -- python $REPO/bench.py --layer $LAYER --dw-kernel ${DWK:-0} > $OUT/pmc_$NAME.log 2>&1
 f=$(find $OUT/pmc_$NAME -name "*counter_collection.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys, collections
