@@ -1,0 +1,105 @@
+"""CPU tier: what the compiler made of the shipped kernels. The gfx950 code objects are taken out of
+libqnnpack_gfx950.so (clang offload bundles in the .hip_fatbin section) and their AMDGPU metadata is read with
+llvm-readelf: no kernel of the default dispatch paths may touch scratch memory (a spill inside a streaming loop is a
+round trip to memory per trip -- three flavours of the staged pointwise kernel had acquired some unnoticed), and the
+register need of the occupancy-critical ones must stay within the wave count they are launched for."""
+import os
+import re
+import shutil
+import struct
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "qnnpack_amd", "libqnnpack_gfx950.so")
+READELF = shutil.which("llvm-readelf") or "/opt/rocm/lib/llvm/bin/llvm-readelf"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _code_objects(blob):
+    pos = 0
+    while True:
+        i = blob.find(MAGIC, pos)
+        if i < 0:
+            return
+        (count,) = struct.unpack_from("<Q", blob, i + 24)
+        off = i + 32
+        for _ in range(count):
+            o, size, tsize = struct.unpack_from("<QQQ", blob, off)
+            off += 24
+            triple = blob[off:off + tsize].decode()
+            off += tsize
+            if "gfx950" in triple and size:
+                yield blob[i + o:i + o + size]
+        pos = i + len(MAGIC)
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    if not os.path.exists(LIB):
+        pytest.skip("library not built")
+    if not os.path.exists(READELF):
+        pytest.skip("llvm-readelf not available")
+    out = {}
+    tmp = tmp_path_factory.mktemp("codeobj")
+    blob = open(LIB, "rb").read()
+    for k, elf in enumerate(_code_objects(blob)):
+        path = tmp / f"co{k}.elf"
+        path.write_bytes(elf)
+        notes = subprocess.run([READELF, "--notes", str(path)], capture_output=True, text=True, check=True).stdout
+        for entry in notes.split("  - .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", entry).group(1)
+            demangled = name
+            out[demangled] = {
+                "vgpr": int(re.search(r"\.vgpr_count:\s+(\d+)", entry).group(1)),
+                "scratch": int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", entry).group(1)),
+                "spill": int(re.search(r"\.vgpr_spill_count:\s+(\d+)", entry).group(1)),
+            }
+    assert len(out) > 100, "expected the library's kernel instantiations"
+    return out
+
+
+# mangled-name fragments of the kernels the automatic dispatch picks for aligned tensors; the
+# generic implicit-GEMM fallback for unaligned / odd-channel tensors (q8_igemm_mfma_kernel, byte gathers) is known to
+# spill in its 1-byte flavours and is reported by test_report_of_spilling_kernels below, not asserted
+DEFAULT_PATH = ["q8_gemm_mfma_256x256_kernelILb0ELi4E", "q8_gemm_mfma_256x256_kernelILb1ELi4E", "q8_pw_stream_staged_kernel", "q8_pw_stream_longk_kernel",
+                "q8_pw_stream_gw_kernel", "q8_pw_stream_gwk_kernel", "q8_conv_stream_c3s_kernel",
+                "q8_dwconv_col3x3_kernel", "q8_conv_wave_reg_kernel", "q8_conv_lds_mfma", "q8_vadd", "q8_gavgpool"]
+
+
+def test_default_path_kernels_do_not_spill(kernels):
+    checked = 0
+    for name, k in kernels.items():
+        if any(f in name for f in DEFAULT_PATH):
+            checked += 1
+            assert k["scratch"] == 0 and k["spill"] == 0, (name, k)
+    assert checked >= 60, checked
+
+
+@pytest.mark.parametrize("fragment,max_vgpr,why", [
+    # 512 VGPRs per SIMD lane, allocated in blocks of 8: n waves per SIMD need <= floor(512 / n / 8) * 8 each
+    ("23q8_dwconv_col3x3_kernelILi1ELi3ELb1ELb1ELb1E", 72, "dot-product depthwise walk, six row buffers: 7 waves per SIMD"),
+    ("23q8_dwconv_col3x3_kernelILi2ELi3ELb1ELb0ELb0E", 80, "stride-2 depthwise walk: the 6 waves per SIMD its plan counts on"),
+    ("26q8_pw_stream_staged_kernelILi1ELi16ELi3ELb1E", 72, "staged pointwise kernel, 1 K block: 7 workgroups per CU"),
+    ("26q8_pw_stream_staged_kernelILi2ELi16ELi3ELb1E", 80, "2 K blocks: 6 per CU"),
+    ("26q8_pw_stream_staged_kernelILi4ELi16ELi3ELb1E", 96, "3-4 K blocks: 5 per CU"),
+    ("26q8_pw_stream_staged_kernelILi7ELi16ELi3ELb1E", 128, "5-7 K blocks: 4 per CU"),
+    ("25q8_conv_stream_c3s_kernelILi3ELb1E", 96, "first-layer kernel: 5 per CU"),
+    ("27q8_gemm_mfma_256x256_kernelILb0ELi4ELi0E", 256, "256x256 GEMM: 2 waves per SIMD"),
+])
+def test_register_budgets_of_the_occupancy_critical_kernels(kernels, fragment, max_vgpr, why):
+    hits = {n: k for n, k in kernels.items() if fragment in n}
+    assert hits, f"kernel {fragment} not found"
+    for name, k in hits.items():
+        assert k["vgpr"] <= max_vgpr, (name, k, why)
+
+
+def test_report_of_spilling_kernels(kernels, capsys):
+    """not an assertion: lists what spills, so that a change that adds to the list shows up in the test log"""
+    spilling = sorted((k["scratch"], n) for n, k in kernels.items() if k["scratch"])
+    with capsys.disabled():
+        print(f"\n{len(spilling)} of {len(kernels)} kernels use scratch:", ", ".join(f"{b} B {n[:70]}" for b, n in spilling[-6:]))
+    assert all("q8_igemm_mfma_kernel" in n or "conv_wave_mfma_kernelILi2E" in n or "row3x3" in n or
+               "q8_gemm_mfma_256x256_kernelILb0ELi2E" in n or "q8_gemm_mfma_256x256_kernelILb1ELi2E" in n
+               for _, n in spilling), "a kernel outside the known fallback / A-B flavours started to spill"
