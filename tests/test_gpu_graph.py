@@ -85,7 +85,9 @@ def test_timing_with_and_without_graph_agree_roughly(qnnp):
         with_graph = qnnp.time_operator(op, 2, 20)
         qnnp.set_option("timing_graph", 0)
         without = qnnp.time_operator(op, 2, 20)
-        assert 0.0 < with_graph <= without * 1.5, (with_graph, without)
+        # (a sanity bound, not a benchmark: a replay should not cost more than the launch loop; 3x leaves room for a
+        #  preempted 20-launch sample on a shared box)
+        assert 0.0 < with_graph <= without * 3.0, (with_graph, without)
         assert_bytes_equal(from_device(d_out), expected, "outputs after timed runs")
     finally:
         qnnp.set_option("timing_graph", 1)
