@@ -470,6 +470,15 @@ def main():
                 "sustained_launch_ms": round(sustained_ms, 5),
                 "sustained_tops": round(gemm_ops / (sustained_ms * 1e-3) / 1e12, 2),
                 "sustained_as": "median of 5 batches of 48 replays of a 64-launch hipGraph (>= 200 ms per batch, 1 s in all), run right before the timed steps"}
+    copy_gbs = None
+    try:
+        # this chip's own streaming ceiling: a plain 16-byte-per-lane copy / read kernel over 1 GiB buffers
+        dbg = qnnpack_amd.load_debug()       # measurement companion library, not the product
+        copy_gbs = round(dbg.copy_probe(False, 1024, 5), 1)
+        roofline["hbm_copy_kernel_gbs"] = copy_gbs
+        roofline["hbm_read_kernel_gbs"] = round(dbg.copy_probe(True, 1024, 5), 1)
+    except Exception as exc:  # noqa: BLE001
+        print(f"# copy probe failed: {exc}", file=sys.stderr)
     if rank == 0:
         # the bare-MFMA rate of this very chip, measured in this process: with random operands the power
         # management holds a lower clock, so this -- not the nominal peak -- is what a kernel can reach at best
@@ -510,6 +519,7 @@ def main():
         extra["q8conv_3x3_56x56x64_b128"] = {
             "kernel": layer.kernel, "ms": round(ms, 4), "tops": round(layer.ops / (ms * 1e-3) / 1e12, 2),
             "gbs": round((layer.in_bytes + layer.out_bytes) / (ms * 1e-3) / 1e9, 1),
+            "frac_of_copy_kernel": round((layer.in_bytes + layer.out_bytes) / (ms * 1e-3) / 1e9 / copy_gbs, 4) if copy_gbs else None,
             "roofline_ms": round(max(layer.ops / (PEAK_I8_TOPS * 1e12), (layer.in_bytes + layer.out_bytes) / (PEAK_HBM_GBS * 1e9)) * 1e3, 4)}
         layer.close()
 
@@ -563,12 +573,14 @@ def main():
             "images_per_s_by_sum_of_layers": round(my_batch / (sum_of_layers_ms * 1e-3) * world, 1),
             "hbm_gbs": round(act_bytes / (sweep_ms * 1e-3) / 1e9, 1),
             "frac_of_hbm_peak": round(act_bytes / (sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "frac_of_copy_kernel": round(act_bytes / (sweep_ms * 1e-3) / 1e9 / copy_gbs, 4) if copy_gbs else None,
             "tops": round(total_ops / (sweep_ms * 1e-3) / 1e12, 2),
             "roofline_images_per_s_per_gpu": round(PEAK_HBM_GBS * 1e9 / (act_bytes / my_batch), 1),
             "layers": rows}
         extra["q8dwconv_mobilenetv2_layers"] = {
             "hbm_gbs": round(dw_bytes / (dw_ms * 1e-3) / 1e9, 1), "ms": round(dw_ms, 4),
-            "frac_of_hbm_peak": round(dw_bytes / (dw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+            "frac_of_hbm_peak": round(dw_bytes / (dw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "frac_of_copy_kernel": round(dw_bytes / (dw_ms * 1e-3) / 1e9 / copy_gbs, 4) if copy_gbs else None}
 
         # ---------------------------------------------------------- depthwise 5x5 / dilated 3x3 and a
         # realistic requantization scale (shift >= 1 epilogue; the reference bench's 0.5 takes the shift-0 one)

@@ -105,5 +105,16 @@ def load_debug():
                 raise RuntimeError(f"qnnp_gfx950_mfma_probe -> {rc}")
             return float(tops.value)
         dbg.mfma_probe = mfma_probe
+        dbg.lib.qnnp_gfx950_copy_probe.restype = ctypes.c_int
+        dbg.lib.qnnp_gfx950_copy_probe.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+
+        def copy_probe(read_only: bool = False, mbytes: int = 1024, reps: int = 5) -> float:
+            """GB/s of a plain 16-byte-per-lane streaming kernel on this chip (copy: bytes read + written)."""
+            gbs = ctypes.c_float(0.0)
+            rc = dbg.lib.qnnp_gfx950_copy_probe(1 if read_only else 0, mbytes, reps, ctypes.byref(gbs))
+            if rc != 0:
+                raise RuntimeError(f"qnnp_gfx950_copy_probe -> {rc}")
+            return float(gbs.value)
+        dbg.copy_probe = copy_probe
         _loaded_debug = dbg
     return _loaded_debug

@@ -210,6 +210,12 @@ enum qnnp_status qnnp_create_add_nc_q8(
   if (token < 0) {
     return qnnp_status_unsupported_hardware;
   }
+  if (qnnp_hip_graph_capturing()) {
+    /* inside qnnp_gfx950_graph_begin ... graph_end on this device only operator launches are recordable: an upload
+     * would become a graph node reading host memory that is freed right after this call */
+    qnnp_hip_leave(token);
+    return qnnp_status_invalid_parameter;
+  }
   const enum qnnp_status status = qnnp_create_add_nc_q8_impl(channels, a_zero_point, a_scale, b_zero_point, b_scale, sum_zero_point, sum_scale, sum_min, sum_max, flags, add_out);
   qnnp_hip_leave(token);
   return status;
@@ -231,6 +237,12 @@ enum qnnp_status qnnp_setup_add_nc_q8(
   const int token = qnnp_hip_enter(op->device);
   if (token < 0) {
     return qnnp_status_invalid_parameter;   /* not a live operator of this library instance */
+  }
+  if (qnnp_hip_graph_capturing()) {
+    /* inside qnnp_gfx950_graph_begin ... graph_end on this device only operator launches are recordable: an upload
+     * would become a graph node reading host memory that is freed right after this call */
+    qnnp_hip_leave(token);
+    return qnnp_status_invalid_parameter;
   }
   const enum qnnp_status status = qnnp_setup_add_nc_q8_impl(op, batch_size, a, a_stride, b, b_stride, sum, sum_stride);
   /* the implementation cleared setup_valid where it began to change the operator: a failed setup leaves it

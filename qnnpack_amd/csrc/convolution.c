@@ -477,6 +477,12 @@ enum qnnp_status qnnp_create_convolution2d_nhwc_q8(
   if (token < 0) {
     return qnnp_status_unsupported_hardware;
   }
+  if (qnnp_hip_graph_capturing()) {
+    /* inside qnnp_gfx950_graph_begin ... graph_end on this device only operator launches are recordable: an upload
+     * would become a graph node reading host memory that is freed right after this call */
+    qnnp_hip_leave(token);
+    return qnnp_status_invalid_parameter;
+  }
   const enum qnnp_status status = qnnp_create_convolution2d_nhwc_q8_impl(input_padding_top, input_padding_right, input_padding_bottom, input_padding_left, kernel_height, kernel_width, subsampling_height, subsampling_width, dilation_height, dilation_width, groups, group_input_channels, group_output_channels, input_zero_point, input_scale, kernel_zero_point, kernel_scale, kernel, bias, output_zero_point, output_scale, output_min, output_max, flags, convolution_out);
   qnnp_hip_leave(token);
   return status;
@@ -499,6 +505,12 @@ enum qnnp_status qnnp_setup_convolution2d_nhwc_q8(
   const int token = qnnp_hip_enter(op->device);
   if (token < 0) {
     return qnnp_status_invalid_parameter;   /* not a live operator of this library instance */
+  }
+  if (qnnp_hip_graph_capturing()) {
+    /* inside qnnp_gfx950_graph_begin ... graph_end on this device only operator launches are recordable: an upload
+     * would become a graph node reading host memory that is freed right after this call */
+    qnnp_hip_leave(token);
+    return qnnp_status_invalid_parameter;
   }
   const enum qnnp_status status = qnnp_setup_convolution2d_nhwc_q8_impl(op, batch_size, input_height, input_width, input, input_pixel_stride, output, output_pixel_stride, threadpool);
   /* the implementation cleared setup_valid where it began to change the operator: a failed setup leaves it

@@ -209,6 +209,12 @@ enum qnnp_status qnnp_gfx950_create_fused_block(
   if (token < 0) {
     return qnnp_status_unsupported_hardware;
   }
+  if (qnnp_hip_graph_capturing()) {
+    /* inside qnnp_gfx950_graph_begin ... graph_end on this device only operator launches are recordable: an upload
+     * would become a graph node reading host memory that is freed right after this call */
+    qnnp_hip_leave(token);
+    return qnnp_status_invalid_parameter;
+  }
   const enum qnnp_status status = qnnp_gfx950_create_fused_block_impl(expand, depthwise, project, residual_add, fused_out);
   qnnp_hip_leave(token);
   return status;
@@ -224,6 +230,12 @@ enum qnnp_status qnnp_gfx950_setup_fused_block(
   const int token = qnnp_hip_enter(op->device);
   if (token < 0) {
     return qnnp_status_invalid_parameter;   /* not a live operator of this library instance */
+  }
+  if (qnnp_hip_graph_capturing()) {
+    /* inside qnnp_gfx950_graph_begin ... graph_end on this device only operator launches are recordable: an upload
+     * would become a graph node reading host memory that is freed right after this call */
+    qnnp_hip_leave(token);
+    return qnnp_status_invalid_parameter;
   }
   const enum qnnp_status status = qnnp_gfx950_setup_fused_block_impl(op, batch_size, input_height, input_width, input, input_stride, output, output_stride);
   /* the implementation cleared setup_valid where it began to change the operator: a failed setup leaves it

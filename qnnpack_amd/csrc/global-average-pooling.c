@@ -199,6 +199,12 @@ enum qnnp_status qnnp_create_global_average_pooling_nwc_q8(
   if (token < 0) {
     return qnnp_status_unsupported_hardware;
   }
+  if (qnnp_hip_graph_capturing()) {
+    /* inside qnnp_gfx950_graph_begin ... graph_end on this device only operator launches are recordable: an upload
+     * would become a graph node reading host memory that is freed right after this call */
+    qnnp_hip_leave(token);
+    return qnnp_status_invalid_parameter;
+  }
   const enum qnnp_status status = qnnp_create_global_average_pooling_nwc_q8_impl(channels, input_zero_point, input_scale, output_zero_point, output_scale, output_min, output_max, flags, global_average_pooling_out);
   qnnp_hip_leave(token);
   return status;
@@ -219,6 +225,12 @@ enum qnnp_status qnnp_setup_global_average_pooling_nwc_q8(
   const int token = qnnp_hip_enter(op->device);
   if (token < 0) {
     return qnnp_status_invalid_parameter;   /* not a live operator of this library instance */
+  }
+  if (qnnp_hip_graph_capturing()) {
+    /* inside qnnp_gfx950_graph_begin ... graph_end on this device only operator launches are recordable: an upload
+     * would become a graph node reading host memory that is freed right after this call */
+    qnnp_hip_leave(token);
+    return qnnp_status_invalid_parameter;
   }
   const enum qnnp_status status = qnnp_setup_global_average_pooling_nwc_q8_impl(op, batch_size, width, input, input_stride, output, output_stride);
   /* the implementation cleared setup_valid where it began to change the operator: a failed setup leaves it

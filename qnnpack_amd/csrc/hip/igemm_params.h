@@ -100,6 +100,6 @@ int pwstream_gw_launch(const IgemmParams& p, hipStream_t stream, const char** na
 
 /* q8gemm256.hip */
 bool gemm256_supported(const IgemmParams& p, uint32_t vec);
-int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, bool waves4);
+int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, bool waves4, bool rows128, bool pingpong);
 
 }  // namespace qnnp

@@ -94,3 +94,81 @@ extern "C" int qnnp_gfx950_mfma_probe(int random_operands, int iters, float* top
   *tops_out = static_cast<float>(ops / (ms * 1e-3) / 1e12);
   return QNNP_HIP_OK;
 }
+
+/*
+ * qnnp_gfx950_copy_probe(): the HBM bandwidth this very chip gives a plain streaming kernel -- 16 bytes per lane,
+ * grid-stride, read + write -- over buffers far larger than the 256 MiB Infinity Cache. SURVEY section 8(d) asks
+ * for HBM fractions against "our own in-process copy kernel" beside the 8 TB/s specification and the guide's
+ * 6.3 TB/s; bench.py reports it as roofline.hbm_copy_gbs / extra.*.frac_of_copy_kernel.
+ */
+namespace {
+
+__global__ __launch_bounds__(256) void copy_probe_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16)
+{
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  // four independent 16-byte loads in flight per lane
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void read_probe_kernel(const uint4* __restrict__ src, uint32_t* __restrict__ sink, size_t n16)
+{
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  uint32_t x = 0;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    x ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+  }
+  for (; i < n16; i += stride) { const uint4 a = src[i]; x ^= a.x ^ a.y ^ a.z ^ a.w; }
+  if (x == 0x12345678u) sink[0] = x;     // never true for the random fill; keeps the loads alive
+}
+
+}  // namespace
+
+/* mode 0: copy (bytes read + bytes written counted), mode 1: read only. `mbytes` per buffer (>= 512 recommended).
+ * *gbs_out = GB/s of the best of `reps` event-timed launches. */
+extern "C" int qnnp_gfx950_copy_probe(int mode, int mbytes, int reps, float* gbs_out)
+{
+  if (gbs_out == nullptr || mbytes <= 0 || reps <= 0) return QNNP_HIP_EINVAL;
+  int device = 0;
+  hipDeviceProp_t props;
+  if (hipGetDevice(&device) != hipSuccess || hipGetDeviceProperties(&props, device) != hipSuccess) return QNNP_HIP_ENODEV;
+  const size_t bytes = static_cast<size_t>(mbytes) << 20;
+  const size_t n16 = bytes / 16;
+  uint4* src = nullptr;
+  uint4* dst = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&src), bytes) != hipSuccess) return QNNP_HIP_ENOMEM;
+  if (hipMalloc(reinterpret_cast<void**>(&dst), mode == 0 ? bytes : 256) != hipSuccess) { (void) hipFree(src); return QNNP_HIP_ENOMEM; }
+  (void) hipMemset(src, 0x5A, bytes);
+  hipEvent_t e0, e1;
+  bool ok = hipEventCreate(&e0) == hipSuccess;
+  if (ok && hipEventCreate(&e1) != hipSuccess) { (void) hipEventDestroy(e0); ok = false; }
+  float best = 0.0f;
+  if (ok) {
+    const dim3 grid(static_cast<unsigned>(props.multiProcessorCount) * 8u), block(256);
+    for (int r = 0; r < reps + 1 && ok; r++) {
+      (void) hipEventRecord(e0, nullptr);
+      if (mode == 0) hipLaunchKernelGGL(copy_probe_kernel, grid, block, 0, nullptr, src, dst, n16);
+      else hipLaunchKernelGGL(read_probe_kernel, grid, block, 0, nullptr, src, reinterpret_cast<uint32_t*>(dst), n16);
+      float ms = 0.0f;
+      ok = hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+           hipEventElapsedTime(&ms, e0, e1) == hipSuccess && hipGetLastError() == hipSuccess && ms > 0.0f;
+      if (ok && r > 0) {       // the first launch is the warm-up
+        const float gbs = static_cast<float>((mode == 0 ? 2.0 : 1.0) * static_cast<double>(bytes) / (ms * 1e-3) / 1e9);
+        if (gbs > best) best = gbs;
+      }
+    }
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
+  }
+  (void) hipFree(src);
+  (void) hipFree(dst);
+  if (!ok || best <= 0.0f) return QNNP_HIP_ELAUNCH;
+  *gbs_out = best;
+  return QNNP_HIP_OK;
+}

@@ -14,14 +14,22 @@ namespace qnnp {
 
 struct PerDeviceOnce {
   std::atomic<uint32_t> done{0};
-  /* true for the first caller on the active device; later callers (and concurrent ones) get false -- the attribute
-   * call is idempotent, so a racing second thread that proceeds to launch a moment early is at worst a launch
-   * the runtime rejects and reports (QNNP_HIP_ELAUNCH), never silent corruption */
-  bool first()
+  /* `if (auto once = guard.begin()) { hipFuncSetAttribute(...); }` -- the body runs until ONE caller has finished it on
+   * the active device: the done bit is published by the scope's destructor, i.e. AFTER the attribute call returned, so a
+   * second thread launching the same kernel at the same moment either sees the bit (the opt-in exists) or makes the
+   * idempotent call itself -- never a launch with > 64 KiB of dynamic LDS ahead of the opt-in. */
+  struct Scope {
+    std::atomic<uint32_t>* word;
+    uint32_t bit;
+    explicit operator bool() const { return word != nullptr; }
+    ~Scope() { if (word != nullptr) word->fetch_or(bit, std::memory_order_release); }
+  };
+  Scope begin()
   {
     const int device = qnnp_hip_device();
     const uint32_t bit = 1u << (static_cast<uint32_t>(device < 0 ? 0 : device) & 31u);
-    return (done.fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;
+    if ((done.load(std::memory_order_acquire) & bit) != 0) return Scope{nullptr, 0u};
+    return Scope{&done, bit};
   }
 };
 

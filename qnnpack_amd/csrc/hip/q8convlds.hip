@@ -324,7 +324,7 @@ template <int TN, bool PIPE, int ABL = 0>
 int launch_one(const IgemmParams& p, const ConvGeom& g, const Plan& pl, uint32_t batch, hipStream_t stream)
 {
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
-  if (attr_once.first()) {
+  if (auto once_scope = attr_once.begin()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_lds_mfma_kernel<TN, PIPE, ABL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       (void) hipGetLastError();

@@ -835,7 +835,7 @@ int launch_reg_as(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hi
   constexpr int kRegWaves = reg_waves<TM>();
   constexpr int kRegThreads = kRegWaves * 64;
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
-  if (attr_once.first()) {
+  if (auto once_scope = attr_once.begin()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_reg_kernel<TM, TN, CB, SEQ, FULL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       (void) hipGetLastError();
@@ -861,7 +861,7 @@ template <int TN, int CB, int KS, int SEQ, bool FULL>
 int launch_as(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, uint32_t lds_bytes, hipStream_t stream)
 {
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
-  if (attr_once.first()) {
+  if (auto once_scope = attr_once.begin()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_mfma_kernel<TN, CB, KS, SEQ, FULL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       (void) hipGetLastError();

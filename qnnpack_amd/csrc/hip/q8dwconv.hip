@@ -1038,6 +1038,10 @@ bool plan_col(DwParams& p)
 {
   if (p.C % 4 != 0 || p.KH != 3 || p.KW != 3 || p.dh != 1 || p.dw != 1) return false;
   if (p.sh != p.sw || (p.sw != 1 && p.sw != 2)) return false;
+  // The walk's steady-state steps fetch row iy_first + t + 2 + NBUF with no lower bound (only the start-up steps
+  // check it): any API-legal padding beyond the window's own reach (top / left > 2, which no 3x3 layer of a real
+  // network has) would index rows before the image. Those shapes take the generic kernels.
+  if (p.pad_top > 2 || p.pad_left > 2) return false;
   // 32-bit byte offsets into both tensors
   const uint64_t in_bytes = static_cast<uint64_t>(p.batch) * p.H * p.W * p.in_stride;
   const uint64_t out_bytes = static_cast<uint64_t>(p.batch) * p.OH * p.OW * p.out_stride;

@@ -419,7 +419,7 @@ extern "C" int qnnp_hip_fused_block_run(const struct qnnp_hip_fused_args* a, con
   if (p.kb3 > p.kblocks3 || (a->has_expand && p.kb1 > p.kblocks1)) return QNNP_HIP_EINVAL;
 
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
-  if (attr_once.first()) {
+  if (auto once_scope = attr_once.begin()) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_fused_block_kernel<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_fused_block_kernel<true>),

@@ -55,14 +55,17 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int kBM = 256;
 constexpr int kBN = 256;
 constexpr int kBK = 64;                        // bytes of K per tile (two 32-deep MFMA sub-steps)
-constexpr int kStages = 4;                     // LDS ring: tile t+3 is being fetched while tile t is multiplied
-constexpr int kATile = kBM * kBK;              // 16 KiB
 constexpr int kWTile = kBN * kBK;              // 16 KiB
-constexpr int kStage = kATile + kWTile;        // 32 KiB
 constexpr uint32_t kFlip = 0x80808080u;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 #ifndef QNNP_DMA_AUX
 #define QNNP_DMA_AUX 0
@@ -84,13 +87,27 @@ static_assert(kWN == 2 && kBK == 64, "row-sum split: each channel-wave owns one 
 // 4 = no MFMA, 8 = no LDS-DMA after the prologue, 16 = no fragment reads after the first tile,
 // 32 = no per-tile wait + barrier; 64 = experiment: static s_setprio 1 for the younger half of the workgroup
 // (waves 4-7) before the main loop (guide T5, static form).
-// WM = waves along rows: 4 -> 8 waves (two per SIMD), 64 x 128 outputs per wave, 12 fragment reads per 16 MFMAs;
-//                        2 -> 4 waves (one per SIMD, the whole register file), 128 x 128 outputs per wave,
-//                             16 fragment reads per 32 MFMAs.
-template <bool IS_CONV, int WM, int ABL = 0>
-__global__ __launch_bounds__(WM * kWN * 64, WM == 4 ? 2 : 1)
+// WM = waves along rows, BM = rows of the workgroup's tile:
+//   WM 4, BM 256 -> 8 waves (two per SIMD), 64 x 128 outputs per wave, 12 fragment reads per 16 MFMAs, 4-slot ring;
+//   WM 2, BM 256 -> 4 waves (one per SIMD, the whole register file), 128 x 128 outputs per wave,
+//                   16 fragment reads per 32 MFMAs;
+//   WM 2, BM 128 -> 4 waves of 64 x 128 outputs, 128 x 256 tile, 3-slot ring of 24 KiB stages = 72 KiB, so TWO
+//                   workgroups share a CU: one's barriers, prologue and epilogue run under the other's multiplies
+//                   (the per-wave loop is the 8-wave flavour's; the L2 -> LDS stream per MFMA grows by half).
+//   PP (WM 4, BM 256 only): the PING-PONG schedule. The two waves of a SIMD (wave w and w + 4) take turns: one issues
+//                   nothing but the 8 MFMAs of a K sub-step (s_setprio 1) while the other reads its next fragments,
+//                   issues its LDS-DMA pieces and does its re-centring / row-sum VALU work; a raw s_barrier swaps the
+//                   roles. The DMA issue stalls (100-185 cycles per piece on a busy CU) and the LDS waits then sit in a
+//                   phase whose wave has no MFMA to issue, beside a partner that has nothing else. One fragment set.
+template <bool IS_CONV, int WM, int BM = 256, int ABL = 0, bool PP = false>
+__global__ __launch_bounds__(WM * kWN * 64, (WM == 4 || BM == 128) ? 2 : 1)
 void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 {
+  static_assert(!PP || (WM == 4 && BM == 256), "ping-pong schedule: 8 waves, 256 x 256 tile");
+  constexpr int kBM = BM;
+  constexpr int kStages = BM == 256 ? 4 : 3;     // LDS ring: tile t + kStages - 1 is being fetched while tile t is multiplied
+  constexpr int kATile = kBM * kBK;              // 16 / 8 KiB
+  constexpr int kStage = kATile + kWTile;        // 32 / 24 KiB
   constexpr int kWM = WM;
   constexpr int kThreads = WM * kWN * 64;
   constexpr int kTM = kBM / (kWM * 32);          // MFMA tiles of 32 rows per wave
@@ -99,7 +116,7 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
   constexpr int kDma = kAChunks + kWFrags;       // LDS-DMA instructions per thread per tile
   constexpr int kMma = kTM * kTN;                // MFMAs per K sub-step
   constexpr int kParts = 2 * kTM;                // recentring parts per fragment set
-  static_assert(kMma - kDma >= kParts, "phase 2 schedule needs one MFMA per recentring part after the DMA pieces");
+  static_assert(kDma % 2 == 0 && kDma * (kStages - 2) < 64, "the DMA of a tile is issued in two halves; vmcnt is 6 bits");
 
   // single LDS object: ring of {A, W} tiles, then kWN x 256 partial row sums
   __shared__ __attribute__((aligned(16))) uint8_t lds[kStages * kStage + kWN * kBM * 4];
@@ -127,7 +144,7 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
     const uint32_t idx = blockIdx.x >> 3;
     const uint32_t q = nwg >> 3, r = nwg & 7u;
     const uint32_t logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    constexpr uint32_t kBand = 4;
+    constexpr uint32_t kBand = 1024 / kBM;      // an XCD's 32 co-resident 256-row (64 128-row) tiles: 1024 rows x 2048 channels
     const uint32_t per_band = kBand * tiles_n;
     const uint32_t band = logical / per_band;
     const uint32_t within = logical - band * per_band;
@@ -331,14 +348,12 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
   // Counted wait: tile `kt` has landed when at most the LDS-DMA groups of the tiles issued after it
   // (kDma instructions each, completing in issue order) are still outstanding.
   auto wait_tile = [&](uint32_t later_tiles_in_flight) {
-    if (later_tiles_in_flight >= 2) {
-      if constexpr (kDma == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    } else if (later_tiles_in_flight == 1) {
-      if constexpr (kDma == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (kStages > 3 && later_tiles_in_flight >= 2) {
+      wait_vmcnt<2 * kDma>();
+    } else if (later_tiles_in_flight >= 1) {
+      wait_vmcnt<kDma>();
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_vmcnt<0>();
     }
   };
 
@@ -347,12 +362,77 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
   const uint32_t s_first = wn;
   const uint32_t s_second = wn ^ 1u;
 
+  if constexpr (PP) {
+    // ---- ping-pong main loop. Interval j lies between barriers j and j + 1; group 0 (waves 0-3, one per SIMD) reads
+    // unit u in interval 2u and multiplies it in 2u + 1, group 1 (waves 4-7) runs one interval behind. A unit is one
+    // K sub-step of a tile: tile kt = u / 2. Tile kt is last read in interval 4 kt + 3 (group 1), so its ring slot is
+    // free from barrier 4 kt + 4 on: the read phases of tile kt + 1 (intervals >= 4 kt + 4) fetch tile kt + 4 ... no:
+    // they fetch tile (kt + 1) + 3 into slot kt % 4. The wait that retires tile kt + 1 sits at the end of the read
+    // phase of (kt, second sub-step), in front of a barrier every reader of tile kt + 1 passes first.
+    const uint32_t group = wave >> 2;
+#pragma unroll
+    for (int t = 0; t < kStages - 1; t++) {
+      if (static_cast<uint32_t>(t) < ktiles) stage(t);
+    }
+    wait_tile(min(static_cast<uint32_t>(kStages - 2), ktiles - 1));
+    __builtin_amdgcn_s_barrier();
+    if (group == 1u) __builtin_amdgcn_s_barrier();          // stagger: group 1 starts one interval late
+    Frags f;
+    auto read_phase = [&](auto fetch_c, uint32_t kt, int half) __attribute__((always_inline)) {
+      constexpr bool FETCH = decltype(fetch_c)::value;
+      const uint8_t* st = lds + (kt % kStages) * kStage;
+      QNNP_PIN();
+      read_frags(st, half == 0 ? s_first : s_second, f);
+      QNNP_PIN();
+      if constexpr (FETCH) {
+#pragma unroll
+        for (int i = 0; i < kDma / 2; i++) stage_piece(kt + kStages - 1, half * (kDma / 2) + i);
+        QNNP_PIN();
+      }
+      if (half == 0) rowsum(f);                               // this wave owns the row sums of its first sub-step
+      flip(f);
+      asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]));
+      settle_w(f);                                            // the LDS wait for the weight fragments belongs HERE
+      QNNP_PIN();
+    };
+    auto multiply_phase = [&]() __attribute__((always_inline)) {
+      QNNP_PIN();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < kMma; i++) mma(f, i);
+      __builtin_amdgcn_s_setprio(0);
+      QNNP_PIN();
+    };
+    uint32_t kt = 0;
+    for (; kt + kStages - 1 < ktiles; kt++) {                 // steady state: tile kt + 3 exists
+      read_phase(std::true_type{}, kt, 0);
+      __builtin_amdgcn_s_barrier();
+      multiply_phase();
+      __builtin_amdgcn_s_barrier();
+      read_phase(std::true_type{}, kt, 1);
+      wait_vmcnt<(kStages - 2) * kDma>();                     // tile kt + 1 resident (kt + 2, kt + 3 may be in flight)
+      __builtin_amdgcn_s_barrier();
+      multiply_phase();
+      __builtin_amdgcn_s_barrier();
+    }
+    for (; kt < ktiles; kt++) {                               // drain: nothing left to fetch
+      read_phase(std::false_type{}, kt, 0);
+      __builtin_amdgcn_s_barrier();
+      multiply_phase();
+      __builtin_amdgcn_s_barrier();
+      read_phase(std::false_type{}, kt, 1);
+      if (kt + 1 < ktiles) wait_tile(ktiles - 1 - (kt + 1));
+      __builtin_amdgcn_s_barrier();
+      multiply_phase();
+      if (!(kt + 1 == ktiles && group == 1u)) __builtin_amdgcn_s_barrier();   // group 1 made one extra at the start
+    }
+  } else {
   // ---- prologue: tiles 0..2 in flight, tile 0 resident, its first fragments recentred ----
 #pragma unroll
   for (int t = 0; t < kStages - 1; t++) {
     if (static_cast<uint32_t>(t) < ktiles) stage(t);
   }
-  wait_tile(min(2u, ktiles - 1));
+  wait_tile(min(static_cast<uint32_t>(kStages - 2), ktiles - 1));
   __builtin_amdgcn_s_barrier();
   Frags fa, fb;
   read_frags(lds, s_first, fa);
@@ -378,6 +458,7 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
    *  - activation fragments are read first and recentred in the shadow of the LAST MFMAs of a phase, so
    *    the LDS wait sits a whole phase after the reads were issued.
    * P1F: phase 1 issues the second half of tile kt+3; MORE: tile kt+1 exists; P2F: tile kt+4 exists.
+   * (With the 3-slot ring of the 128-row flavour read kt+2 / kt+3: the distances are kStages - 1 and kStages.)
    */
   constexpr int kHalf = kDma / 2;                 // LDS-DMA pieces per phase
   constexpr int kDmaGap = kMma / kHalf;           // one piece every kDmaGap MFMAs
@@ -396,7 +477,7 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
       if (!(ABL & 4)) mma(fa, i);
       QNNP_PIN();
       if constexpr (P1F) {
-        if (i % kDmaGap == 0 && !(ABL & 8)) stage_piece(kt + 3, kHalf + i / kDmaGap);
+        if (i % kDmaGap == 0 && i / kDmaGap < kHalf && !(ABL & 8)) stage_piece(kt + kStages - 1, kHalf + i / kDmaGap);
         QNNP_PIN();
       }
       if (i >= kMma - kFlipMma) {
@@ -420,15 +501,14 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
     if constexpr (MORE) {
       // tile kt+1 must be resident; issued after it so far: tiles kt+2 .. min(kt+3, ktiles-1), complete
       if constexpr (P1F || P2F) {
-        if constexpr (kDma == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        wait_vmcnt<(kStages - 2) * kDma>();
 #ifdef QNNP_ENABLE_ABLATION
         QNNP_PIN();
         if (stamp) QNNP_TRACE_WAVE(p, 1024 + blockIdx.x, wave, (kt - 20) * 4 + 1);
         QNNP_PIN();
 #endif
       } else {
-        const uint32_t last = min(kt + 3, ktiles - 1);
+        const uint32_t last = min(kt + kStages - 1, ktiles - 1);
         wait_tile(last - (kt + 1));
       }
       __builtin_amdgcn_s_barrier();
@@ -448,7 +528,7 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
       if (!(ABL & 4)) mma(fb, i);
       QNNP_PIN();
       if constexpr (P2F) {
-        if (i % kDmaGap == 0 && !(ABL & 8)) stage_piece(kt + 4, i / kDmaGap);
+        if (i % kDmaGap == 0 && i / kDmaGap < kHalf && !(ABL & 8)) stage_piece(kt + kStages, i / kDmaGap);
         QNNP_PIN();
       }
       if constexpr (MORE) {
@@ -472,24 +552,25 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 #endif
   };
 
-  // (the prologue above staged tiles 0..2; tile 3 completes the ring)
-  if (ktiles > 3) stage(3);
+  // (the prologue above staged tiles 0..kStages-2; one more completes the ring)
+  if (ktiles > static_cast<uint32_t>(kStages - 1)) stage(kStages - 1);
   if constexpr ((ABL & 64) != 0) {
     if (wave >= static_cast<uint32_t>(kWM * kWN / 2)) __builtin_amdgcn_s_setprio(1);
   }
   uint32_t kt = 0;
-  if (ktiles > 4) {
+  if (ktiles > static_cast<uint32_t>(kStages)) {
     iteration(std::false_type{}, std::true_type{}, std::true_type{}, 0u);
-    for (kt = 1; kt + 4 < ktiles; kt++) {                 // steady state
+    for (kt = 1; kt + kStages < ktiles; kt++) {           // steady state
       iteration(std::true_type{}, std::true_type{}, std::true_type{}, kt);
     }
-    iteration(std::true_type{}, std::true_type{}, std::false_type{}, kt);   // kt == ktiles - 4
+    iteration(std::true_type{}, std::true_type{}, std::false_type{}, kt);   // kt == ktiles - kStages
     kt++;
   }
   for (; kt + 1 < ktiles; kt++) {                          // drain: nothing left to fetch
     iteration(std::false_type{}, std::true_type{}, std::false_type{}, kt);
   }
   iteration(std::false_type{}, std::false_type{}, std::false_type{}, kt);   // last tile
+  }  // !PP
 #undef QNNP_PIN
 
   QNNP_TRACE(p, blockIdx.x, 0, 2);
@@ -595,29 +676,40 @@ bool gemm256_supported(const IgemmParams& p, uint32_t vec)
   return vec == 16 && p.fill_table != nullptr && p.rows >= 1 && p.k_total % 16 == 0;
 }
 
-template <bool IS_CONV, int WM>
+template <bool IS_CONV, int WM, int BM = 256>
 static int launch256(const IgemmParams& p, const dim3& grid, hipStream_t stream)
 {
-  hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<IS_CONV, WM>), grid, dim3(WM * kWN * 64), 0, stream, p);
+  hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<IS_CONV, WM, BM>), grid, dim3(WM * kWN * 64), 0, stream, p);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
 /* waves4 = false: 8 waves (two per SIMD), 64 x 128 outputs per wave -- the default;
  * waves4 = true:  4 waves (one per SIMD, the whole register file), 128 x 128 per wave: a third less LDS read
  *                 traffic and a higher sustained clock, but every issue stall is exposed (A/B flavour). */
-int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, bool waves4)
+int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, bool waves4, bool rows128, bool pingpong)
 {
-  const uint32_t tiles_m = (p.rows + kBM - 1) / kBM;
+  const uint32_t bm = rows128 ? 128u : 256u;
+  const uint32_t tiles_m = (p.rows + bm - 1) / bm;
   const uint32_t tiles_n = (p.n_pad + kBN - 1) / kBN;
   const dim3 grid(tiles_m * tiles_n, groups, 1);
   const bool conv = p.offsets != nullptr;
+  if (rows128) {
+    *name = conv ? "q8_gemm_mfma_128x256_conv" : "q8_gemm_mfma_128x256";
+    return conv ? launch256<true, 2, 128>(p, grid, stream) : launch256<false, 2, 128>(p, grid, stream);
+  }
+  if (pingpong) {
+    *name = conv ? "q8_gemm_mfma_256x256_pp_conv" : "q8_gemm_mfma_256x256_pp";
+    if (conv) hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<true, 4, 256, 0, true>), grid, dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 4, 256, 0, true>), grid, dim3(512), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+  }
 #ifdef QNNP_ENABLE_ABLATION
   if (!conv) {
     const char* env = getenv("QNNP_GFX950_ABLATE");
     const int abl = env != nullptr ? atoi(env) : 0;
     *name = waves4 ? "q8_gemm_mfma_256x256_w4" : "q8_gemm_mfma_256x256";
-#define QNNP_ABL_CASE(V) case V: if (waves4) hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 2, V>), grid, dim3(256), 0, stream, p); \
-        else hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 4, V>), grid, dim3(512), 0, stream, p); \
+#define QNNP_ABL_CASE(V) case V: if (waves4) hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 2, 256, V>), grid, dim3(256), 0, stream, p); \
+        else hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 4, 256, V>), grid, dim3(512), 0, stream, p); \
         return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
     switch (abl) {
       case 0: break;

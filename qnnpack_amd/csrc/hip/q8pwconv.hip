@@ -1112,7 +1112,7 @@ int launch_pw(const IgemmParams& p, uint32_t lds_bytes, hipStream_t stream)
 {
   auto kernel = q8_pw_stream_mfma_kernel<KB, VEC, D2S>;
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
-  if (attr_once.first()) {
+  if (auto once_scope = attr_once.begin()) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
   }
   // LDS bounds the residency: kMaxLds -> 2 per CU, half of that -> 4
@@ -1217,7 +1217,7 @@ int launch_pw_staged_as(const IgemmParams& p, const StagedPlan& plan, hipStream_
 {
   auto kernel = q8_pw_stream_staged_kernel<KB, VEC, SEQ, FULL>;
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
-  if (attr_once.first()) {
+  if (auto once_scope = attr_once.begin()) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
   }
   const uint32_t units = (p.rows + 31u) / 32u;
@@ -1320,7 +1320,7 @@ int launch_longk_as(const IgemmParams& p, const StagedPlan& plan, hipStream_t st
 {
   auto kernel = q8_pw_stream_longk_kernel<KBMAX, SEQ, FULL>;
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
-  if (attr_once.first()) {
+  if (auto once_scope = attr_once.begin()) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsLongK);
   }
   const uint32_t units = (p.rows + 31u) / 32u;
@@ -1407,7 +1407,7 @@ int convstream_c3_launch(const IgemmParams& p, hipStream_t stream, const char** 
       requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
         auto kernel = q8_conv_stream_c3s_kernel<decltype(seq)::value, decltype(full)::value>;
         static qnnp::PerDeviceOnce attr_once_s;   // (one per instantiation of this lambda body)
-        if (attr_once_s.first()) {
+        if (auto once_scope = attr_once_s.begin()) {
           (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
         }
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), staged_bytes, stream, p, log_cpr);
@@ -1416,7 +1416,7 @@ int convstream_c3_launch(const IgemmParams& p, hipStream_t stream, const char** 
     }
   }
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
-  if (attr_once.first()) {
+  if (auto once_scope = attr_once.begin()) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(q8_conv_stream_c3_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
   }

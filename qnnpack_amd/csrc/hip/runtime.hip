@@ -46,17 +46,28 @@ struct DeviceCtx {
 DeviceCtx g_dev[kMaxDevices];
 std::mutex g_bind_lock;
 std::atomic<int> g_primary{-1};
+// Initialization generation: bumped by every shutdown. Thread-local selections and capture state remember the
+// generation they were made in; a stale one (another thread deinitialized and re-initialized the library since)
+// reads as "none", so that thread falls back to the primary device instead of to a context that no longer exists.
+std::atomic<uint32_t> g_generation{1};
 
 // per-thread state
 thread_local int t_selected = -1;        // device chosen with qnnp_hip_select (-1: the primary device)
+thread_local uint32_t t_selected_gen = 0;
 thread_local int t_active = -1;          // context entered through qnnp_hip_enter (-1: the selected device)
 struct Capture {
   bool on = false;
   int device = -1;
   hipStream_t stream = nullptr;
   bool owns_stream = false;
+  uint32_t generation = 0;
 };
 thread_local Capture t_cap;
+
+inline bool capture_live()
+{
+  return t_cap.on && t_cap.generation == g_generation.load(std::memory_order_acquire);
+}
 
 struct Timer {
   hipEvent_t start;
@@ -68,7 +79,7 @@ inline bool ok(hipError_t e) { return e == hipSuccess; }
 inline int current_index()
 {
   if (t_active >= 0) return t_active;
-  if (t_selected >= 0) return t_selected;
+  if (t_selected >= 0 && t_selected_gen == g_generation.load(std::memory_order_acquire)) return t_selected;
   return g_primary.load(std::memory_order_acquire);
 }
 
@@ -82,8 +93,14 @@ inline DeviceCtx* ctx()
 // the stream launches of the calling thread go to: its capture stream while it records a graph on this device
 inline hipStream_t launch_stream(const DeviceCtx* c)
 {
-  if (t_cap.on && t_cap.device == c->device) return t_cap.stream;
+  if (capture_live() && t_cap.device == c->device) return t_cap.stream;
   return c->stream.load(std::memory_order_acquire);
+}
+
+// the calling thread is recording a hipGraph on THIS context's device
+inline bool capturing_on(const DeviceCtx* c)
+{
+  return capture_live() && t_cap.device == c->device;
 }
 
 int bind_locked(int device)
@@ -173,8 +190,10 @@ int qnnp_hip_shutdown(void)
   }
   if (previous >= 0) (void) hipSetDevice(previous);
   g_primary.store(-1, std::memory_order_release);
+  g_generation.fetch_add(1, std::memory_order_acq_rel);   // every thread's selection / capture state is now stale
   t_selected = -1;
   t_active = -1;
+  t_cap = Capture();
   return QNNP_HIP_OK;
 }
 
@@ -192,6 +211,7 @@ int qnnp_hip_select(int device)
 {
   if (device < 0 || device >= kMaxDevices || !g_dev[device].bound.load(std::memory_order_acquire)) return QNNP_HIP_ENODEV;
   t_selected = device;
+  t_selected_gen = g_generation.load(std::memory_order_acquire);
   return QNNP_HIP_OK;
 }
 
@@ -307,20 +327,23 @@ void qnnp_hip_free(void* p)
 
 /* async = 0: the copy is complete on return AND ordered behind everything already enqueued on the library
  * stream (a blocking null-stream copy would not be, for a non-blocking library stream: a table re-uploaded
- * by setup could land under a kernel of the previous run that is still in flight). */
+ * by setup could land under a kernel of the previous run that is still in flight).
+ * While the calling thread records a hipGraph on this device every copy / fill is REFUSED: it would become a graph
+ * node whose host source (a table setup frees right afterwards) dangles at replay, and the synchronizing forms
+ * would invalidate the capture. create / setup / the memcpy helpers therefore fail with invalid_parameter inside
+ * qnnp_gfx950_graph_begin ... graph_end; only operator launches on device pointers are recordable. */
 int qnnp_hip_h2d(void* dst, const void* src, size_t bytes, int async)
 {
   if (bytes == 0) return QNNP_HIP_OK;
   const DeviceCtx* c = ctx();
   if (c == nullptr) return QNNP_HIP_ENODEV;
-  hipStream_t s = launch_stream(c);
+  if (capturing_on(c)) return QNNP_HIP_EINVAL;
+  hipStream_t s = c->stream.load(std::memory_order_acquire);
   if (!ok(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s))) {
     (void) hipGetLastError();
     return QNNP_HIP_ELAUNCH;
   }
-  if (!async && !(t_cap.on && t_cap.device == c->device)) {
-    return ok(hipStreamSynchronize(s)) ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
-  }
+  if (!async) return ok(hipStreamSynchronize(s)) ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
   return QNNP_HIP_OK;
 }
 
@@ -329,7 +352,8 @@ int qnnp_hip_d2h(void* dst, const void* src, size_t bytes, int async)
   if (bytes == 0) return QNNP_HIP_OK;
   const DeviceCtx* c = ctx();
   if (c == nullptr) return QNNP_HIP_ENODEV;
-  hipStream_t s = launch_stream(c);
+  if (capturing_on(c)) return QNNP_HIP_EINVAL;
+  hipStream_t s = c->stream.load(std::memory_order_acquire);
   if (!ok(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s))) {
     (void) hipGetLastError();
     return QNNP_HIP_ELAUNCH;
@@ -343,7 +367,8 @@ int qnnp_hip_memset(void* dst, int value, size_t bytes)
   if (bytes == 0) return QNNP_HIP_OK;
   const DeviceCtx* c = ctx();
   if (c == nullptr) return QNNP_HIP_ENODEV;
-  hipStream_t s = launch_stream(c);
+  if (capturing_on(c)) return QNNP_HIP_EINVAL;
+  hipStream_t s = c->stream.load(std::memory_order_acquire);
   if (!ok(hipMemsetAsync(dst, value, bytes, s))) return QNNP_HIP_ELAUNCH;
   return ok(hipStreamSynchronize(s)) ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
@@ -411,12 +436,19 @@ void qnnp_hip_timer_destroy(void* timer)
  * Capture state belongs to the capturing THREAD: its launches on that device go to the capture stream, every
  * other thread keeps launching on the context's stream. */
 
-int qnnp_hip_graph_capturing(void) { return t_cap.on ? 1 : 0; }
+/* 1 only while the calling thread records on the ACTIVE context's device: an operator of another GPU run from a
+ * thread that captures on GPU A is launched live on its own device's stream (launch_stream), so its caller must take
+ * the live path too -- synchronize as usual, never report "recorded". */
+int qnnp_hip_graph_capturing(void)
+{
+  const DeviceCtx* c = ctx();
+  return c != nullptr && capturing_on(c) ? 1 : 0;
+}
 
 int qnnp_hip_graph_begin(void)
 {
   const DeviceCtx* c = ctx();
-  if (c == nullptr || t_cap.on) return QNNP_HIP_EINVAL;
+  if (c == nullptr || capture_live()) return QNNP_HIP_EINVAL;
   hipStream_t s = c->stream.load(std::memory_order_acquire);
   bool owns = false;
   if (s == nullptr) {                    // the legacy default stream cannot be captured: the graph gets its own
@@ -436,6 +468,7 @@ int qnnp_hip_graph_begin(void)
     return QNNP_HIP_ELAUNCH;
   }
   t_cap.on = true;
+  t_cap.generation = g_generation.load(std::memory_order_acquire);
   t_cap.device = c->device;
   t_cap.stream = s;
   t_cap.owns_stream = owns;
@@ -452,7 +485,7 @@ struct Graph {
 
 int qnnp_hip_graph_end(void** out)
 {
-  if (!t_cap.on || out == nullptr) return QNNP_HIP_EINVAL;
+  if (!capture_live() || out == nullptr) return QNNP_HIP_EINVAL;
   const Capture cap = t_cap;
   t_cap = Capture();
   hipGraph_t graph = nullptr;

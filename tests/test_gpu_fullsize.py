@@ -13,9 +13,13 @@ from oracle import o1
 pytestmark = pytest.mark.gpu
 
 
-def test_c2_q8gemm_4096_cubed(qnnp):
-    """configs[1]: q8gemm M=N=K=4096 through qnnp_fully_connected_nc_q8."""
+@pytest.mark.parametrize("variant,kernel", [(0, "q8_gemm_mfma_256x256"), (10, "q8_gemm_mfma_128x256"),
+                                            (11, "q8_gemm_mfma_256x256_pp")], ids=["auto", "rows128", "pingpong"])
+def test_c2_q8gemm_4096_cubed(qnnp, variant, kernel):
+    """configs[1]: q8gemm M=N=K=4096 through qnnp_fully_connected_nc_q8 -- the shipped kernel and the two A/B structures
+    of round 3 (128 x 256 tiles with two workgroups per CU; the ping-pong schedule)."""
     import torch
+    qnnp.set_option("gemm_kernel", variant)
     M = N = K = 4096
     rng = np.random.default_rng(0x51A0 + 2)
     a = rng.integers(0, 256, size=(M, K), dtype=np.uint8)
@@ -36,7 +40,7 @@ def test_c2_q8gemm_4096_cubed(qnnp):
         d_c = to_device(np.full(M * N, FILL, np.uint8))
         qnnp.setup_fully_connected_nc_q8(op, M, d_a, K, d_c, N)
         qnnp.run_operator(op)
-        assert qnnp.operator_kernel(op) == "q8_gemm_mfma_256x256", qnnp.operator_kernel(op)
+        assert qnnp.operator_kernel(op) == kernel, qnnp.operator_kernel(op)
         c = from_device(d_c).reshape(M, N)
         assert_bytes_equal(c[sample].reshape(-1), expected.reshape(-1), "4096^3 sampled rows vs oracle")
         assert c.min() < 64 and c.max() > 192, "outputs should span the uint8 range"
@@ -48,6 +52,7 @@ def test_c2_q8gemm_4096_cubed(qnnp):
         c2 = from_device(d_c2).reshape(M, N)
         assert np.array_equal(c2[::-1], c), "row permutation equivariance violated at 4096^3"
     finally:
+        qnnp.set_option("gemm_kernel", 0)
         qnnp.delete_operator(op)
 
 
@@ -93,10 +98,16 @@ MOBILENETV2_DW = [(112, 1, 32), (112, 2, 96), (56, 1, 144), (56, 2, 144), (28, 1
                   (14, 1, 384), (14, 1, 576), (14, 2, 576), (7, 1, 960)]
 
 
+@pytest.mark.parametrize("kzp", [127, 100], ids=lambda v: f"kzp{v}")
+@pytest.mark.parametrize("batch", [8, 128], ids=lambda v: f"batch{v}")
 @pytest.mark.parametrize("h,s,c", MOBILENETV2_DW, ids=lambda v: str(v))
-def test_c4_mobilenetv2_depthwise_layers(qnnp, h, s, c):
-    batch = 8
-    case = ConvCase(f"c4_dw_{h}_{s}_{c}", (h, h), (3, 3), (1, 1, 1, 1), subsampling=(s, s), groups=c, batch=batch)
+def test_c4_mobilenetv2_depthwise_layers(qnnp, h, s, c, batch, kzp):
+    """Batch 128 is what bench.py times (segments per wave, XCD ranges and the walk all depend on the row count);
+    kernel zero point 127 (the bench's) takes the int8 dot-product walk at stride 1, kernel zero point 100 leaves
+    neither w - kzp nor kzp - w inside int8 and forces the int16 pair walk (`dw_wrange == 0`). Every image is checked."""
+    if kzp != 127 and batch != 128:
+        pytest.skip("the pair walk at small batches is covered by tests/test_gpu_dwcol.py")
+    case = ConvCase(f"c4_dw_{h}_{s}_{c}", (h, h), (3, 3), (1, 1, 1, 1), subsampling=(s, s), groups=c, batch=batch, kzp=kzp)
     inp, kernel, bias = conv_tensors(case)
     o1.set_threads(8)
     shape = o1.conv_shape(batch, h, h, case.padding, (3, 3), (s, s), (1, 1), c, 1, 1, c)
@@ -104,6 +115,7 @@ def test_c4_mobilenetv2_depthwise_layers(qnnp, h, s, c):
     oscale, ozp = output_quantization(acc)
     expected = o1.requantize_rows(acc.reshape(-1, c), np.float32(1.0) / oscale, ozp, 0, 255).reshape(-1)
     o1.set_threads(1)
+    assert np.mean((expected == 0) | (expected == 255)) < 0.10
     op = qnnp.create_convolution2d_nhwc_q8(1, 1, 1, 1, 3, 3, s, s, 1, 1, c, 1, 1, case.izp, 1.0, case.kzp, 1.0,
                                            kernel, bias, ozp, float(oscale), 0, 255, 0)
     try:
@@ -112,9 +124,9 @@ def test_c4_mobilenetv2_depthwise_layers(qnnp, h, s, c):
         qnnp.setup_convolution2d_nhwc_q8(op, batch, h, h, d_in, c, d_out, c)
         qnnp.run_operator(op)
         kname = qnnp.operator_kernel(op)
-        # the column-sliding window kernel (q8dwconv.hip make_plan)
-        assert kname == ("q8_dwconv_col_3x3_dot4" if s == 1 else "q8_dwconv_col_3x3"), kname   # kzp 127: int8 walk
-        assert_bytes_equal(from_device(d_out), expected, f"C4 depthwise {h}x{h} s{s} C{c} vs oracle")
+        # the column-sliding window kernel (q8dwconv.hip make_plan); kzp 127: int8 walk at stride 1
+        assert kname == ("q8_dwconv_col_3x3_dot4" if s == 1 and kzp == 127 else "q8_dwconv_col_3x3"), kname
+        assert_bytes_equal(from_device(d_out), expected, f"C4 depthwise {h}x{h} s{s} C{c} batch {batch} kzp {kzp} vs oracle")
     finally:
         qnnp.delete_operator(op)
 

@@ -12,14 +12,16 @@ from _runner import assert_bytes_equal, conv_expected, conv_run, fc_expected, fc
 pytestmark = pytest.mark.gpu
 
 
-# gemm_kernel option -> kernel-name suffix (8-wave default / 4-wave A/B flavour)
-_SUFFIX = {2: "", 4: "_w4"}
+# gemm_kernel option -> kernel name: 8-wave default / 4-wave A/B flavour / 128 x 256 tiles with two workgroups per CU /
+# the ping-pong schedule (round 3: the two structures DESIGN section 9 had listed as untried)
+_NAME = {2: "q8_gemm_mfma_256x256", 4: "q8_gemm_mfma_256x256_w4", 10: "q8_gemm_mfma_128x256",
+         11: "q8_gemm_mfma_256x256_pp"}
 
 
-@pytest.fixture(params=[2, 4], ids=["w8", "w4"])
+@pytest.fixture(params=sorted(_NAME), ids=lambda v: _NAME[v].replace("q8_gemm_mfma_", ""))
 def big(qnnp, request):
     qnnp.set_option("gemm_kernel", request.param)
-    qnnp._flavour = _SUFFIX[request.param]
+    qnnp._kname = _NAME[request.param]
     yield qnnp
     qnnp.set_option("gemm_kernel", 0)
 
@@ -27,7 +29,7 @@ def big(qnnp, request):
 def _fc(big, case):
     expected, quant = fc_expected(case)
     out, kname = fc_run(big, case, quant, to_device=to_device, from_device=from_device)
-    assert kname == "q8_gemm_mfma_256x256" + big._flavour, kname
+    assert kname == big._kname, kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 
 
@@ -75,7 +77,7 @@ def test_unaligned_output_uses_byte_stores(big):
 def test_convolution_forms(big, case):
     expected, quant, out_hw = conv_expected(case)
     out, kname = conv_run(big, case, quant, out_hw, to_device=to_device, from_device=from_device)
-    want = "q8_gemm_mfma_256x256" + big._flavour + ("_conv" if case.kernel_size != (1, 1) else "")
+    want = big._kname + ("_conv" if case.kernel_size != (1, 1) else "")
     assert kname == want, kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 

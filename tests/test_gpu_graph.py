@@ -92,3 +92,39 @@ def test_timing_with_and_without_graph_agree_roughly(qnnp):
     finally:
         qnnp.set_option("timing_graph", 1)
         qnnp.delete_operator(op)
+
+
+def test_create_setup_and_copies_are_refused_during_capture(qnnp):
+    """An upload recorded into a graph would read host memory that create / setup free right afterwards, and the
+    synchronizing copies would invalidate the capture: everything but operator launches answers
+    invalid_parameter between graph_begin and graph_end, the capture stays valid, and the operator keeps working."""
+    from qnnpack_amd import QnnpackError
+    case = ConvCase("g_refuse", (12, 12), (3, 3), (1, 1, 1, 1), gic=16, goc=32, batch=2)
+    op, d_in, d_out, expected = _make_conv(qnnp, case)
+    inp, kernel, bias = conv_tensors(case)
+    scratch = qnnp.malloc(256)
+    host = np.zeros(256, np.uint8)
+    try:
+        qnnp.graph_begin()
+        try:
+            with pytest.raises(QnnpackError):
+                qnnp.setup_convolution2d_nhwc_q8(op, case.batch, 12, 12, d_in, case.in_stride, d_out, case.out_stride)
+            with pytest.raises(QnnpackError):
+                qnnp.create_convolution2d_nhwc_q8(1, 1, 1, 1, 3, 3, 1, 1, 1, 1, 1, 16, 32, 127, 1.0, 127, 1.0,
+                                                  kernel, bias, 127, 1000.0, 0, 255, 0)
+            with pytest.raises(QnnpackError):
+                qnnp.memcpy_h2d(scratch, host)
+            with pytest.raises(QnnpackError):
+                qnnp.memcpy_d2h(host, scratch)
+            with pytest.raises(QnnpackError):
+                qnnp.memset(scratch, 0, 256)
+            # the refused setup left the operator unrunnable by design? no: it was refused before it touched anything
+            qnnp.run_operator(op)
+        finally:
+            graph = qnnp.graph_end()
+        qnnp.graph_launch(graph)
+        assert_bytes_equal(from_device(d_out), expected, "graph recorded around refused calls vs oracle")
+        qnnp.graph_destroy(graph)
+    finally:
+        qnnp.free(scratch)
+        qnnp.delete_operator(op)

@@ -86,7 +86,9 @@ def test_default_path_kernels_do_not_spill(kernels):
     ("26q8_pw_stream_staged_kernelILi4ELi16ELi3ELb1E", 96, "3-4 K blocks: 5 per CU"),
     ("26q8_pw_stream_staged_kernelILi7ELi16ELi3ELb1E", 128, "5-7 K blocks: 4 per CU"),
     ("25q8_conv_stream_c3s_kernelILi3ELb1E", 96, "first-layer kernel: 5 per CU"),
-    ("27q8_gemm_mfma_256x256_kernelILb0ELi4ELi0E", 256, "256x256 GEMM: 2 waves per SIMD"),
+    ("27q8_gemm_mfma_256x256_kernelILb0ELi4ELi256ELi0ELb0E", 256, "256x256 GEMM: 2 waves per SIMD"),
+    ("27q8_gemm_mfma_256x256_kernelILb0ELi4ELi256ELi0ELb1E", 256, "256x256 GEMM, ping-pong schedule: 2 waves per SIMD"),
+    ("27q8_gemm_mfma_256x256_kernelILb0ELi2ELi128ELi0ELb0E", 256, "128x256 GEMM: two 4-wave workgroups per CU"),
 ])
 def test_register_budgets_of_the_occupancy_critical_kernels(kernels, fragment, max_vgpr, why):
     hits = {n: k for n, k in kernels.items() if fragment in n}
