@@ -29,7 +29,9 @@ _loaded_debug = None
 
 
 def library_path() -> str:
-    return os.path.join(_PKG_DIR, _LIB_NAME)
+    # QNNP_GFX950_LIBRARY: measurement aid -- load another build of the library (an `ABLATION=1` build with in-kernel
+    # cycle stamps, an older build for a same-box A/B) in place of the product
+    return os.environ.get("QNNP_GFX950_LIBRARY") or os.path.join(_PKG_DIR, _LIB_NAME)
 
 
 def debug_library_path() -> str:

@@ -829,6 +829,309 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
   if (wave == 0) { QNNP_TRACE(p, blockIdx.x, 3, 3); QNNP_TRACE(p, blockIdx.x, 3, 4); QNNP_TRACE(p, blockIdx.x, 3, 5); }
 }
 
+
+/*
+ * The WEIGHT-STATIONARY flavour (round 3; default for 3x3 / stride 1): a wave keeps EVERY weight fragment of the layer
+ * in registers -- 9 taps x CB x TN fragments of 16 bytes per lane, 144 VGPRs for 64 -> 64 channels -- for its whole
+ * life, so that the K loop of a unit (4 rows x 8 positions x all channels, 36 MFMAs) reads nothing from LDS but the two
+ * activation fragments of a tap: 18 ds_read_b128 per unit instead of 54. What the counters said about the register-path
+ * kernel above (profiles/r03/pmc_conv3x3_*: first PMC passes this kernel family ever got): matrix pipe 36 % busy, the
+ * LDS array 49 % busy of which a sixth bank conflicts, waves stalled on instruction issue 45 % of their cycles with
+ * four of them per SIMD walking fetch / fix-up / K loop / epilogue as one chain each. Here: two waves per SIMD
+ * (the register file allows no more), a third of the LDS traffic, and per unit a chain of K loop (matrix pipe) and
+ * epilogue + fix-up (VALU) of about the same length, so the two waves of a SIMD settle into opposite phases.
+ * The weights go through LDS once per workgroup (LDS-DMA, 36 KiB), every wave then reads its copy with 36 ds_read_b128.
+ */
+constexpr int kWsWaves = 8;
+constexpr uint32_t kWsPixBytes = 1024;             // per wave: one dword per 16-byte patch chunk (the pixel's sum, replicated)
+
+inline uint32_t ws_lds_bytes(const WaveArgs& a) { return a.head_bytes + kWsWaves * (a.patch_bytes + kWsPixBytes); }
+
+/* What the first two versions of this kernel taught (stamps + PMC, profiles/r03): with weights in registers, with two
+ * patches in flight, with the epilogue software-pipelined into the next K loop -- always 4.1-4.3 k cycles per unit and
+ * wave, two waves per SIMD. 2 x ~520 instructions in 4.15 k cycles is ONE INSTRUCTION PER FOUR CYCLES PER SIMD, and the
+ * round-2 kernel (four waves of 572 instructions per 9.4 k cycles) sits on the same line: a SIMD issues one instruction
+ * every four cycles whatever the number of waves and whatever their mix. A unit's 36 MFMAs occupy the matrix pipe for
+ * 1152 cycles = 288 issue slots: the kernel is bound by its INSTRUCTION COUNT, and the budget is 8 instructions per
+ * MFMA. This version is written against that budget:
+ *   - the patch is fetched through a buffer descriptor with per-lane offsets that are constants of the kernel (one
+ *     v_add per piece; the 64-bit address arithmetic, bounds tests and selects of the flat-address version were ~100
+ *     instructions per unit); pixels outside the image are fetched from wherever the offset lands (in range: some other
+ *     pixel; out of range: the hardware returns zeros) and REPLACED by the zero point in the fix-up pass of border
+ *     units only (wave-uniform branch; 61 % of the units of a 56 x 56 image are interior);
+ *   - unit coordinates in 32-bit scalar arithmetic (the tensor is < 2^31 bytes: launcher);
+ *   - every lane writes its pixel sum (no exec-mask dance around a quarter-populated store). */
+template <int TN, int CB, int SEQ, bool FULL>
+__global__ __launch_bounds__(kWsWaves * 64, 2)
+void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [weights][bias][counter][waves x (patch | pixel sums)]
+  constexpr uint32_t kPR = 6u;                     // patch rows (10 columns) of a 4 x 8 unit
+  constexpr int NP = (kPR * 10u * CB * 2u + 63u) / 64u;   // 1 KiB pieces of the patch
+  uint8_t* w_lds = lds;
+  int32_t* bias_lds = reinterpret_cast<int32_t*>(lds + a.w_bytes);
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint8_t* patch = lds + a.head_bytes + wave * (a.patch_bytes + kWsPixBytes);
+  int32_t* pix = reinterpret_cast<int32_t*>(patch + a.patch_bytes);
+
+  const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * a.units / gridDim.x);
+  const uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * a.units / gridDim.x);
+
+  constexpr uint32_t cin = CB * 32u;
+  constexpr uint32_t log_cin = CB == 1 ? 5u : 6u;
+  constexpr uint32_t cpp = cin >> 4;               // 16-byte chunks per pixel
+  constexpr uint32_t log_cpp = log_cin - 4u;
+  constexpr uint32_t pvec = kPR * 10u * cpp;       // chunks of the patch
+  const uint32_t tiles = a.tiles_x * a.tiles_y;
+  const uint32_t fill4 = p.izp_fill;               // the raw zero point in every byte
+  const uint32_t khalf = lane >> 5;
+
+  // ---- the gather pattern of a patch is the same for every unit: per piece u this lane's chunk v = lane + 64 u is pixel
+  //      (py, px) of the patch, source chunk (v % cpp) ^ swz(py); only the patch origin moves ----
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.input), 0, static_cast<int>(a.units / tiles * p.image_stride), 0x00020000);   // (launcher: < 2^31)
+  uint32_t rel[NP], pyx[NP];
+#pragma unroll
+  for (int u = 0; u < NP; u++) {
+    const uint32_t v = min(lane + u * 64u, pvec - 1u);
+    const uint32_t sl = v & (cpp - 1u);
+    const uint32_t q = v >> log_cpp;
+    const uint32_t py = (q * 6554u) >> 16;                 // q / 10 for q < 100
+    const uint32_t px = q - py * 10u;
+    rel[u] = (py * g.W + px) * p.input_stride + ((sl ^ (py & (cpp - 1u))) << 4);
+    pyx[u] = (py << 16) | px;
+  }
+  struct Raw { v4i x[NP]; };
+  struct Where { uint32_t origin; int32_t iy0, ix0; uint32_t out_img, oy0, ox0; bool border; };   // (wave-uniform)
+  auto locate = [&](uint32_t unit) __attribute__((always_inline)) -> Where {
+    const uint32_t img = div_magic(unit, a.inv_tiles);
+    const uint32_t rr = unit - img * tiles;
+    const uint32_t tyi = div_magic(rr, a.inv_tiles_x);
+    const uint32_t txi = rr - tyi * a.tiles_x;
+    Where w;
+    w.oy0 = tyi * 4u;
+    w.ox0 = txi * 8u;
+    w.iy0 = static_cast<int32_t>(w.oy0) - static_cast<int32_t>(g.pad_top);
+    w.ix0 = static_cast<int32_t>(w.ox0) - static_cast<int32_t>(g.pad_left);
+    // byte offset of the patch's first pixel inside the tensor, modulo 2^32: negative for the first rows / columns --
+    // those lanes then see an offset past the descriptor's range (zeros) or some other pixel, and the fix-up replaces them
+    w.origin = img * static_cast<uint32_t>(p.image_stride) +
+        static_cast<uint32_t>(w.iy0 * static_cast<int32_t>(g.W) + w.ix0) * p.input_stride;
+    w.out_img = img * g.OH * g.OW * p.n;
+    w.border = w.iy0 < 0 || w.ix0 < 0 || w.iy0 + static_cast<int32_t>(kPR) > static_cast<int32_t>(g.H) ||
+               w.ix0 + 10 > static_cast<int32_t>(g.W);
+    return w;
+  };
+  auto fetch_piece = [&](const Where& w, int u, Raw& r) __attribute__((always_inline)) {
+    r.x[u] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, rel[u] + w.origin, 0, 0));
+  };
+  // the fetched patch: (border units: pixels outside the image become the zero point,) re-centred into LDS, per-pixel
+  // channel sums (of a') beside it
+  auto fix_up = [&](Raw& r, const Where& w) __attribute__((always_inline)) {
+    const uint32_t patch_off = lds_off(patch);
+    const uint32_t pix_off = lds_off(pix);
+    if (w.border) {
+#pragma unroll
+      for (int u = 0; u < NP; u++) {
+        const int32_t iy = w.iy0 + static_cast<int32_t>(pyx[u] >> 16);
+        const int32_t ix = w.ix0 + static_cast<int32_t>(pyx[u] & 0xFFFFu);
+        const bool inb = static_cast<uint32_t>(iy) < g.H && static_cast<uint32_t>(ix) < g.W;
+        r.x[u].x = inb ? r.x[u].x : static_cast<int>(fill4);
+        r.x[u].y = inb ? r.x[u].y : static_cast<int>(fill4);
+        r.x[u].z = inb ? r.x[u].z : static_cast<int>(fill4);
+        r.x[u].w = inb ? r.x[u].w : static_cast<int>(fill4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NP; u++) {
+      const uint32_t v = lane + u * 64u;
+      if ((u + 1) * 64u <= pvec || v < pvec) {             // (only the last piece is partly populated)
+        const v4i x = r.x[u];
+        uint32_t sum = __builtin_amdgcn_sad_u8(x.x, 0u, 0u);
+        sum = __builtin_amdgcn_sad_u8(x.y, 0u, sum);
+        sum = __builtin_amdgcn_sad_u8(x.z, 0u, sum);
+        sum = __builtin_amdgcn_sad_u8(x.w, 0u, sum);
+        sum += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(sum), 0xB1, 0xF, 0xF, false));        // lane ^ 1
+        if (cpp > 2) sum += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(sum), 0x4E, 0xF, 0xF, false));   // lane ^ 2
+        ds_write16_raw(patch_off + v * 16u, make_uint4(x.x ^ kFlip, x.y ^ kFlip, x.z ^ kFlip, x.w ^ kFlip));
+        ds_write4_raw(pix_off + v * 4u, static_cast<int32_t>(sum) - 128 * static_cast<int32_t>(cin));   // (all cpp lanes of the pixel)
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  };
+
+  // ---- prologue: first patch requested first (an HBM round trip), then weights + bias by LDS-DMA, once per workgroup
+  uint32_t cur = lo + wave;                        // round-robin walk: every unit costs the same, a counter buys no balance
+  Raw raw;
+  Where here = locate(min(cur, a.units - 1u));
+#pragma unroll
+  for (int u = 0; u < NP; u++) fetch_piece(here, u, raw);
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.output, 0, static_cast<int>(a.units / tiles * g.OH * g.OW * p.n), 0x00020000);   // (launcher: < 2^31)
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const uint32_t pieces = a.w_bytes >> 10;
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(p.packed_w) + lane * 16u;
+    for (uint32_t i = wave; i < pieces; i += kWsWaves) dma16(src + i * 1024u, w_lds + i * 1024u);
+    if (wave == kWsWaves - 1 && lane < p.n / 4u) {
+      dma16(reinterpret_cast<const uint8_t*>(p.bias2) + lane * 16u, reinterpret_cast<uint8_t*>(bias_lds));
+    }
+  }
+  fix_up(raw, here);                                // needs the patch only
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- every weight fragment into registers, for good ----
+  const uint32_t kblocks = p.k_pad / 32;
+  v4i wreg[9][CB][TN];
+  {
+    const uint8_t* w_lane = w_lds + lane * 16;
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+      for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++)
+          wreg[t][cb][tn] = *reinterpret_cast<const v4i*>(w_lane + (tn * kblocks + t * CB + cb) * 1024u);
+  }
+
+  const uint32_t i0 = lane & 31u;                  // position of this lane inside the unit
+  const uint32_t ty = i0 >> 3;
+  const uint32_t rowbase = (ty * 10u + (i0 & 7u)) << log_cin;
+  struct AF { v4i a[CB]; };
+  uint32_t unit_no = 0;
+  (void) unit_no;
+#define WS_STAMP(slot) do { if (wave == 0) { QNNP_TRACE(p, blockIdx.x, unit_no, slot); } } while (0)
+  while (cur < hi) {
+    WS_STAMP(0);
+    const Where next = locate(min(cur + kWsWaves, a.units - 1u));
+
+    // accumulators start at the folded bias
+    v16i acc[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const v4i b = *reinterpret_cast<const v4i*>(bias_lds + tn * 32 + rg * 8 + khalf * 4);
+        acc[tn][rg * 4 + 0] = b.x;
+        acc[tn][rg * 4 + 1] = b.y;
+        acc[tn][rg * 4 + 2] = b.z;
+        acc[tn][rg * 4 + 3] = b.w;
+      }
+    {
+      const uint8_t* abase[3][CB];
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++) {
+        const uint32_t swz = (ty + ky) & (cpp - 1u);
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) abase[ky][cb] = patch + rowbase + ky * 10 * cin + ((((cb << 1) | khalf) ^ swz) << 4);
+      }
+      auto read_a = [&](auto t_c, AF& f) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_c)::value;
+        constexpr int ky = t / 3, kx = t % 3;
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) f.a[cb] = *reinterpret_cast<const v4i*>(abase[ky][cb] + kx * cin);
+      };
+      auto mma = [&](auto t_c, const AF& f) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_c)::value;
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+          for (int tn = 0; tn < TN; tn++)
+            acc[tn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wreg[t][cb][tn], f.a[cb], acc[tn], 0, 0, 0);
+      };
+      // the next unit's patch is requested piece by piece between the taps
+      auto piece = [&](int u) __attribute__((always_inline)) { if (u < NP) fetch_piece(next, u, raw); };
+#define QNNP_T(n) std::integral_constant<int, n>{}
+      AF f0, f1;
+      WS_STAMP(1);
+      read_a(QNNP_T(0), f0);
+      read_a(QNNP_T(1), f1); mma(QNNP_T(0), f0);
+      read_a(QNNP_T(2), f0); mma(QNNP_T(1), f1); piece(0);
+      read_a(QNNP_T(3), f1); mma(QNNP_T(2), f0); piece(1);
+      read_a(QNNP_T(4), f0); mma(QNNP_T(3), f1); piece(2);
+      read_a(QNNP_T(5), f1); mma(QNNP_T(4), f0); piece(3);
+      read_a(QNNP_T(6), f0); mma(QNNP_T(5), f1); piece(4);
+      read_a(QNNP_T(7), f1); mma(QNNP_T(6), f0); piece(5);
+      read_a(QNNP_T(8), f0); mma(QNNP_T(7), f1); piece(6);
+      mma(QNNP_T(8), f0);
+#undef QNNP_T
+    }
+    WS_STAMP(2);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- fused epilogue: row term, requantization into the (now free) patch buffer, 16-byte stores ----
+    {
+      int32_t s = 0;
+      const int32_t* pq = pix + (ty * 10u + (i0 & 7u)) * cpp;
+#pragma unroll
+      for (int t = 0; t < 9; t++) s += pq[((t / 3) * 10 + (t % 3)) * cpp];
+      const int32_t rowterm = with_rq_offset<SEQ>(p.row_coeff * s);
+#pragma unroll
+      for (int tn = 0; tn < TN; tn++) {
+        uint32_t pk[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          pk[rg] = q31_requantize_pack4<SEQ, FULL, false>(
+              add_wrap(acc[tn][rg * 4 + 0], rowterm), add_wrap(acc[tn][rg * 4 + 1], rowterm),
+              add_wrap(acc[tn][rg * 4 + 2], rowterm), add_wrap(acc[tn][rg * 4 + 3], rowterm), p.rq);
+        }
+        const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+        // this lane now holds 16 consecutive channels of ITS position: tn * 32 + khalf * 16 .. + 15. Stored directly --
+        // no staging image, no read-back: the round trip through LDS cost ~370 cycles per unit of pure latency (two
+        // dependent ds_read -> store pairs) for the sake of whole-line stores, and with two waves per SIMD nothing hides it
+        const v4i v = {static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
+        const uint32_t oy = here.oy0 + ty;
+        const uint32_t ox = here.ox0 + (i0 & 7u);
+        const bool ok = oy < g.OH && ox < g.OW;
+        __builtin_amdgcn_raw_buffer_store_b128(
+            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc,
+            ok ? here.out_img + (oy * g.OW + ox) * p.n + tn * 32 + khalf * 16 : 0xFFFFFFF0u, 0, 0);
+      }
+      WS_STAMP(3);
+    }
+    WS_STAMP(4);
+    // ---- the next unit's patch (fetched between the taps) into the patch buffer ----
+    fix_up(raw, next);
+    WS_STAMP(5);
+    unit_no++;
+    here = next;
+    cur += kWsWaves;
+  }
+#undef WS_STAMP
+}
+
+template <int TN, int CB, int SEQ, bool FULL>
+int launch_ws_as(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hipStream_t stream)
+{
+  static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
+  if (auto once_scope = attr_once.begin()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_ws_kernel<TN, CB, SEQ, FULL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      (void) hipGetLastError();
+    }
+  }
+  const uint32_t want = (a.units + kWsWaves - 1) / kWsWaves;
+  const uint32_t grid = want < p.cu_count ? want : p.cu_count;
+  hipLaunchKernelGGL((q8_conv_wave_ws_kernel<TN, CB, SEQ, FULL>), dim3(grid), dim3(kWsWaves * 64), ws_lds_bytes(a), stream, p, g, a);
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+template <int TN, int CB>
+int launch_ws(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hipStream_t stream)
+{
+  int rc = QNNP_HIP_EINVAL;
+  requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+    rc = launch_ws_as<TN, CB, decltype(seq)::value, decltype(full)::value>(p, g, a, stream);
+  });
+  return rc;
+}
+
+
 template <int TM, int TN, int CB, int SEQ, bool FULL>
 int launch_reg_as(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hipStream_t stream)
 {
@@ -897,7 +1200,7 @@ bool convwave_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups
   return make_args(p, g, batch, &a, &lds_bytes);
 }
 
-int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipStream_t stream, const char** name)
+int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipStream_t stream, const char** name, int flavour)
 {
   WaveArgs a;
   uint32_t lds_bytes = 0;
@@ -906,6 +1209,17 @@ int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hip
   const bool k33 = g.KH == 3 && g.KW == 3 && g.sh == 1 && g.sw == 1 && g.dh == 1 && g.dw == 1;
   // 3x3 / stride 1: the register-path kernel when its LDS fits and the output is addressable with 32-bit offsets
   const uint64_t out_bytes = static_cast<uint64_t>(batch) * g.OH * g.OW * p.n;
+  if (k33 && out_bytes < (UINT64_C(1) << 31) && flavour != 1) {
+    // weights in registers (q8_conv_wave_ws_kernel): the default; "gemm_kernel" = 12 keeps the round-2 register-path kernel
+    bool ok = false;
+    const WaveArgs ar = reg_args<1>(a, p, g, batch, &ok);
+    const uint64_t in_bytes = static_cast<uint64_t>(batch) * p.image_stride;    // (32-bit buffer offsets)
+    if (ok && in_bytes < (UINT64_C(1) << 31) && ws_lds_bytes(ar) <= kLdsLimit) {
+      *name = "q8_conv_wave_ws_mfma";
+      if (p.kc == 32) return p.n == 32 ? launch_ws<1, 1>(p, g, ar, stream) : launch_ws<2, 1>(p, g, ar, stream);
+      return p.n == 32 ? launch_ws<1, 2>(p, g, ar, stream) : launch_ws<2, 2>(p, g, ar, stream);
+    }
+  }
   if (k33 && out_bytes < (UINT64_C(1) << 31)) {
     int tm = 1;                                    // 4x8-position units (see reg_waves)
 #ifdef QNNP_ENABLE_ABLATION

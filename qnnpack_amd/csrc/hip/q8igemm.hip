@@ -574,10 +574,12 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   const bool wave_shape = a->offsets != nullptr && !pad3 && a->rows_per_image > 0 && p.store_mode == 2 &&
       qnnp::convwave_supported(p, geom, a->groups, vec, a->rows / a->rows_per_image);
   const bool wave_k33 = geom.KH == 3 && geom.KW == 3 && geom.sh == 1 && geom.sw == 1 && geom.dh == 1 && geom.dw == 1;
-  const bool wave_ok = wave_shape && (a->variant == 8 || (a->variant == 0 && wave_k33 && a->rows >= 16384u));
-  if (a->variant == 8 && !wave_ok) return QNNP_HIP_EINVAL;
+  // ("gemm_kernel" = 12: the same family with the round-2 register-path kernel instead of the weight-stationary one)
+  const bool wave_forced = a->variant == 8 || a->variant == 12;
+  const bool wave_ok = wave_shape && (wave_forced || (a->variant == 0 && wave_k33 && a->rows >= 16384u));
+  if (wave_forced && !wave_ok) return QNNP_HIP_EINVAL;
   if (wave_ok) {
-    const int rc_wave = qnnp::convwave_launch(p, geom, a->rows / a->rows_per_image, stream, &name);
+    const int rc_wave = qnnp::convwave_launch(p, geom, a->rows / a->rows_per_image, stream, &name, a->variant == 12 ? 1 : 0);
     if (kernel_name != nullptr) *kernel_name = name;
     return rc_wave;
   }

@@ -11,11 +11,18 @@ from _runner import assert_bytes_equal, conv_expected, conv_run
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def waveconv(qnnp):
-    qnnp.set_option("gemm_kernel", 8)
+# "gemm_kernel" = 8: the family with its default 3x3 / stride 1 flavour (weights in registers, round 3);
+# "gemm_kernel" = 12: the same with the round-2 register-path kernel kept for A/B
+@pytest.fixture(params=[8, 12], ids=["ws", "reg"])
+def waveconv(qnnp, request):
+    qnnp.set_option("gemm_kernel", request.param)
+    qnnp._variant = request.param
     yield qnnp
     qnnp.set_option("gemm_kernel", 0)
+
+
+def _is_k33(case):
+    return case.kernel_size == (3, 3) and case.subsampling == (1, 1) and case.dilation == (1, 1)
 
 
 CASES = [
@@ -45,7 +52,8 @@ CASES = [
 def test_wave_convolution_matches_oracle(waveconv, case):
     expected, quant, out_hw = conv_expected(case)
     out, kname = conv_run(waveconv, case, quant, out_hw, to_device=to_device, from_device=from_device)
-    assert kname == "q8_conv_wave_mfma", kname
+    want = "q8_conv_wave_ws_mfma" if (waveconv._variant == 8 and _is_k33(case)) else "q8_conv_wave_mfma"
+    assert kname == want, kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 
 

@@ -78,7 +78,7 @@ def test_c3_q8conv_3x3_56x56x64_batch128(qnnp):
         d_out = to_device(np.full(128 * img, FILL, np.uint8))
         qnnp.setup_convolution2d_nhwc_q8(op, 128, 56, 56, d_in, 64, d_out, 64)
         qnnp.run_operator(op)
-        assert qnnp.operator_kernel(op) == "q8_conv_wave_mfma", qnnp.operator_kernel(op)
+        assert qnnp.operator_kernel(op) == "q8_conv_wave_ws_mfma", qnnp.operator_kernel(op)
         out = from_device(d_out).reshape(128, img)
         for j, i in enumerate(sample):
             assert_bytes_equal(out[i], expected[j], f"C3 image {i} vs oracle")

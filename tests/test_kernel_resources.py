@@ -65,7 +65,7 @@ def kernels(tmp_path_factory):
 # spill in its 1-byte flavours and is reported by test_report_of_spilling_kernels below, not asserted
 DEFAULT_PATH = ["q8_gemm_mfma_256x256_kernelILb0ELi4E", "q8_gemm_mfma_256x256_kernelILb1ELi4E", "q8_pw_stream_staged_kernel", "q8_pw_stream_longk_kernel",
                 "q8_pw_stream_gw_kernel", "q8_pw_stream_gwk_kernel", "q8_conv_stream_c3s_kernel",
-                "q8_dwconv_col3x3_kernel", "q8_conv_wave_reg_kernel", "q8_conv_lds_mfma", "q8_vadd", "q8_gavgpool"]
+                "q8_dwconv_col3x3_kernel", "q8_conv_wave_reg_kernel", "q8_conv_wave_ws_kernel", "q8_conv_lds_mfma", "q8_vadd", "q8_gavgpool"]
 
 
 def test_default_path_kernels_do_not_spill(kernels):
