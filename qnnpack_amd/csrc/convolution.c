@@ -257,6 +257,24 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
       qnnp_log_error("failed to place %zu bytes of packed weights on the device", w_bytes + b_bytes);
       goto error;
     }
+    if (kc_slot == 4 && kernel_height <= 4 && kernel_width * 3 <= 16 && dilation_height == 1 && dilation_width == 1 &&
+        n_pad <= 64) {
+      /* first layers: the row-slot image beside the tap-slot one (hip/q8convc3.hip takes it when pixels are dense) */
+      const size_t r_bytes = (size_t) n_pad * 64;
+      int8_t* host_rows = (int8_t*) malloc(r_bytes);
+      if (host_rows == NULL) {
+        qnnp_log_error("failed to allocate %zu bytes for packed weights", r_bytes);
+        goto error;
+      }
+      qnnp_pack_conv_rows16((uint32_t) group_output_channels, kernel_height, kernel_width, 3, n_pad, kernel, host_rows);
+      op->d_weights_rows16 = qnnp_hip_alloc(r_bytes);
+      const int placed = op->d_weights_rows16 != NULL && qnnp_hip_h2d(op->d_weights_rows16, host_rows, r_bytes, 0) == QNNP_HIP_OK;
+      free(host_rows);
+      if (!placed) {
+        qnnp_log_error("failed to place %zu bytes of packed weights on the device", r_bytes);
+        goto error;
+      }
+    }
   }
   free(host_weights);
   free(host_bias);

@@ -98,6 +98,10 @@ int pwstream_longk_launch(const IgemmParams& p, hipStream_t stream, const char**
 bool pwstream_gw_supported(const IgemmParams& p, uint32_t groups, uint32_t vec);
 int pwstream_gw_launch(const IgemmParams& p, hipStream_t stream, const char** name);
 
+/* q8convc3.hip */
+bool conv_c3rows_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, const int8_t* w_rows16, uint32_t real_kc);
+int conv_c3rows_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_rows16, hipStream_t stream, const char** name);
+
 /* q8gemm256.hip */
 bool gemm256_supported(const IgemmParams& p, uint32_t vec);
 int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, bool waves4, bool rows128, bool pingpong);

@@ -1,0 +1,395 @@
+/*
+ * q8convc3.hip -- first-layer convolution (3 input channels, small window) as ONE 16-byte fetch per kernel row.
+ *
+ * Same operator and arithmetic as the other implicit-GEMM kernels (replaces q8conv_ukernel_4x4c2__sse2,
+ * src/q8conv/4x4c2-sse2.c:14-273, + compute_q8conv, src/operator-run.c:183-217, 837-842, + the indirection buffer,
+ * src/indirection.c:18-79) for the network-entry layers of bench/convolution.cc (MobileNetV2 line 457: 224x224x3 ->
+ * 112x112x32, 3x3 stride 2).
+ *
+ * Why a third kernel for this shape: the offset-table kernel of q8pwconv.hip (q8_conv_stream_c3s_kernel) gathers a
+ * pixel's nine taps with eight unaligned dword loads per lane and assembles the MFMA operand from them -- 245 VALU + 140
+ * scalar instructions per 32 output pixels for ONE useful MFMA, and a SIMD issues one instruction per four cycles
+ * whatever its waves do: 22 us of the 35 were instruction issue with no memory operation at all.
+ * With dense 3-byte pixels the kx * 3 + c bytes of ONE kernel row are contiguous in memory: KW * 3 <= 16 bytes starting at
+ * pixel (oy*s + ky - pad, ox*s - pad). So K is laid out as [ky][16-byte row slot] -- K = 16 * KH <= 64, the slot's unused
+ * bytes meet zero weights -- and a lane's MFMA operand half IS the 16 bytes it loads: two loads per lane and unit, no
+ * assembly. What it costs: a second MFMA per 32 x 32 outputs (K 27 -> 48), which the matrix pipe does not notice.
+ *   - unit = 32 consecutive flattened output pixels; lane (p, h) owns pixel p and row slots ky = h, h + 2;
+ *   - pixels outside the image: the slot is fetched from wherever its address lands (the descriptor returns zeros out of
+ *     range) and the bytes of out-of-image taps are REPLACED by the zero point -- in units that touch the border only
+ *     (wave-uniform branch on a ballot);
+ *   - row sums over the real K positions only: v_dot4_u32_u8 against a 0/1 byte mask (the slot's junk bytes do not count);
+ *   - weights (two fragments per 32 channels) and folded bias live in registers: no LDS, no barrier;
+ *   - epilogue: row term, Q31 requantization, v_permlane32_swap -> 16 contiguous channels per lane, one 16-byte store
+ *     per lane and 32 channels: a wave writes its 32 pixels x 32 bytes as one contiguous kilobyte.
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "igemm_params.h"
+#include "requant.hip.h"
+
+namespace qnnp {
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int kC3Waves = 4;
+constexpr int kC3Threads = kC3Waves * 64;
+constexpr uint32_t kFlip = 0x80808080u;
+
+struct C3Geom {
+  uint32_t H, W, OH, OW;
+  uint32_t KH, KW;
+  uint32_t sh, sw;
+  uint32_t pad_top, pad_left;
+  uint32_t segs, pairs;       // 16-column segments per output row, row pairs per image
+  uint32_t inv_segs;          // ceil(2^32 / segs) (0: divisor 1); exact while units * segs < 2^32 (launcher)
+  uint32_t inv_pairs;         // the same for pairs
+  const int8_t* w_rows16;     // MFMA fragments of the [ky][16] K layout: [n_pad / 32][2][64 lanes][16 bytes]
+  uint32_t abl;               // measurement builds only (QNNP_C3R_ABL): 1 = 16-byte aligned loads, 2 = no stores, 4 = no loads
+};
+
+__device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t inv) { return inv != 0u ? __umulhi(n, inv) : n; }
+
+// bytes [lo, hi) of a dword (lo, hi relative to the dword's first byte, any integers): 0xFF in each such byte
+__device__ __forceinline__ uint32_t byte_range_mask(int32_t lo, int32_t hi)
+{
+  lo = lo < 0 ? 0 : (lo > 4 ? 4 : lo);
+  hi = hi < 0 ? 0 : (hi > 4 ? 4 : hi);
+  if (hi <= lo) return 0u;
+  const uint64_t ones = ~UINT64_C(0);
+  const uint32_t upto_hi = static_cast<uint32_t>(~(ones << (8 * hi)));      // hi in 0..4: the shift is < 64
+  const uint32_t upto_lo = static_cast<uint32_t>(~(ones << (8 * lo)));
+  return upto_hi & ~upto_lo;
+}
+
+/* UNIT = 2 output rows x 16 output columns of one image (32 pixels; lane (p, h): row p >> 4, column p & 15 of the
+ * unit, K half h). Everything that locates a unit is scalar arithmetic; a lane's byte offsets are constants of the
+ * kernel plus one scalar per unit. Whether a unit touches the image border (some tap outside the image) or the tensor's
+ * first / last bytes is a scalar test as well: the byte surgery below runs in those units only.
+ *
+ * The per-pixel term (128 - kzp) * sum_k a'(pixel, k) is made BY THE MATRIX CORE: a second pair of weight fragments holds
+ * (128 - kzp) at every real K position of EVERY channel, and its product with the same activation operand accumulates
+ * into the same registers -- two more MFMAs per 32 x 32 outputs on an idle pipe instead of 6 v_dot4 + a cross-half exchange
+ * + a multiply + 16 adds per lane (an instruction is an instruction to the issue port: DESIGN section 4.2c).
+ * (128 - kzp = 128, i.e. kernel zero point 0, does not fit int8: it is applied as 64 + 64 by two such pairs.) */
+template <int NB, int ND, int RCP, int SEQ, bool FULL>
+__global__ __launch_bounds__(kC3Threads, 4)
+void q8_conv_c3rows_kernel(const IgemmParams p, const C3Geom cg)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t px = lane & 31u;
+  const uint32_t h = lane >> 5;
+  const uint32_t prow = px >> 4, pcol = px & 15u;
+
+  const uint32_t kbytes = cg.KW * 3u;                       // real bytes of a slot (<= 16; launcher)
+  // ---- weights, row-term fragments and bias (+ the requantization offset) of all NB channel blocks into registers ----
+  v4i w[NB][2];
+  v16i bias[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++) {
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      w[nb][kb] = *reinterpret_cast<const v4i*>(cg.w_rows16 + ((nb * 2 + kb) * 64u + lane) * 16u);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const v4i b = *reinterpret_cast<const v4i*>(p.bias2 + nb * 32 + rg * 8 + h * 4);
+      bias[nb][rg * 4 + 0] = with_rq_offset<SEQ>(b.x); bias[nb][rg * 4 + 1] = with_rq_offset<SEQ>(b.y);
+      bias[nb][rg * 4 + 2] = with_rq_offset<SEQ>(b.z); bias[nb][rg * 4 + 3] = with_rq_offset<SEQ>(b.w);
+    }
+  }
+  // row-term fragments: lane (n, h) of K block kb holds row slot ky = 2 kb + h of "channel" n -- the same 16 bytes for
+  // every n: rc at the real positions of a real slot, 0 elsewhere
+  v4i wrc[RCP][2];
+  {
+    const int32_t rc = p.row_coeff;                         // 128 - kernel zero point: 1 .. 128 (0: no term at all)
+#pragma unroll
+    for (int part = 0; part < RCP; part++) {
+      const int32_t piece = RCP == 1 ? rc : (part == 0 ? rc / 2 : rc - rc / 2);
+      const uint32_t b4 = (static_cast<uint32_t>(piece) & 0xFFu) * 0x01010101u;
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        const bool real = kb * 2u + h < cg.KH;
+        int* d = reinterpret_cast<int*>(&wrc[part][kb]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          d[i] = real ? static_cast<int>(byte_range_mask(0 - 4 * i, static_cast<int32_t>(kbytes) - 4 * i) & b4) : 0;
+        }
+      }
+    }
+  }
+
+  const uint32_t in_bytes = static_cast<uint32_t>(p.input_end - p.input);          // (launcher: < 2^31)
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.input), 0, static_cast<int>(in_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.output, 0, static_cast<int>((p.rows - 1u) * p.output_stride + p.n), 0x00020000);   // (launcher: < 2^31)
+
+  // ---- per-lane constants: byte offset of the lane's two row slots relative to the unit's first window, of its output
+  //      pixel relative to the unit's first one ----
+  const uint32_t row_bytes = cg.W * 3u;
+  uint32_t lane_in[2];
+  bool slot_real[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; kb++) {
+    const uint32_t ky = kb * 2u + h;
+    slot_real[kb] = ky < cg.KH;
+    lane_in[kb] = (prow * cg.sh + (slot_real[kb] ? ky : 0u)) * row_bytes + pcol * cg.sw * 3u;
+  }
+  const uint32_t lane_out = (prow * cg.OW + pcol) * p.output_stride + h * 16u;
+  const uint32_t fill4 = (p.izp_fill & 0xFFu) * 0x01010101u;
+
+  // x: sixteen bytes from the dword-aligned address at or below the slot's first byte; tail (ND == 4 only): the dword
+  // behind them. A buffer load whose address is not a multiple of four costs the texture-address unit several passes
+  // (measured on this kernel: 31.9 us with byte-aligned, 23.8 us with dword- or 16-byte-aligned addresses, same bytes), so
+  // the slot is fetched from the dword below and moved into place with three v_alignbyte.
+  struct Slots { v4i x[2]; uint32_t tail[2]; };
+  // delta: bytes by which a slot's load address was moved to keep all 16 bytes inside the tensor (non-zero only in the
+  // first rows of the first image and the last rows of the last one: a buffer load that starts before the tensor or
+  // straddles its end returns zeros for every dword that is not wholly inside, real tap bytes included)
+  struct Unit { uint32_t out0; int32_t iy0, ix0; uint32_t rows_left, cols_left; bool border, edge; int32_t delta[2]; };
+  auto locate = [&](uint32_t unit) __attribute__((always_inline)) -> Unit {       // scalar
+    const uint32_t t = div_magic(unit, cg.inv_segs);
+    const uint32_t seg = unit - t * cg.segs;
+    const uint32_t img = div_magic(t, cg.inv_pairs);
+    const uint32_t pair = t - img * cg.pairs;
+    const uint32_t oy = pair * 2u, ox = seg * 16u;
+    Unit u;
+    u.iy0 = static_cast<int32_t>(oy * cg.sh) - static_cast<int32_t>(cg.pad_top);
+    u.ix0 = static_cast<int32_t>(ox * cg.sw) - static_cast<int32_t>(cg.pad_left);
+    u.rows_left = cg.OH - oy;                                // output rows / columns of the image from this unit on
+    u.cols_left = cg.OW - ox;
+    u.out0 = ((img * cg.OH + oy) * cg.OW + ox) * p.output_stride;
+    // first / last input row and column any lane of the unit touches
+    const int32_t iy_last = u.iy0 + static_cast<int32_t>(cg.sh + cg.KH) - 1;
+    const int32_t ix_last = u.ix0 + static_cast<int32_t>(15u * cg.sw + cg.KW) - 1;
+    u.border = u.iy0 < 0 || u.ix0 < 0 || iy_last >= static_cast<int32_t>(cg.H) || ix_last >= static_cast<int32_t>(cg.W);
+    u.edge = img == 0u || (img + 1u) * cg.OH * cg.OW >= p.rows;      // windows that may reach the tensor's first / last bytes
+    u.delta[0] = u.delta[1] = 0;
+    return u;
+  };
+  // byte offset of the unit's first window inside the tensor, modulo 2^32 (negative for the first row / column: out of
+  // the descriptor's range -> zeros, or some other pixel; either way replaced below)
+  auto origin = [&](uint32_t unit, const Unit& u) __attribute__((always_inline)) -> uint32_t {
+    const uint32_t t = div_magic(unit, cg.inv_segs);
+    const uint32_t img = div_magic(t, cg.inv_pairs);
+    return img * static_cast<uint32_t>(p.image_stride) + static_cast<uint32_t>(u.iy0 * static_cast<int32_t>(cg.W) + u.ix0) * 3u;
+  };
+  auto fetch = [&](uint32_t unit, Unit& u, Slots& s, int32_t (&delta)[2]) __attribute__((always_inline)) {
+    const uint32_t org = origin(unit, u);
+    uint32_t addr[2] = {org + lane_in[0], org + lane_in[1]};
+    if (u.edge) {                                          // (scalar branch; address arithmetic only: the loads are below)
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        const int32_t want = static_cast<int32_t>(addr[kb]);
+        const int32_t last = static_cast<int32_t>(in_bytes) - 16;
+        const int32_t got = want < 0 ? 0 : (want > last ? last : want);   // (byte-aligned: the tensor's last bytes must stay in reach; 2 images of the batch pay for it)
+        delta[kb] = got - want;
+        addr[kb] = static_cast<uint32_t>(got);
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        delta[kb] = -static_cast<int32_t>(addr[kb] & 3u);      // 0 .. -3: loaded byte j + 3.. is slot byte j
+        addr[kb] &= ~3u;
+      }
+    }
+#ifdef QNNP_ENABLE_ABLATION
+    if (cg.abl & 1u) { addr[0] &= ~15u; addr[1] &= ~15u; }
+    if (cg.abl & 8u) { addr[0] &= ~3u; addr[1] &= ~3u; }
+    if (cg.abl & 16u) { addr[0] &= ~7u; addr[1] &= ~7u; }
+    if (cg.abl & 4u) { addr[0] = addr[1] = (lane & 3u) * 16u; }
+#endif
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      s.x[kb] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, addr[kb], 0, 0));
+      if constexpr (ND > 3) s.tail[kb] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, addr[kb] + 16u, 0, 0);
+    }
+  };
+
+  const uint32_t units = (p.rows / (cg.OH * cg.OW)) * cg.pairs * cg.segs;
+  const uint32_t unit_stride = gridDim.x * kC3Waves;
+  uint32_t unit = blockIdx.x * kC3Waves + wave;
+  if (unit >= units) return;
+
+  // one unit: its slots were requested a trip ago
+  auto process = [&](const Unit& u, Slots& s, const int32_t (&delta)[2]) __attribute__((always_inline)) {
+    if (u.border || u.edge) {                              // (scalar) taps outside the image -> the zero point
+      const int32_t ix0 = u.ix0 + static_cast<int32_t>(pcol * cg.sw);
+      const int32_t iy0 = u.iy0 + static_cast<int32_t>(prow * cg.sh);
+      const int32_t left = ix0 < 0 ? -ix0 : 0;                                              // pixels
+      const int32_t right = ix0 + static_cast<int32_t>(cg.KW) - static_cast<int32_t>(cg.W);   // > 0: pixels past the row
+      const int32_t lo = 3 * left;
+      const int32_t hi = static_cast<int32_t>(kbytes) - 3 * (right > 0 ? right : 0);
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        const bool row_out = slot_real[kb] && static_cast<uint32_t>(iy0 + static_cast<int32_t>(kb * 2u + h)) >= cg.H;
+        if (delta[kb] != 0 && !row_out) {
+          // the load was moved by delta bytes: slot byte j is loaded byte j - delta (a slot moved DOWN by 1..3 bytes whose
+          // last real byte sits in the tail dword only exists in windows 5 pixels wide: the tail is shifted in below)
+          const uint32_t tail_in = (ND > 3 && delta[kb] < 0 && delta[kb] >= -3)
+              ? s.tail[kb] << (8u * static_cast<uint32_t>(4 + delta[kb])) : 0u;
+          uint64_t l64 = static_cast<uint32_t>(s.x[kb].x) | (static_cast<uint64_t>(static_cast<uint32_t>(s.x[kb].y)) << 32);
+          uint64_t h64 = static_cast<uint32_t>(s.x[kb].z) | (static_cast<uint64_t>(static_cast<uint32_t>(s.x[kb].w)) << 32);
+          const int32_t dl = delta[kb] > 15 ? 15 : (delta[kb] < -15 ? -15 : delta[kb]);
+          if (dl > 0) {
+            const uint32_t sh = 8u * static_cast<uint32_t>(dl);
+            if (sh >= 64u) { h64 = l64 << (sh - 64u); l64 = 0; }
+            else { h64 = (h64 << sh) | (l64 >> (64u - sh)); l64 <<= sh; }
+          } else {
+            const uint32_t sh = 8u * static_cast<uint32_t>(-dl);
+            if (sh >= 64u) { l64 = h64 >> (sh - 64u); h64 = 0; }
+            else { l64 = (l64 >> sh) | (h64 << (64u - sh)); h64 >>= sh; }
+          }
+          s.x[kb].x = static_cast<int>(static_cast<uint32_t>(l64)); s.x[kb].y = static_cast<int>(static_cast<uint32_t>(l64 >> 32));
+          s.x[kb].z = static_cast<int>(static_cast<uint32_t>(h64)); s.x[kb].w = static_cast<int>(static_cast<uint32_t>(h64 >> 32) | tail_in);
+        }
+        int* xs = reinterpret_cast<int*>(&s.x[kb]);
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+          // bytes of the slot that ARE image pixels
+          const uint32_t keep = row_out ? 0u : byte_range_mask(lo - 4 * d, hi - 4 * d);
+          xs[d] = static_cast<int>((static_cast<uint32_t>(xs[d]) & keep) | (fill4 & ~keep));
+        }
+      }
+    }
+    else {
+      // interior: the slot starts 0..3 bytes into the loaded dwords
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        const uint32_t shb = static_cast<uint32_t>(-delta[kb]);
+        const uint32_t d0 = static_cast<uint32_t>(s.x[kb].x), d1 = static_cast<uint32_t>(s.x[kb].y);
+        const uint32_t d2 = static_cast<uint32_t>(s.x[kb].z), d3 = static_cast<uint32_t>(s.x[kb].w);
+        s.x[kb].x = static_cast<int>(__builtin_amdgcn_alignbyte(d1, d0, shb));
+        s.x[kb].y = static_cast<int>(__builtin_amdgcn_alignbyte(d2, d1, shb));
+        s.x[kb].z = static_cast<int>(__builtin_amdgcn_alignbyte(d3, d2, shb));
+        if constexpr (ND > 3) s.x[kb].w = static_cast<int>(__builtin_amdgcn_alignbyte(s.tail[kb], d3, shb));
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      s.x[kb].x ^= static_cast<int>(kFlip); s.x[kb].y ^= static_cast<int>(kFlip);
+      s.x[kb].z ^= static_cast<int>(kFlip); s.x[kb].w ^= static_cast<int>(kFlip);
+    }
+    const bool pixel_ok = prow < u.rows_left && pcol < u.cols_left;
+    const uint32_t out_off = u.out0 + lane_out;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[nb][0], s.x[0], bias[nb], 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[nb][1], s.x[1], acc, 0, 0, 0);
+#pragma unroll
+      for (int part = 0; part < RCP; part++) {
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wrc[part][0], s.x[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wrc[part][1], s.x[1], acc, 0, 0, 0);
+      }
+      uint32_t pk[4];
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        pk[rg] = q31_requantize_pack4<SEQ, FULL>(acc[rg * 4 + 0], acc[rg * 4 + 1], acc[rg * 4 + 2], acc[rg * 4 + 3], p.rq);
+      }
+      const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+      const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+      const v4i v = {static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
+      bool ok = pixel_ok && nb * 32u + h * 16u < p.n;          // (n % 16 == 0: launcher)
+#ifdef QNNP_ENABLE_ABLATION
+      if (cg.abl & 2u) ok = ok && v.x == 0x12345678;
+#endif
+      __builtin_amdgcn_raw_buffer_store_b128(
+          __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc,
+          ok ? out_off + nb * 32u : 0xFFFFFFF0u, 0, 0);
+    }
+  };
+
+  Unit ua = locate(unit), ub;
+  Slots sa, sb;
+  int32_t da[2], db[2];
+  fetch(unit, ua, sa, da);
+  // (two copies of the body with the register sets swapping roles: a loop-carried copy of a just-loaded register is a
+  //  wait for it, DESIGN section 4.3 rule 4)
+  for (;;) {
+    uint32_t next = min(unit + unit_stride, units - 1u);
+    ub = locate(next);
+    fetch(next, ub, sb, db);
+    process(ua, sa, da);
+    if (unit + unit_stride >= units) break;
+    unit = next;
+    next = min(unit + unit_stride, units - 1u);
+    ua = locate(next);
+    fetch(next, ua, sa, da);
+    process(ub, sb, db);
+    if (unit + unit_stride >= units) break;
+    unit = next;
+  }
+}
+
+template <int NB, int ND, int RCP>
+int launch_c3rows(const IgemmParams& p, const C3Geom& cg, hipStream_t stream)
+{
+  const uint32_t units = (p.rows / (cg.OH * cg.OW)) * cg.pairs * cg.segs;
+  uint32_t grid = p.cu_count * 4u;                         // four 4-wave workgroups per CU
+  const uint32_t needed = (units + kC3Waves - 1) / kC3Waves;
+  if (grid > needed) grid = needed;
+  requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+    hipLaunchKernelGGL((q8_conv_c3rows_kernel<NB, ND, RCP, decltype(seq)::value, decltype(full)::value>), dim3(grid),
+                       dim3(kC3Threads), 0, stream, p, cg);
+  });
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+}  // namespace
+
+/* dense 3-byte pixels, one group, window rows of <= 16 bytes and <= 4 rows, 32 or 64 output channels in whole 16-byte
+ * pieces, tensors addressable with 32-bit offsets */
+bool conv_c3rows_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, const int8_t* w_rows16, uint32_t real_kc)
+{
+  if (w_rows16 == nullptr || groups != 1 || real_kc != 3 || p.input_stride != 3) return false;
+  if (g.KW * 3u > 16u || g.KH == 0 || g.KH > 4 || g.dh != 1 || g.dw != 1) return false;
+  if (p.n_pad > 64 || p.n % 16u != 0 || p.output_stride % 16u != 0 || (reinterpret_cast<uintptr_t>(p.output) & 15u) != 0) return false;
+  if (p.rows == 0 || p.rows_per_image == 0 || g.OW == 0 || g.OH == 0 || p.rows_per_image != g.OH * g.OW) return false;
+  if (p.rows % p.rows_per_image != 0) return false;
+  const uint64_t in_bytes = static_cast<uint64_t>(p.input_end - p.input);
+  const uint64_t out_bytes = static_cast<uint64_t>(p.rows) * p.output_stride;
+  if (in_bytes < 16 || in_bytes >= (UINT64_C(1) << 31) || out_bytes >= (UINT64_C(1) << 31)) return false;
+  // units = images x row pairs x 16-column segments; the reciprocal divisions of the unit index are exact while
+  // dividend * divisor < 2^32
+  const uint64_t segs = (g.OW + 15u) / 16u, pairs = (g.OH + 1u) / 2u;
+  const uint64_t units = static_cast<uint64_t>(p.rows / p.rows_per_image) * pairs * segs;
+  if (units * segs >= (UINT64_C(1) << 32) || units * pairs >= (UINT64_C(1) << 32)) return false;
+  return p.row_coeff >= -127 && p.row_coeff <= 128;
+}
+
+int conv_c3rows_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_rows16, hipStream_t stream, const char** name)
+{
+  C3Geom cg;
+  cg.H = g.H; cg.W = g.W; cg.OH = g.OH; cg.OW = g.OW; cg.KH = g.KH; cg.KW = g.KW; cg.sh = g.sh; cg.sw = g.sw;
+  cg.pad_top = g.pad_top; cg.pad_left = g.pad_left;
+  cg.segs = (g.OW + 15u) / 16u;
+  cg.pairs = (g.OH + 1u) / 2u;
+  cg.inv_segs = cg.segs > 1 ? static_cast<uint32_t>(((UINT64_C(1) << 32) + cg.segs - 1) / cg.segs) : 0u;
+  cg.inv_pairs = cg.pairs > 1 ? static_cast<uint32_t>(((UINT64_C(1) << 32) + cg.pairs - 1) / cg.pairs) : 0u;
+  cg.w_rows16 = w_rows16;
+  cg.abl = 0;
+#ifdef QNNP_ENABLE_ABLATION
+  if (const char* env = getenv("QNNP_C3R_ABL")) cg.abl = static_cast<uint32_t>(atoi(env));
+#endif
+  *name = "q8_conv_c3rows_mfma";
+  const bool wide = g.KW * 3u > 12u;
+  const bool two = p.n_pad > 32;
+  if (p.row_coeff == 128) {         // kernel zero point 0: the row-term weight does not fit int8, applied as 64 + 64
+    if (wide) return two ? launch_c3rows<2, 4, 2>(p, cg, stream) : launch_c3rows<1, 4, 2>(p, cg, stream);
+    return two ? launch_c3rows<2, 3, 2>(p, cg, stream) : launch_c3rows<1, 3, 2>(p, cg, stream);
+  }
+  if (wide) return two ? launch_c3rows<2, 4, 1>(p, cg, stream) : launch_c3rows<1, 4, 1>(p, cg, stream);
+  return two ? launch_c3rows<2, 3, 1>(p, cg, stream) : launch_c3rows<1, 3, 1>(p, cg, stream);
+}
+
+}  // namespace qnnp

@@ -21,6 +21,7 @@ enum qnnp_status qnnp_delete_operator(qnnp_operator_t op)
    * runtime then frees by pointer on whatever device is current, which HIP accepts) */
   const int token = qnnp_hip_enter(op->device);
   qnnp_hip_free(op->d_weights);
+  qnnp_hip_free(op->d_weights_rows16);
   qnnp_hip_free(op->d_bias);
   qnnp_hip_free(op->d_dwm_x);
   qnnp_hip_free(op->d_dwm_bias);

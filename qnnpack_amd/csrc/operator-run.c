@@ -184,6 +184,7 @@ static int launch(struct qnnp_operator* op, const void* input, const void* input
         .input = (const uint8_t*) input,
         .output = (uint8_t*) output,
         .packed_w = (const int8_t*) op->d_weights,
+        .packed_w_rows16 = is_conv ? (const int8_t*) op->d_weights_rows16 : NULL,
         .bias2 = op->d_bias,
         .offsets = is_conv ? op->d_offsets : NULL,
         .rows = (uint32_t) op->batch_size * output_size,

@@ -104,6 +104,7 @@ struct qnnp_operator {
 
   /* ---- device-side state owned by the operator ---- */
   void* d_weights;        /* igemm: int8 fragment panels; dwconv: int16 [taps][c_pad] */
+  void* d_weights_rows16; /* igemm, 3-channel first layers: the [ky][16-byte row slot] fragment image (pack.h), or NULL */
   int32_t* d_bias;        /* igemm: bias2 [groups][n_pad]; dwconv: bias1 [c_pad] */
   uint32_t n_pad;         /* igemm */
   uint32_t k_pad;         /* igemm */

@@ -88,6 +88,36 @@ static inline void qnnp_pack_igemm_w_slots(
   }
 }
 
+/*
+ * Row-slot image for 3-channel first layers (hip/q8convc3.hip): packed K index = ky * 16 + kx * 3 + c -- one 16-byte
+ * slot per kernel ROW (the kx * 3 + c bytes of a row are contiguous in a dense 3-byte-pixel image, so the device kernel
+ * fetches a slot with one 16-byte load); the unused bytes of a slot and the slots beyond the kernel are zero weights.
+ * k_pad = 64 (kernel_height <= 4, kernel_width * 3 <= 16). Same fragment geometry as the images above; the folded bias
+ * is the one qnnp_pack_igemm_w_slots makes (it depends on the real taps only).
+ * Source kernel layout: [oc][ky][kx][ic] (single group).
+ */
+static inline void qnnp_pack_conv_rows16(
+    uint32_t n, uint32_t kh, uint32_t kw, uint32_t kc, uint32_t n_pad,
+    const uint8_t* kernel, int8_t* packed /* [n_pad / 32][2][64][16] */)
+{
+  memset(packed, 0, (size_t) n_pad * 64);
+  for (uint32_t col = 0; col < n; col++) {
+    const uint32_t nb = col / 32;
+    const uint32_t lane_lo = col % 32;
+    for (uint32_t ky = 0; ky < kh; ky++) {
+      for (uint32_t kx = 0; kx < kw; kx++) {
+        for (uint32_t c = 0; c < kc; c++) {
+          const int32_t ws = (int32_t) kernel[(((size_t) col * kh + ky) * kw + kx) * kc + c] - 128;
+          const uint32_t kp = ky * 16 + kx * kc + c;
+          const uint32_t kb = kp / 32;
+          const uint32_t lane = lane_lo + 32 * ((kp % 32) / 16);
+          packed[((((size_t) nb * 2 + kb) * 64) + lane) * 16 + (kp % 16)] = (int8_t) ws;
+        }
+      }
+    }
+  }
+}
+
 static inline void qnnp_pack_igemm_w(
     uint32_t groups, uint32_t n, uint32_t k_total,
     uint32_t n_pad, uint32_t k_pad,

@@ -1,0 +1,86 @@
+"""GPU tier: the first-layer kernel that fetches one 16-byte row slot per kernel row (q8_conv_c3rows_kernel in
+qnnpack_amd/csrc/hip/q8convc3.hip), forced with "gemm_kernel" = 14, against the scalar oracle: first-layer shapes,
+strides 1 / 2 / 3, every padding side (so that windows hang over each border and over corners), window heights 1..4 and
+widths 1..5, 16 / 32 / 48 / 64 output channels, ragged last unit, zero points and clamps, batches whose images meet
+inside a 32-pixel unit, the tensor's first and last pixel (the slot of the last pixel reads past the tensor's end: the
+descriptor returns zeros there, and those bytes meet zero weights)."""
+import pytest
+
+from _cases import ConvCase
+from _gpu import from_device, to_device
+from _runner import assert_bytes_equal, conv_expected, conv_run
+
+pytestmark = pytest.mark.gpu
+KERNEL = "q8_conv_c3rows_mfma"
+
+
+def _pad(h, w):
+    return (h, w, h, w)
+
+
+CASES = [
+    ConvCase("r_3x3_s2_first_layer", (32, 32), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=32, batch=2),
+    ConvCase("r_3x3_s2_224", (224, 224), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=32),
+    ConvCase("r_3x3_s1_pad", (13, 11), (3, 3), _pad(1, 1), gic=3, goc=32, batch=3),
+    ConvCase("r_3x3_nopad", (9, 9), (3, 3), gic=3, goc=32),
+    ConvCase("r_3x3_s2_odd_images_meet_in_a_unit", (9, 7), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=32, batch=5),
+    ConvCase("r_3x3_pad_right_bottom_only", (10, 12), (3, 3), (0, 2, 2, 0), gic=3, goc=32, batch=2),
+    ConvCase("r_3x3_pad_left_top_2", (10, 12), (3, 3), (2, 0, 0, 2), gic=3, goc=32, batch=2),
+    ConvCase("r_3x3_s3", (17, 19), (3, 3), _pad(1, 1), subsampling=(3, 3), gic=3, goc=32),
+    ConvCase("r_3x3_s2x1", (16, 9), (3, 3), _pad(1, 1), subsampling=(2, 1), gic=3, goc=32),
+    ConvCase("r_1x1_s2", (9, 9), (1, 1), subsampling=(2, 2), gic=3, goc=32),
+    ConvCase("r_2x2_s2", (10, 12), (2, 2), subsampling=(2, 2), gic=3, goc=16, batch=3),
+    ConvCase("r_4x4_pad", (11, 10), (4, 4), (1, 2, 2, 1), gic=3, goc=64),
+    ConvCase("r_4x5_wide_window", (12, 14), (4, 5), (1, 2, 2, 2), gic=3, goc=48, batch=2),
+    ConvCase("r_1x5", (6, 20), (1, 5), (0, 2, 0, 2), gic=3, goc=32),
+    ConvCase("r_3x1_tall", (20, 5), (3, 1), (1, 0, 1, 0), gic=3, goc=32),
+    ConvCase("r_window_wider_than_image", (5, 2), (3, 3), _pad(1, 1), gic=3, goc=32, batch=4),
+    ConvCase("r_one_pixel_image", (1, 1), (3, 3), _pad(1, 1), gic=3, goc=32, batch=70),
+    ConvCase("r_3x3_n16", (9, 10), (3, 3), _pad(1, 1), gic=3, goc=16),
+    ConvCase("r_3x3_n64", (9, 10), (3, 3), _pad(1, 1), gic=3, goc=64, batch=2),
+    ConvCase("r_3x3_out_stride", (8, 8), (3, 3), _pad(1, 1), gic=3, goc=32, output_pixel_stride=48),
+    ConvCase("r_3x3_zp", (10, 10), (3, 3), _pad(1, 1), gic=3, goc=32, izp=9, kzp=200),
+    ConvCase("r_3x3_zp_extremes", (10, 10), (3, 3), _pad(1, 1), gic=3, goc=32, izp=255, kzp=0),
+    ConvCase("r_3x3_zp_extremes2", (10, 10), (3, 3), _pad(1, 1), gic=3, goc=32, izp=0, kzp=255),
+    ConvCase("r_3x3_clamp", (10, 10), (3, 3), _pad(1, 1), gic=3, goc=32, qmin=90, qmax=160),
+    ConvCase("r_3x3_many_units", (64, 48), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=32, batch=40),
+]
+
+
+@pytest.fixture()
+def rows16(qnnp):
+    qnnp.set_option("gemm_kernel", 14)
+    yield qnnp
+    qnnp.set_option("gemm_kernel", 0)
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
+def test_row_slot_kernel_matches_oracle(rows16, case):
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(rows16, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == KERNEL, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("case", [
+    ConvCase("r_bad_pixel_stride", (9, 10), (3, 3), _pad(1, 1), gic=3, goc=32, input_pixel_stride=5),
+    ConvCase("r_bad_1x7", (6, 20), (1, 7), (0, 3, 0, 3), gic=3, goc=32),
+    ConvCase("r_bad_5x3", (12, 12), (5, 3), (2, 1, 2, 1), gic=3, goc=32),
+    ConvCase("r_bad_dilated", (12, 12), (3, 3), _pad(2, 2), dilation=(2, 2), gic=3, goc=32),
+    ConvCase("r_bad_n24", (9, 9), (3, 3), _pad(1, 1), gic=3, goc=24),
+    ConvCase("r_bad_n96", (9, 9), (3, 3), _pad(1, 1), gic=3, goc=96),
+    ConvCase("r_bad_4_channels", (9, 9), (3, 3), _pad(1, 1), gic=4, goc=32),
+], ids=lambda c: c.name)
+def test_unsupported_shapes_are_reported_not_silently_rerouted(rows16, case):
+    from qnnpack_amd import QnnpackError
+    expected, quant, out_hw = conv_expected(case)
+    with pytest.raises(QnnpackError):
+        conv_run(rows16, case, quant, out_hw, to_device=to_device, from_device=from_device)
+
+
+def test_automatic_dispatch_takes_the_row_slot_kernel_for_the_first_layer(qnnp):
+    case = ConvCase("r_auto_112", (112, 112), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=32, batch=2)
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == KERNEL, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} (automatic) vs oracle")
