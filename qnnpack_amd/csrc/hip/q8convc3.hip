@@ -81,7 +81,7 @@ __device__ __forceinline__ uint32_t byte_range_mask(int32_t lo, int32_t hi)
  * + a multiply + 16 adds per lane (an instruction is an instruction to the issue port: DESIGN section 4.2c).
  * (128 - kzp = 128, i.e. kernel zero point 0, does not fit int8: it is applied as 64 + 64 by two such pairs.) */
 template <int NB, int ND, int RCP, int SEQ, bool FULL>
-__global__ __launch_bounds__(kC3Threads, 4)
+__global__ __launch_bounds__(kC3Threads, NB == 1 ? 4 : 3)
 void q8_conv_c3rows_kernel(const IgemmParams p, const C3Geom cg)
 {
   const uint32_t lane = threadIdx.x & 63u;
@@ -335,7 +335,7 @@ template <int NB, int ND, int RCP>
 int launch_c3rows(const IgemmParams& p, const C3Geom& cg, hipStream_t stream)
 {
   const uint32_t units = (p.rows / (cg.OH * cg.OW)) * cg.pairs * cg.segs;
-  uint32_t grid = p.cu_count * 4u;                         // four 4-wave workgroups per CU
+  uint32_t grid = p.cu_count * (NB == 1 ? 4u : 3u);        // four (three with 64 channels) 4-wave workgroups per CU
   const uint32_t needed = (units + kC3Waves - 1) / kC3Waves;
   if (grid > needed) grid = needed;
   requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
