@@ -325,11 +325,99 @@ def cpu_baseline_sweep(batch=16, seconds_budget=10.0, threads=None):
                       f"{best_threads}-thread pthreadpool (OpenMP shim; best of 8..{host} threads), {dt:.1f} s"}
 
 
+def stub_mode():
+    """QNNP_BENCH_STUB=1: harness self-test (tests/test_bench_harness.py). The launcher, the rank / world-size checks,
+    the barrier-bracketed timed region, the max-over-ranks reduction and the JSON assembly run exactly as in a real run,
+    over gloo on CPU, with a sleep standing in for the device step. The line it prints says so (`data`: "stub")."""
+    return os.environ.get("QNNP_BENCH_STUB") == "1"
+
+
+def assemble_line(*, world, steps, warmup, ms_per_step, ev_ms_per_rank, gemm_kernel, info, roofline, cpu, extra, data):
+    """The one JSON line of the contract. value = whole-job int8 TOPS: every rank runs its own replica of the 4096^3
+    GEMM (no batch to shard: "replicas only"), so the job processes `world` GEMMs per step in max-over-ranks time."""
+    gemm_ops = 2.0 * 4096 ** 3
+    value = world * gemm_ops / (ms_per_step * 1e-3) / 1e12
+    if roofline is not None and world > 1:
+        # N > 1: rank 0's kernel is the one in `roofline`; every rank's launch time travels beside it
+        roofline = dict(roofline)
+        roofline["per_rank_launch_ms"] = [round(v, 5) for v in ev_ms_per_rank]
+        roofline["per_rank_frac"] = [round(gemm_ops / (v * 1e-3) / 1e12 / PEAK_I8_TOPS, 4) for v in ev_ms_per_rank]
+    return {
+        "metric": "q8gemm_int8_tops", "value": round(value, 2), "unit": "TOPS",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": data,
+        "config": {"workload": "q8gemm M=N=K=4096 uint8 (qnnp_fully_connected_nc_q8, int8 MFMA, fused Q31 requantize)"
+                               + (" -- one replica per GPU" if world > 1 else ""),
+                   "kernel": gemm_kernel, "device": info["arch"], "compute_units": info["compute_units"],
+                   "pct_of_i8_mfma_peak": round(100.0 * value / world / PEAK_I8_TOPS, 2)},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "extra": extra,
+    }
+
+
+def gather_floats(value, world):
+    """[value of rank 0, ..., value of rank world-1] on every rank (all_gather over the harness process group)."""
+    if world <= 1:
+        return [float(value)]
+    import torch
+    import torch.distributed as dist
+    device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
+def run_stub(args, world, rank):
+    """The harness with a sleep for a step (see stub_mode): same barriers, same reductions, same line."""
+    import torch.distributed as dist
+    from qnnpack_amd.shard import job_time_ms, shard_batch
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    step_s = 0.002 * (1.0 + 0.5 * rank)                    # the last rank is the slow one
+    for _ in range(args.warmup):
+        time.sleep(step_s)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(step_s)
+    local_ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    barrier()
+    ms_per_step = job_time_ms(local_ms, world)
+    per_rank = gather_floats(local_ms, world)
+    total_batch = args.sweep_batch * world
+    start, my_batch = shard_batch(total_batch, world, rank)
+    sweep_ms = job_time_ms(0.5 * (1.0 + 0.5 * rank), world)
+    extra = {"mobilenetv2_sweep": {"images_per_s": round(total_batch / (sweep_ms * 1e-3), 1), "batch_per_gpu": my_batch,
+                                   "shard_start": start, "ms_per_batch": round(sweep_ms, 4), "timed_as": "stub"}}
+    roofline = {"bound": "mfma", "kernel": "stub", "achieved": None, "peak": round(PEAK_I8_TOPS, 1), "unit": "TOP/s",
+                "frac": None, "traffic": None}
+    cpu = {"value": None, "unit": "TOPS", "cores": 0, "kind": "stub", "sample": "none (harness self-test)"} if rank == 0 else None
+    if rank == 0:
+        print(json.dumps(assemble_line(world=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
+                                       ev_ms_per_rank=per_rank, gemm_kernel="stub",
+                                       info={"arch": "stub", "compute_units": 0}, roofline=roofline, cpu=cpu,
+                                       extra=extra, data="stub (no device work: harness self-test)")), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def spawn_ranks(n_gpus, argv):
     """`python bench.py --gpus N` without a launcher: re-run this file under torch.distributed.run, one rank per GPU.
     Fails loudly when the node has fewer than N GPUs (a 1-GPU number must never be reported as an N-GPU one)."""
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if stub_mode():
+        have = n_gpus                                      # harness self-test: ranks are CPU processes
     if have < n_gpus:
         print(f"bench.py: --gpus {n_gpus} requested but this node shows {have} GPU(s); refusing to run fewer ranks",
               file=sys.stderr)
@@ -368,15 +456,19 @@ def main():
         # the harness barrier only -- the data path has no collective)
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-GPU run as {args.gpus}")
+    if stub_mode():
+        run_stub(args, world, rank)
+        return
+
+    import torch
+    import torch.distributed as dist
+
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
     if torch.cuda.device_count() < max(world, local_rank + 1):
         raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)              # before the process group: RCCL binds to the current device
@@ -453,8 +545,8 @@ def main():
     gemm_kernel = lib.operator_kernel(op)
     # the same K launches by HIP events on the launch stream: kernel time without the host's share of the region
     ev_ms = ev0.elapsed_time(ev1) / args.steps
+    ev_ms_per_rank = gather_floats(ev_ms, world)
     gemm_ops = 2.0 * M * N * K
-    value = world * gemm_ops / (ms_per_step * 1e-3) / 1e12
     achieved = gemm_ops / (ev_ms * 1e-3) / 1e12
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -613,26 +705,17 @@ def main():
         extra["next_rows"] = next_rows_bench(lib, torch, my_batch, args.warmup, max(args.steps // 2, 5))
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_gemm()
+    if rank == 0 and not args.no_cpu_baseline:
+        # the reference's SSE2 path on this box's host cores: the full sample at N = 1, a shorter one at N > 1 (the
+        # other ranks wait at the closing barrier meanwhile) -- a SCALE line carries its baseline too
+        cpu = cpu_baseline_gemm(12.0 if world == 1 else 5.0)
         if "mobilenetv2_sweep" in extra:
-            extra["mobilenetv2_sweep"]["cpu_baseline"] = cpu_baseline_sweep()
+            extra["mobilenetv2_sweep"]["cpu_baseline"] = cpu_baseline_sweep(seconds_budget=10.0 if world == 1 else 4.0)
 
     if rank == 0:
-        line = {
-            "metric": "q8gemm_int8_tops", "value": round(value, 2), "unit": "TOPS",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "q8gemm M=N=K=4096 uint8 (qnnp_fully_connected_nc_q8, int8 MFMA, fused Q31 requantize)"
-                                   + (" -- one replica per GPU" if world > 1 else ""),
-                       "kernel": gemm_kernel, "device": info["arch"], "compute_units": info["compute_units"],
-                       "pct_of_i8_mfma_peak": round(100.0 * value / world / PEAK_I8_TOPS, 2)},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-            "extra": extra,
-        }
-        print(json.dumps(line), flush=True)
+        print(json.dumps(assemble_line(world=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
+                                       ev_ms_per_rank=ev_ms_per_rank, gemm_kernel=gemm_kernel, info=info,
+                                       roofline=roofline, cpu=cpu, extra=extra, data="synthetic")), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,98 @@
+"""CPU tier: bench.py's multi-rank harness, end to end, without a GPU. QNNP_BENCH_STUB=1 replaces the device step by a
+sleep (rank r is 1 + r/2 times slower than rank 0) and RCCL by gloo; everything else is the code the driver's SCALE run
+goes through: `python bench.py --gpus N` re-launching itself under torch.distributed.run on 127.0.0.1, the WORLD_SIZE
+check, the barrier-bracketed timed region, the max-over-ranks time, the batch shards of the sweep and the one JSON line
+(whole-job value, per-rank launch times, a cpu_baseline object at N > 1 as well)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**extra):
+    env = dict(os.environ)
+    env["QNNP_BENCH_STUB"] = "1"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra)
+    return env
+
+
+def _line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("gpus", [1, 2, 3])
+def test_bench_spawns_its_ranks_and_prints_one_line(gpus):
+    res = subprocess.run([sys.executable, BENCH, "--gpus", str(gpus), "--steps", "6", "--warmup", "1", "--sweep-batch", "10"],
+                         env=_env(), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = _line(res.stdout)
+    assert line["n_gpus"] == gpus and line["steps"] == 6 and line["warmup"] == 1
+    assert line["metric"] == "q8gemm_int8_tops" and line["unit"] == "TOPS" and line["scaling"] == "weak"
+    assert line["data"].startswith("stub")
+    # the slowest rank (the last one: 2 ms x (1 + (N-1)/2) per step) sets the job time
+    slowest = 2.0 * (1.0 + 0.5 * (gpus - 1))
+    assert slowest * 0.95 <= line["ms_per_step"] <= slowest * 1.6, line["ms_per_step"]
+    # whole-job value: N replicas of the GEMM per step of the slowest rank
+    expected = gpus * 2.0 * 4096 ** 3 / (line["ms_per_step"] * 1e-3) / 1e12
+    assert abs(line["value"] - expected) <= 0.01 * expected
+    assert line["cpu_baseline"] is not None                     # N > 1 lines carry the baseline object too
+    sweep = line["extra"]["mobilenetv2_sweep"]
+    assert sweep["batch_per_gpu"] == 10 and sweep["shard_start"] == 0       # rank 0's shard of 10 x N images
+    if gpus > 1:
+        per_rank = line["roofline"]["per_rank_launch_ms"]
+        assert len(per_rank) == gpus and per_rank == sorted(per_rank)       # rank r sleeps longer than rank r-1
+        assert "one replica per GPU" in line["config"]["workload"]
+
+
+def test_launcher_world_size_mismatch_is_refused():
+    """started by a launcher with a world size other than --gpus: never report an M-rank run as an N-GPU one"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--steps", "2", "--warmup", "0"],
+                         env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0
+    assert "refusing" in (res.stderr + res.stdout)
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_fewer_gpus_than_ranks_is_refused_without_the_stub():
+    """the real path on this GPU-less box: --gpus 2 must fail loudly, not fall back to fewer ranks or to the CPU"""
+    env = _env()
+    env.pop("QNNP_BENCH_STUB")
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs: the refusal cannot be provoked")
+    assert res.returncode != 0
+    assert "refusing" in res.stderr or "needs" in res.stderr or "GPU" in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_assemble_line_contract_fields():
+    sys.path.insert(0, ROOT)
+    import bench
+    line = bench.assemble_line(world=8, steps=20, warmup=5, ms_per_step=0.07, ev_ms_per_rank=[0.066 + 0.001 * r for r in range(8)],
+                               gemm_kernel="q8_gemm_mfma_256x256", info={"arch": "gfx950", "compute_units": 256},
+                               roofline={"bound": "mfma", "achieved": 2080.0, "peak": 5033.2, "unit": "TOP/s", "frac": 0.41,
+                                         "traffic": 1}, cpu={"value": 1.1, "unit": "TOPS", "cores": 16, "kind": "reference",
+                                                             "sample": "x"}, extra={}, data="synthetic")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 8 and line["vs_baseline"] is None and line["dtype"] == "u8"
+    assert abs(line["value"] - 8 * 2 * 4096 ** 3 / 0.07e-3 / 1e12) < 1.0
+    assert len(line["roofline"]["per_rank_launch_ms"]) == 8 and len(line["roofline"]["per_rank_frac"]) == 8
+    assert "model" not in line["config"]

@@ -213,3 +213,18 @@ def test_one_process_drives_two_gpus(qnnp):
     out = torch.zeros(expected.size, dtype=torch.uint8, device="cuda:0")
     assert qnnp.setup_convolution2d_nhwc_q8_status(op, case.batch, 28, 28, foreign, 64, out, 64) == Status.invalid_parameter
     qnnp.delete_operator(op)
+
+
+def test_thread_per_gpu_example_runs(qnnp):
+    """examples/multi_gpu_threads.py: the one-process / one-thread-per-GPU form on however many GPUs the box has (a second
+    caller of the path the two-GPU test above covers; with one GPU it still selects and binds the device from a worker
+    thread and checks the shard against the unsharded run)."""
+    import torch
+    from examples import multi_gpu_threads
+    qnnp.set_stream(None)
+    try:
+        assert multi_gpu_threads.main(["--batch", "6", "--rounds", "2"]) == 0
+    finally:
+        qnnp.set_stream(torch.cuda.current_stream().cuda_stream)
+        qnnp.set_device(0)
+        qnnp.set_async(False)
