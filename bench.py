@@ -18,7 +18,8 @@ Secondary numbers travel in the same JSON line under "extra" (not separate bench
   * the 31-layer MobileNetV2 conv sweep (configs[4], bench/convolution.cc:453-536) as images/s with the
     batch sharded across ranks (no collective), each layer timed as its own operator like the reference bench,
   * "mobilenetv2_network": the WHOLE network (examples/mobilenetv2.py: 52 convolutions, 10 residual adds, global
-    average pooling, classifier = 64 chained operators) as one hipGraph replay, images/s,
+    average pooling, classifier = 64 chained operators) as one hipGraph replay, images/s; "..._adds_folded": the
+    same with the residual adds carried by the project convolutions (54 launches),
   * "next_rows": the operators SURVEY.md section 8f ranks after the hot path (deconvolution, add, pooling).
 
 The timed region is EXACTLY K steps between barriers (wall clock, max over ranks -> `value`), bracketed on the
@@ -116,7 +117,7 @@ class ConvLayer:
         self.inputs = self.outputs = None
 
 
-def network_bench(lib, torch, batch, total_batch, world, warmup, iters, fuse=False):
+def network_bench(lib, torch, batch, total_batch, world, warmup, iters, fuse=False, fold_adds=False):
     """Every operator of a real quantized MobileNetV2 forward pass (examples/mobilenetv2.py: 52 convolutions, 10 residual
     adds, global average pooling, classifier), chained on device buffers with their true dependencies and replayed as one
     hipGraph. Unlike the 31-shape sweep each tensor is produced by the previous operator, so it may still sit in the
@@ -124,7 +125,7 @@ def network_bench(lib, torch, batch, total_batch, world, warmup, iters, fuse=Fal
     from examples import mobilenetv2 as mnv2
     from qnnpack_amd.shard import job_time_ms
     plan = mnv2.build_plan()
-    net = mnv2.DeviceNetwork(lib, torch, plan, batch, fuse=fuse)
+    net = mnv2.DeviceNetwork(lib, torch, plan, batch, fuse=fuse, fold_adds=fold_adds)
     try:
         gen = torch.Generator(device="cuda")
         gen.manual_seed(91)
@@ -135,6 +136,7 @@ def network_bench(lib, torch, batch, total_batch, world, warmup, iters, fuse=Fal
         job_ms = job_time_ms(ms, world)
         act = mnv2.algorithmic_bytes(plan, batch)
         return {"operators": len(plan.ops), "launches": len(net.schedule), "fused_blocks": len(net.fused),
+                "adds_in_conv_epilogues": len(net.folded),
                 "images_per_s": round(total_batch / (job_ms * 1e-3), 1),
                 "batch_per_gpu": batch, "ms_per_batch": round(job_ms, 4), "timed_as": "one hipGraph replay of the chained operators",
                 "activation_gbs": round(act / (ms * 1e-3) / 1e9, 1), "tops": round(mnv2.operations(plan, batch) / (ms * 1e-3) / 1e12, 2),
@@ -697,6 +699,10 @@ def main():
         # ---------------------------------------------------------- the whole network (64 chained operators, one hipGraph)
         extra["mobilenetv2_network"] = network_bench(lib, torch, my_batch, total_batch, world, args.warmup,
                                                      max(args.steps // 2, 5))
+        # the same network with the ten residual adds riding in their project convolutions' epilogues
+        # (qnnp_gfx950_attach_residual_add: 54 launches, the project outputs are never written)
+        extra["mobilenetv2_network_adds_folded"] = network_bench(lib, torch, my_batch, total_batch, world, args.warmup,
+                                                                 max(args.steps // 2, 5), fold_adds=True)
         # the same network with every inverted-residual block as ONE fused operator (qnnp_gfx950_create_fused_block)
         extra["mobilenetv2_network_fused"] = network_bench(lib, torch, my_batch, total_batch, world, args.warmup,
                                                            max(args.steps // 2, 5), fuse=True)

@@ -165,7 +165,8 @@ class DeviceNetwork:
     (qnnp_gfx950_create_fused_block) and runs it in their place wherever the fused kernel takes the block; the
     expanded tensors of those blocks are then never written."""
 
-    def __init__(self, lib, torch, plan: Plan, batch: int, quant: Optional[Dict[str, Quant]] = None, fuse: bool = False):
+    def __init__(self, lib, torch, plan: Plan, batch: int, quant: Optional[Dict[str, Quant]] = None, fuse: bool = False,
+                 fold_adds: bool = False):
         self.lib, self.plan, self.batch = lib, plan, batch
         self.buffers = {t: torch.empty(tensor_bytes(plan, t, batch), dtype=torch.uint8, device="cuda")
                         for t in plan.shapes}
@@ -204,6 +205,22 @@ class DeviceNetwork:
         self.fused = {}
         self.fused_handles = []
         self.schedule = [(op.name, h) for op, h in zip(plan.ops, self.handles)]
+        # fold_adds: every residual add rides in its project convolution (qnnp_gfx950_attach_residual_add): the
+        # convolution is re-bound to write the add's output tensor, the project output tensor is never written
+        self.folded = {}
+        if fold_adds and not fuse:
+            skip = set()
+            for i, op in enumerate(plan.ops):
+                if op.kind != "add" or i == 0 or plan.ops[i - 1].dst != op.src[1] or plan.ops[i - 1].kind != "conv":
+                    continue
+                conv = plan.ops[i - 1]
+                cin, cout = conv.groups * conv.gic, conv.groups * conv.goc
+                lib.setup_convolution2d_nhwc_q8(self.handles[i - 1], batch, conv.hw[0], conv.hw[1],
+                                                self.buffers[conv.src[0]], cin, self.buffers[op.dst], cout)
+                lib.attach_residual_add(self.handles[i - 1], self.handles[i], self.buffers[op.src[0]], cout)
+                self.folded[conv.name] = (i - 1, i)
+                skip.add(i)
+            self.schedule = [(op.name, h) for i, (op, h) in enumerate(zip(plan.ops, self.handles)) if i not in skip]
         if fuse:
             from qnnpack_amd import QnnpackError
             replaced = {}

@@ -106,6 +106,24 @@ enum qnnp_status qnnp_gfx950_setup_fused_block(
     qnnp_operator_t fused, size_t batch_size, size_t input_height, size_t input_width,
     const uint8_t* input, size_t input_stride, uint8_t* output, size_t output_stride);
 
+/* Residual add folded into a convolution (no reference counterpart: there it is a convolution operator followed by
+ * an add operator, src/add.c). After a successful qnnp_setup_convolution2d_nhwc_q8 / qnnp_setup_fully_connected_nc_q8
+ * of `convolution` on DEVICE pointers, attach an add operator created with qnnp_create_add_nc_q8 whose channel count
+ * is the convolution's output channel count: from then on qnnp_run_operator(convolution) writes
+ *     output = add(a = residual pixel, b = convolution output pixel)
+ * bit-identical to running `convolution` and then `add` set up with (a = residual, b = the convolution's output).
+ * The add's parameters are copied (the add operator may be deleted); `residual` is caller-owned device memory,
+ * residual_stride bytes between pixels, and may be the convolution's input tensor or any other tensor except its
+ * output. The next setup of `convolution` detaches it. The add rides in the convolution kernel's epilogue where that
+ * kernel carries it (pointwise layers: every MobileNetV2 project layer; needs residual_stride == output stride and
+ * the output's alignment), otherwise the add kernel is launched in place behind the convolution.
+ * qnnp_gfx950_operator_residual_folded: after a run, 1 = epilogue, 0 = separate launch, -1 = nothing attached.
+ * Status: invalid_parameter (NULL / wrong operator kinds / channel mismatch / no valid setup / during capture),
+ * unsupported_parameter (host-memory endpoints). */
+enum qnnp_status qnnp_gfx950_attach_residual_add(
+    qnnp_operator_t convolution, qnnp_operator_t add, const uint8_t* residual, size_t residual_stride);
+int qnnp_gfx950_operator_residual_folded(qnnp_operator_t op);
+
 /* Kernel-variant control for A/B measurement and tests. Keys:
  *   "gemm_kernel":   0 = auto, 1 = generic MFMA implicit-GEMM kernel, 2 = 256x256 LDS-DMA MFMA kernel,
  *                    3 = LDS-tiled direct-convolution MFMA kernel (convolutions only),

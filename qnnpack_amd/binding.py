@@ -317,6 +317,10 @@ class Gfx950Library(QnnpackLibrary):
         L.qnnp_gfx950_create_fused_block.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]
         L.qnnp_gfx950_setup_fused_block.restype = c_int
         L.qnnp_gfx950_setup_fused_block.argtypes = [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t]
+        L.qnnp_gfx950_attach_residual_add.restype = c_int
+        L.qnnp_gfx950_attach_residual_add.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
+        L.qnnp_gfx950_operator_residual_folded.restype = c_int
+        L.qnnp_gfx950_operator_residual_folded.argtypes = [c_void_p]
         L.qnnp_gfx950_set_option.restype = c_int
         L.qnnp_gfx950_set_option.argtypes = [c_char_p, c_int]
         L.qnnp_gfx950_operator_kernel.restype = c_char_p
@@ -404,6 +408,19 @@ class Gfx950Library(QnnpackLibrary):
         st = self.setup_fused_block_status(*args)
         if st != Status.success:
             raise QnnpackError("qnnp_gfx950_setup_fused_block", st)
+
+    # ---- residual add folded into a convolution (qnnpack_gfx950.h) ----
+    def attach_residual_add_status(self, convolution, add, residual, residual_stride) -> Status:
+        return Status(self.lib.qnnp_gfx950_attach_residual_add(convolution, add, address_of(residual), residual_stride))
+
+    def attach_residual_add(self, convolution, add, residual, residual_stride) -> None:
+        st = self.attach_residual_add_status(convolution, add, residual, residual_stride)
+        if st != Status.success:
+            raise QnnpackError("qnnp_gfx950_attach_residual_add", st)
+
+    def operator_residual_folded(self, op) -> int:
+        """After a run: 1 = the add rode in the convolution kernel's epilogue, 0 = separate launch, -1 = none attached."""
+        return int(self.lib.qnnp_gfx950_operator_residual_folded(op))
 
     # ---- hipGraph capture of operator launches (qnnpack_gfx950.h) ----
     def graph_begin(self) -> None:

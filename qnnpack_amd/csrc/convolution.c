@@ -365,6 +365,7 @@ static enum qnnp_status qnnp_setup_convolution2d_nhwc_q8_impl(
 
   /* reference convolution.c:409-426 */
   op->setup_valid = 0;   /* until every check, allocation and upload below has succeeded */
+  op->residual = NULL;   /* an attached residual add belongs to the previous binding (residual.c) */
   op->dw_plan.key = 0;   /* depthwise launch plan: recomputed at the next run */
   op->batch_size = batch_size;
   op->input_height = input_height;

@@ -559,6 +559,25 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
     p.store_mode = 1;
   }
 
+  // Fused residual add: carried by the pointwise streaming kernels' epilogues (what a MobileNet-style project layer runs
+  // on) when the residual rows are laid out like the output rows; everything else reports "not folded" and the caller
+  // adds in place with the stand-alone kernel.
+  p.residual = nullptr;
+  p.residual_stride = 0;
+  if (a->residual_folded != nullptr) *a->residual_folded = 0;
+  if (a->residual != nullptr) {
+    if (a->residual_add == nullptr || a->residual_folded == nullptr) return QNNP_HIP_EINVAL;
+    const uintptr_t res_addr = reinterpret_cast<uintptr_t>(a->residual);
+    const uint32_t align = p.store_mode == 2 ? 16u : 4u;
+    if (p.store_mode != 0 && a->groups == 1 && a->d2s_stride_h == 0 && a->offsets == nullptr &&
+        a->residual_stride == a->output_stride && res_addr % align == 0) {
+      p.residual = a->residual;
+      p.residual_stride = a->residual_stride;
+      p.add = *a->residual_add;
+    }
+  }
+  auto folded = [&]() { if (p.residual != nullptr) *a->residual_folded = 1; };
+
   hipStream_t stream = reinterpret_cast<hipStream_t>(qnnp_hip_get_stream());
   const char* name = nullptr;
   // Dense convolutions with power-of-two channel counts: LDS-tiled direct convolution (input read once).
@@ -613,6 +632,7 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   if (pw_ok && (a->variant == 5 || (a->variant == 0 && a->rows >= 2048))) {
     const int rc_pw = qnnp::pwstream_launch(p, vec, stream, &name);
     if (kernel_name != nullptr) *kernel_name = name;
+    if (rc_pw == QNNP_HIP_OK) folded();
     return rc_pw;
   }
   // Long reductions over few rows with 16-byte aligned rows on both sides: weights of a channel column in LDS, every
@@ -628,6 +648,7 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   if (lk_ok && (a->variant == 9 || (a->variant == 0 && lk_auto))) {
     const int rc_lk = qnnp::pwstream_longk_launch(p, stream, &name);
     if (kernel_name != nullptr) *kernel_name = name;
+    if (rc_lk == QNNP_HIP_OK) folded();
     return rc_lk;
   }
   // Small problems with a long reduction (late MobileNet layers, classifier heads): one wave per 32x32 block,
@@ -640,6 +661,7 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   if (gw_ok && (a->variant == 6 || (a->variant == 0 && generic_tiles <= 400u))) {
     const int rc_gw = qnnp::pwstream_gw_launch(p, stream, &name);
     if (kernel_name != nullptr) *kernel_name = name;
+    if (rc_gw == QNNP_HIP_OK) folded();
     return rc_gw;
   }
   // Large MFMA-bound problems take the 256x256 LDS-DMA kernel; everything else the generic one.

@@ -218,6 +218,12 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
               acc, bias4, rowterm, phase_row, (nb - phase * p.d2s_nbpp) * 32, khalf, row_ok, p);
           continue;
         }
+        if (p.residual != nullptr) {                      // (wave-uniform) project layer with its residual add folded in
+          const uint8_t* res_row = p.residual + static_cast<uint64_t>(row_ok ? m : 0u) * p.residual_stride;
+          igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 2, true>(
+              acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p, res_row, &p.add);
+          continue;
+        }
         igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 2>(
             acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p);
       }
@@ -234,6 +240,36 @@ __device__ __forceinline__ void stream_copy_out(
     const IgemmParams& p, uint32_t lane)
 {
   const uint32_t rows_here = min(32u, p.rows - unit * 32u);
+  if (p.residual != nullptr) {
+    // fused residual add: the same walk, each 16-byte piece summed with the residual's bytes of the same pixel and
+    // channels (launcher: residual rows are laid out like the output rows, 16-byte aligned)
+    const uint64_t block_ofs = static_cast<uint64_t>(unit) * 32u * p.output_stride + c0;
+    const uint8_t* res = p.residual + block_ofs;
+    uint8_t* blk = p.output + block_ofs;
+    if (whole_dense) {
+      const uint32_t bytes = rows_here * p.n;
+      for (uint32_t o = lane * 16; o < bytes; o += 1024) {
+        const uint4 r = *reinterpret_cast<const uint4*>(res + o);
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + o);
+        *reinterpret_cast<uint4*>(blk + o) = make_uint4(add_quantize4(r.x, v.x, p.add), add_quantize4(r.y, v.y, p.add),
+                                                        add_quantize4(r.z, v.z, p.add), add_quantize4(r.w, v.w, p.add));
+      }
+    } else {
+      const uint32_t pieces = 32u << log_cpr;
+      for (uint32_t q = lane; q < pieces; q += 64) {
+        const uint32_t rr = q >> log_cpr;
+        const uint32_t cb = (q - (rr << log_cpr)) * 16u;
+        if (rr < rows_here && cb < cw) {
+          const uint64_t o = static_cast<uint64_t>(rr) * p.output_stride + cb;
+          const uint4 r = *reinterpret_cast<const uint4*>(res + o);
+          const uint4 v = *reinterpret_cast<const uint4*>(stage + q * 16u);
+          *reinterpret_cast<uint4*>(blk + o) = make_uint4(add_quantize4(r.x, v.x, p.add), add_quantize4(r.y, v.y, p.add),
+                                                          add_quantize4(r.z, v.z, p.add), add_quantize4(r.w, v.w, p.add));
+        }
+      }
+    }
+    return;
+  }
   if (whole_dense) {
     const uint32_t bytes = rows_here * p.n;
     uint8_t* blk = p.output + static_cast<uint64_t>(unit) * 32u * p.n;
@@ -665,6 +701,12 @@ void q8_pw_stream_gw_kernel(const IgemmParams p)
   const int32_t rowterm = p.row_coeff * static_cast<int32_t>(rs - 128u * p.k_total);
   uint8_t* out_row = p.output + static_cast<uint64_t>(rb * 32u + row_in_block) * p.output_stride;
   requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
+    if (p.residual != nullptr) {
+      const uint8_t* res_row = p.residual + static_cast<uint64_t>(row_ok ? rb * 32u + row_in_block : 0u) * p.residual_stride;
+      igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 0, true>(
+          acc, bias4, with_rq_offset<decltype(shift0)::value>(rowterm), out_row, nb * 32, khalf, row_ok, p, res_row, &p.add);
+      return;
+    }
     igemm_store_tile<decltype(shift0)::value, decltype(full)::value>(
         acc, bias4, with_rq_offset<decltype(shift0)::value>(rowterm), out_row, nb * 32, khalf, row_ok, p);
   });
@@ -760,6 +802,12 @@ void q8_pw_stream_gwk_kernel(const IgemmParams p)
   uint8_t* out_row = p.output + static_cast<uint64_t>(rb * 32u + row_in_block) * p.output_stride;
   requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
     const int32_t rowterm = with_rq_offset<decltype(shift0)::value>(p.row_coeff * rsc);
+    if (p.residual != nullptr) {
+      const uint8_t* res_row = p.residual + static_cast<uint64_t>(row_ok ? rb * 32u + row_in_block : 0u) * p.residual_stride;
+      igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 0, true>(
+          acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p, res_row, &p.add);
+      return;
+    }
     igemm_store_tile<decltype(shift0)::value, decltype(full)::value>(
         acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p);
   });

@@ -128,6 +128,7 @@ struct qnnp_hip_igemm_phase {
   uint32_t reserved;
 };
 
+struct qnnp_hip_add_params;
 struct qnnp_hip_igemm_args {
   const uint8_t* input;
   uint8_t* output;
@@ -170,6 +171,14 @@ struct qnnp_hip_igemm_args {
   uint32_t input_height, input_width, output_height, output_width;
   uint32_t kernel_height, kernel_width, stride_height, stride_width, dilation_height, dilation_width;
   uint32_t pad_top, pad_left;
+  /* optional fused residual add (qnnpack_gfx950.h qnnp_gfx950_setup_convolution_residual_add_nhwc_q8):
+   * output = add(a = residual pixel, b = the requantized convolution output) with the add operator's parameters.
+   * Kernels that carry the add in their epilogue set *residual_folded = 1; for the others the caller launches the
+   * stand-alone add kernel in place on `output` (operator-run.c). residual == NULL: off. */
+  const uint8_t* residual;
+  uint32_t residual_stride;   /* bytes between residual pixels */
+  const struct qnnp_hip_add_params* residual_add;
+  uint32_t* residual_folded;
 };
 int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* args, const char** kernel_name);
 

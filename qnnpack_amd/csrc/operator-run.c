@@ -60,7 +60,7 @@ enum qnnp_status qnnp_bind_endpoint(const void* ptr, size_t span, int* on_device
 /* Enqueue the operator's kernel on the library stream of the active context, reading `input` and
  * writing `output` (both device pointers). */
 
-static int launch(struct qnnp_operator* op, const void* input, const void* input2, void* output)
+static int launch_kernel(struct qnnp_operator* op, const void* input, const void* input2, void* output)
 {
   switch (op->ukernel_type) {
     case qnnp_ukernel_type_dwconv:
@@ -217,6 +217,10 @@ static int launch(struct qnnp_operator* op, const void* input, const void* input
         .dilation_width = op->dilation_width,
         .pad_top = op->input_padding_top,
         .pad_left = op->input_padding_left,
+        .residual = (const uint8_t*) op->residual,
+        .residual_stride = (uint32_t) op->residual_pixel_stride,
+        .residual_add = &op->residual_params,
+        .residual_folded = &op->residual_folded,
       };
       return qnnp_hip_igemm_run(&args, &op->kernel_name);
     }
@@ -256,6 +260,30 @@ static int launch(struct qnnp_operator* op, const void* input, const void* input
     default:
       return QNNP_HIP_EINVAL;
   }
+}
+
+static int launch(struct qnnp_operator* op, const void* input, const void* input2, void* output)
+{
+  op->residual_folded = 0;
+  const int rc = launch_kernel(op, input, input2, output);
+  if (rc != QNNP_HIP_OK || op->residual == NULL || op->residual_folded) {
+    return rc;
+  }
+  /* attached residual add (residual.c) the convolution kernel does not carry: the add kernel, in place on the output */
+  const size_t out_channels = (size_t) op->groups * op->group_output_channels;
+  const struct qnnp_hip_vadd_args args = {
+    .a = (const uint8_t*) op->residual,
+    .b = (const uint8_t*) output,
+    .sum = (uint8_t*) output,
+    .rows = op->batch_size * op->output_height * op->output_width,
+    .channels = (uint32_t) out_channels,
+    .a_stride = op->residual_pixel_stride,
+    .b_stride = op->output_pixel_stride,
+    .sum_stride = op->output_pixel_stride,
+    .params = op->residual_params,
+  };
+  const char* add_kernel = NULL;
+  return qnnp_hip_vadd_run(&args, &add_kernel);
 }
 
 static enum qnnp_status run_operator(qnnp_operator_t op)

@@ -85,6 +85,15 @@ struct qnnp_operator {
   const struct qnnp_operator* fused_project;
   const struct qnnp_operator* fused_add;        /* may be NULL */
 
+  /* residual add attached to a convolution (residual.c, qnnp_gfx950_attach_residual_add): the operator then writes
+   * add(a = residual pixel, b = convolution output) -- in the convolution kernel's epilogue where that kernel carries
+   * it, else by an in-place launch of the add kernel behind it. Caller-owned device memory; cleared by the next
+   * convolution setup. */
+  const void* residual;
+  size_t residual_pixel_stride;
+  struct qnnp_hip_add_params residual_params;
+  uint32_t residual_folded;   /* last launch: 1 = in the epilogue, 0 = separate add launch */
+
   /* add / global average pooling (reference operator.h:58, 66-67, 75-100) */
   size_t channels;
   const void* input2;

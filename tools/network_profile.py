@@ -5,9 +5,10 @@ import torch, qnnpack_amd
 from examples import mobilenetv2 as mnv2
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 fuse = len(sys.argv) > 2 and sys.argv[2] == "fuse"
+fold = len(sys.argv) > 2 and sys.argv[2] == "fold"      # residual adds in the project convolutions' epilogues
 lib = qnnpack_amd.load(); lib.initialize(); lib.set_stream(torch.cuda.current_stream().cuda_stream)
 plan = mnv2.build_plan()
-net = mnv2.DeviceNetwork(lib, torch, plan, batch, fuse=fuse)
+net = mnv2.DeviceNetwork(lib, torch, plan, batch, fuse=fuse, fold_adds=fold)
 net.buffers[0].copy_(torch.randint(0, 256, (net.buffers[0].numel(),), dtype=torch.uint8, device="cuda"))
 net.run(); net.capture()
 total = net.time_ms(3, 20)
@@ -24,7 +25,11 @@ for name, h in net.schedule:
     else:
         op = by_name[name]
         nbytes = sum(mnv2.tensor_bytes(plan, s, batch) for s in op.src) + mnv2.tensor_bytes(plan, op.dst, batch)
-        rows.append((ms, name, net.kernels[name], plan.shapes[op.src[0]], plan.shapes[op.dst], nbytes))
+        kern = net.kernels[name]
+        if name in net.folded:
+            nbytes += mnv2.tensor_bytes(plan, op.dst, batch)                   # the residual read
+            kern += "+add" if lib.operator_residual_folded(h) == 1 else " then add"
+        rows.append((ms, name, kern, plan.shapes[op.src[0]], plan.shapes[op.dst], nbytes))
 print(f"graph replay {total*1e3:.1f} us; sum of individually timed operators {sum(r[0] for r in rows)*1e3:.1f} us")
 for ms, name, kern, sin, sout, nbytes in rows:
     print(f"{ms*1e3:7.2f} us  {nbytes/ms/1e6:7.0f} GB/s  {name:22s} {kern:26s} {sin} -> {sout}")
