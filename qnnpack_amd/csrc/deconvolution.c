@@ -493,6 +493,7 @@ static enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8_impl(
   }
 
   op->variant = 1;   /* the offset-table kernel: the table, not the geometry, defines this operator */
+  op->deconv_stream = qnnp_state.opt_gemm_kernel == 13 ? 2 : (qnnp_state.opt_gemm_kernel == 1 ? 1 : 0);
   if (op->deconv_phases != 0) {
     if (op->offsets_in_h == input_height && op->offsets_in_w == input_width &&
         op->offsets_in_stride == input_pixel_stride) {

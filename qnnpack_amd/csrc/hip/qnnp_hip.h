@@ -182,6 +182,28 @@ struct qnnp_hip_igemm_args {
 };
 int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* args, const char** kernel_name);
 
+/* ---- q8 deconvolution, stride 2, 3x3 / 4x4 kernels (q8deconv.hip) --------------------------------------
+ * One streaming kernel over the input pixels in place of the phase-table GEMMs above (same packed per-phase
+ * sub-kernels and folded biases, deconvolution.c; phase = py * 2 + px with py = (oy + pad_top) % 2).
+ * QNNP_HIP_EINVAL = outside the kernel's range (channels % 32, channels > 128, weights beyond LDS, alignment):
+ * the caller keeps the phase-table path. */
+struct qnnp_hip_deconv_s2_args {
+  const uint8_t* input;
+  uint8_t* output;
+  const int8_t* packed_w[4];
+  const int32_t* bias2[4];
+  uint32_t k_pad[4];
+  uint32_t batch, input_height, input_width, output_height, output_width;
+  uint32_t kernel_height, kernel_width, pad_top, pad_left;
+  uint32_t channels;          /* input channels (one group) */
+  uint32_t n, n_pad;          /* output channels, round_up(n, 32) */
+  uint32_t input_stride, output_stride;
+  int32_t row_coeff;          /* 128 - kernel_zero_point */
+  uint32_t input_zero_point;
+  struct qnnp_hip_requant rq;
+};
+int qnnp_hip_deconv_s2_run(const struct qnnp_hip_deconv_s2_args* args, const char** kernel_name);
+
 /* ---- q8 depthwise convolution ------------------------------------------
  * Replaces q8dwconv_ukernel_up8x9__sse2 (src/q8dwconv/up8x9-sse2.c:14-372) and
  * q8dwconv_ukernel_mp8x25__sse2 (src/q8dwconv/mp8x25-sse2.c:14-742) plus

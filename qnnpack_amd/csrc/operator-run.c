@@ -146,6 +146,44 @@ static int launch_kernel(struct qnnp_operator* op, const void* input, const void
         }
         /* the streaming kernel cannot take these tensors (alignment): the phase GEMMs below can */
       }
+      if (op->transposed && op->deconv_phases == 4 && op->deconv_stream != 1 && op->groups == 1 &&
+          op->stride_height == 2 && op->stride_width == 2 && op->dilation_height == 1 && op->dilation_width == 1 &&
+          op->kernel_height == op->kernel_width && (op->kernel_height == 3 || op->kernel_height == 4)) {
+        /* stride 2, 3x3 / 4x4: one streaming kernel over the input pixels, all four phases (q8deconv.hip) */
+        struct qnnp_hip_deconv_s2_args sargs = {
+          .input = (const uint8_t*) input,
+          .output = (uint8_t*) output,
+          .batch = (uint32_t) op->batch_size,
+          .input_height = (uint32_t) op->input_height,
+          .input_width = (uint32_t) op->input_width,
+          .output_height = (uint32_t) op->output_height,
+          .output_width = (uint32_t) op->output_width,
+          .kernel_height = op->kernel_height,
+          .kernel_width = op->kernel_width,
+          .pad_top = op->input_padding_top,
+          .pad_left = op->input_padding_left,
+          .channels = (uint32_t) op->group_input_channels,
+          .n = (uint32_t) op->group_output_channels,
+          .n_pad = op->n_pad,
+          .input_stride = (uint32_t) op->input_pixel_stride,
+          .output_stride = (uint32_t) op->output_pixel_stride,
+          .row_coeff = 128 - (int32_t) op->kernel_zero_point,
+          .input_zero_point = op->input_zero_point,
+          .rq = op->requant,
+        };
+        for (int ph = 0; ph < 4; ph++) {
+          sargs.packed_w[ph] = (const int8_t*) op->phase[ph].d_weights;
+          sargs.bias2[ph] = op->phase[ph].d_bias;
+          sargs.k_pad[ph] = op->phase[ph].k_pad;
+        }
+        const int rc_s2 = qnnp_hip_deconv_s2_run(&sargs, &op->kernel_name);
+        if (rc_s2 != QNNP_HIP_EINVAL || op->deconv_stream == 2) {
+          return rc_s2;
+        }
+        /* outside the streaming kernel's range (channel multiple, LDS, alignment): the phase GEMMs below */
+      } else if (op->transposed && op->deconv_stream == 2) {
+        return QNNP_HIP_EINVAL;
+      }
       if (op->transposed && op->deconv_phases != 0) {
         /* strided deconvolution: one dense implicit GEMM per output phase, all in one launch (deconvolution.c) */
         if (op->phase_table_entries == 0) return QNNP_HIP_OK;

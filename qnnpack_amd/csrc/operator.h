@@ -67,6 +67,7 @@ struct qnnp_operator {
   uint32_t phase_max_k_pad;
   int deconv_d2s;              /* 1: kernel == stride, no padding: also packed as ONE pointwise GEMM with
                                 * depth-to-space stores (d_weights / d_bias / n_pad / k_pad), tried first at run */
+  int deconv_stream;           /* stride-2 streaming kernel (q8deconv.hip): 0 auto, 1 never, 2 forced ("gemm_kernel" 1 / 13 at setup) */
   struct qnnp_deconv_phase phase[QNNP_MAX_DECONV_PHASES];
 
   /* bound at setup (reference operator.h:59-73): caller-owned, not copied */

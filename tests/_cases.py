@@ -300,6 +300,39 @@ EXTRA_DECONV_CASES = [
 ]
 
 
+# Stride 2 with 3x3 / 4x4 kernels and channels % 32 == 0: the streaming kernel over the input pixels (q8deconv.hip)
+STREAM_DECONV_CASES = [
+    DeconvCase("ds_3x3s2_c64_n32_adjust", (28, 28), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=64, goc=32, batch=2,
+               adjustment=(1, 1)),
+    DeconvCase("ds_3x3s2_c32_n48_odd", (7, 9), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=32, goc=48, batch=3),
+    DeconvCase("ds_3x3s2_c96_n16_nopad", (6, 5), (3, 3), subsampling=(2, 2), gic=96, goc=16, batch=2),
+    DeconvCase("ds_3x3s2_c128_n32_asym_pad", (5, 6), (3, 3), (2, 0, 0, 1), subsampling=(2, 2), gic=128, goc=32),
+    DeconvCase("ds_3x3s2_c32_n20_dword_stores", (9, 8), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=32, goc=20, batch=2),
+    DeconvCase("ds_3x3s2_c32_n19_byte_stores", (9, 8), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=32, goc=19, batch=2),
+    DeconvCase("ds_3x3s2_c64_n32_strides", (8, 9), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=64, goc=32, batch=2,
+               input_pixel_stride=80, output_pixel_stride=48),
+    DeconvCase("ds_3x3s2_c32_n32_zp_0_255", (7, 7), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=32, goc=32, izp=0, kzp=255),
+    DeconvCase("ds_3x3s2_c32_n32_zp_255_0", (7, 7), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=32, goc=32, izp=255, kzp=0),
+    DeconvCase("ds_3x3s2_c64_n32_qrange", (8, 8), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=64, goc=32, qmin=40, qmax=200,
+               adjustment=(1, 0)),
+    DeconvCase("ds_3x3s2_c32_n16_one_pixel", (1, 1), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=32, goc=16, batch=5),
+    DeconvCase("ds_4x4s2p1_c64_n32", (13, 11), (4, 4), _pad(1, 1), subsampling=(2, 2), gic=64, goc=32, batch=2),
+    DeconvCase("ds_4x4s2_c32_n48_nopad", (6, 7), (4, 4), subsampling=(2, 2), gic=32, goc=48, batch=3),
+    DeconvCase("ds_4x4s2p1_c96_n24_adjust", (5, 9), (4, 4), _pad(1, 1), subsampling=(2, 2), gic=96, goc=24, adjustment=(1, 1)),
+    DeconvCase("ds_3x3s2_c64_n96_many_units", (33, 35), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=64, goc=96, batch=4,
+               adjustment=(1, 1)),
+]
+# the same family outside the streaming kernel's range: the phase GEMMs
+STREAM_DECONV_FALLBACK_CASES = [
+    DeconvCase("dsf_3x3s2_c160", (6, 6), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=160, goc=16),          # channels > 128
+    DeconvCase("dsf_3x3s2_c64_unaligned_rows", (6, 6), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=64, goc=16,
+               input_pixel_stride=72),
+    DeconvCase("dsf_4x4s2_c128_n128_lds", (5, 5), (4, 4), _pad(1, 1), subsampling=(2, 2), gic=128, goc=128),  # 256 KiB of weights
+    DeconvCase("dsf_3x3s2_grouped", (6, 6), (3, 3), _pad(1, 1), subsampling=(2, 2), groups=2, gic=32, goc=16),
+    DeconvCase("dsf_3x4s2", (6, 6), (3, 4), _pad(1, 1), subsampling=(2, 2), gic=32, goc=16),
+]
+
+
 def deconv_tensors(case: DeconvCase):
     """Seeded input / kernel / bias; kernel in the deconvolution layout [g][ic][kh][kw][oc]
     (test/deconvolution-operator-tester.h:355, :411)."""

@@ -82,6 +82,17 @@ int qnnp_hip_graph_sync(void* graph) { (void) graph; return QNNP_HIP_EINVAL; }
 void qnnp_hip_graph_destroy(void* graph) { (void) graph; }
 
 /* ---- "kernels": check the argument block against the documented layout, touch every buffer end to end ---- */
+int qnnp_hip_deconv_s2_run(const struct qnnp_hip_deconv_s2_args* a, const char** kernel_name)
+{
+  (void) kernel_name;
+  if (a == NULL || a->batch == 0) return QNNP_HIP_EINVAL;
+  for (int ph = 0; ph < 4; ph++) {
+    touch(a->packed_w[ph], (size_t) a->n_pad * a->k_pad[ph]);
+    touch(a->bias2[ph], (size_t) a->n_pad * 4);
+  }
+  return QNNP_HIP_EINVAL;   /* "outside the streaming kernel's range": the host then takes the phase-table path */
+}
+
 int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const char** kernel_name)
 {
   if (a == NULL || a->rows == 0 || a->n == 0 || a->n_pad % 32 != 0 || a->k_pad % 64 != 0 || a->n_pad < a->n) return QNNP_HIP_EINVAL;

@@ -5,22 +5,57 @@ behaviour (reference src/deconvolution.c:69-129, :225-243)."""
 import numpy as np
 import pytest
 
-from _cases import DECONV_CASES, EXTRA_DECONV_CASES, deconv_tensors
+from _cases import (DECONV_CASES, EXTRA_DECONV_CASES, STREAM_DECONV_CASES, STREAM_DECONV_FALLBACK_CASES,
+                    deconv_tensors)
 from _gpu import from_device, to_device
 from _runner import assert_bytes_equal, deconv_expected, deconv_run
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", DECONV_CASES + EXTRA_DECONV_CASES, ids=lambda c: c.name)
+def _expected_kernel(case):
+    if case.name.startswith("dx_d2s_") or case.name == "dx_2x2s2_c64_n32":
+        return "q8_pw_stream_d2s_mfma"
+    if case.name.startswith("ds_") or case.name == "dx_4x4s2p1_c32_n16":
+        return "q8_deconv_s2_stream"
+    return "q8_igemm_mfma"
+
+
+@pytest.mark.parametrize("case", DECONV_CASES + EXTRA_DECONV_CASES + STREAM_DECONV_CASES + STREAM_DECONV_FALLBACK_CASES,
+                         ids=lambda c: c.name)
 def test_deconvolution_matches_oracle_device_tensors(qnnp, case):
     expected, quant, out_hw = deconv_expected(case)
     out, kname = deconv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
     if case.batch:
-        expect = "q8_pw_stream_d2s_mfma" if (case.name.startswith("dx_d2s_") or case.name == "dx_2x2s2_c64_n32") \
-            else "q8_igemm_mfma"
-        assert kname is not None and kname.startswith(expect), kname
+        assert kname is not None and kname.startswith(_expected_kernel(case)), kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("case", STREAM_DECONV_CASES, ids=lambda c: c.name)
+def test_streaming_and_phase_table_kernels_agree(qnnp, case):
+    """"gemm_kernel" = 1 keeps the phase-table GEMMs, 13 forces the streaming kernel: same bytes, both against the oracle."""
+    expected, quant, out_hw = deconv_expected(case)
+    for variant, want in ((1, "q8_igemm_mfma"), (13, "q8_deconv_s2_stream")):
+        qnnp.set_option("gemm_kernel", variant)
+        try:
+            out, kname = deconv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
+        finally:
+            qnnp.set_option("gemm_kernel", 0)
+        assert kname.startswith(want), kname
+        assert_bytes_equal(out, expected, f"gemm_kernel={variant} {kname} [{case.name}]")
+
+
+def test_forced_streaming_kernel_outside_its_range_is_refused(qnnp):
+    from qnnpack_amd import QnnpackError, Status
+    case = next(c for c in STREAM_DECONV_FALLBACK_CASES if c.name == "dsf_3x3s2_c160")
+    expected, quant, out_hw = deconv_expected(case)
+    qnnp.set_option("gemm_kernel", 13)
+    try:
+        with pytest.raises(QnnpackError) as err:
+            deconv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
+        assert err.value.status == Status.unsupported_parameter
+    finally:
+        qnnp.set_option("gemm_kernel", 0)
 
 
 @pytest.mark.parametrize("case", [c for c in DECONV_CASES if c.name in
