@@ -203,6 +203,22 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
         goto error;
       }
     }
+    /* 5x5 likewise: eight rows (pack.h qnnp_pack_dwconv_dot4_5x5) */
+    if (kernel_height == 5 && kernel_width == 5 && op->dw_wrange != 0) {
+      const size_t q_bytes = sizeof(uint32_t) * 8 * c_pad;
+      uint32_t* host_q = (uint32_t*) malloc(q_bytes);
+      int ok = host_q != NULL;
+      if (ok) {
+        qnnp_pack_dwconv_dot4_5x5(c_pad, op->dw_wrange, (const int16_t*) host_weights, host_bias, host_q);
+        op->d_dw_dot4 = qnnp_hip_alloc(q_bytes);
+        ok = op->d_dw_dot4 != NULL && qnnp_hip_h2d(op->d_dw_dot4, host_q, q_bytes, 0) == QNNP_HIP_OK;
+      }
+      free(host_q);
+      if (!ok) {
+        qnnp_log_error("failed to place %zu bytes of depthwise dot-product weights on the device", q_bytes);
+        goto error;
+      }
+    }
     /* second image: int8 weight parts + folded bias for the matrix-core depthwise kernel */
     {
       const uint32_t c_pad32 = qnnp_round_up_u32(groups, 32);

@@ -54,6 +54,17 @@ uint32_t qnnp_debug_pack_dwconv_dot4(
   return range;
 }
 
+/* the same for 5x5 operators (kernel H): `image` holds 8 * c_pad words (pack.h qnnp_pack_dwconv_dot4_5x5) */
+uint32_t qnnp_debug_pack_dwconv_dot4_5x5(
+    uint32_t channels, uint32_t c_pad, uint8_t izp, uint8_t kzp, const uint8_t* kernel, const int32_t* bias,
+    int16_t* wadj /* [25][c_pad] scratch */, int32_t* bias1 /* [c_pad] scratch */, uint32_t* image)
+{
+  qnnp_pack_dwconv_w(channels, c_pad, 5, 5, izp, kzp, kernel, bias, wadj, bias1);
+  const uint32_t range = qnnp_dwconv_weight_range(wadj, (size_t) 25 * c_pad);
+  if (range != 0) qnnp_pack_dwconv_dot4_5x5(c_pad, range, wadj, bias1, image);
+  return range;
+}
+
 void qnnp_debug_conv2d_offsets(
     size_t input_height, size_t input_width, size_t input_pixel_stride,
     size_t output_height, size_t output_width,

@@ -1134,6 +1134,340 @@ int launch_col(const DwParams& geometry, hipStream_t stream)
 }
 
 // --------------------------------------------------------------------------
+// Kernel H: column-sliding register window, 5x5, stride 1 | 2, weights in int8 range (v_dot4_i32_i8)
+// --------------------------------------------------------------------------
+/*
+ * Kernel G's int8 dot-product walk for 5x5 windows (replaces q8dwconv_ukernel_mp8x25__sse2, reference
+ * src/q8dwconv/mp8x25-sse2.c:14-742, for these shapes). A lane owns a 4-channel group of one output column and walks
+ * down the output rows of its segment; an input row is five dwords (window columns 0..4, four channels each):
+ *   - columns 0..3 are transposed ONCE into per-channel quads T[r][c] = (col0, col1, col2, col3) -- eight v_perm -- and
+ *     serve the five output rows whose windows contain the row: five v_dot4_i32_i8 per channel against
+ *     WQ[ky][c] = (x_ky0, x_ky1, x_ky2, x_ky3);
+ *   - column 4 needs no transpose of its own: V[c] holds channel c's column-4 bytes of the FOUR rows before the newest
+ *     one, slid along by one v_perm per channel and row, and meets WV[c] = (x_04, x_14, x_24, x_34) in one dot product;
+ *     the newest row's column-4 dword meets the one-hot W5[c] = x_44 at byte c.
+ * Per output dword at stride 1: 5 loads, 5 v_xor, 12 v_perm, 28 dot products, the requantization, one store -- ~65
+ * instructions against the ~150 of the LDS-tiled kernel's int16 pair walk (25 LDS reads, 52 v_perm, 52 v_dot2).
+ * x = w - kzp with a' = a ^ 0x80, or x = kzp - w with a' = a ^ 0x7f (DwParams::wrange, as kernel G); the host packs
+ * the register image (pack.h qnnp_pack_dwconv_dot4_5x5: rows 0..4 WQ, 5 WV, 6 W5, 7 the bias that goes with a').
+ * Rows: row r of the walk lives in raw buffer r % 5 until it is transposed into T[r % 5]; the buffer is re-loaded at
+ * once with row r + 5, so five rows are always in flight and no register is ever copied (five steps per trip).
+ */
+template <int S, bool FIX, int SEQ, bool FULL>
+__device__ __forceinline__ void dwconv_col5x5_body(
+    const DwParams& p, const uint32_t n, const uint32_t oy0, const uint32_t oy1, const uint32_t ox, const uint32_t cg,
+    const bool (&okc)[5])
+{
+  const uint32_t kx = p.wrange == 2u ? 0x7f7f7f7fu : 0x80808080u;    // wave-uniform
+  uint4 wqv[5];
+#pragma unroll
+  for (int ky = 0; ky < 5; ky++) wqv[ky] = *reinterpret_cast<const uint4*>(p.dot4 + ky * p.c_pad + cg);
+  const uint4 wvv = *reinterpret_cast<const uint4*>(p.dot4 + 5u * p.c_pad + cg);
+  const uint4 w5v = *reinterpret_cast<const uint4*>(p.dot4 + 6u * p.c_pad + cg);
+  const int4 bv = *reinterpret_cast<const int4*>(p.dot4 + 7u * p.c_pad + cg);
+
+  const uint32_t fill = p.izp * 0x01010101u;
+  const uint32_t row_bytes = p.W * p.in_stride;
+  // buffer addressing as kernel G: per lane constant byte offsets inside a row, per row a SCALAR offset
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.input), 0, static_cast<int>(p.batch * p.H * row_bytes), 0x00020000);
+  const int32_t ix0 = static_cast<int32_t>(ox * S) - static_cast<int32_t>(p.pad_left);
+  uint32_t coff[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) coff[k] = cg + (okc[k] ? static_cast<uint32_t>(ix0 + k) : 0u) * p.in_stride;
+  const uint32_t img_off = n * p.H * row_bytes;                     // wave-uniform
+  const int32_t iy_first = static_cast<int32_t>(oy0 * S) - static_cast<int32_t>(p.pad_top);
+
+  struct Row { uint32_t c[5]; bool ok; };
+  // (the loads are ALWAYS issued: a row outside the image is clamped to a valid one and replaced afterwards, see kernel
+  //  G. "Afterwards" is where the row is CONSUMED -- settle() -- not here: a select on a register just requested is a
+  //  wait for it, and the rows are requested five steps ahead.)
+  auto load_row = [&](auto, int32_t iy) __attribute__((always_inline)) -> Row {
+    Row r;
+    // (always clamped -- scalar work -- whatever the step knows about the rows it CONSUMES: a steady-state step may
+    //  well request a row below the image, for the checked steps behind it)
+    r.ok = iy >= 0 && iy < static_cast<int32_t>(p.H);
+    iy = iy < 0 ? 0 : (iy >= static_cast<int32_t>(p.H) ? static_cast<int32_t>(p.H) - 1 : iy);
+    const uint32_t ro = img_off + static_cast<uint32_t>(iy) * row_bytes;      // scalar
+#pragma unroll
+    for (int k = 0; k < 5; k++) r.c[k] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[k], ro, 0);
+    return r;
+  };
+  constexpr std::true_type kChecked{};
+  constexpr std::false_type kInside{};
+  // padding columns (per lane) and padding rows (per wave; CHECK = false: the caller knows the rows it consumes are
+  // inside the image -- the steady-state steps)
+  auto settle = [&](auto check, Row& r) __attribute__((always_inline)) {
+    constexpr bool CHECK = decltype(check)::value;
+    if constexpr (FIX) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) r.c[k] = okc[k] ? r.c[k] : fill;
+    }
+    if constexpr (CHECK) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) r.c[k] = r.ok ? r.c[k] : fill;
+    }
+  };
+
+  struct Quads { uint32_t q[4]; };
+  // columns 0..3 of a row -> per channel c the bytes (col0, col1, col2, col3), re-centred; e = column 4, re-centred
+  auto transpose = [kx](const Row& r, Quads& t, uint32_t& e) __attribute__((always_inline)) {
+    const uint32_t d0 = r.c[0] ^ kx, d1 = r.c[1] ^ kx, d2 = r.c[2] ^ kx, d3 = r.c[3] ^ kx;
+    e = r.c[4] ^ kx;
+    // (pinned here: left to itself hipcc keeps the RAW dword alive past the re-load of its buffer -- a register copy per
+    //  step, and the copies of freshly loaded registers at the top of the trip are s_waitcnt vmcnt(6): every row of
+    //  the previous trip had to land before the next began, 49 % of the wave cycles waiting)
+    asm volatile("" : "+v"(e));
+    const uint32_t lo01 = __builtin_amdgcn_perm(d1, d0, 0x05010400u);    // (d0.b0, d1.b0, d0.b1, d1.b1)
+    const uint32_t hi01 = __builtin_amdgcn_perm(d1, d0, 0x07030602u);    // (d0.b2, d1.b2, d0.b3, d1.b3)
+    const uint32_t lo23 = __builtin_amdgcn_perm(d3, d2, 0x05010400u);
+    const uint32_t hi23 = __builtin_amdgcn_perm(d3, d2, 0x07030602u);
+    t.q[0] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
+    t.q[1] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
+    t.q[2] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
+    t.q[3] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
+  };
+  // V[c] = (V[c].b1, V[c].b2, V[c].b3, e.bc): one row further down column 4
+  auto slide = [](uint32_t (&v)[4], uint32_t e) __attribute__((always_inline)) {
+    v[0] = __builtin_amdgcn_perm(e, v[0], 0x04030201u);
+    v[1] = __builtin_amdgcn_perm(e, v[1], 0x05030201u);
+    v[2] = __builtin_amdgcn_perm(e, v[2], 0x06030201u);
+    v[3] = __builtin_amdgcn_perm(e, v[3], 0x07030201u);
+  };
+
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.output, 0, static_cast<int>(p.batch * p.OH * p.OW * p.out_stride), 0x00020000);
+  const uint32_t out_voff = ox * p.out_stride + cg;
+  uint32_t out_soff = (n * p.OH + oy0) * p.OW * p.out_stride;       // scalar, advances one output row per step
+  const uint32_t out_step = p.OW * p.out_stride;
+
+  // The first ten rows less S are requested at once, before the weights are moved to their registers: rows 0..4 into
+  // their buffers, rows 5..9-S -- whose buffers still hold rows 0..4-S -- into the start-up buffers X, which the first
+  // trip consumes in their place. Without X a wave's second batch of rows was requested only after the first had
+  // arrived and been transposed: two memory round trips before step 1, 43 % of a 14-step wave's lifetime in s_waitcnt
+  // (PMC, 28x28x240 batch 128: SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES).
+  Row rb[5], X[5 - S];
+#pragma unroll
+  for (int r = 0; r < 5; r++) rb[r] = load_row(kChecked, iy_first + r);
+#pragma unroll
+  for (int r = 0; r < 5 - S; r++) X[r] = load_row(kChecked, iy_first + 5 + r);
+  __builtin_amdgcn_sched_barrier(0);
+  uint32_t wq[5][4], wv[4], w5[4];
+  int32_t bias[4];
+#pragma unroll
+  for (int ky = 0; ky < 5; ky++) { wq[ky][0] = wqv[ky].x; wq[ky][1] = wqv[ky].y; wq[ky][2] = wqv[ky].z; wq[ky][3] = wqv[ky].w; }
+  wv[0] = wvv.x; wv[1] = wvv.y; wv[2] = wvv.z; wv[3] = wvv.w;
+  w5[0] = w5v.x; w5[1] = w5v.y; w5[2] = w5v.z; w5[3] = w5v.w;
+  // the offset rounding sequences (requant.hip.h) take accumulator + 2^31: folded into the bias, once per thread
+  bias[0] = qnnp::with_rq_offset<SEQ>(bv.x); bias[1] = qnnp::with_rq_offset<SEQ>(bv.y);
+  bias[2] = qnnp::with_rq_offset<SEQ>(bv.z); bias[3] = qnnp::with_rq_offset<SEQ>(bv.w);
+
+  Quads tq[5];
+  uint32_t V[4] = {0u, 0u, 0u, 0u};
+  // rows 0 .. 4 - S of the walk are part of the first window only: transposed here, their buffers re-loaded
+#pragma unroll
+  for (int r = 0; r < 5 - S; r++) {
+    uint32_t e;
+    settle(kChecked, rb[r]);
+    transpose(rb[r], tq[r], e);
+    slide(V, e);
+    rb[r] = load_row(kChecked, iy_first + r + 10);                  // (row r + 5 is on its way to X[r])
+  }
+
+  const uint32_t steps = oy1 - oy0;
+  uint32_t t = 0;
+  // steps whose window (rows iy_first + S*t .. + 4) is inside the image: t < t_inside (from the second trip on the
+  // rows are below the top padding: pad_top <= 4)
+  const int32_t inside = static_cast<int32_t>(p.H) - 5 - iy_first;
+  const uint32_t t_inside = inside < 0 ? 0u : min(steps, static_cast<uint32_t>(inside) / S + 1u);
+
+  // FIRST: the first trip (t = PH): rows 5..9-S come from X and their buffers are not re-loaded (they already hold
+  // the row after next)
+  auto step = [&](auto phase, auto check, auto first) __attribute__((always_inline)) {
+    constexpr int PH = decltype(phase)::value;
+    constexpr bool FIRST = decltype(first)::value;
+    uint32_t e_new = 0;
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+      const int rel = S * PH + 5 - S + k;                                // row of the walk, first trip (a constant after unrolling)
+      const int slot = rel % 5;
+      uint32_t e;
+      // (a steady-state step consumes rows that are inside the image: its own re-loads lie further down)
+      if (FIRST && rel >= 5 && rel < 10 - S) {
+        settle(check, X[rel - 5]);
+        transpose(X[rel - 5], tq[slot], e);
+      } else {
+        settle(check, rb[slot]);
+        transpose(rb[slot], tq[slot], e);
+        rb[slot] = load_row(check, iy_first + static_cast<int32_t>(S * t) + (5 - S) + k + 5);
+      }
+      if (k < S - 1) slide(V, e); else e_new = e;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int32_t acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(acc[c]) : "v"(tq[(S * PH) % 5].q[c]), "v"(wq[0][c]), "v"(bias[c]));
+    }
+#pragma unroll
+    for (int ky = 1; ky < 5; ky++) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        acc[c] = __builtin_amdgcn_sdot4(static_cast<int32_t>(tq[(S * PH + ky) % 5].q[c]), static_cast<int32_t>(wq[ky][c]), acc[c], false);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      acc[c] = __builtin_amdgcn_sdot4(static_cast<int32_t>(V[c]), static_cast<int32_t>(wv[c]), acc[c], false);
+      acc[c] = __builtin_amdgcn_sdot4(static_cast<int32_t>(e_new), static_cast<int32_t>(w5[c]), acc[c], false);
+    }
+    const uint32_t packed = qnnp::q31_requantize_pack4<SEQ, FULL>(acc[0], acc[1], acc[2], acc[3], p.rq);
+    __builtin_amdgcn_raw_buffer_store_b32(packed, out_rsrc, out_voff, out_soff, 0);
+    out_soff += out_step;
+    slide(V, e_new);
+    t++;
+  };
+  using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>; using P3 = std::integral_constant<int, 3>;
+  using P4 = std::integral_constant<int, 4>;
+  constexpr std::true_type kFirst{};
+  constexpr std::false_type kLater{};
+  do {                                             // the first trip
+    step(P0{}, kChecked, kFirst);
+    if (t >= steps) return;
+    step(P1{}, kChecked, kFirst);
+    if (t >= steps) return;
+    step(P2{}, kChecked, kFirst);
+    if (t >= steps) return;
+    step(P3{}, kChecked, kFirst);
+    if (t >= steps) return;
+    step(P4{}, kChecked, kFirst);
+  } while (false);
+  if (t + 5 <= t_inside) {
+    // The first trip issues fewer loads than a steady one (X), and hipcc's wait for the oldest row at the top of the
+    // steady loop is the minimum over both ways in: entered from the first trip it came out as vmcnt(5) -- everything but
+    // the newest row -- on EVERY trip. With nothing in flight on the way in (rows 9..13 were requested five steps ago)
+    // the back edge alone decides: vmcnt(25).
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+    do {                                           // steady state: straight-line body, counted waits
+      step(P0{}, kInside, kLater); step(P1{}, kInside, kLater); step(P2{}, kInside, kLater); step(P3{}, kInside, kLater);
+      step(P4{}, kInside, kLater);
+    } while (t + 5 <= t_inside);
+  }
+  while (t < steps) {                              // the last steps of a segment (and of the image: padding rows)
+    step(P0{}, kChecked, kLater);
+    if (t >= steps) break;
+    step(P1{}, kChecked, kLater);
+    if (t >= steps) break;
+    step(P2{}, kChecked, kLater);
+    if (t >= steps) break;
+    step(P3{}, kChecked, kLater);
+    if (t >= steps) break;
+    step(P4{}, kChecked, kLater);
+  }
+}
+
+template <int S, int SEQ, bool FULL>
+__global__ __launch_bounds__(kColThreads)
+void q8_dwconv_col5x5_kernel(const DwParams p)
+{
+  // wave -> (image, row segment, 64-dword chunk of the flattened output row), as kernel G
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t b = blockIdx.x;
+  if (p.xcd_ranges != 0u) {
+    const uint32_t q = gridDim.x >> 3, r = gridDim.x & 7u, xcd = b & 7u;
+    b = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (b >> 3);
+  }
+  const uint32_t w = __builtin_amdgcn_readfirstlane(b * (kColThreads / 64) + (threadIdx.x >> 6));
+  auto div_by = [](uint32_t x, uint32_t inv) __attribute__((always_inline)) { return inv != 0u ? __umulhi(x, inv) : x; };
+  const uint32_t wb = div_by(w, p.inv_bands);
+  const uint32_t chunk = w - wb * p.bands;
+  const uint32_t n = div_by(wb, p.inv_slabs);
+  const uint32_t seg = wb - n * p.slabs;
+  if (n >= p.batch) return;
+  const uint32_t q4 = p.C >> 2;
+  const uint32_t cols = p.OW * q4;
+  uint32_t j = chunk * 64u + lane;
+  if (j >= cols) j = cols - 1u;                    // lanes past the end repeat the last dword column: harmless
+  const uint32_t ox = div_by(j, p.inv_q4);
+  const uint32_t cg = (j - ox * q4) * 4u;
+  const uint32_t oy0 = seg * p.TOH;
+  const uint32_t oy1 = min(p.OH, oy0 + p.TOH);
+  const int32_t ix0 = static_cast<int32_t>(ox * S) - static_cast<int32_t>(p.pad_left);
+  bool okc[5];
+  bool all_ok = true;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    okc[k] = ix0 + k >= 0 && ix0 + k < static_cast<int32_t>(p.W);
+    all_ok = all_ok && okc[k];
+  }
+  if (__builtin_amdgcn_ballot_w64(!all_ok) != 0) {
+    dwconv_col5x5_body<S, true, SEQ, FULL>(p, n, oy0, oy1, ox, cg, okc);
+  } else {
+    const bool yes[5] = {true, true, true, true, true};
+    dwconv_col5x5_body<S, false, SEQ, FULL>(p, n, oy0, oy1, ox, cg, yes);
+  }
+}
+
+// geometry of kernel H: as plan_col (`bands` = 64-dword chunks per flattened output row, `slabs` = row segments)
+bool plan_col5(DwParams& p)
+{
+  if (p.C % 4 != 0 || p.KH != 5 || p.KW != 5 || p.dh != 1 || p.dw != 1) return false;
+  if (p.sh != p.sw || (p.sw != 1 && p.sw != 2)) return false;
+  if (p.wrange != 1u && p.wrange != 2u) return false;
+  if (p.dot4 == nullptr) return false;
+  // (the steady-state steps fetch row iy_first + S*t + 10 - S + k with no lower bound: >= 0 while pad_top <= 5)
+  if (p.pad_top > 4 || p.pad_left > 4) return false;
+  const uint64_t in_bytes = static_cast<uint64_t>(p.batch) * p.H * p.W * p.in_stride;
+  const uint64_t out_bytes = static_cast<uint64_t>(p.batch) * p.OH * p.OW * p.out_stride;
+  if (in_bytes >= (UINT64_C(1) << 31) || out_bytes >= (UINT64_C(1) << 32)) return false;
+  const uint32_t cols = p.OW * (p.C / 4);
+  const uint32_t chunks = (cols + 63u) / 64u;
+  // row segments: each re-loads its four halo rows and transposes them again; ~one round of four waves per SIMD
+  const uint64_t waves_per_seg = static_cast<uint64_t>(p.batch) * chunks;
+  const uint64_t slots = static_cast<uint64_t>(p.cu_count) * 4u * 4u;
+  uint32_t segs = static_cast<uint32_t>((slots + waves_per_seg - 1) / waves_per_seg);
+  const uint32_t min_rows = p.sw == 2 ? 7u : 10u;  // (56x56x72 s2, batch 128: 7-row segments 18.6 us, 14-row 20.2, 28-row 29.3)
+  uint32_t max_segs = p.OH / min_rows;
+  if (max_segs < 1) max_segs = 1;
+  if (segs > max_segs) segs = max_segs;
+  if (segs < 1) segs = 1;
+  uint32_t toh = (p.OH + segs - 1) / segs;
+  if (const uint32_t forced = col_rows_override()) toh = forced < p.OH ? forced : p.OH;
+  p.TOH = toh;
+  p.slabs = (p.OH + toh - 1) / toh;
+  p.bands = chunks;
+  const uint64_t waves = static_cast<uint64_t>(p.batch) * p.slabs * chunks;
+  const uint64_t dmax = chunks > p.slabs ? chunks : p.slabs;
+  if ((waves + 8u * (kColThreads / 64)) * dmax >= (UINT64_C(1) << 32)) return false;
+  if (static_cast<uint64_t>(cols) * (p.C / 4) >= (UINT64_C(1) << 32)) return false;
+  return waves < (UINT64_C(1) << 31);
+}
+
+int launch_col5(const DwParams& geometry, hipStream_t stream)
+{
+  DwParams p = geometry;
+  auto reciprocal = [](uint32_t d) { return d > 1u ? static_cast<uint32_t>(((UINT64_C(1) << 32) + d - 1u) / d) : 0u; };
+  p.inv_bands = reciprocal(p.bands);
+  p.inv_slabs = reciprocal(p.slabs);
+  p.inv_q4 = reciprocal(p.C / 4u);
+  p.xcd_ranges = (static_cast<uint64_t>(p.batch) * p.H * p.W * p.in_stride +
+                  static_cast<uint64_t>(p.batch) * p.OH * p.OW * p.out_stride) <= (UINT64_C(96) << 20) ? 1u : 0u;
+  const uint64_t waves = static_cast<uint64_t>(p.batch) * p.slabs * p.bands;
+  const uint32_t blocks = static_cast<uint32_t>((waves + (kColThreads / 64) - 1) / (kColThreads / 64));
+  qnnp::requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+    constexpr int kSeq = decltype(seq)::value;
+    constexpr bool kFull = decltype(full)::value;
+    if (p.sw == 1) {
+      hipLaunchKernelGGL((q8_dwconv_col5x5_kernel<1, kSeq, kFull>), dim3(blocks), dim3(kColThreads), 0, stream, p);
+    } else {
+      hipLaunchKernelGGL((q8_dwconv_col5x5_kernel<2, kSeq, kFull>), dim3(blocks), dim3(kColThreads), 0, stream, p);
+    }
+  });
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+// --------------------------------------------------------------------------
 // Kernel D: matrix cores, 3x3, any stride / dilation, C % 16 == 0
 // --------------------------------------------------------------------------
 /*
@@ -1650,7 +1984,7 @@ int launch_lds(const DwParams& p, bool vec16, hipStream_t stream)
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
-enum : uint32_t { kPlanDirect = 1, kPlanLds33, kPlanLds55, kPlanRow, kPlanMfma, kPlanMfmaLds, kPlanCol };
+enum : uint32_t { kPlanDirect = 1, kPlanLds33, kPlanLds55, kPlanRow, kPlanMfma, kPlanMfmaLds, kPlanCol, kPlanCol5 };
 
 // measurement knob, read once: LDS budget per workgroup of the LDS-tiled kernel in KiB
 uint32_t lds_budget()
@@ -1677,7 +2011,10 @@ int make_plan(DwParams& p, const struct qnnp_hip_dwconv_args* a, uintptr_t in_ad
   else if (p.C % 4 == 0 && p.out_stride % 4 == 0 && out_addr % 4 == 0) p.store_mode = 1;
   plan->vec16 = 0;
   plan->kernel = 0;
-  if (a->variant == 6) {
+  if (a->variant == 6 && k55) {
+    if (!aligned4 || !plan_col5(p)) return QNNP_HIP_EINVAL;
+    plan->kernel = kPlanCol5;
+  } else if (a->variant == 6) {
     if (!aligned4 || !plan_col(p)) return QNNP_HIP_EINVAL;
     plan->kernel = kPlanCol;
   } else if (a->variant == 5) {
@@ -1691,6 +2028,9 @@ int make_plan(DwParams& p, const struct qnnp_hip_dwconv_args* a, uintptr_t in_ad
     // matrix-core kernels on every one of the ten MobileNetV2 depthwise layers at batch 128 (same-box A/B,
     // scripts/gpu_dwab.sh, profiles/r02/dwconv_kernel_ab_*.txt).
     plan->kernel = kPlanCol;
+  } else if (a->variant == 0 && k55 && aligned4 && plan_col5(p)) {
+    // 5x5, dilation 1, stride 1 | 2, weights in int8 range: the same walk with five-row windows (kernel H)
+    plan->kernel = kPlanCol5;
   } else if (a->variant == 0 && k33 && p.OW >= 56 && p.C <= 96 && plan_mfma_lds(p, a)) {
     // (shapes kernel G declines, e.g. tensors beyond its 32-bit offsets) large images with few channels: the
     // matrix-core kernel with the LDS-staged band
@@ -1787,6 +2127,9 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
     case kPlanCol:
       if (kernel_name != nullptr) *kernel_name = col_uses_dot4(p) ? "q8_dwconv_col_3x3_dot4" : "q8_dwconv_col_3x3";
       return launch_col(p, stream);
+    case kPlanCol5:
+      if (kernel_name != nullptr) *kernel_name = "q8_dwconv_col_5x5_dot4";
+      return launch_col5(p, stream);
     case kPlanLds33:
       if (kernel_name != nullptr) *kernel_name = "q8_dwconv_lds_3x3";
       return launch_lds<3, 3>(p, plan->vec16 != 0, stream);

@@ -231,7 +231,7 @@ struct qnnp_hip_dwconv_args {
   const int32_t* dwm_bias;    /* [c_pad32] */
   uint32_t dwm_parts;         /* 1..3 parts in use */
   uint32_t w_range;           /* qnnp_dwconv_weight_range of wadj (pack.h): 0 unknown / neither, 1, 2 */
-  const uint32_t* dot4;       /* [4][c_pad] qnnp_pack_dwconv_dot4 image (3x3, w_range 1 / 2), else NULL */
+  const uint32_t* dot4;       /* w_range 1 / 2: [4][c_pad] qnnp_pack_dwconv_dot4 image (3x3) or [8][c_pad] qnnp_pack_dwconv_dot4_5x5 (5x5), else NULL */
   uint32_t c_pad32;
   uint32_t batch;
   uint32_t input_height, input_width;

@@ -123,7 +123,7 @@ struct qnnp_operator {
   void* d_dwm_x;          /* dwconv, MFMA kernel: int8 [3][taps][c_pad32] weight parts (pack.h) */
   int32_t* d_dwm_bias;    /* dwconv, MFMA kernel: int32 [c_pad32] */
   uint32_t dwm_parts;     /* 1..3 */
-  void* d_dw_dot4;        /* dwconv 3x3, dw_wrange != 0: uint32 [4][c_pad] register image of the int8 dot-product walk (pack.h) */
+  void* d_dw_dot4;        /* dwconv 3x3 / 5x5, dw_wrange != 0: uint32 [4 | 8][c_pad] register image of the int8 dot-product walk (pack.h) */
   uint32_t dw_wrange;     /* qnnp_dwconv_weight_range (pack.h): 0, 1 (w - kzp fits int8), 2 (kzp - w does) */
   uint32_t c_pad32;
 

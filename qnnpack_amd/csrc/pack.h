@@ -226,6 +226,41 @@ static inline void qnnp_pack_dwconv_dot4(
 }
 
 /*
+ * The same for 5x5 depthwise operators (q8dwconv.hip, kernel H), eight rows of c_pad words:
+ *   image[ky][c], ky = 0..4 = (x_ky0, x_ky1, x_ky2, x_ky3)   columns 0..3 of kernel row ky, met by the transposed quads
+ *   image[5][c]             = (x_04, x_14, x_24, x_34)       column 4 of kernel rows 0..3, met by the sliding column
+ *   image[6][c]             = x_44 at byte c % 4, else 0     column 4 of the newest row: one-hot against the raw dword
+ *   image[7][c]             = bias1[c] + (128 | 127) * sum_taps (w - kzp)
+ * x = w - kzp (class 1) or kzp - w (class 2) as int8.
+ */
+static inline void qnnp_pack_dwconv_dot4_5x5(
+    uint32_t c_pad, uint32_t range, const int16_t* wadj /* [25][c_pad] */, const int32_t* bias1 /* [c_pad] */,
+    uint32_t* image /* [8][c_pad] */)
+{
+  for (uint32_t c = 0; c < c_pad; c++) {
+    uint32_t xsum = 0, col4 = 0;
+    for (uint32_t r = 0; r < 5; r++) {
+      uint32_t q = 0;
+      for (uint32_t k = 0; k < 5; k++) {
+        const uint32_t x = (uint32_t) (int32_t) wadj[(size_t) (r * 5 + k) * c_pad + c];
+        xsum += x;
+        const uint32_t b = (range == 2 ? 0u - x : x) & 0xFFu;
+        if (k < 4) {
+          q |= b << (8 * k);
+        } else if (r < 4) {
+          col4 |= b << (8 * r);
+        } else {
+          image[(size_t) 6 * c_pad + c] = b << (8 * (c & 3u));
+        }
+      }
+      image[(size_t) r * c_pad + c] = q;
+    }
+    image[(size_t) 5 * c_pad + c] = col4;
+    image[(size_t) 7 * c_pad + c] = (uint32_t) bias1[c] + (range == 2 ? 127u : 128u) * xsum;
+  }
+}
+
+/*
  * depthwise image for the MFMA kernel (q8dwconv.hip, kernel D): the signed tap weights
  *     x[t][c] = w[c][t] - kzp   in [-255, 255]
  * do not fit int8, so they are split into up to three int8 parts x = x0 + x1 + x2

@@ -289,6 +289,57 @@ def test_depthwise_dot4_register_image(debug_hooks, izp, kzp, lo, hi, expect):
     assert np.array_equal(lhs, rhs)
 
 
+@pytest.mark.parametrize("izp,kzp,lo,hi,expect", [
+    (127, 127, 0, 255, 2), (3, 128, 0, 255, 1), (255, 100, 40, 200, 1), (0, 1, 0, 129, 2), (9, 1, 0, 130, 0),
+    (200, 77, 77, 77, 1)])
+def test_depthwise_dot4_5x5_register_image(debug_hooks, izp, kzp, lo, hi, expect):
+    """qnnp_pack_dwconv_dot4_5x5 (pack.h), the register image of the 5x5 column walk (q8dwconv.hip, kernel H): replay
+    the walk's arithmetic for one output -- five quads (columns 0..3 of a kernel row), the sliding column-4 dword of kernel
+    rows 0..3, the one-hot weight against the newest row's raw column-4 dword (whose other three bytes are OTHER
+    channels' activations) -- and compare with bias + sum_t (a_t - izp) * (w_t - kzp)."""
+    import ctypes
+    L = debug_hooks.lib
+    fn = L.qnnp_debug_pack_dwconv_dot4_5x5
+    fn.restype = ctypes.c_uint32
+    fn.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint8, ctypes.c_uint8] + [ctypes.c_void_p] * 5
+    rng = np.random.default_rng(izp * 256 + kzp + hi + 5)
+    C, c_pad = 24, 32
+    kernel = rng.integers(lo, hi + 1, size=(C, 25)).astype(np.uint8)
+    kernel[0, 0], kernel[C - 1, 24] = lo, hi
+    bias = rng.integers(-2**31, 2**31, size=C).astype(np.int32)
+    wadj = np.empty(25 * c_pad, np.int16); bias1 = np.empty(c_pad, np.int32)
+    image = np.full(8 * c_pad, 0x5A5A5A5A, np.uint32)
+    got = fn(C, c_pad, izp, kzp, kernel.ctypes.data, bias.ctypes.data, wadj.ctypes.data, bias1.ctypes.data, image.ctypes.data)
+    assert got == expect
+    if expect == 0:
+        assert (image == 0x5A5A5A5A).all()
+        return
+    image = image.reshape(8, c_pad)
+    assert not image[:7, C:].any(), "padding channels multiply to zero"
+    w8 = image[:7].view(np.int8).reshape(7, c_pad, 4).astype(np.int64)
+    sign = 1 if expect == 1 else -1
+    x = (kernel.astype(np.int64) - kzp).reshape(C, 5, 5)
+    assert np.array_equal(w8[:5, :C].transpose(1, 0, 2), sign * x[:, :, :4])               # quads
+    assert np.array_equal(w8[5, :C], sign * x[:, :4, 4])                                    # column 4, kernel rows 0..3
+    for c in range(C):
+        onehot = np.zeros(4, np.int64); onehot[c & 3] = sign * x[c, 4, 4]
+        assert np.array_equal(w8[6, c], onehot)
+    # the walk on random activations: a[ky][kx][channel]
+    a = rng.integers(0, 256, size=(5, 5, C), dtype=np.uint8)
+    a[0, 0], a[4, 4] = 0, 255
+    kx = 0x80 if expect == 1 else 0x7F
+    a8 = (a ^ kx).view(np.int8).astype(np.int64)
+    acc = image[7, :C].astype(np.int64).copy()
+    for c in range(C):
+        for ky in range(5):
+            acc[c] += (a8[ky, :4, c] * w8[ky, c]).sum()                                    # T[ky].q[c] . WQ[ky][c]
+        acc[c] += (a8[:4, 4, c] * w8[5, c]).sum()                                          # V[c] . WV[c]
+        group = (c // 4) * 4
+        acc[c] += (a8[4, 4, group:group + 4] * w8[6, c]).sum()                             # raw column-4 dword . W5[c]
+    rhs = (bias.astype(np.int64) + ((a.astype(np.int64) - izp).transpose(2, 0, 1) * x).sum(axis=(1, 2))) & 0xFFFFFFFF
+    assert np.array_equal(acc & 0xFFFFFFFF, rhs)
+
+
 @pytest.mark.parametrize("kzp", [127, 128, 100])
 @pytest.mark.parametrize("shape", [((6, 7), 8, (1, 1, 1, 1)), ((5, 5), 20, (0, 0, 0, 0)), ((4, 9), 12, (2, 1, 0, 2))],
                          ids=["6x7c8", "5x5c20_nopad", "4x9c12_asym"])
