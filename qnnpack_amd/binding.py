@@ -12,6 +12,7 @@ anything with a ``data_ptr()`` method (e.g. a torch tensor on the bound GPU).
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32, c_void_p
 from enum import IntEnum
 from typing import Optional
@@ -317,10 +318,13 @@ class Gfx950Library(QnnpackLibrary):
         L.qnnp_gfx950_create_fused_block.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]
         L.qnnp_gfx950_setup_fused_block.restype = c_int
         L.qnnp_gfx950_setup_fused_block.argtypes = [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t]
-        L.qnnp_gfx950_attach_residual_add.restype = c_int
-        L.qnnp_gfx950_attach_residual_add.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
-        L.qnnp_gfx950_operator_residual_folded.restype = c_int
-        L.qnnp_gfx950_operator_residual_folded.argtypes = [c_void_p]
+        # (QNNP_GFX950_LIBRARY may point at an OLDER build for a same-box A/B: entry points younger than it are then
+        #  simply not bound; the product library must have them all -- tests/test_abi.py)
+        if hasattr(L, "qnnp_gfx950_attach_residual_add") or not os.environ.get("QNNP_GFX950_LIBRARY"):
+            L.qnnp_gfx950_attach_residual_add.restype = c_int
+            L.qnnp_gfx950_attach_residual_add.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
+            L.qnnp_gfx950_operator_residual_folded.restype = c_int
+            L.qnnp_gfx950_operator_residual_folded.argtypes = [c_void_p]
         L.qnnp_gfx950_set_option.restype = c_int
         L.qnnp_gfx950_set_option.argtypes = [c_char_p, c_int]
         L.qnnp_gfx950_operator_kernel.restype = c_char_p

@@ -70,12 +70,13 @@ struct IgemmParams {
   // input pixel (img, iy, ix); its channel block nb belongs to phase nb / d2s_nbpp = (py, px) and is stored at output
   // pixel (img, iy*d2s_sh + py, ix*d2s_sw + px), channels (nb % d2s_nbpp)*32.. of p.n. d2s_sh == 0: off.
   uint32_t d2s_sh, d2s_sw, d2s_in_h, d2s_in_w, d2s_nbpp;
-  // fused residual add (pointwise streaming kernels only): the requantized bytes of pixel m are summed, as operand b of
-  // qnnp_add_quantize, with the bytes at residual + m*residual_stride (operand a) before they are stored. NULL: off.
+  RequantDev rq;
+  // fused residual add (pointwise streaming kernels only, their RES flavours): the requantized bytes of pixel m are
+  // summed, as operand b of qnnp_add_quantize, with the bytes at residual + m*residual_stride (operand a) before they
+  // are stored. NULL: off. (Behind everything else: the kernels that never look at it keep their argument offsets.)
   const uint8_t* residual;
   uint32_t residual_stride;
   qnnp_hip_add_params add;
-  RequantDev rq;
 };
 
 /* convolution geometry for the LDS-tiled direct-convolution kernel */

@@ -50,7 +50,10 @@ constexpr uint32_t kMaxLds = 64 * 1024;     // weights + bias: two workgroups pe
  * only 8-byte aligned, e.g. 24 channels) */
 /* D2S: depth-to-space stores (igemm_params.h) -- a deconvolution whose kernel equals its stride is this pointwise
  * GEMM with stride_h*stride_w times the channels, each phase's block landing on its own output pixel. */
-template <int KB, int VEC, bool D2S = false>
+/* RES: the residual add of igemm_params.h rides in the epilogue -- a kernel of its own, so that layers without one
+ * run exactly the code they ran before it existed (as a wave-uniform run-time branch it cost them 2-6 %, same box:
+ * 28x28x144 -> 32 6.7 -> 7.1 us, 56x56x144 -> 24 15.8 -> 16.4) */
+template <int KB, int VEC, bool D2S = false, bool RES = false>
 __global__ __launch_bounds__(kThreads, (KB <= 5) ? 4 : 2)
 void q8_pw_stream_mfma_kernel(const IgemmParams p)
 {
@@ -218,7 +221,7 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
               acc, bias4, rowterm, phase_row, (nb - phase * p.d2s_nbpp) * 32, khalf, row_ok, p);
           continue;
         }
-        if (p.residual != nullptr) {                      // (wave-uniform) project layer with its residual add folded in
+        if constexpr (RES) {                              // project layer with its residual add folded in
           const uint8_t* res_row = p.residual + static_cast<uint64_t>(row_ok ? m : 0u) * p.residual_stride;
           igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 2, true>(
               acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p, res_row, &p.add);
@@ -235,12 +238,13 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
  * is one contiguous run, 1 KiB per store instruction. Otherwise row chunks: the image has 2^log_cpr 16-byte pieces
  * per row (pitch 16 << log_cpr), of which the first cw bytes exist; consecutive lanes take consecutive pieces of a
  * row. c0 = first channel of the chunk. */
+template <bool RES = false>
 __device__ __forceinline__ void stream_copy_out(
     const uint8_t* stage, bool whole_dense, uint32_t log_cpr, uint32_t unit, uint32_t c0, uint32_t cw,
     const IgemmParams& p, uint32_t lane)
 {
   const uint32_t rows_here = min(32u, p.rows - unit * 32u);
-  if (p.residual != nullptr) {
+  if constexpr (RES) {
     // fused residual add: the same walk, each 16-byte piece summed with the residual's bytes of the same pixel and
     // channels (launcher: residual rows are laid out like the output rows, 16-byte aligned)
     const uint64_t block_ofs = static_cast<uint64_t>(unit) * 32u * p.output_stride + c0;
@@ -321,7 +325,7 @@ constexpr int staged_waves(int kb) { return kb <= 1 ? 7 : (kb == 2 ? 6 : (kb <= 
 
 /* SEQ / FULL: the requantization flavour (requant.hip.h), chosen on the host -- one kernel per flavour, so that the
  * common ones are not charged the registers of the rare ones */
-template <int KB, int VEC, int SEQ, bool FULL>
+template <int KB, int VEC, int SEQ, bool FULL, bool RES = false>
 __global__ __launch_bounds__(kThreads, staged_waves(KB))
 void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const uint32_t log_cpr)
 {
@@ -467,7 +471,7 @@ void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const u
 #ifdef QNNP_ENABLE_ABLATION
       if (p.izp_fill & 1u) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); if (next >= units) break; unit = next; continue; }
 #endif
-      stream_copy_out(stage, whole_dense, log_cpr, unit, c0, cw, p, lane);
+      stream_copy_out<RES>(stage, whole_dense, log_cpr, unit, c0, cw, p, lane);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // read back before the next unit overwrites it
       if (next >= units) break;
       unit = next;
@@ -486,7 +490,7 @@ void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const u
 constexpr uint32_t kMaxLdsLongK = 96 * 1024;
 constexpr int longk_waves(int kbmax) { return kbmax <= 12 ? 4 : (kbmax <= 20 ? 3 : 2); }
 
-template <int KBMAX, int SEQ, bool FULL>
+template <int KBMAX, int SEQ, bool FULL, bool RES = false>
 __global__ __launch_bounds__(kThreads, longk_waves(KBMAX))
 void q8_pw_stream_longk_kernel(const IgemmParams p, const uint32_t nbp, const uint32_t log_cpr)
 {
@@ -601,7 +605,7 @@ void q8_pw_stream_longk_kernel(const IgemmParams p, const uint32_t nbp, const ui
       igemm_stage_tile<SEQ, FULL, false, 2>(acc, bias4, rowterm, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < cw);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
-    stream_copy_out(stage, whole_dense, log_cpr, unit, c0, cw, p, lane);
+    stream_copy_out<RES>(stage, whole_dense, log_cpr, unit, c0, cw, p, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // read back before the next unit overwrites it
     const uint32_t next = unit + unit_stride;
     if (next >= units) break;
@@ -620,6 +624,7 @@ void q8_pw_stream_longk_kernel(const IgemmParams p, const uint32_t nbp, const ui
  */
 constexpr int kGwUnroll = 4;
 
+template <bool RES>
 __global__ __launch_bounds__(kThreads, 4)
 void q8_pw_stream_gw_kernel(const IgemmParams p)
 {
@@ -701,7 +706,7 @@ void q8_pw_stream_gw_kernel(const IgemmParams p)
   const int32_t rowterm = p.row_coeff * static_cast<int32_t>(rs - 128u * p.k_total);
   uint8_t* out_row = p.output + static_cast<uint64_t>(rb * 32u + row_in_block) * p.output_stride;
   requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
-    if (p.residual != nullptr) {
+    if constexpr (RES) {
       const uint8_t* res_row = p.residual + static_cast<uint64_t>(row_ok ? rb * 32u + row_in_block : 0u) * p.residual_stride;
       igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 0, true>(
           acc, bias4, with_rq_offset<decltype(shift0)::value>(rowterm), out_row, nb * 32, khalf, row_ok, p, res_row, &p.add);
@@ -721,7 +726,7 @@ void q8_pw_stream_gw_kernel(const IgemmParams p)
  * 0's through LDS (12 KiB), and wave 0 requantizes and stores. int32 partial sums are exact, so the split is
  * bit-invisible.
  */
-template <int kGwkDepth>       // K blocks a wave has in flight: 4 or 8
+template <int kGwkDepth, bool RES>       // K blocks a wave has in flight: 4 or 8
 __global__ __launch_bounds__(kThreads, 4)
 void q8_pw_stream_gwk_kernel(const IgemmParams p)
 {
@@ -802,7 +807,7 @@ void q8_pw_stream_gwk_kernel(const IgemmParams p)
   uint8_t* out_row = p.output + static_cast<uint64_t>(rb * 32u + row_in_block) * p.output_stride;
   requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
     const int32_t rowterm = with_rq_offset<decltype(shift0)::value>(p.row_coeff * rsc);
-    if (p.residual != nullptr) {
+    if constexpr (RES) {
       const uint8_t* res_row = p.residual + static_cast<uint64_t>(row_ok ? rb * 32u + row_in_block : 0u) * p.residual_stride;
       igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 0, true>(
           acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p, res_row, &p.add);
@@ -1155,10 +1160,13 @@ void q8_conv_stream_c3s_kernel(const IgemmParams p, const uint32_t log_cpr)
   }
 }
 
-template <int KB, int VEC, bool D2S = false>
+template <int KB, int VEC, bool D2S = false, bool RES = false>
 int launch_pw(const IgemmParams& p, uint32_t lds_bytes, hipStream_t stream)
 {
-  auto kernel = q8_pw_stream_mfma_kernel<KB, VEC, D2S>;
+  if constexpr (!RES && !D2S) {
+    if (p.residual != nullptr) return launch_pw<KB, VEC, false, true>(p, lds_bytes, stream);
+  }
+  auto kernel = q8_pw_stream_mfma_kernel<KB, VEC, D2S, RES>;
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
   if (auto once_scope = attr_once.begin()) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
@@ -1260,10 +1268,13 @@ bool plan_staged(const IgemmParams& p, uint32_t kb, StagedPlan* plan)
   return true;
 }
 
-template <int KB, int VEC, int SEQ, bool FULL>
+template <int KB, int VEC, int SEQ, bool FULL, bool RES = false>
 int launch_pw_staged_as(const IgemmParams& p, const StagedPlan& plan, hipStream_t stream)
 {
-  auto kernel = q8_pw_stream_staged_kernel<KB, VEC, SEQ, FULL>;
+  if constexpr (!RES && VEC == 16) {               // (a residual implies 16-byte aligned rows: q8igemm.hip)
+    if (p.residual != nullptr) return launch_pw_staged_as<KB, VEC, SEQ, FULL, true>(p, plan, stream);
+  }
+  auto kernel = q8_pw_stream_staged_kernel<KB, VEC, SEQ, FULL, RES>;
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
   if (auto once_scope = attr_once.begin()) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
@@ -1363,10 +1374,13 @@ bool plan_longk(const IgemmParams& p, StagedPlan* plan, int* kbmax)
   return true;
 }
 
-template <int KBMAX, int SEQ, bool FULL>
+template <int KBMAX, int SEQ, bool FULL, bool RES = false>
 int launch_longk_as(const IgemmParams& p, const StagedPlan& plan, hipStream_t stream)
 {
-  auto kernel = q8_pw_stream_longk_kernel<KBMAX, SEQ, FULL>;
+  if constexpr (!RES) {
+    if (p.residual != nullptr) return launch_longk_as<KBMAX, SEQ, FULL, true>(p, plan, stream);
+  }
+  auto kernel = q8_pw_stream_longk_kernel<KBMAX, SEQ, FULL, RES>;
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
   if (auto once_scope = attr_once.begin()) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsLongK);
@@ -1523,15 +1537,22 @@ int pwstream_gw_launch(const IgemmParams& p, hipStream_t stream, const char** na
   if (split_k) {
     *name = "q8_pw_stream_gwk_mfma";
     const uint32_t per_wave = ((p.k_total + 31u) / 32u + kWaves - 1) / kWaves;
+    const bool res = p.residual != nullptr;
     if (per_wave <= 4) {
-      hipLaunchKernelGGL(q8_pw_stream_gwk_kernel<4>, dim3(units), dim3(kThreads), 0, stream, p);
+      if (res) hipLaunchKernelGGL((q8_pw_stream_gwk_kernel<4, true>), dim3(units), dim3(kThreads), 0, stream, p);
+      else hipLaunchKernelGGL((q8_pw_stream_gwk_kernel<4, false>), dim3(units), dim3(kThreads), 0, stream, p);
     } else {
-      hipLaunchKernelGGL(q8_pw_stream_gwk_kernel<8>, dim3(units), dim3(kThreads), 0, stream, p);
+      if (res) hipLaunchKernelGGL((q8_pw_stream_gwk_kernel<8, true>), dim3(units), dim3(kThreads), 0, stream, p);
+      else hipLaunchKernelGGL((q8_pw_stream_gwk_kernel<8, false>), dim3(units), dim3(kThreads), 0, stream, p);
     }
     return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
   }
   *name = "q8_pw_stream_gw_mfma";
-  hipLaunchKernelGGL(q8_pw_stream_gw_kernel, dim3((units + kWaves - 1) / kWaves), dim3(kThreads), 0, stream, p);
+  if (p.residual != nullptr) {
+    hipLaunchKernelGGL(q8_pw_stream_gw_kernel<true>, dim3((units + kWaves - 1) / kWaves), dim3(kThreads), 0, stream, p);
+  } else {
+    hipLaunchKernelGGL(q8_pw_stream_gw_kernel<false>, dim3((units + kWaves - 1) / kWaves), dim3(kThreads), 0, stream, p);
+  }
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
