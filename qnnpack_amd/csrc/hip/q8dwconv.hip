@@ -553,6 +553,10 @@ __device__ __forceinline__ void dwconv_col3x3_body(
     const DwParams& p, const uint32_t n, const uint32_t oy0, const uint32_t oy1, const uint32_t ox, const uint32_t cg,
     const bool ok0, const bool ok1, const bool ok2)
 {
+  // kLate: the walks of the default path (int8 dot-product walk at stride 1, pair walk at stride 2) replace padding
+  // where a row is CONSUMED, not where it is requested; the int16 pair walks at stride 1 (weights outside the int8
+  // classes) keep the round-2 scheme
+  constexpr bool kLate = QUAD || S == 2;
   // tap weights: W01[r] = (w_r0, w_r1) pairs, WQA = (0, w_02), WQB = (w_12, w_22); per channel of the group
   uint32_t w01[3][4], wqa[4], wqb[4];
   // QUAD flavour: W4[r] = (x_r0, x_r1, x_r2, 0) as int8, x = +-(w - kzp) (see the step below)
@@ -595,6 +599,30 @@ __device__ __forceinline__ void dwconv_col3x3_body(
       // the offset rounding sequences (requant.hip.h) take accumulator + 2^31: folded into the bias, once per thread
       bias[c] = qnnp::with_rq_offset<SEQ>(bias[c]);
     }
+    if constexpr (kLate && FIX) {
+      // Padding COLUMNS of this lane are never loaded (out-of-range offsets: the buffer returns 0) and never selected:
+      // reading 0 where the input zero point belongs is a per-lane constant -- izp * (the column's weights) -- that goes
+      // into the bias here, once, instead of three v_cndmask per step on registers just requested (which made every step
+      // of a border wave wait for its newest row: s_waitcnt vmcnt(3) / vmcnt(0) in the loop, ISA of the round-2 build).
+      const bool okc[3] = {ok0, ok1, ok2};
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        int32_t sum = 0;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            int32_t x;
+            if constexpr (QUAD) x = static_cast<int8_t>(w4[r][c] >> (8 * k));            // +-(w - kzp), as multiplied
+            else x = static_cast<int16_t>(lo16(tw[r * 3 + k], c));                       // w - kzp
+            sum += okc[k] ? 0 : x;
+          }
+        }
+        // QUAD multiplies a' = a ^ kx: a' (izp) - a'(0) = izp (kx = 0x80) or -izp (0x7f); the pair walks multiply a itself
+        const int32_t step = (QUAD && p.wrange == 2u) ? -static_cast<int32_t>(p.izp) : static_cast<int32_t>(p.izp);
+        bias[c] = qnnp::add_wrap(bias[c], step * sum);
+      }
+    }
   };
   // (the pair walks unpack at once: with the raw taps live across the first row requests they need 93-98 VGPRs
   //  instead of 79-82, a wave per SIMD less, and the stride-2 layers measured no better for the overlap)
@@ -619,10 +647,18 @@ __device__ __forceinline__ void dwconv_col3x3_body(
   coff[0] = cg + (ok0 ? static_cast<uint32_t>(ix0) : 0u) * p.in_stride;
   coff[1] = cg + (ok1 ? static_cast<uint32_t>(ix0 + 1) : 0u) * p.in_stride;
   coff[2] = cg + (ok2 ? static_cast<uint32_t>(ix0 + 2) : 0u) * p.in_stride;
+  // what a padding ROW reads at this lane's columns: the input zero point -- or 0 at a padding column of a kLate walk
+  uint32_t fillk[3] = {fill, fill, fill};
+  if constexpr (kLate && FIX) {
+    // (beyond the descriptor's extent -- plan_col keeps the tensor below 2^31 bytes: the load returns 0)
+    if (!ok0) { coff[0] = 0x80000000u; fillk[0] = 0u; }
+    if (!ok1) { coff[1] = 0x80000000u; fillk[1] = 0u; }
+    if (!ok2) { coff[2] = 0x80000000u; fillk[2] = 0u; }
+  }
   const uint32_t img_off = n * p.H * row_bytes;                     // wave-uniform
   const int32_t iy_first = static_cast<int32_t>(oy0 * S) - static_cast<int32_t>(p.pad_top);
 
-  struct Row { uint32_t c[3]; };
+  struct Row { uint32_t c[3]; bool ok; };
   // One input row: three dwords. The loads are ALWAYS issued (a row outside the image is clamped to a valid one and
   // its values replaced afterwards, wave-uniformly): a branch around the loads makes the number of outstanding
   // operations path-dependent, and hipcc then falls back to s_waitcnt vmcnt(<3) right behind the newest loads --
@@ -636,21 +672,34 @@ __device__ __forceinline__ void dwconv_col3x3_body(
       row_ok = iy >= 0 && iy < static_cast<int32_t>(p.H);
       iy = iy < 0 ? 0 : (iy >= static_cast<int32_t>(p.H) ? static_cast<int32_t>(p.H) - 1 : iy);
     }
+    r.ok = row_ok;
     const uint32_t ro = img_off + static_cast<uint32_t>(iy) * row_adv;        // scalar
     r.c[0] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[0], ro, 0);
     r.c[1] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[1], ro, 0);
     r.c[2] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[2], ro, 0);
-    if constexpr (FIX) {
-      r.c[0] = ok0 ? r.c[0] : fill;
-      r.c[1] = ok1 ? r.c[1] : fill;
-      r.c[2] = ok2 ? r.c[2] : fill;
-    }
-    if constexpr (CHECK) {
-      r.c[0] = row_ok ? r.c[0] : fill;
-      r.c[1] = row_ok ? r.c[1] : fill;
-      r.c[2] = row_ok ? r.c[2] : fill;
+    if constexpr (!kLate) {
+      // (a select on a register just requested is a wait for it: the kLate walks do this in settle(), at the use)
+      if constexpr (FIX) {
+        r.c[0] = ok0 ? r.c[0] : fill;
+        r.c[1] = ok1 ? r.c[1] : fill;
+        r.c[2] = ok2 ? r.c[2] : fill;
+      }
+      if constexpr (CHECK) {
+        r.c[0] = row_ok ? r.c[0] : fill;
+        r.c[1] = row_ok ? r.c[1] : fill;
+        r.c[2] = row_ok ? r.c[2] : fill;
+      }
     }
     return r;
+  };
+  // kLate walks: a padding ROW becomes the zero point where it is consumed (CHECK = false: the caller knows the row is
+  // inside the image -- the steady-state steps, whose rows lie between the first trip's and the ones they request)
+  auto settle = [&](auto check, Row& r) __attribute__((always_inline)) {
+    if constexpr (kLate && decltype(check)::value) {
+      r.c[0] = r.ok ? r.c[0] : fillk[0];
+      r.c[1] = r.ok ? r.c[1] : fillk[1];
+      r.c[2] = r.ok ? r.c[2] : fillk[2];
+    }
   };
   constexpr std::true_type kChecked{};
   constexpr std::false_type kInside{};
@@ -742,8 +791,10 @@ __device__ __forceinline__ void dwconv_col3x3_body(
         r5 = load_row(kChecked, iy_first + 5);
       }
       unpack_weights();
+      settle(kChecked, r0);
       Quad q0 = quad(r0);
       r0 = load_row(kChecked, iy_first + NBUF);
+      settle(kChecked, r1);
       Quad q1 = quad(r1);
       r1 = load_row(kChecked, iy_first + NBUF + 1);
       Quad q2;
@@ -754,6 +805,7 @@ __device__ __forceinline__ void dwconv_col3x3_body(
       const uint32_t t_inside = inside <= 0 ? 0u : (static_cast<uint32_t>(inside) < steps ? static_cast<uint32_t>(inside) : steps);
 #define QNNP_DW_COL_STEPQ(CHECK, TA, TB, TC, RC)                                      \
       {                                                                             \
+        settle(CHECK, RC);                                                          \
         TC = quad(RC);                                      /* T[t+2] */            \
         RC = load_row(CHECK, iy_first + static_cast<int32_t>(t) + 2 + NBUF);        \
         __builtin_amdgcn_sched_barrier(0);                                          \
@@ -764,6 +816,8 @@ __device__ __forceinline__ void dwconv_col3x3_body(
         finish(acc);                                                                \
         t++;                                                                        \
       }
+      // (a steady-state step consumes row iy_first + t + 2 >= 0 -- plan_col: pad_top <= 2, the rows above the image
+      //  were settled above -- and requests a row inside the image: what it consumes lies between the two)
       if constexpr (DEEP) {
         while (t + 6 <= t_inside) {                // steady state: straight-line body, counted waits
           QNNP_DW_COL_STEPQ(kInside, q0, q1, q2, r2)
@@ -923,17 +977,22 @@ __device__ __forceinline__ void dwconv_col3x3_body(
       const int32_t inside = (static_cast<int32_t>(p.H) - 5 - iy_first) / 2;
       const uint32_t t_inside = (static_cast<int32_t>(p.H) - 5 - iy_first) <= 0 ? 0u :
           (static_cast<uint32_t>(inside) < steps ? static_cast<uint32_t>(inside) : steps);
-      Pair ha = pair(r0.c[0], r0.c[1]);
-      Pair qa = pair(r0.c[2], r0.c[2]);
+      Row r0s = r0;
+      settle(kChecked, r0s);
+      Pair ha = pair(r0s.c[0], r0s.c[1]);
+      Pair qa = pair(r0s.c[2], r0s.c[2]);
       Pair hb, qb;
       uint32_t t = 0;
 #define QNNP_DW_COL_STEP2(CHECK, HA, HC, QA, QC, RA, RB)                            \
       {                                                                             \
+        settle(CHECK, RA);                                                          \
+        settle(CHECK, RB);                                                          \
         const Pair hmid = pair(RA.c[0], RA.c[1]);           /* H[2t+1] */           \
         HC = pair(RB.c[0], RB.c[1]);                        /* H[2t+2] = H[2(t+1)] */ \
         QC = pair(RA.c[2], RB.c[2]);                        /* (col2 @ 2t+1, col2 @ 2t+2) */ \
         RA = load_row(CHECK, iy_first + 2 * static_cast<int32_t>(t) + 5);           \
         RB = load_row(CHECK, iy_first + 2 * static_cast<int32_t>(t) + 6);           \
+        __builtin_amdgcn_sched_barrier(0);   /* (left alone the scheduler sinks the loads to the end of the trip) */ \
         int32_t acc[4];                                                             \
         dot_first(HA, w01[0], bias, acc);                                           \
         dot(hmid, w01[1], acc);                                                     \
@@ -943,9 +1002,20 @@ __device__ __forceinline__ void dwconv_col3x3_body(
         finish(acc);                                                                \
         t++;                                                                        \
       }
-      while (t + 2 <= t_inside) {
-        QNNP_DW_COL_STEP2(kInside, ha, hb, qa, qb, a1, a2)
-        QNNP_DW_COL_STEP2(kInside, hb, ha, qb, qa, c1, c2)
+      if (iy_first + 1 < 0) {                      // padding 2: row 1 of the walk is above the image -- one checked trip
+        QNNP_DW_COL_STEP2(kChecked, ha, hb, qa, qb, a1, a2)
+        if (t >= steps) return;
+        QNNP_DW_COL_STEP2(kChecked, hb, ha, qb, qa, c1, c2)
+      }
+      if (t + 2 <= t_inside) {
+        // (hipcc sizes the waits at a loop header for the fewest operations in flight over all ways in; entered from the
+        //  checked first trip that came out as vmcnt(1) on every trip. With the queue drained once on the way in, the back
+        //  edge alone decides)
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+        do {
+          QNNP_DW_COL_STEP2(kInside, ha, hb, qa, qb, a1, a2)
+          QNNP_DW_COL_STEP2(kInside, hb, ha, qb, qa, c1, c2)
+        } while (t + 2 <= t_inside);
       }
       while (t < steps) {
         QNNP_DW_COL_STEP2(kChecked, ha, hb, qa, qb, a1, a2)
