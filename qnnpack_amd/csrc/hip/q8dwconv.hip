@@ -668,7 +668,9 @@ __device__ __forceinline__ void dwconv_col3x3_body(
     constexpr bool CHECK = decltype(check)::value;
     Row r;
     bool row_ok = true;
-    if constexpr (CHECK) {
+    // (kLate walks: always -- the clamp is scalar work, and a steady-state step may request a row below the image for the
+    //  checked steps behind it; what makes a step "steady" there is that the row it CONSUMES is inside)
+    if constexpr (CHECK || kLate) {
       row_ok = iy >= 0 && iy < static_cast<int32_t>(p.H);
       iy = iy < 0 ? 0 : (iy >= static_cast<int32_t>(p.H) ? static_cast<int32_t>(p.H) - 1 : iy);
     }
@@ -800,8 +802,8 @@ __device__ __forceinline__ void dwconv_col3x3_body(
       Quad q2;
       uint32_t t = 0;
       QNNP_DW_TRACE(p, 2);
-      // steps whose prefetched row (iy_first + t + 2 + NBUF) is inside the image: t < t_inside
-      const int32_t inside = static_cast<int32_t>(p.H) - (2 + NBUF) - iy_first;
+      // steps whose newest window row (iy_first + t + 2) is inside the image: t < t_inside
+      const int32_t inside = static_cast<int32_t>(p.H) - 2 - iy_first;
       const uint32_t t_inside = inside <= 0 ? 0u : (static_cast<uint32_t>(inside) < steps ? static_cast<uint32_t>(inside) : steps);
 #define QNNP_DW_COL_STEPQ(CHECK, TA, TB, TC, RC)                                      \
       {                                                                             \
@@ -973,9 +975,9 @@ __device__ __forceinline__ void dwconv_col3x3_body(
       Row a2 = load_row(kChecked, iy_first + 2);
       Row c1 = load_row(kChecked, iy_first + 3);
       Row c2 = load_row(kChecked, iy_first + 4);
-      // steps whose prefetched rows (iy_first + 2t + 5, + 6) are inside the image: t < t_inside
-      const int32_t inside = (static_cast<int32_t>(p.H) - 5 - iy_first) / 2;
-      const uint32_t t_inside = (static_cast<int32_t>(p.H) - 5 - iy_first) <= 0 ? 0u :
+      // steps whose window rows (iy_first + 2t + 1, + 2) are inside the image: t < t_inside
+      const int32_t inside = (static_cast<int32_t>(p.H) - 1 - iy_first) / 2;
+      const uint32_t t_inside = (static_cast<int32_t>(p.H) - 1 - iy_first) <= 0 ? 0u :
           (static_cast<uint32_t>(inside) < steps ? static_cast<uint32_t>(inside) : steps);
       Row r0s = r0;
       settle(kChecked, r0s);
