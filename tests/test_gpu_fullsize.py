@@ -226,3 +226,62 @@ def test_c2_q8gemm_4096_cubed_full_output_vs_compiled_reference(qnnp):
         want = o1.requantize_rows(acc, np.float32(0.75), 127, 1, 254)
         o1.set_threads(1)
         assert_bytes_equal(got[rows].reshape(-1), want.reshape(-1), "4096^3 every 8th row vs oracle (no prebuilt reference here)")
+
+
+@pytest.mark.parametrize("h,c,s", [(56, 72, 2), (28, 240, 1), (14, 672, 1)], ids=lambda v: str(v))
+def test_next_row_depthwise_5x5_bench_shapes_batch128(qnnp, h, c, s):
+    """bench.py's MobileNetV3-style 5x5 depthwise rows (extra.q8dwconv_5x5_...) at the benched batch, whole output
+    against the oracle, with accumulator-derived quantization so that the bytes span their range."""
+    batch = 128
+    case = ConvCase(f"dw5_{h}_{c}_s{s}", (h, h), (5, 5), (2, 2, 2, 2), subsampling=(s, s), groups=c, gic=1, goc=1, batch=batch)
+    inp, kernel, bias = conv_tensors(case)
+    o1.set_threads(16)
+    try:
+        shape = o1.conv_shape(batch, h, h, case.padding, (5, 5), (s, s), (1, 1), c, 1, 1, c)
+        acc = o1.conv2d_acc(shape, inp, kernel, bias, case.izp, case.kzp)
+        oscale, ozp = output_quantization(acc)
+        expected = o1.requantize_rows(acc.reshape(-1, c), np.float32(1.0) / oscale, ozp, 0, 255).reshape(-1)
+    finally:
+        o1.set_threads(1)
+    assert np.count_nonzero((expected == 0) | (expected == 255)) < 0.1 * expected.size
+    op = qnnp.create_convolution2d_nhwc_q8(2, 2, 2, 2, 5, 5, s, s, 1, 1, c, 1, 1, case.izp, 1.0, case.kzp, 1.0, kernel, bias,
+                                           ozp, float(oscale), 0, 255, 0)
+    try:
+        d_in, d_out = to_device(inp), to_device(np.full(expected.size, FILL, np.uint8))
+        qnnp.setup_convolution2d_nhwc_q8(op, batch, h, h, d_in, c, d_out, c)
+        qnnp.run_operator(op)
+        assert qnnp.operator_kernel(op) == "q8_dwconv_col_5x5_dot4"
+        assert_bytes_equal(from_device(d_out), expected, f"kernel H, {h}x{h}x{c} stride {s}, batch 128")
+    finally:
+        qnnp.delete_operator(op)
+
+
+def test_next_row_deconvolution_3x3_s2_bench_shape_batch128(qnnp):
+    """bench.py's next_rows.q8deconv_3x3s2_28x28x64_32 at the benched batch: 28x28x64 -> 56x56x32, 3x3, stride 2, padding 1,
+    adjustment 1 -- whole output against the oracle."""
+    batch, H, cin, cout = 128, 28, 64, 32
+    rng = np.random.default_rng(0xDEC0)
+    inp = rng.integers(0, 256, size=batch * H * H * cin, dtype=np.uint8)
+    kernel = rng.integers(0, 256, size=(1, cin, 3, 3, cout), dtype=np.uint8)
+    bias = rng.integers(-10000, 10001, size=cout, dtype=np.int32)
+    izp, kzp = 127, 127
+    o1.set_threads(16)
+    try:
+        shape = o1.conv_shape(batch, H, H, (1, 1, 1, 1), (3, 3), (2, 2), (1, 1), 1, cin, cout)
+        acc = o1.deconv2d_acc(shape, (1, 1), inp, kernel, bias, izp, kzp)
+        oscale, ozp = output_quantization(acc)
+        expected = o1.requantize_rows(acc.reshape(-1, cout), np.float32(1.0) / oscale, ozp, 0, 255).reshape(-1)
+        oh, ow = o1.deconv_output_hw(shape, (1, 1))
+    finally:
+        o1.set_threads(1)
+    assert (oh, ow) == (56, 56)
+    op = qnnp.create_deconvolution2d_nhwc_q8(1, 1, 1, 1, 1, 1, 3, 3, 2, 2, 1, 1, 1, cin, cout, izp, 1.0, kzp, 1.0, kernel, bias,
+                                             ozp, float(oscale), 0, 255, 0)
+    try:
+        d_in, d_out = to_device(inp), to_device(np.full(expected.size, FILL, np.uint8))
+        qnnp.setup_deconvolution2d_nhwc_q8(op, batch, H, H, d_in, cin, d_out, cout)
+        qnnp.run_operator(op)
+        assert qnnp.operator_kernel(op) == "q8_deconv_s2_stream_3x3"
+        assert_bytes_equal(from_device(d_out), expected, "stride-2 deconvolution, bench shape, batch 128")
+    finally:
+        qnnp.delete_operator(op)
