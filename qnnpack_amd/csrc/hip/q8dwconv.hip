@@ -1495,11 +1495,15 @@ bool plan_col5(DwParams& p)
   if (in_bytes >= (UINT64_C(1) << 31) || out_bytes >= (UINT64_C(1) << 32)) return false;
   const uint32_t cols = p.OW * (p.C / 4);
   const uint32_t chunks = (cols + 63u) / 64u;
-  // row segments: each re-loads its four halo rows and transposes them again; ~one round of four waves per SIMD
+  // Row segments. A wave's start-up (weights, ten row requests, four transposes, two memory round trips) is worth about
+  // as much as fourteen steps, so segments stay LONG -- 28 output rows or the whole image -- and there are only as many
+  // as bring the launch to about six waves per SIMD. Measured with the waits of the walk fixed (batch 128, us per launch,
+  // segments of 7 / 14 / 28 / 56 / 112 rows): 56x56x72 s2 17.2 / 15.2 / 14.6; 28x28x240 - / 25.1 / 23.0; 112x112x32
+  // - / 41.9 / 35.8 / 36.5 / 42.4.
   const uint64_t waves_per_seg = static_cast<uint64_t>(p.batch) * chunks;
-  const uint64_t slots = static_cast<uint64_t>(p.cu_count) * 4u * 4u;
-  uint32_t segs = static_cast<uint32_t>((slots + waves_per_seg - 1) / waves_per_seg);
-  const uint32_t min_rows = p.sw == 2 ? 7u : 10u;  // (56x56x72 s2, batch 128: 7-row segments 18.6 us, 14-row 20.2, 28-row 29.3)
+  const uint64_t target = static_cast<uint64_t>(p.cu_count) * 4u * 6u;
+  uint32_t segs = static_cast<uint32_t>((target + waves_per_seg - 1) / waves_per_seg);
+  const uint32_t min_rows = 28;
   uint32_t max_segs = p.OH / min_rows;
   if (max_segs < 1) max_segs = 1;
   if (segs > max_segs) segs = max_segs;
