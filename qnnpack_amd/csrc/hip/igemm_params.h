@@ -110,6 +110,6 @@ int conv_c3rows_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_
 
 /* q8gemm256.hip */
 bool gemm256_supported(const IgemmParams& p, uint32_t vec);
-int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, bool waves4, bool rows128, bool pingpong);
+int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, bool waves4, bool rows128, bool pingpong, int lean);   /* lean: 0 never, 1 where supported, 2 forced (EINVAL otherwise) */
 
 }  // namespace qnnp

@@ -78,6 +78,29 @@ __device__ __forceinline__ void dma16(const uint8_t* src, uint8_t* lds_wave_base
       (__attribute__((address_space(3))) void*) lds_wave_base, 16, 0, QNNP_DMA_AUX);
 }
 
+/* The saddr form: 64-bit wave-uniform base in an SGPR pair + 32-bit lane offset. hipcc selects the VGPR-pair form for
+ * the builtin whatever the shape of the address expression (one v_lshl_add_u64 per piece), hence the instruction itself;
+ * m0 = LDS destination of lane 0, as the builtin sets it. */
+__device__ __forceinline__ void dma16_saddr(const uint8_t* base, uint32_t lane_offset, uint8_t* lds_wave_base)
+{
+  const uint32_t lds_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+      (__attribute__((address_space(3))) uint8_t*) lds_wave_base));
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               : : "v"(lane_offset), "s"(base), "s"(lds_addr) : "m0");
+}
+/* The same in two halves, for the main loop: m0 is written one MFMA ahead of the load, which is the wait state the
+ * pair needs (no s_nop). Nothing else in that loop touches m0. */
+__device__ __forceinline__ void dma16_set_m0(uint8_t* lds_wave_base)
+{
+  const uint32_t lds_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+      (__attribute__((address_space(3))) uint8_t*) lds_wave_base));
+  asm volatile("s_mov_b32 m0, %0" : : "s"(lds_addr) : "m0");
+}
+__device__ __forceinline__ void dma16_saddr_m0_set(const uint8_t* base, uint32_t lane_offset)
+{
+  asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(lane_offset), "s"(base) : "m0");
+}
+
 constexpr int kWN = 2;                         // waves along channels (each 128 channels = 4 MFMA tiles)
 constexpr int kTN = kBN / (kWN * 32);
 static_assert(kWN == 2 && kBK == 64, "row-sum split: each channel-wave owns one of the two K sub-steps");
@@ -99,11 +122,18 @@ static_assert(kWN == 2 && kBK == 64, "row-sum split: each channel-wave owns one 
 //                   issues its LDS-DMA pieces and does its re-centring / row-sum VALU work; a raw s_barrier swaps the
 //                   roles. The DMA issue stalls (100-185 cycles per piece on a busy CU) and the LDS waits then sit in a
 //                   phase whose wave has no MFMA to issue, beside a partner that has nothing else. One fragment set.
-template <bool IS_CONV, int WM, int BM = 256, int ABL = 0, bool PP = false>
+//   LEAN (plain GEMM, WM 4, BM 256 only; the launcher checks K % 64 == 0, N % 256 == 0 and the 32-bit offset ranges):
+//                   the same schedule with fewer instructions between the MFMAs. LDS-DMA sources are a wave-uniform
+//                   64-bit base (SALU: one add-with-carry per K tile) plus a loop-invariant 32-bit lane offset -- the
+//                   saddr form of global_load_lds -- instead of per-piece 64-bit VALU adds and the K / N padding
+//                   selects; the steady state is unrolled over the four ring slots, so fragment and DMA destination
+//                   addresses are loop-invariant registers plus immediates.
+template <bool IS_CONV, int WM, int BM = 256, int ABL = 0, bool PP = false, bool LEAN = false>
 __global__ __launch_bounds__(WM * kWN * 64, (WM == 4 || BM == 128) ? 2 : 1)
 void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 {
   static_assert(!PP || (WM == 4 && BM == 256), "ping-pong schedule: 8 waves, 256 x 256 tile");
+  static_assert(!LEAN || (!IS_CONV && !PP && WM == 4 && BM == 256 && ABL == 0), "lean flavour: the default 8-wave GEMM only");
   constexpr int kBM = BM;
   constexpr int kStages = BM == 256 ? 4 : 3;     // LDS ring: tile t + kStages - 1 is being fetched while tile t is multiplied
   constexpr int kATile = kBM * kBK;              // 16 / 8 KiB
@@ -201,11 +231,45 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
     w_kstep[i] = valid ? 2048u : 0u;
   }
 
+  // lean flavour: wave-uniform bases + loop-invariant 32-bit lane offsets (every K tile and channel block exists)
+  const uint8_t* a_base = nullptr;
+  const uint8_t* w_base = nullptr;
+  uint32_t a_voff[kAChunks];
+  uint32_t w_voff[kWFrags];
+  if constexpr (LEAN) {
+    a_base = p.input + static_cast<uint64_t>(m_tile * kBM) * p.input_stride + static_cast<uint64_t>(g) * p.kc;
+#pragma unroll
+    for (int i = 0; i < kAChunks; i++) {
+      const uint32_t r = (i * kThreads + tid) >> 2;
+      uint32_t m = m_tile * kBM + r;
+      if (m >= p.rows) m = p.rows - 1;
+      a_voff[i] = (m - m_tile * kBM) * p.input_stride + a_chunk[i] * 16;
+    }
+    // fragment F = i * 8 + wave: channel block nb0 + i * 4 + (wave >> 1), K block (wave & 1) of the tile's two
+    w_base = reinterpret_cast<const uint8_t*>(p.packed_w) + static_cast<uint64_t>(g) * nblocks * kblocks * 1024 +
+        (static_cast<uint64_t>(nb0 + (wave >> 1)) * kblocks + (wave & 1u)) * 1024;
+#pragma unroll
+    for (int i = 0; i < kWFrags; i++) w_voff[i] = lane * 16 + static_cast<uint32_t>(i) * (kWM * kWN / 2) * kblocks * 1024;
+  }
+
   // One K tile = exactly kDma LDS-DMA instructions per thread (the vmcnt arithmetic depends on it):
-  // pieces 0..kAChunks-1 = activation chunks, the rest = weight fragments.
-  auto stage_piece = [&](uint32_t kt, int piece) {
-    uint8_t* a_dst = lds + (kt % kStages) * kStage;
+  // pieces 0..kAChunks-1 = activation chunks, the rest = weight fragments. `slot` = kt % kStages (a literal in the
+  // unrolled steady state of the lean flavour).
+  auto stage_piece = [&](uint32_t kt, int piece, uint32_t slot) __attribute__((always_inline)) {
+    uint8_t* a_dst = lds + slot * kStage;
     uint8_t* w_dst = a_dst + kATile;
+    if constexpr (LEAN) {
+      if (piece < kAChunks) {
+        const uint8_t* tile = a_base + static_cast<uint64_t>(kt) * kBK;            // scalar
+        dma16_saddr(tile, a_voff[piece], a_dst + (piece * kThreads + wave * 64) * 16);
+      } else {
+        const int i = piece - kAChunks;
+        const uint32_t F = i * (kWM * kWN) + wave;
+        const uint8_t* tile = w_base + static_cast<uint64_t>(kt) * 2048;           // scalar
+        dma16_saddr(tile, w_voff[i], w_dst + F * 1024);
+      }
+      return;
+    }
     if (piece < kAChunks) {
       const int i = piece;
       const uint32_t kk = kt * kBK + a_chunk[i] * 16;
@@ -231,7 +295,17 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
   };
   auto stage = [&](uint32_t kt) {
 #pragma unroll
-    for (int piece = 0; piece < kDma; piece++) stage_piece(kt, piece);
+    for (int piece = 0; piece < kDma; piece++) stage_piece(kt, piece, kt % kStages);
+  };
+  // lean flavour, main loop: stage_piece in two halves around an MFMA (dma16_set_m0)
+  auto piece_m0 = [&](int piece, uint32_t slot) __attribute__((always_inline)) {
+    uint8_t* a_dst = lds + slot * kStage;
+    if (piece < kAChunks) dma16_set_m0(a_dst + (piece * kThreads + wave * 64) * 16);
+    else dma16_set_m0(a_dst + kATile + ((piece - kAChunks) * (kWM * kWN) + wave) * 1024);
+  };
+  auto piece_load = [&](uint32_t kt, int piece) __attribute__((always_inline)) {
+    if (piece < kAChunks) dma16_saddr_m0_set(a_base + static_cast<uint64_t>(kt) * kBK, a_voff[piece]);
+    else dma16_saddr_m0_set(w_base + static_cast<uint64_t>(kt) * 2048, w_voff[piece - kAChunks]);
   };
 
   // Accumulators start at the folded bias (the MFMAs add into them): the loads ride under the prologue's DMA
@@ -283,6 +357,37 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 #pragma unroll
     for (int tn = 0; tn < kTN; tn++) {
       f.w[tn] = *reinterpret_cast<const v4i*>(st + w_fbase + (tn * 2 + ksub) * 1024);
+    }
+  };
+  // lean flavour, ring slot known at compile time: loop-invariant address registers (the ds_read immediate reaches
+  // 64 KiB, so one register per half of the ring) + immediates; sub 0 = this wave's first K sub-step, 1 = its second
+  uint32_t a_off[2][kTM][2];
+  uint32_t w_off[2][2];
+  if constexpr (LEAN) {
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      const uint32_t ksub = sub == 0 ? wn : (wn ^ 1u);
+#pragma unroll
+      for (int hi = 0; hi < 2; hi++) {
+#pragma unroll
+        for (int tm = 0; tm < kTM; tm++) {
+          a_off[sub][tm][hi] = (a_fbase[tm] ^ (ksub << 5)) + hi * 2 * kStage;
+          asm volatile("" : "+v"(a_off[sub][tm][hi]));
+        }
+        w_off[sub][hi] = w_fbase + ksub * 1024 + hi * 2 * kStage;
+        asm volatile("" : "+v"(w_off[sub][hi]));
+      }
+    }
+  }
+  auto read_frags_slot = [&](uint32_t slot, int sub, Frags& f) __attribute__((always_inline)) {
+    const uint32_t hi = slot >> 1, imm = (slot & 1u) * kStage;
+#pragma unroll
+    for (int tm = 0; tm < kTM; tm++) {
+      f.a[tm] = *reinterpret_cast<const v4i*>(lds + a_off[sub][tm][hi] + imm);
+    }
+#pragma unroll
+    for (int tn = 0; tn < kTN; tn++) {
+      f.w[tn] = *reinterpret_cast<const v4i*>(lds + w_off[sub][hi] + imm + tn * 2048);
     }
   };
   auto flip = [&](Frags& f) {
@@ -386,7 +491,7 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
       QNNP_PIN();
       if constexpr (FETCH) {
 #pragma unroll
-        for (int i = 0; i < kDma / 2; i++) stage_piece(kt + kStages - 1, half * (kDma / 2) + i);
+        for (int i = 0; i < kDma / 2; i++) stage_piece(kt + kStages - 1, half * (kDma / 2) + i, (kt + kStages - 1) % kStages);
         QNNP_PIN();
       }
       if (half == 0) rowsum(f);                               // this wave owns the row sums of its first sub-step
@@ -463,25 +568,37 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
   constexpr int kHalf = kDma / 2;                 // LDS-DMA pieces per phase
   constexpr int kDmaGap = kMma / kHalf;           // one piece every kDmaGap MFMAs
   constexpr int kFlipMma = kParts / 2;            // the last kFlipMma MFMAs of a phase carry 2 recentring parts each
-  auto iteration = [&](auto p1f_c, auto more_c, auto p2f_c, uint32_t kt) __attribute__((always_inline)) {
+  auto iteration = [&](auto p1f_c, auto more_c, auto p2f_c, uint32_t kt, uint32_t slot, auto known_c) __attribute__((always_inline)) {
+    constexpr bool KNOWN = decltype(known_c)::value;     // `slot` is a literal (lean flavour's unrolled steady state)
     constexpr bool P1F = decltype(p1f_c)::value;
     constexpr bool MORE = decltype(more_c)::value;
     constexpr bool P2F = decltype(p2f_c)::value;
-    const uint8_t* st = lds + (kt % kStages) * kStage;
+    const uint8_t* st = lds + slot * kStage;              // slot == kt % kStages
 
     QNNP_PIN();
-    if (!(ABL & 16)) read_frags(st, s_second, fb);
+    if constexpr (KNOWN) read_frags_slot(slot, 1, fb);
+    else if (!(ABL & 16)) read_frags(st, s_second, fb);
     QNNP_PIN();
 #pragma unroll
     for (int i = 0; i < kMma; i++) {
+      if constexpr (LEAN && P1F) {
+        if (i % kDmaGap == 0 && i / kDmaGap < kHalf) piece_m0(kHalf + i / kDmaGap, (slot + kStages - 1) % kStages);
+        QNNP_PIN();
+      }
       if (!(ABL & 4)) mma(fa, i);
       QNNP_PIN();
-      if constexpr (P1F) {
-        if (i % kDmaGap == 0 && i / kDmaGap < kHalf && !(ABL & 8)) stage_piece(kt + kStages - 1, kHalf + i / kDmaGap);
+      if constexpr (LEAN && P1F) {
+        if (i % kDmaGap == 0 && i / kDmaGap < kHalf) piece_load(kt + kStages - 1, kHalf + i / kDmaGap);
+        QNNP_PIN();
+      } else if constexpr (P1F) {
+        if (i % kDmaGap == 0 && i / kDmaGap < kHalf && !(ABL & 8)) stage_piece(kt + kStages - 1, kHalf + i / kDmaGap, (slot + kStages - 1) % kStages);
         QNNP_PIN();
       }
       if (i >= kMma - kFlipMma) {
         const int h = (i - (kMma - kFlipMma)) * 2;
+        if constexpr (LEAN) {
+          if (h == 0) { __builtin_amdgcn_s_waitcnt(0xC07F); QNNP_PIN(); }   // lgkmcnt(0) once: the reads were issued a phase ago
+        }
         if (!(ABL & 2)) {
           flip_part(fb, h);
           flip_part(fb, h + 1);
@@ -520,20 +637,31 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 #endif
 
     if constexpr (MORE) {
-      if (!(ABL & 16)) read_frags(lds + ((kt + 1) % kStages) * kStage, s_first, fa);
+      if constexpr (KNOWN) read_frags_slot((slot + 1) % kStages, 0, fa);
+      else if (!(ABL & 16)) read_frags(lds + ((slot + 1) % kStages) * kStage, s_first, fa);
     }
     QNNP_PIN();
 #pragma unroll
     for (int i = 0; i < kMma; i++) {
+      if constexpr (LEAN && P2F) {
+        if (i % kDmaGap == 0 && i / kDmaGap < kHalf) piece_m0(i / kDmaGap, slot);
+        QNNP_PIN();
+      }
       if (!(ABL & 4)) mma(fb, i);
       QNNP_PIN();
-      if constexpr (P2F) {
-        if (i % kDmaGap == 0 && i / kDmaGap < kHalf && !(ABL & 8)) stage_piece(kt + kStages, i / kDmaGap);
+      if constexpr (LEAN && P2F) {
+        if (i % kDmaGap == 0 && i / kDmaGap < kHalf) piece_load(kt + kStages, i / kDmaGap);
+        QNNP_PIN();
+      } else if constexpr (P2F) {
+        if (i % kDmaGap == 0 && i / kDmaGap < kHalf && !(ABL & 8)) stage_piece(kt + kStages, i / kDmaGap, slot);
         QNNP_PIN();
       }
       if constexpr (MORE) {
         if (i >= kMma - kFlipMma) {
           const int h = (i - (kMma - kFlipMma)) * 2;
+          if constexpr (LEAN) {
+            if (h == 0) { __builtin_amdgcn_s_waitcnt(0xC07F); QNNP_PIN(); }
+          }
           if (!(ABL & 2)) {
             rowsum_part(fa, h);
             flip_part(fa, h);
@@ -559,17 +687,27 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
   }
   uint32_t kt = 0;
   if (ktiles > static_cast<uint32_t>(kStages)) {
-    iteration(std::false_type{}, std::true_type{}, std::true_type{}, 0u);
-    for (kt = 1; kt + kStages < ktiles; kt++) {           // steady state
-      iteration(std::true_type{}, std::true_type{}, std::true_type{}, kt);
+    iteration(std::false_type{}, std::true_type{}, std::true_type{}, 0u, 0u, std::false_type{});
+    kt = 1;
+    if constexpr (LEAN) {
+      static_assert(kStages == 4, "unrolled over the ring");
+      for (; kt + 3 + kStages < ktiles; kt += 4) {         // steady state, ring slots as literals
+        iteration(std::true_type{}, std::true_type{}, std::true_type{}, kt, 1u, std::true_type{});
+        iteration(std::true_type{}, std::true_type{}, std::true_type{}, kt + 1, 2u, std::true_type{});
+        iteration(std::true_type{}, std::true_type{}, std::true_type{}, kt + 2, 3u, std::true_type{});
+        iteration(std::true_type{}, std::true_type{}, std::true_type{}, kt + 3, 0u, std::true_type{});
+      }
     }
-    iteration(std::true_type{}, std::true_type{}, std::false_type{}, kt);   // kt == ktiles - kStages
+    for (; kt + kStages < ktiles; kt++) {                  // steady state
+      iteration(std::true_type{}, std::true_type{}, std::true_type{}, kt, kt % kStages, std::false_type{});
+    }
+    iteration(std::true_type{}, std::true_type{}, std::false_type{}, kt, kt % kStages, std::false_type{});   // kt == ktiles - kStages
     kt++;
   }
   for (; kt + 1 < ktiles; kt++) {                          // drain: nothing left to fetch
-    iteration(std::false_type{}, std::true_type{}, std::false_type{}, kt);
+    iteration(std::false_type{}, std::true_type{}, std::false_type{}, kt, kt % kStages, std::false_type{});
   }
-  iteration(std::false_type{}, std::false_type{}, std::false_type{}, kt);   // last tile
+  iteration(std::false_type{}, std::false_type{}, std::false_type{}, kt, kt % kStages, std::false_type{});   // last tile
   }  // !PP
 #undef QNNP_PIN
 
@@ -686,7 +824,15 @@ static int launch256(const IgemmParams& p, const dim3& grid, hipStream_t stream)
 /* waves4 = false: 8 waves (two per SIMD), 64 x 128 outputs per wave -- the default;
  * waves4 = true:  4 waves (one per SIMD, the whole register file), 128 x 128 per wave: a third less LDS read
  *                 traffic and a higher sustained clock, but every issue stall is exposed (A/B flavour). */
-int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, bool waves4, bool rows128, bool pingpong)
+/* lean flavour (same schedule, fewer instructions around the MFMAs): plain GEMM whose K tiles and channel blocks all
+ * exist, lane offsets within 32 bits */
+bool gemm256_lean_supported(const IgemmParams& p)
+{
+  return p.offsets == nullptr && p.k_total == p.k_pad && p.k_pad % kBK == 0 && p.n_pad % kBN == 0 &&
+         p.k_pad <= (1u << 22) && static_cast<uint64_t>(p.input_stride) * 256u < (1ull << 32);
+}
+
+int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, bool waves4, bool rows128, bool pingpong, int lean)
 {
   const uint32_t bm = rows128 ? 128u : 256u;
   const uint32_t tiles_m = (p.rows + bm - 1) / bm;
@@ -720,6 +866,12 @@ int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, co
 #undef QNNP_ABL_CASE
   }
 #endif
+  if (!waves4 && lean != 0 && gemm256_lean_supported(p)) {
+    *name = "q8_gemm_mfma_256x256_lean";
+    hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 4, 256, 0, false, true>), grid, dim3(512), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+  }
+  if (lean > 1) return QNNP_HIP_EINVAL;        // forced and not applicable
   if (conv) {
     *name = waves4 ? "q8_gemm_mfma_256x256_w4_conv" : "q8_gemm_mfma_256x256_conv";
     return waves4 ? launch256<true, 2>(p, grid, stream) : launch256<true, 4>(p, grid, stream);

@@ -13,11 +13,13 @@ from oracle import o1
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant,kernel", [(0, "q8_gemm_mfma_256x256"), (10, "q8_gemm_mfma_128x256"),
-                                            (11, "q8_gemm_mfma_256x256_pp")], ids=["auto", "rows128", "pingpong"])
+@pytest.mark.parametrize("variant,kernel", [(0, "q8_gemm_mfma_256x256_lean"), (2, "q8_gemm_mfma_256x256"),
+                                            (10, "q8_gemm_mfma_128x256"), (11, "q8_gemm_mfma_256x256_pp")],
+                         ids=["auto", "general", "rows128", "pingpong"])
 def test_c2_q8gemm_4096_cubed(qnnp, variant, kernel):
-    """configs[1]: q8gemm M=N=K=4096 through qnnp_fully_connected_nc_q8 -- the shipped kernel and the two A/B structures
-    of round 3 (128 x 256 tiles with two workgroups per CU; the ping-pong schedule)."""
+    """configs[1]: q8gemm M=N=K=4096 through qnnp_fully_connected_nc_q8 -- the shipped kernel (the lean flavour of the
+    256 x 256 kernel is what "auto" picks for this shape), the general flavour it came from, and the two A/B structures of
+    round 3 (128 x 256 tiles with two workgroups per CU; the ping-pong schedule)."""
     import torch
     qnnp.set_option("gemm_kernel", variant)
     M = N = K = 4096
@@ -205,7 +207,7 @@ def test_c2_q8gemm_4096_cubed_full_output_vs_compiled_reference(qnnp):
         d_c = to_device(np.full(M * N, FILL, np.uint8))
         qnnp.setup_fully_connected_nc_q8(op, M, d_a, K, d_c, N)
         qnnp.run_operator(op)
-        assert qnnp.operator_kernel(op) == "q8_gemm_mfma_256x256", qnnp.operator_kernel(op)
+        assert qnnp.operator_kernel(op) == "q8_gemm_mfma_256x256_lean", qnnp.operator_kernel(op)
         got = from_device(d_c).reshape(M, N)
     finally:
         qnnp.delete_operator(op)

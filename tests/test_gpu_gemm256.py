@@ -1,12 +1,14 @@
 """GPU tier: the 256x256 LDS-DMA MFMA kernel (qnnpack_amd/csrc/hip/q8gemm256.hip), forced with the
 "gemm_kernel" = 2 option, against the scalar oracle -- tile-edge sweeps in M, N and K, grouped and
 convolution (offset-table) forms, zero-point variants. The auto-selected path for BASELINE configs[1]
-(4096^3) is this kernel; tests/test_gpu_fullsize.py asserts that."""
+(4096^3) is this kernel's lean flavour ("gemm_kernel" = 15; picked by auto when K % 64 == 0 and N % 256 == 0);
+tests/test_gpu_fullsize.py asserts that."""
 import numpy as np
 import pytest
 
 from _cases import ConvCase, FcCase
 from _gpu import from_device, to_device
+from qnnpack_amd.binding import QnnpackError
 from _runner import assert_bytes_equal, conv_expected, conv_run, fc_expected, fc_run
 
 pytestmark = pytest.mark.gpu
@@ -46,6 +48,52 @@ def test_n_edges(big, n):
 @pytest.mark.parametrize("k", [16, 32, 48, 64, 80, 112, 128, 144, 256, 272, 384, 1024])
 def test_k_edges(big, k):
     _fc(big, FcCase(f"b_k{k}", 270, k, 260))
+
+
+# ---- the lean flavour ("gemm_kernel" = 15: saddr LDS-DMA, steady state unrolled over the ring): plain GEMMs whose K is a
+# multiple of 64 and whose N is a multiple of 256; forced, so an unsupported shape is refused instead of rerouted ----
+@pytest.fixture
+def lean(qnnp):
+    qnnp.set_option("gemm_kernel", 15)
+    qnnp._kname = "q8_gemm_mfma_256x256_lean"
+    yield qnnp
+    qnnp.set_option("gemm_kernel", 0)
+
+
+@pytest.mark.parametrize("m", [1, 31, 255, 256, 257, 300, 1000])
+@pytest.mark.parametrize("k", [64, 128, 256, 320, 512, 576, 1088])      # 1 ... 17 K tiles: every prologue / drain shape
+def test_lean_m_and_k(lean, m, k):
+    _fc(lean, FcCase(f"lean_m{m}_k{k}", m, k, 256))
+
+
+@pytest.mark.parametrize("n", [256, 512, 768])
+@pytest.mark.parametrize("kw", [dict(), dict(izp=0, kzp=0), dict(izp=255, kzp=255), dict(izp=3, kzp=250), dict(qmin=128)],
+                         ids=lambda d: "_".join(f"{k}{v}" for k, v in d.items()) or "default")
+def test_lean_n_and_quantization(lean, n, kw):
+    _fc(lean, FcCase(f"lean_n{n}_" + "_".join(f"{k}{v}" for k, v in kw.items()), 520, 704, n, **kw))
+
+
+def test_lean_strided_rows(lean):
+    _fc(lean, FcCase("lean_strided", 300, 640, 256, input_stride=656, output_stride=264))
+
+
+# (shapes the dispatcher hands to this kernel by itself: K beyond the streaming kernels' 1024, more than 400 generic tiles)
+@pytest.mark.parametrize("k,n,kernel", [(1088, 2048, "q8_gemm_mfma_256x256_lean"), (1104, 2048, "q8_gemm_mfma_256x256"),
+                                        (1088, 2080, "q8_gemm_mfma_256x256")])
+def test_auto_takes_the_lean_flavour_where_it_applies(qnnp, k, n, kernel):
+    case = FcCase(f"auto_k{k}_n{n}", 3328, k, n)
+    expected, quant = fc_expected(case)
+    out, kname = fc_run(qnnp, case, quant, to_device=to_device, from_device=from_device)
+    assert kname == kernel, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("k,n", [(80, 256), (640, 260), (48, 512)])
+def test_lean_refuses_what_it_cannot_take(lean, k, n):
+    case = FcCase(f"lean_refused_k{k}_n{n}", 300, k, n)
+    expected, quant = fc_expected(case)
+    with pytest.raises(QnnpackError):
+        fc_run(lean, case, quant, to_device=to_device, from_device=from_device)
 
 
 @pytest.mark.parametrize("kw", [dict(izp=0, kzp=0), dict(izp=255, kzp=255), dict(izp=128, kzp=128),

@@ -9,7 +9,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 NAMES = {0: "shipped 256x256 (8 waves, interleaved)", 2: "256x256 forced", 4: "256x256 4 waves 128x128/wave",
-         10: "128x256 x 2 workgroups per CU", 11: "256x256 ping-pong + setprio"}
+         10: "128x256 x 2 workgroups per CU", 11: "256x256 ping-pong + setprio",
+         15: "256x256 lean (saddr DMA, ring unrolled)"}
 
 
 def main():
