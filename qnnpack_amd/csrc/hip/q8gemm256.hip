@@ -133,7 +133,7 @@ __global__ __launch_bounds__(WM * kWN * 64, (WM == 4 || BM == 128) ? 2 : 1)
 void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 {
   static_assert(!PP || (WM == 4 && BM == 256), "ping-pong schedule: 8 waves, 256 x 256 tile");
-  static_assert(!LEAN || (!IS_CONV && !PP && WM == 4 && BM == 256 && ABL == 0), "lean flavour: the default 8-wave GEMM only");
+  static_assert(!LEAN || (!IS_CONV && !PP && BM == 256 && ABL == 0), "lean flavour: plain GEMM, 256 x 256 tiles");
   constexpr int kBM = BM;
   constexpr int kStages = BM == 256 ? 4 : 3;     // LDS ring: tile t + kStages - 1 is being fetched while tile t is multiplied
   constexpr int kATile = kBM * kBK;              // 16 / 8 KiB
@@ -866,9 +866,10 @@ int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, co
 #undef QNNP_ABL_CASE
   }
 #endif
-  if (!waves4 && lean != 0 && gemm256_lean_supported(p)) {
-    *name = "q8_gemm_mfma_256x256_lean";
-    hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 4, 256, 0, false, true>), grid, dim3(512), 0, stream, p);
+  if (lean != 0 && gemm256_lean_supported(p)) {
+    *name = waves4 ? "q8_gemm_mfma_256x256_w4_lean" : "q8_gemm_mfma_256x256_lean";
+    if (waves4) hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 2, 256, 0, false, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 4, 256, 0, false, true>), grid, dim3(512), 0, stream, p);
     return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
   }
   if (lean > 1) return QNNP_HIP_EINVAL;        // forced and not applicable

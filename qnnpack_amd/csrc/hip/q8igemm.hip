@@ -667,11 +667,12 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   // Large MFMA-bound problems take the 256x256 LDS-DMA kernel; everything else the generic one.
   const bool big_ok = !pad3 && qnnp::gemm256_supported(p, vec);
   const bool big_auto = a->n >= 256 && a->k_total >= 512 && a->rows >= 2048;
-  const bool big_forced = a->variant == 2 || a->variant == 4 || a->variant == 10 || a->variant == 11 || a->variant == 15;   // 10: 128 x 256 tiles, two workgroups per CU; 11: ping-pong schedule; 15: lean flavour
+  const bool big_forced = a->variant == 2 || a->variant == 4 || a->variant == 10 || a->variant == 11 || a->variant == 15 || a->variant == 16;   // 10: 128 x 256 tiles, two workgroups per CU; 11: ping-pong schedule; 15: lean flavour
   if (big_forced && !big_ok) return QNNP_HIP_EINVAL;
   int rc;
   if (big_ok && (big_forced || (a->variant == 0 && big_auto))) {
-    rc = qnnp::gemm256_launch(p, a->groups, stream, &name, a->variant == 4, a->variant == 10, a->variant == 11, a->variant == 15 ? 2 : (a->variant == 0 ? 1 : 0));   // ("gemm_kernel" = 2 keeps the general flavour for A/B)
+    rc = qnnp::gemm256_launch(p, a->groups, stream, &name, a->variant == 4 || a->variant == 16, a->variant == 10, a->variant == 11,
+                               (a->variant == 15 || a->variant == 16) ? 2 : (a->variant == 0 ? 1 : 0));   // 16: the 4-wave flavour, lean;   // ("gemm_kernel" = 2 keeps the general flavour for A/B)
   } else {
     if (pad3) {
       rc = dispatch_tile<4, true, true>(p, a->groups, stream, &name);

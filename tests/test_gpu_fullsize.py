@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("variant,kernel", [(0, "q8_gemm_mfma_256x256_lean"), (2, "q8_gemm_mfma_256x256"),
-                                            (10, "q8_gemm_mfma_128x256"), (11, "q8_gemm_mfma_256x256_pp")],
-                         ids=["auto", "general", "rows128", "pingpong"])
+                                            (10, "q8_gemm_mfma_128x256"), (11, "q8_gemm_mfma_256x256_pp"),
+                                            (16, "q8_gemm_mfma_256x256_w4_lean")],
+                         ids=["auto", "general", "rows128", "pingpong", "w4_lean"])
 def test_c2_q8gemm_4096_cubed(qnnp, variant, kernel):
     """configs[1]: q8gemm M=N=K=4096 through qnnp_fully_connected_nc_q8 -- the shipped kernel (the lean flavour of the
     256 x 256 kernel is what "auto" picks for this shape), the general flavour it came from, and the two A/B structures of

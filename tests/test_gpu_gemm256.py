@@ -52,10 +52,14 @@ def test_k_edges(big, k):
 
 # ---- the lean flavour ("gemm_kernel" = 15: saddr LDS-DMA, steady state unrolled over the ring): plain GEMMs whose K is a
 # multiple of 64 and whose N is a multiple of 256; forced, so an unsupported shape is refused instead of rerouted ----
-@pytest.fixture
-def lean(qnnp):
-    qnnp.set_option("gemm_kernel", 15)
-    qnnp._kname = "q8_gemm_mfma_256x256_lean"
+# (16: the same for the 4-wave A/B flavour)
+_LEAN = {15: "q8_gemm_mfma_256x256_lean", 16: "q8_gemm_mfma_256x256_w4_lean"}
+
+
+@pytest.fixture(params=sorted(_LEAN), ids=lambda v: _LEAN[v].replace("q8_gemm_mfma_256x256_", ""))
+def lean(qnnp, request):
+    qnnp.set_option("gemm_kernel", request.param)
+    qnnp._kname = _LEAN[request.param]
     yield qnnp
     qnnp.set_option("gemm_kernel", 0)
 
