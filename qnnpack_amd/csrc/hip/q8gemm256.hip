@@ -80,13 +80,14 @@ __device__ __forceinline__ void dma16(const uint8_t* src, uint8_t* lds_wave_base
 
 /* The saddr form: 64-bit wave-uniform base in an SGPR pair + 32-bit lane offset. hipcc selects the VGPR-pair form for
  * the builtin whatever the shape of the address expression (one v_lshl_add_u64 per piece), hence the instruction itself;
- * m0 = LDS destination of lane 0, as the builtin sets it. */
+ * m0 = LDS destination of lane 0, as the builtin sets it. (m0 is a reserved register: hipcc ignores it in a clobber list.
+ * Nothing else in the lean kernels touches it -- tests/test_kernel_resources.py disassembles them and checks.) */
 __device__ __forceinline__ void dma16_saddr(const uint8_t* base, uint32_t lane_offset, uint8_t* lds_wave_base)
 {
   const uint32_t lds_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
       (__attribute__((address_space(3))) uint8_t*) lds_wave_base));
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-               : : "v"(lane_offset), "s"(base), "s"(lds_addr) : "m0");
+               : : "v"(lane_offset), "s"(base), "s"(lds_addr));
 }
 /* The same in two halves, for the main loop: m0 is written one MFMA ahead of the load, which is the wait state the
  * pair needs (no s_nop). Nothing else in that loop touches m0. */
@@ -94,11 +95,11 @@ __device__ __forceinline__ void dma16_set_m0(uint8_t* lds_wave_base)
 {
   const uint32_t lds_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
       (__attribute__((address_space(3))) uint8_t*) lds_wave_base));
-  asm volatile("s_mov_b32 m0, %0" : : "s"(lds_addr) : "m0");
+  asm volatile("s_mov_b32 m0, %0" : : "s"(lds_addr));
 }
 __device__ __forceinline__ void dma16_saddr_m0_set(const uint8_t* base, uint32_t lane_offset)
 {
-  asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(lane_offset), "s"(base) : "m0");
+  asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(lane_offset), "s"(base));
 }
 
 constexpr int kWN = 2;                         // waves along channels (each 128 channels = 4 MFMA tiles)

@@ -105,3 +105,35 @@ def test_report_of_spilling_kernels(kernels, capsys):
     assert all("q8_igemm_mfma_kernel" in n or "conv_wave_mfma_kernelILi2E" in n or "row3x3" in n or
                "q8_gemm_mfma_256x256_kernelILb0ELi2E" in n or "q8_gemm_mfma_256x256_kernelILb1ELi2E" in n
                for _, n in spilling), "a kernel outside the known fallback / A-B flavours started to spill"
+
+
+OBJDUMP = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def test_lean_gemm_is_the_only_writer_of_m0_in_its_kernels(tmp_path):
+    """The lean GEMM flavour issues its LDS-DMA as inline assembly and writes m0 itself, in the main loop one MFMA
+    AHEAD of the load that uses it (q8gemm256.hip, dma16_set_m0). That is only sound while nothing the compiler emits
+    in those kernels touches m0: every m0 reference in their disassembly must be one of the kernel's own
+    `s_mov_b32 m0, sN`, and every LDS-DMA must be the saddr form the inline assembly spells out."""
+    if not os.path.exists(LIB):
+        pytest.skip("library not built")
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    blob = open(LIB, "rb").read()
+    seen = 0
+    for k, elf in enumerate(_code_objects(blob)):
+        path = tmp_path / f"co{k}.elf"
+        path.write_bytes(elf)
+        dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", str(path)], capture_output=True, text=True, check=True).stdout
+        for m in re.finditer(r"^[0-9a-f]+ <(\S*q8_gemm_mfma_256x256_kernel\S*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", dis, re.S | re.M):
+            name, body = m.group(1), m.group(2)
+            if not name.endswith("ELb0ELb1EEEvNS_11IgemmParamsE"):      # <..., PP = false, LEAN = true>
+                continue
+            seen += 1
+            m0_lines = [ln.strip() for ln in body.split("\n") if re.search(r"\bm0\b", ln)]
+            assert m0_lines, name
+            for ln in m0_lines:
+                assert re.match(r"s_mov_b32 m0, s\d+\b", ln), (name, ln)
+            dma = [ln.strip() for ln in body.split("\n") if "global_load_lds" in ln]
+            assert dma and all(re.match(r"global_load_lds_dwordx4 v\d+, s\[\d+:\d+\]", ln) for ln in dma), (name, dma[:3])
+    assert seen == 2, seen          # the 8-wave flavour and the 4-wave A/B flavour
