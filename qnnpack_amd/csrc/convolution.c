@@ -27,6 +27,7 @@
 #include "indirection.h"
 #include "log.h"
 #include "operator.h"
+#include "bias-pair.h"
 #include "pack.h"
 #include "requantization.h"
 #include "state.h"
@@ -266,11 +267,10 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
     op->k_pad = k_pad;
     op->kc_slot = kc_slot;
     op->d_weights = qnnp_hip_alloc(w_bytes);
-    op->d_bias = (int32_t*) qnnp_hip_alloc(b_bytes);
+    op->d_bias = qnnp_upload_bias_pair((const int32_t*) host_bias, (size_t) groups * n_pad);   /* bias-pair.h */
     if (op->d_weights == NULL || op->d_bias == NULL ||
-        qnnp_hip_h2d(op->d_weights, host_weights, w_bytes, 0) != QNNP_HIP_OK ||
-        qnnp_hip_h2d(op->d_bias, host_bias, b_bytes, 0) != QNNP_HIP_OK) {
-      qnnp_log_error("failed to place %zu bytes of packed weights on the device", w_bytes + b_bytes);
+        qnnp_hip_h2d(op->d_weights, host_weights, w_bytes, 0) != QNNP_HIP_OK) {
+      qnnp_log_error("failed to place %zu bytes of packed weights on the device", w_bytes + 2 * b_bytes);
       goto error;
     }
     if (kc_slot == 4 && kernel_height <= 4 && kernel_width * 3 <= 16 && dilation_height == 1 && dilation_width == 1 &&

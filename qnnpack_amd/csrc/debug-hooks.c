@@ -162,6 +162,38 @@ void qnnp_debug_requant_fast_offset(
   }
 }
 
+/* the lane forms (hip/requant_math.h, qnnp_requant_lane_*): the kernel hands over a + 2^31 with acc = a + rowterm; the
+ * row term enters through the per-lane addend. `kind_out`: 0 none (the other sequences answer), 1 shift 0, 2 bounded */
+void qnnp_debug_requant_lane(
+    size_t count, const int32_t* acc, const int32_t* rowterm, float scale, uint8_t zero_point, uint8_t qmin, uint8_t qmax,
+    uint32_t accumulator_bits, uint8_t* out, int* kind_out)
+{
+  const struct qnnp_hip_requant rq = qnnp_compute_requant(scale, zero_point, qmin, qmax);
+  struct qnnp_requant_fast f = qnnp_requant_fast_init(rq.multiplier, rq.shift);
+  const int folded = qnnp_requant_fast_fold_zero_point(&f, (uint32_t) rq.output_zero_point);
+  (void) qnnp_requant_fast_enable_bounded(&f, (uint32_t) rq.output_zero_point, folded, accumulator_bits);
+  (void) qnnp_requant_fast_enable_offset(&f);
+  const struct qnnp_requant_lane l = qnnp_requant_lane_init(f, (uint32_t) rq.output_zero_point, folded, accumulator_bits);
+  if (kind_out != NULL) *kind_out = (int) l.kind;
+  const int32_t zp_late = folded ? 0 : rq.output_zero_point;
+  int32_t lo = rq.output_min_less_zero_point + (folded ? rq.output_zero_point : 0);
+  const int32_t hi = rq.output_max_less_zero_point + (folded ? rq.output_zero_point : 0);
+  if (lo > hi) lo = hi;
+  for (size_t i = 0; i < count; i++) {
+    int32_t y;
+    if (l.kind == 0) {
+      y = qnnp_requant_scale_via_offset(acc[i], f);
+    } else {
+      const uint32_t u = (uint32_t) acc[i] - (uint32_t) rowterm[i] + UINT32_C(0x80000000);   /* a + 2^31 */
+      const uint64_t addend = qnnp_requant_lane_addend(rowterm[i], l);
+      y = l.kind == 1 ? qnnp_requant_lane_s0(u, addend, l) : qnnp_requant_lane_sn(u, addend, l);
+    }
+    if (y < lo) y = lo;
+    if (y > hi) y = hi;
+    out[i] = (uint8_t) (y + zp_late);
+  }
+}
+
 void qnnp_debug_pack_igemm_w_slots(
     uint32_t groups, uint32_t n, uint32_t ks, uint32_t kc, uint32_t kc_slot, uint32_t n_pad, uint32_t k_pad,
     uint8_t izp, uint8_t kzp, const uint8_t* kernel, const int32_t* bias,

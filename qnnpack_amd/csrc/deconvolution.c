@@ -36,6 +36,7 @@
 #include "indirection.h"
 #include "log.h"
 #include "operator.h"
+#include "bias-pair.h"
 #include "pack.h"
 #include "requantization.h"
 #include "state.h"
@@ -233,10 +234,9 @@ static enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8_impl(
           qnnp_pack_igemm_w_slots(groups, (uint32_t) goc, taps, (uint32_t) gic, kc_slot, n_pad, ph->k_pad,
               input_zero_point, kernel_zero_point, sub, bias, (int8_t*) packed, host_bias);
           ph->d_weights = qnnp_hip_alloc(w_bytes);
-          ph->d_bias = (int32_t*) qnnp_hip_alloc(b_bytes);
+          ph->d_bias = qnnp_upload_bias_pair((const int32_t*) host_bias, (size_t) groups * n_pad);   /* bias-pair.h */
           ok = ph->d_weights != NULL && ph->d_bias != NULL &&
-              qnnp_hip_h2d(ph->d_weights, packed, w_bytes, 0) == QNNP_HIP_OK &&
-              qnnp_hip_h2d(ph->d_bias, host_bias, b_bytes, 0) == QNNP_HIP_OK;
+              qnnp_hip_h2d(ph->d_weights, packed, w_bytes, 0) == QNNP_HIP_OK;
         }
         free(packed);
         op->deconv_phases = py * stride_width + px + 1;   /* so that delete frees what exists so far */
@@ -282,10 +282,9 @@ static enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8_impl(
         qnnp_pack_igemm_w_slots(1, d2s_cols, 1, (uint32_t) gic, kc_slot, d2s_cols, d2s_k_pad,
             input_zero_point, kernel_zero_point, mat, cols_bias, (int8_t*) packed, packed_bias);
         op->d_weights = qnnp_hip_alloc(dw_bytes);
-        op->d_bias = (int32_t*) qnnp_hip_alloc(db_bytes);
+        op->d_bias = qnnp_upload_bias_pair(packed_bias, db_bytes / sizeof(int32_t));   /* bias-pair.h */
         ok = op->d_weights != NULL && op->d_bias != NULL &&
-            qnnp_hip_h2d(op->d_weights, packed, dw_bytes, 0) == QNNP_HIP_OK &&
-            qnnp_hip_h2d(op->d_bias, packed_bias, db_bytes, 0) == QNNP_HIP_OK;
+            qnnp_hip_h2d(op->d_weights, packed, dw_bytes, 0) == QNNP_HIP_OK;
       }
       free(mat);
       free(cols_bias);
@@ -316,10 +315,9 @@ static enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8_impl(
   op->k_pad = k_pad;
   op->kc_slot = kc_slot;
   op->d_weights = qnnp_hip_alloc(w_bytes);
-  op->d_bias = (int32_t*) qnnp_hip_alloc(b_bytes);
+  op->d_bias = qnnp_upload_bias_pair((const int32_t*) host_bias, (size_t) groups * n_pad);   /* bias-pair.h */
   if (op->d_weights == NULL || op->d_bias == NULL ||
-      qnnp_hip_h2d(op->d_weights, host_weights, w_bytes, 0) != QNNP_HIP_OK ||
-      qnnp_hip_h2d(op->d_bias, host_bias, b_bytes, 0) != QNNP_HIP_OK) {
+      qnnp_hip_h2d(op->d_weights, host_weights, w_bytes, 0) != QNNP_HIP_OK) {
     qnnp_log_error("failed to place %zu bytes of packed weights on the device", w_bytes + b_bytes);
     goto error;
   }

@@ -18,6 +18,7 @@
 #include "hip/qnnp_hip.h"
 #include "log.h"
 #include "operator.h"
+#include "bias-pair.h"
 #include "pack.h"
 #include "requantization.h"
 #include "state.h"
@@ -117,11 +118,10 @@ static enum qnnp_status qnnp_create_fully_connected_nc_q8_impl(
   op->k_pad = k_pad;
   op->kc_slot = (uint32_t) input_channels;
   op->d_weights = qnnp_hip_alloc(w_bytes);
-  op->d_bias = (int32_t*) qnnp_hip_alloc(b_bytes);
+  op->d_bias = qnnp_upload_bias_pair(host_bias, n_pad);      /* bias-pair.h */
   if (op->d_weights == NULL || op->d_bias == NULL ||
-      qnnp_hip_h2d(op->d_weights, host_weights, w_bytes, 0) != QNNP_HIP_OK ||
-      qnnp_hip_h2d(op->d_bias, host_bias, b_bytes, 0) != QNNP_HIP_OK) {
-    qnnp_log_error("failed to place %zu bytes of packed weights on the device", w_bytes + b_bytes);
+      qnnp_hip_h2d(op->d_weights, host_weights, w_bytes, 0) != QNNP_HIP_OK) {
+    qnnp_log_error("failed to place %zu bytes of packed weights on the device", w_bytes + 2 * b_bytes);
     goto error;
   }
   free(host_weights);

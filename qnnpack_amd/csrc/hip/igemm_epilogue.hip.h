@@ -69,6 +69,8 @@ __device__ __forceinline__ void igemm_store_tile(
       }
     }
   }
+  // (the store code is spelled out here and not shared with igemm_store_pk4 on purpose: the generic byte-gather kernels
+  //  that end in this function run at the register limit, and their code must not move when the lane forms change)
   if (p.store_mode == 2) {
     // before: lane l      : pk[rg] = channels 8rg + 0..3     lane l+32: channels 8rg + 4..7
     // after : lane l      : {pk0, pk2, pk1, pk3} = channels 0..15
@@ -95,6 +97,55 @@ __device__ __forceinline__ void igemm_store_tile(
       }
     }
   }
+}
+
+/* the four packed dwords of a lane's 32 x 32 tile row (pk[rg] = channels ncol0 + 8 rg + 4 khalf .. + 3) -> global */
+__device__ __forceinline__ void igemm_store_pk4(
+    const uint32_t (&pk)[4], uint8_t* out_row, uint32_t ncol0, uint32_t khalf, bool row_ok, const IgemmParams& p)
+{
+  if (p.store_mode == 2) {
+    // before: lane l      : pk[rg] = channels 8rg + 0..3     lane l+32: channels 8rg + 4..7
+    // after : lane l      : {pk0, pk2, pk1, pk3} = channels 0..15
+    //         lane l + 32 : {pk0, pk2, pk1, pk3} = channels 16..31
+    const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+    const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+    const uint32_t c = ncol0 + khalf * 16;
+    if (row_ok && c < p.n) {
+      *reinterpret_cast<uint4*>(out_row + c) = make_uint4(s02[0], s02[1], s13[0], s13[1]);
+    }
+  } else {
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const uint32_t c = ncol0 + rg * 8 + khalf * 4;
+      if (row_ok && c < p.n) {
+        if (p.store_mode == 1) {
+          *reinterpret_cast<uint32_t*>(out_row + c) = pk[rg];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (c + j < p.n) out_row[c + j] = static_cast<uint8_t>(pk[rg] >> (8 * j));
+          }
+        }
+      }
+    }
+  }
+}
+
+/* The same for the lane forms of the requantization (requant.hip.h): the accumulators started from the bias table
+ * that carries 2^31, `addend` = lane_addend(row term of this lane's row). */
+template <int SEQ, bool FULL_RANGE>
+__device__ __forceinline__ void igemm_store_tile_lane(
+    const epi_v16i& acc, uint64_t addend, uint8_t* out_row, uint32_t ncol0, uint32_t khalf, bool row_ok,
+    const IgemmParams& p)
+{
+  uint32_t pk[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) {
+    pk[rg] = q31_requantize_pack4_lane<SEQ, FULL_RANGE>(
+        static_cast<uint32_t>(acc[rg * 4 + 0]), static_cast<uint32_t>(acc[rg * 4 + 1]),
+        static_cast<uint32_t>(acc[rg * 4 + 2]), static_cast<uint32_t>(acc[rg * 4 + 3]), addend, p.lane, p.rq);
+  }
+  igemm_store_pk4(pk, out_row, ncol0, khalf, row_ok, p);
 }
 
 /*
@@ -130,6 +181,27 @@ __device__ __forceinline__ void igemm_stage_tile_rq(
     } else {
       pk[rg] = q31_requantize_pack4<SHIFT0, FULL_RANGE>(v0, v1, v2, v3, rq);
     }
+  }
+  const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+  const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+  if (write_ok) {
+    *reinterpret_cast<uint4*>(lds_row + col0 + khalf * 16) = make_uint4(s02[0], s02[1], s13[0], s13[1]);
+  }
+}
+
+/* The same for the lane forms of the requantization (requant.hip.h): the accumulators started from the bias table
+ * that carries 2^31, `addend` = lane_addend(row term of this lane's row). */
+template <int SEQ, bool FULL_RANGE>
+__device__ __forceinline__ void igemm_stage_tile_lane(
+    const epi_v16i& acc, uint64_t addend, uint8_t* lds_row, uint32_t col0, uint32_t khalf, const IgemmParams& p,
+    bool write_ok = true)
+{
+  uint32_t pk[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) {
+    pk[rg] = q31_requantize_pack4_lane<SEQ, FULL_RANGE>(
+        static_cast<uint32_t>(acc[rg * 4 + 0]), static_cast<uint32_t>(acc[rg * 4 + 1]),
+        static_cast<uint32_t>(acc[rg * 4 + 2]), static_cast<uint32_t>(acc[rg * 4 + 3]), addend, p.lane, p.rq);
   }
   const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
   const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);

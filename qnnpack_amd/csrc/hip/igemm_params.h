@@ -77,6 +77,9 @@ struct IgemmParams {
   const uint8_t* residual;
   uint32_t residual_stride;
   qnnp_hip_add_params add;
+  // lane forms of the requantization (requant.hip.h; the kernels instantiated for kRqShift0Lane / kRqBoundedLane only)
+  qnnp_requant_lane lane;
+  const int32_t* bias2u;     // bias2 + 2^31, laid out like bias2 (bias-pair.h), or NULL (then lane.kind == 0)
 };
 
 /* convolution geometry for the LDS-tiled direct-convolution kernel */

@@ -977,7 +977,8 @@ void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArg
     const uint8_t* src = reinterpret_cast<const uint8_t*>(p.packed_w) + lane * 16u;
     for (uint32_t i = wave; i < pieces; i += kWsWaves) dma16(src + i * 1024u, w_lds + i * 1024u);
     if (wave == kWsWaves - 1 && lane < p.n / 4u) {
-      dma16(reinterpret_cast<const uint8_t*>(p.bias2) + lane * 16u, reinterpret_cast<uint8_t*>(bias_lds));
+      // (lane forms of the requantization: bias + 2^31, the second half of the pair table)
+      dma16(reinterpret_cast<const uint8_t*>(rq_is_lane<SEQ>() ? p.bias2u : p.bias2) + lane * 16u, reinterpret_cast<uint8_t*>(bias_lds));
     }
   }
   fix_up(raw, here);                                // needs the patch only
@@ -1070,14 +1071,22 @@ void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArg
 #pragma unroll
       for (int t = 0; t < 9; t++) s += pq[((t / 3) * 10 + (t % 3)) * cpp];
       const int32_t rowterm = with_rq_offset<SEQ>(p.row_coeff * s);
+      uint64_t row_addend = 0;                       // lane forms: the row term rides in the multiply-add's addend
+      if constexpr (rq_is_lane<SEQ>()) row_addend = lane_addend(rowterm, p.lane);
 #pragma unroll
       for (int tn = 0; tn < TN; tn++) {
         uint32_t pk[4];
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
-          pk[rg] = q31_requantize_pack4<SEQ, FULL, false>(
-              add_wrap(acc[tn][rg * 4 + 0], rowterm), add_wrap(acc[tn][rg * 4 + 1], rowterm),
-              add_wrap(acc[tn][rg * 4 + 2], rowterm), add_wrap(acc[tn][rg * 4 + 3], rowterm), p.rq);
+          if constexpr (rq_is_lane<SEQ>()) {
+            pk[rg] = q31_requantize_pack4_lane<SEQ, FULL>(
+                static_cast<uint32_t>(acc[tn][rg * 4 + 0]), static_cast<uint32_t>(acc[tn][rg * 4 + 1]),
+                static_cast<uint32_t>(acc[tn][rg * 4 + 2]), static_cast<uint32_t>(acc[tn][rg * 4 + 3]), row_addend, p.lane, p.rq);
+          } else {
+            pk[rg] = q31_requantize_pack4<SEQ, FULL, false>(
+                add_wrap(acc[tn][rg * 4 + 0], rowterm), add_wrap(acc[tn][rg * 4 + 1], rowterm),
+                add_wrap(acc[tn][rg * 4 + 2], rowterm), add_wrap(acc[tn][rg * 4 + 3], rowterm), p.rq);
+          }
         }
         const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
         const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
@@ -1125,7 +1134,7 @@ template <int TN, int CB>
 int launch_ws(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hipStream_t stream)
 {
   int rc = QNNP_HIP_EINVAL;
-  requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+  requant_dispatch_lane(p.rq, p.lane, [&](auto seq, auto full) {
     rc = launch_ws_as<TN, CB, decltype(seq)::value, decltype(full)::value>(p, g, a, stream);
   });
   return rc;

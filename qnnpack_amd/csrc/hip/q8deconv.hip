@@ -61,6 +61,7 @@ struct DeconvParams {
   uint32_t store_mode;
   const uint8_t* fill;         // 16 bytes of the input zero point
   RequantDev rq;
+  qnnp_requant_lane lane;      // lane forms of the requantization (requant.hip.h)
 };
 
 constexpr int taps_of(int k, int phase) { return (k - phase + 1) / 2; }     // taps ky = phase, phase + 2, ... < k
@@ -93,15 +94,18 @@ void q8_deconv_s2_stream_kernel(const DeconvParams p)
           (__attribute__((address_space(3))) void*) (lds + p.lds_w[ph] + f * 1024), 16, 0, 0);
     }
     const uint32_t bias_chunks = p.n_pad / 4;
+    // (lane forms of the requantization: bias + 2^31, the second half of the phase's pair table)
+    const int32_t* bias_src = p.bias[ph] + (rq_is_lane<SEQ>() ? p.n_pad : 0u);
     for (uint32_t c0 = wave * 64; c0 < bias_chunks; c0 += kThreads) {
       const uint32_t c = min(c0 + lane, bias_chunks - 1);
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(p.bias[ph]) + c * 16),
+          (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(bias_src) + c * 16),
           (__attribute__((address_space(3))) void*) (lds + p.lds_bias + ph * p.n_pad * 4 + c0 * 16), 16, 0, 0);
     }
   }
 
   IgemmParams sp{};                         // what igemm_store_tile reads
+  sp.lane = p.lane;
   sp.rq = p.rq;
   sp.n = p.n;
   sp.store_mode = p.store_mode;
@@ -189,6 +193,8 @@ void q8_deconv_s2_stream_kernel(const DeconvParams p)
             if (j < ny && i < nx) sum += rs[j][i];
         const int32_t rowterm = with_rq_offset<SEQ>(
             p.row_coeff * static_cast<int32_t>(sum - 128u * 32u * static_cast<uint32_t>(CB * ny * nx)));
+        uint64_t row_addend = 0;                 // lane forms: the row term rides in the multiply-add's addend
+        if constexpr (rq_is_lane<SEQ>()) row_addend = lane_addend(rowterm, p.lane);
         const uint8_t* wf = lds + p.lds_w[ph] + lane * 16;
         const int4* bias4p = reinterpret_cast<const int4*>(lds + p.lds_bias + ph * p.n_pad * 4);
         for (uint32_t nb = 0; nb < nblocks; nb++) {
@@ -218,7 +224,11 @@ void q8_deconv_s2_stream_kernel(const DeconvParams p)
               }
             }
           }
-          igemm_store_tile<SEQ, FULL, false, 2>(acc, bias4, rowterm, out_row, nb * 32, khalf, ok, sp);
+          if constexpr (rq_is_lane<SEQ>()) {
+            igemm_store_tile_lane<SEQ, FULL>(acc, row_addend, out_row, nb * 32, khalf, ok, sp);
+          } else {
+            igemm_store_tile<SEQ, FULL, false, 2>(acc, bias4, rowterm, out_row, nb * 32, khalf, ok, sp);
+          }
           __builtin_amdgcn_sched_barrier(0);              // (one accumulator tile alive at a time: the other waves of the SIMD fill the gaps)
         }
       }
@@ -251,7 +261,7 @@ template <int CB, int KH, int KW>
 int launch_as(const DeconvParams& p, uint32_t lds_bytes, hipStream_t stream)
 {
   int rc = QNNP_HIP_EINVAL;
-  requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+  requant_dispatch_lane(p.rq, p.lane, [&](auto seq, auto full) {
     rc = launch_flavour<CB, KH, KW, decltype(seq)::value, decltype(full)::value>(p, lds_bytes, stream);
   });
   return rc;
@@ -329,6 +339,8 @@ extern "C" int qnnp_hip_deconv_s2_run(const struct qnnp_hip_deconv_s2_args* a, c
   if (table == nullptr) return QNNP_HIP_EINVAL;
   p.fill = table + (a->input_zero_point & 0xFFu) * 16u;
   p.rq = make_requant_dev(a->rq);
+  p.lane = make_requant_lane(a->rq);
+  if (a->bias2_pair == 0) p.lane.kind = 0;      // no pair tables to start from: the offset forms
   hipStream_t stream = reinterpret_cast<hipStream_t>(qnnp_hip_get_stream());
   if (kernel_name != nullptr) *kernel_name = k33 ? "q8_deconv_s2_stream_3x3" : "q8_deconv_s2_stream_4x4";
   return k33 ? launch_cb<3, 3>(p, cb, lds, stream) : launch_cb<4, 4>(p, cb, lds, stream);

@@ -530,6 +530,9 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   p.izp_fill = pad3 ? ((a->input_zero_point & 0xFFu) * 0x00010101u) | 0x80000000u
                     : (a->input_zero_point & 0xFFu) * 0x01010101u;
   p.rq = qnnp::make_requant_dev(a->rq);
+  p.lane = qnnp::make_requant_lane(a->rq);
+  p.bias2u = a->bias2_pair != 0 ? a->bias2 + static_cast<size_t>(a->groups) * a->n_pad : nullptr;
+  if (p.bias2u == nullptr) p.lane.kind = 0;      // no table to start from: the offset forms
   p.fill_table = qnnp_hip_fill_table();
   p.trace = nullptr;
 #ifdef QNNP_ENABLE_ABLATION

@@ -357,10 +357,12 @@ void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const u
     }
     uint8_t* lds_bias = lds + nbp * KB * 1024;
     const uint32_t bias_chunks = nbn * 8u;                // 16-byte pieces
+    // (lane forms of the requantization: the accumulators start from bias + 2^31, the second half of the pair table)
+    const int32_t* bias_src = rq_is_lane<SEQ>() ? p.bias2u : p.bias2;
     for (uint32_t q0 = wave * 64; q0 < bias_chunks; q0 += kThreads) {
       const uint32_t q = min(q0 + lane, bias_chunks - 1); // the tail lanes repeat the last piece (same bytes)
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(p.bias2 + c0) + q * 16),
+          (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(bias_src + c0) + q * 16),
           (__attribute__((address_space(3))) void*) (lds_bias + q0 * 16), 16, 0, 0);
     }
   }
@@ -439,6 +441,8 @@ void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const u
       load_rows(min(next, units - 1u), raw);              // always issued (the last one of a wave is wasted)
       // (+ 2^31 for the offset rounding sequences, requant.hip.h: the accumulators start from bias + this)
       const int32_t rowterm = with_rq_offset<decltype(shift0)::value>(p.row_coeff * static_cast<int32_t>(rs - raw_to_centred));
+      uint64_t row_addend = 0;                              // lane forms: the row term as the multiply-add's addend
+      if constexpr (rq_is_lane<SEQ>()) row_addend = lane_addend(rowterm, p.lane);
       uint8_t* img = stage + row_in_block * pitch;
       for (uint32_t nb = 0; nb < nbn; nb++) {
         v16i acc;
@@ -458,8 +462,12 @@ void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const u
           acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a[kb], acc, 0, 0, 0);
         }
         // (every lane takes part in the half-wave exchange inside; a lane's 16 channels exist or not)
-        igemm_stage_tile<decltype(shift0)::value, decltype(full)::value, false, 2>(
-            acc, bias4, rowterm, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < cw);
+        if constexpr (rq_is_lane<SEQ>()) {
+          igemm_stage_tile_lane<SEQ, FULL>(acc, row_addend, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < cw);
+        } else {
+          igemm_stage_tile<decltype(shift0)::value, decltype(full)::value, false, 2>(
+              acc, bias4, rowterm, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < cw);
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
       // the next unit's rows: first use here, so the wait for them lands before this unit's stores
@@ -521,10 +529,11 @@ void q8_pw_stream_longk_kernel(const IgemmParams p, const uint32_t nbp, const ui
     }
     uint8_t* lds_bias = lds + nbp * kbn * 1024;
     const uint32_t bias_chunks = nbn * 8u;
+    const int32_t* bias_src = rq_is_lane<SEQ>() ? p.bias2u : p.bias2;   // (lane forms: bias + 2^31, the pair table's second half)
     for (uint32_t q0 = wave * 64; q0 < bias_chunks; q0 += kThreads) {
       const uint32_t q = min(q0 + lane, bias_chunks - 1);
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(p.bias2 + c0) + q * 16),
+          (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(bias_src + c0) + q * 16),
           (__attribute__((address_space(3))) void*) (lds_bias + q0 * 16), 16, 0, 0);
     }
   }
@@ -582,6 +591,8 @@ void q8_pw_stream_longk_kernel(const IgemmParams p, const uint32_t nbp, const ui
   for (;;) {
     const uint32_t rs = recentre(a);
     const int32_t rowterm = with_rq_offset<SEQ>(p.row_coeff * static_cast<int32_t>(rs - raw_to_centred));
+    uint64_t row_addend = 0;
+    if constexpr (rq_is_lane<SEQ>()) row_addend = lane_addend(rowterm, p.lane);
     uint8_t* img = stage + row_in_block * pitch;
     for (uint32_t nb = 0; nb < nbn; nb++) {
       v16i acc;
@@ -602,7 +613,11 @@ void q8_pw_stream_longk_kernel(const IgemmParams p, const uint32_t nbp, const ui
           acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a[kb], acc, 0, 0, 0);
         }
       }
-      igemm_stage_tile<SEQ, FULL, false, 2>(acc, bias4, rowterm, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < cw);
+      if constexpr (rq_is_lane<SEQ>()) {
+        igemm_stage_tile_lane<SEQ, FULL>(acc, row_addend, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < cw);
+      } else {
+        igemm_stage_tile<SEQ, FULL, false, 2>(acc, bias4, rowterm, img, nb * 32, khalf, p, nb * 32 + khalf * 16 < cw);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
     stream_copy_out<RES>(stage, whole_dense, log_cpr, unit, c0, cw, p, lane);
@@ -1303,7 +1318,7 @@ template <int KB, int VEC>
 int launch_pw_staged(const IgemmParams& p, const StagedPlan& plan, hipStream_t stream)
 {
   int rc = QNNP_HIP_EINVAL;
-  requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+  requant_dispatch_lane(p.rq, p.lane, [&](auto seq, auto full) {
     rc = launch_pw_staged_as<KB, VEC, decltype(seq)::value, decltype(full)::value>(p, plan, stream);
   });
   return rc;
@@ -1397,7 +1412,7 @@ template <int KBMAX>
 int launch_longk(const IgemmParams& p, const StagedPlan& plan, hipStream_t stream)
 {
   int rc = QNNP_HIP_EINVAL;
-  requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+  requant_dispatch_lane(p.rq, p.lane, [&](auto seq, auto full) {
     rc = launch_longk_as<KBMAX, decltype(seq)::value, decltype(full)::value>(p, plan, stream);
   });
   return rc;

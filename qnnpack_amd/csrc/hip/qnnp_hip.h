@@ -179,6 +179,10 @@ struct qnnp_hip_igemm_args {
   uint32_t residual_stride;   /* bytes between residual pixels */
   const struct qnnp_hip_add_params* residual_add;
   uint32_t* residual_folded;
+  /* 1: `bias2` is a pair table (bias-pair.h) -- groups * n_pad values followed by the same values + 2^31, which the
+   * kernels that use the lane forms of the requantization start their accumulators from. 0: those kernels keep the
+   * offset forms. */
+  uint32_t bias2_pair;
 };
 int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* args, const char** kernel_name);
 
@@ -201,6 +205,7 @@ struct qnnp_hip_deconv_s2_args {
   int32_t row_coeff;          /* 128 - kernel_zero_point */
   uint32_t input_zero_point;
   struct qnnp_hip_requant rq;
+  uint32_t bias2_pair;        /* 1: every bias2[ph] is a pair table (bias-pair.h): n_pad values, then the same + 2^31 */
 };
 int qnnp_hip_deconv_s2_run(const struct qnnp_hip_deconv_s2_args* args, const char** kernel_name);
 

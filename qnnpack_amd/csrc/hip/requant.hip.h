@@ -88,6 +88,21 @@ constexpr int kRqBounded = 2;    // shift >= 1, accumulators bounded at create t
  * Only kernels that call requant_dispatch_ofs see them. */
 constexpr int kRqShift0Ofs = 3;
 constexpr int kRqBoundedOfs = 4;
+/* lane forms (requant_math.h, qnnp_requant_lane_*): the kernel hands over a + 2^31 where a = bias + dot product -- its
+ * accumulators start from a bias table that carries the 2^31 -- and the row term rides in a per-lane 64-bit addend of
+ * the multiply-add (lane_addend below, once per row block): no add per output value at all. Only kernels that call
+ * requant_dispatch_lane see them. */
+constexpr int kRqShift0Lane = 5;
+constexpr int kRqBoundedLane = 6;
+template <int SEQ> constexpr bool rq_is_lane() { return SEQ == kRqShift0Lane || SEQ == kRqBoundedLane; }
+
+inline qnnp_requant_lane make_requant_lane(const qnnp_hip_requant& rq)
+{
+  qnnp_requant_fast f = qnnp_requant_fast_init(rq.multiplier, rq.shift);
+  const int folded = qnnp_requant_fast_fold_zero_point(&f, static_cast<uint32_t>(rq.output_zero_point));
+  (void) qnnp_requant_fast_enable_bounded(&f, static_cast<uint32_t>(rq.output_zero_point), folded, rq.accumulator_bits);
+  return qnnp_requant_lane_init(f, static_cast<uint32_t>(rq.output_zero_point), folded, rq.accumulator_bits);
+}
 
 /* Two's-complement add. Accumulators that carry the 2^31 offset wrap around BY DESIGN, and a plain signed + lets the
  * compiler assume they do not: it turned bias + INT32_MIN into bias | 0x80000000 (right only for bias >= 0). Every
@@ -122,6 +137,30 @@ __device__ __forceinline__ int32_t with_rq_offset(int32_t x)
 __device__ __forceinline__ uint32_t requant_mad_hi(uint32_t np, uint32_t mult_v, uint64_t addend)
 {
   return static_cast<uint32_t>((static_cast<uint64_t>(np) * mult_v + addend) >> 32);
+}
+
+/* four scaled values -> clamp -> four bytes of one dword (channel c at byte c) */
+template <bool FULL_RANGE>
+__device__ __forceinline__ uint32_t clamp_pack4(int32_t y0, int32_t y1, int32_t y2, int32_t y3, const RequantDev& rq)
+{
+  if constexpr (FULL_RANGE) {
+    // the y's already carry the zero point; clamp to [0, 255] == saturation, two values per instruction:
+    //   i32 -> i16 (signed saturation) -> u8 (unsigned saturation).
+    // The first saturation cannot change the result: +-32767 still lands outside [0, 255] on the correct side.
+    const auto p01 = __builtin_amdgcn_cvt_pk_i16(y0, y1);
+    const auto p23 = __builtin_amdgcn_cvt_pk_i16(y2, y3);
+    uint32_t lo, hi;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(lo) : "v"(p01));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(hi) : "v"(p23));
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);   // {lo.b0, lo.b1, hi.b0, hi.b1}
+  } else {
+    y0 = clamp_med3(y0, rq.qmin, rq.qmax) + rq.zp_late;
+    y1 = clamp_med3(y1, rq.qmin, rq.qmax) + rq.zp_late;
+    y2 = clamp_med3(y2, rq.qmin, rq.qmax) + rq.zp_late;
+    y3 = clamp_med3(y3, rq.qmin, rq.qmax) + rq.zp_late;
+    return static_cast<uint32_t>(y0) | (static_cast<uint32_t>(y1) << 8) | (static_cast<uint32_t>(y2) << 16) |
+           (static_cast<uint32_t>(y3) << 24);
+  }
 }
 
 /* VMULT = false: leave the operand placement to the compiler (the wave-per-block 3x3 convolution measured 25.3 -> 26.6
@@ -159,24 +198,35 @@ __device__ __forceinline__ uint32_t q31_requantize_pack4(
     y0 = qnnp_requant_scale_sn(n0, rq.f); y1 = qnnp_requant_scale_sn(n1, rq.f);
     y2 = qnnp_requant_scale_sn(n2, rq.f); y3 = qnnp_requant_scale_sn(n3, rq.f);
   }
-  if constexpr (FULL_RANGE) {
-    // the y's already carry the zero point; clamp to [0, 255] == saturation, two values per instruction:
-    //   i32 -> i16 (signed saturation) -> u8 (unsigned saturation).
-    // The first saturation cannot change the result: +-32767 still lands outside [0, 255] on the correct side.
-    const auto p01 = __builtin_amdgcn_cvt_pk_i16(y0, y1);
-    const auto p23 = __builtin_amdgcn_cvt_pk_i16(y2, y3);
-    uint32_t lo, hi;
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(lo) : "v"(p01));
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(hi) : "v"(p23));
-    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);   // {lo.b0, lo.b1, hi.b0, hi.b1}
-  } else {
-    y0 = clamp_med3(y0, rq.qmin, rq.qmax) + rq.zp_late;
-    y1 = clamp_med3(y1, rq.qmin, rq.qmax) + rq.zp_late;
-    y2 = clamp_med3(y2, rq.qmin, rq.qmax) + rq.zp_late;
-    y3 = clamp_med3(y3, rq.qmin, rq.qmax) + rq.zp_late;
-    return static_cast<uint32_t>(y0) | (static_cast<uint32_t>(y1) << 8) | (static_cast<uint32_t>(y2) << 16) |
-           (static_cast<uint32_t>(y3) << 24);
+  return clamp_pack4<FULL_RANGE>(y0, y1, y2, y3, rq);
+}
+
+/* L of this lane's row (requant_math.h): once per row block */
+__device__ __forceinline__ uint64_t lane_addend(int32_t rowterm, const qnnp_requant_lane& l)
+{
+  return static_cast<uint64_t>(static_cast<uint32_t>(rowterm) + 0x80000000u) * l.mult2 + l.konst;
+}
+
+/* u = a + 2^31 for four channels of one row; `addend` = lane_addend of that row. The multiplier stays the scalar
+ * operand of the multiply-add (one per VOP3 instruction on gfx9), the addend is the lane's register pair. */
+template <int SEQ, bool FULL_RANGE>
+__device__ __forceinline__ uint32_t q31_requantize_pack4_lane(
+    uint32_t u0, uint32_t u1, uint32_t u2, uint32_t u3, uint64_t addend, const qnnp_requant_lane& l, const RequantDev& rq)
+{
+  static_assert(rq_is_lane<SEQ>(), "lane forms only");
+  const uint32_t m2 = l.mult2;
+  int32_t y0 = static_cast<int32_t>(static_cast<uint32_t>((static_cast<uint64_t>(u0) * m2 + addend) >> 32));
+  int32_t y1 = static_cast<int32_t>(static_cast<uint32_t>((static_cast<uint64_t>(u1) * m2 + addend) >> 32));
+  int32_t y2 = static_cast<int32_t>(static_cast<uint32_t>((static_cast<uint64_t>(u2) * m2 + addend) >> 32));
+  int32_t y3 = static_cast<int32_t>(static_cast<uint32_t>((static_cast<uint64_t>(u3) * m2 + addend) >> 32));
+  if constexpr (SEQ == kRqBoundedLane) {
+    const uint32_t k1 = l.k1, sh = l.shift;
+    y0 = qnnp_asr32(static_cast<int32_t>(static_cast<uint32_t>(y0) + static_cast<uint32_t>(qnnp_asr32(y0, 31)) + k1), sh);
+    y1 = qnnp_asr32(static_cast<int32_t>(static_cast<uint32_t>(y1) + static_cast<uint32_t>(qnnp_asr32(y1, 31)) + k1), sh);
+    y2 = qnnp_asr32(static_cast<int32_t>(static_cast<uint32_t>(y2) + static_cast<uint32_t>(qnnp_asr32(y2, 31)) + k1), sh);
+    y3 = qnnp_asr32(static_cast<int32_t>(static_cast<uint32_t>(y3) + static_cast<uint32_t>(qnnp_asr32(y3, 31)) + k1), sh);
   }
+  return clamp_pack4<FULL_RANGE>(y0, y1, y2, y3, rq);
 }
 
 /* Calls f(shift0_tag, full_range_tag) with the compile-time tags matching `rq` (one uniform branch tree). */
@@ -206,6 +256,26 @@ __host__ __device__ __forceinline__ void requant_dispatch_ofs(const RequantDev& 
     if (rq.full_range) f(Shift0Ofs{}, std::true_type{}); else f(Shift0Ofs{}, std::false_type{});
   } else if (rq.f.bounded && rq.full_range) {
     f(BoundedOfs{}, std::true_type{});
+  } else {
+    if (rq.full_range) f(General{}, std::true_type{}); else f(General{}, std::false_type{});
+  }
+}
+
+/* The same for kernels that implement the lane forms (host side: picks the kernel instantiation). The shift-0 corner
+ * whose zero point cannot be folded (the single largest multiplier) keeps the offset form. */
+template <typename F>
+__host__ __device__ __forceinline__ void requant_dispatch_lane(const RequantDev& rq, const qnnp_requant_lane& lane, F&& f)
+{
+  using Shift0Lane = std::integral_constant<int, kRqShift0Lane>;
+  using BoundedLane = std::integral_constant<int, kRqBoundedLane>;
+  using Shift0Ofs = std::integral_constant<int, kRqShift0Ofs>;
+  using General = std::integral_constant<int, kRqGeneral>;
+  if (lane.kind == 1) {
+    if (rq.full_range) f(Shift0Lane{}, std::true_type{}); else f(Shift0Lane{}, std::false_type{});
+  } else if (lane.kind == 2 && rq.full_range) {
+    f(BoundedLane{}, std::true_type{});
+  } else if (rq.f.shift == 0) {
+    if (rq.full_range) f(Shift0Ofs{}, std::true_type{}); else f(Shift0Ofs{}, std::false_type{});
   } else {
     if (rq.full_range) f(General{}, std::true_type{}); else f(General{}, std::false_type{});
   }

@@ -194,6 +194,76 @@ QNNP_HD int32_t qnnp_requant_scale_sn_bounded_ofs(uint32_t np, const struct qnnp
   return qnnp_asr32(r1 + (int32_t) (np >> 31), f.shift);
 }
 
+/*
+ * Lane forms (round 3). The accumulator of the MFMA kernels is n = a + rowterm, with a = bias + dot product (what the
+ * matrix cores deliver when they start from the bias) and rowterm = the kernel-zero-point term of the output ROW -- one
+ * value per lane in the MFMA layout. The forms above need n itself, i.e. one add per output value; these do not:
+ *     u = a + 2^31 (mod 2^32)      -- the bias the accumulators start from carries the 2^31, nothing per value
+ *     t = u * 2M + L               -- one unsigned 32x32+64 multiply-add per value
+ *     L = (rowterm + 2^31) * 2M + K   per lane and row block (one multiply-add), K = 2^31 + Z * 2^32 - 2^33 * M
+ * so that t == n * 2M + 2^31 + Z * 2^32 (mod 2^64): high32(t) = floor((n*M + 2^30) / 2^31) + Z = q + Z, the Q31
+ * product (|q| <= |n| always fits).
+ *     shift == 0 (kind 1, Z = zero point): y = high32(t), nothing else.
+ *     shift >= 1 (kind 2, Z = 0):          y = (q + (q >>arith 31) + 2^(s-1) + zp * 2^s) >>arith s
+ * The second line takes the sign of the rounding correction from q instead of n: the normative (n < 0) and (q < 0)
+ * differ only for n < 0 with q == 0 (products in [-1/2, 0)), and at q == 0 the correction cannot change the result
+ * ((2^(s-1) - 1) >> s == 2^(s-1) >> s == 0). Needs q + 2^(s-1) + zp * 2^s within 32 bits: the bounded form's
+ * preconditions (|n| < 2^30, s <= 20). Three instructions after the multiply-add like the bounded offset form -- the
+ * saving is the add that made n. Both kinds need a itself inside int32 (not only n): operators with accumulators
+ * bounded at create time. Kind 0: not applicable (the caller keeps its other sequence).
+ */
+struct qnnp_requant_lane {
+  uint64_t konst;      /* K */
+  uint32_t mult2;      /* 2M */
+  uint32_t k1;         /* 2^(s-1) + zp * 2^s   (kind 2) */
+  uint32_t shift;
+  uint32_t kind;
+};
+
+QNNP_HD struct qnnp_requant_lane qnnp_requant_lane_init(const struct qnnp_requant_fast f, uint32_t zero_point, int zero_point_folded,
+                                                         uint32_t accumulator_bits)
+{
+  struct qnnp_requant_lane l;
+  const uint64_t m = (uint64_t) (uint32_t) f.multiplier;
+  l.mult2 = (uint32_t) (m << 1);
+  l.shift = f.shift;
+  l.k1 = 0;
+  l.kind = 0;
+  l.konst = 0;
+  /* both kinds need a = n - rowterm inside int32 (u is a + 2^31 reduced mod 2^32): guaranteed when the operator's
+   * accumulators are bounded at create time (|n| < 2^30 with the reduction length that bound implies, K < 2^14, so
+   * |rowterm| <= 2^14 * K < 2^28); without a bound the caller keeps the forms that only need n itself */
+  const int bounded_acc = accumulator_bits >= 1 && accumulator_bits <= 30;
+  if (f.shift == 0 && zero_point_folded && bounded_acc) {
+    l.kind = 1;
+    l.konst = (UINT64_C(1) << 31) + ((uint64_t) zero_point << 32) - (m << 33);
+  } else if (f.shift >= 1 && f.bounded) {
+    l.kind = 2;
+    l.konst = (UINT64_C(1) << 31) - (m << 33);
+    l.k1 = (UINT32_C(1) << (f.shift - 1)) + (zero_point << f.shift);
+  }
+  return l;
+}
+
+/* L of a lane: rowterm is the row's kernel-zero-point term (any int32) */
+QNNP_HD uint64_t qnnp_requant_lane_addend(int32_t rowterm, const struct qnnp_requant_lane l)
+{
+  return (uint64_t) ((uint32_t) rowterm + UINT32_C(0x80000000)) * (uint64_t) l.mult2 + l.konst;
+}
+
+/* u = a + 2^31 (mod 2^32); returns y (zero point included), before the clamp */
+QNNP_HD int32_t qnnp_requant_lane_s0(uint32_t u, uint64_t addend, const struct qnnp_requant_lane l)
+{
+  return (int32_t) (uint32_t) (((uint64_t) u * (uint64_t) l.mult2 + addend) >> 32);
+}
+
+QNNP_HD int32_t qnnp_requant_lane_sn(uint32_t u, uint64_t addend, const struct qnnp_requant_lane l)
+{
+  const int32_t q = (int32_t) (uint32_t) (((uint64_t) u * (uint64_t) l.mult2 + addend) >> 32);
+  const uint32_t v = (uint32_t) q + (uint32_t) qnnp_asr32(q, 31) + l.k1;
+  return qnnp_asr32((int32_t) v, l.shift);
+}
+
 QNNP_HD int32_t qnnp_requant_scale(int32_t n, const struct qnnp_requant_fast f)
 {
   if (f.shift == 0) return qnnp_requant_scale_s0(n, f);

@@ -116,6 +116,7 @@ static int launch_kernel(struct qnnp_operator* op, const void* input, const void
           .output = (uint8_t*) output,
           .packed_w = (const int8_t*) op->d_weights,
           .bias2 = op->d_bias,
+          .bias2_pair = 1,
           .offsets = NULL,
           .rows = (uint32_t) (op->batch_size * op->input_height * op->input_width),
           .rows_per_image = (uint32_t) (op->input_height * op->input_width),
@@ -170,6 +171,7 @@ static int launch_kernel(struct qnnp_operator* op, const void* input, const void
           .row_coeff = 128 - (int32_t) op->kernel_zero_point,
           .input_zero_point = op->input_zero_point,
           .rq = op->requant,
+          .bias2_pair = 1,
         };
         for (int ph = 0; ph < 4; ph++) {
           sargs.packed_w[ph] = (const int8_t*) op->phase[ph].d_weights;
@@ -224,6 +226,7 @@ static int launch_kernel(struct qnnp_operator* op, const void* input, const void
         .packed_w = (const int8_t*) op->d_weights,
         .packed_w_rows16 = is_conv ? (const int8_t*) op->d_weights_rows16 : NULL,
         .bias2 = op->d_bias,
+        .bias2_pair = 1,
         .offsets = is_conv ? op->d_offsets : NULL,
         .rows = (uint32_t) op->batch_size * output_size,
         .rows_per_image = output_size,

@@ -8,7 +8,8 @@ import json,sys
 d=json.loads(open(sys.argv[1]).read())
 e=d["extra"]; s=e["mobilenetv2_sweep"]
 print({k:d[k] for k in ("value",)}, d["roofline"]["sustained_launch_ms"], "conv3x3", e["q8conv_3x3_56x56x64_b128"]["ms"], "dw", e["q8dwconv_mobilenetv2_layers"]["ms"],
-      "sweep", s["images_per_s"], "net", e["mobilenetv2_network"]["images_per_s"])
+      "sweep", s["images_per_s"], "net", e["mobilenetv2_network"]["images_per_s"], "folded", e.get("mobilenetv2_network_adds_folded", {}).get("images_per_s"),
+      "deconv3x3s2", e.get("next_rows", {}).get("q8deconv_3x3s2_28x28x64_32", {}).get("ms"))
 print(" ".join(f"{r['layer']}:{r['ms']*1000:.1f}" for r in s["layers"]))
 PY
 }

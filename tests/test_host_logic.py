@@ -199,6 +199,90 @@ def test_offset_requantization_forms_match_oracle(debug_hooks):
         assert np.array_equal(out, o1.q31_requantize(acc, scale, 9, 0, 255)), (scale, bits)
 
 
+def test_lane_requantization_forms_match_oracle(debug_hooks):
+    """hip/requant_math.h, qnnp_requant_lane_*: the forms in which the row term enters through a per-lane addend of the
+    multiply-add and the sign of the rounding correction comes from the Q31 product -- no add per output value.
+    acc = a + rowterm is what the oracle sees; the form sees a + 2^31 and the row term separately."""
+    import ctypes
+    L = debug_hooks.lib
+    fn = L.qnnp_debug_requant_lane
+    fn.restype = None
+    fn.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_uint8, ctypes.c_uint8,
+                   ctypes.c_uint8, ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    rng = np.random.default_rng(14)
+    clamps = [(0, 0, 255), (127, 0, 255), (255, 0, 255), (100, 128, 255), (7, 5, 9)]
+
+    def rowterms(acc, lim):
+        rt = rng.integers(-lim, lim, size=acc.size).astype(np.int64)
+        rt[::7] = 0
+        rt[1::11] = acc[1::11]                       # a == 0
+        # keep a = acc - rowterm inside int32 (it is a bias plus a dot product)
+        a = acc.astype(np.int64) - rt
+        rt = np.where((a >= -2**31) & (a < 2**31), rt, 0)
+        return rt.astype(np.int32)
+
+    # shift 0: accumulators bounded at create time (a = acc - rowterm must fit int32 beside acc itself)
+    for bits in (30, 24):
+        lim = 2 ** bits
+        acc = rng.integers(-lim + 1, lim, size=1 << 19).astype(np.int32)
+        acc[:10] = [-lim + 1, lim - 1, 0, -1, 1, -(lim // 2), lim // 2, -lim + 2, -2, 2]
+        rt = rowterms(acc, 2**28)
+        for scale in [0.5, 0.50000006, 0.6180339, 0.75, 0.99, float.fromhex("0x1.FFFFFCp-1"), float.fromhex("0x1.FFFFFEp-1")]:
+            for zp, qmin, qmax in clamps:
+                out = np.empty(acc.size, np.uint8)
+                kind = ctypes.c_int(-1)
+                fn(acc.size, acc.ctypes.data, rt.ctypes.data, np.float32(scale), zp, qmin, qmax, bits, out.ctypes.data, ctypes.byref(kind))
+                # (the single largest multiplier with a zero point that cannot be folded keeps the other sequence)
+                assert kind.value in (0, 1) and (kind.value == 1 or scale == float.fromhex("0x1.FFFFFEp-1")), scale
+                assert np.array_equal(out, o1.q31_requantize(acc, scale, zp, qmin, qmax)), (scale, zp, qmin, qmax)
+    # shift 0 without a bound: not applicable (the offset form answers, for every int32 accumulator)
+    acc = rng.integers(-2**31, 2**31, size=1 << 16).astype(np.int32)
+    acc[:8] = [-2**31, 2**31 - 1, 0, -1, 1, -2**30, 2**30, -2**31 + 1]
+    rt = rowterms(acc, 2**31)
+    for scale in [0.5, 0.75]:
+        out = np.empty(acc.size, np.uint8)
+        kind = ctypes.c_int(-1)
+        fn(acc.size, acc.ctypes.data, rt.ctypes.data, np.float32(scale), 0, 0, 255, 0, out.ctypes.data, ctypes.byref(kind))
+        assert kind.value == 0
+        assert np.array_equal(out, o1.q31_requantize(acc, scale, 0, 0, 255)), scale
+    # bounded shift >= 1: ties of the second rounding on both sides of zero, and the n < 0 with q == 0 band
+    for bits in (30, 27, 20, 12):
+        lim = 2 ** bits
+        acc = rng.integers(-lim + 1, lim, size=1 << 19).astype(np.int32)
+        special = [-lim + 1, lim - 1, 0, -1, 1, -2, -3, 2, -(lim // 2)]
+        for s in range(1, 21):
+            for k in range(-12, 13):
+                special += [v for v in ((k << s) + (1 << (s - 1)) + d for d in (-1, 0, 1)) if -lim < v < lim]
+        acc[:len(special)] = np.array(special, dtype=np.int64).astype(np.int32)
+        rt = rowterms(acc, lim)
+        for scale in [0.49999997, 0.25, 0.3, 1 / 255.0, 0.0031, 2.0 ** -12, 1.7e-5, 2.0 ** -20, 1.9e-6]:
+            for zp, qmin, qmax in clamps:
+                out = np.empty(acc.size, np.uint8)
+                kind = ctypes.c_int(-1)
+                fn(acc.size, acc.ctypes.data, rt.ctypes.data, np.float32(scale), zp, qmin, qmax, bits, out.ctypes.data, ctypes.byref(kind))
+                assert kind.value == 2, (scale, bits)
+                assert np.array_equal(out, o1.q31_requantize(acc, scale, zp, qmin, qmax)), (bits, scale, zp, qmin, qmax)
+    # exhaustive around zero for small multipliers' neighbourhoods: every n in [-70000, 70000]
+    acc = np.arange(-70000, 70001, dtype=np.int32)
+    rt = rowterms(acc, 2**20)
+    for scale in [0.49999997, 0.4, 0.26, 0.25, 0.1, 1 / 255.0, 2.0 ** -9, 3.1e-4]:
+        for zp in (0, 3, 128, 255):
+            out = np.empty(acc.size, np.uint8)
+            kind = ctypes.c_int(-1)
+            fn(acc.size, acc.ctypes.data, rt.ctypes.data, np.float32(scale), zp, 0, 255, 24, out.ctypes.data, ctypes.byref(kind))
+            assert kind.value == 2
+            assert np.array_equal(out, o1.q31_requantize(acc, scale, zp, 0, 255)), (scale, zp)
+    # not applicable: shift >= 1 without a bound
+    acc = rng.integers(-2**31, 2**31, size=1 << 14).astype(np.int32)
+    rt = rowterms(acc, 2**31)
+    out = np.empty(acc.size, np.uint8)
+    for scale, bits in [(0.25, 0), (0.25, 31), (2.0 ** -22, 20)]:
+        kind = ctypes.c_int(-1)
+        fn(acc.size, acc.ctypes.data, rt.ctypes.data, np.float32(scale), 9, 0, 255, bits, out.ctypes.data, ctypes.byref(kind))
+        assert kind.value == 0, (scale, bits)
+        assert np.array_equal(out, o1.q31_requantize(acc, scale, 9, 0, 255)), (scale, bits)
+
+
 def test_accumulator_bound(debug_hooks):
     """requantization.h, qnnp_accumulator_bits: |bias| + K * 255^2 < 2^bits, 0 when it does not fit 31 bits."""
     import ctypes
