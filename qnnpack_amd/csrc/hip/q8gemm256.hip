@@ -78,6 +78,16 @@ __device__ __forceinline__ void dma16(const uint8_t* src, uint8_t* lds_wave_base
       (__attribute__((address_space(3))) void*) lds_wave_base, 16, 0, QNNP_DMA_AUX);
 }
 
+/* a wave-uniform pointer, in scalar registers for good (a uniform value the compiler happened to compute with vector
+ * instructions -- a 64-bit multiply, say -- would reach an "s" asm operand as a VGPR pair: an assembler error) */
+__device__ __forceinline__ const uint8_t* scalar_ptr(const uint8_t* ptr)
+{
+  const uint64_t v = reinterpret_cast<uint64_t>(ptr);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+  return reinterpret_cast<const uint8_t*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
 /* The saddr form: 64-bit wave-uniform base in an SGPR pair + 32-bit lane offset. hipcc selects the VGPR-pair form for
  * the builtin whatever the shape of the address expression (one v_lshl_add_u64 per piece), hence the instruction itself;
  * m0 = LDS destination of lane 0, as the builtin sets it. (m0 is a reserved register: hipcc ignores it in a clobber list.
@@ -238,7 +248,7 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
   uint32_t a_voff[kAChunks];
   uint32_t w_voff[kWFrags];
   if constexpr (LEAN) {
-    a_base = p.input + static_cast<uint64_t>(m_tile * kBM) * p.input_stride + static_cast<uint64_t>(g) * p.kc;
+    a_base = scalar_ptr(p.input + static_cast<uint64_t>(m_tile * kBM) * p.input_stride + static_cast<uint64_t>(g) * p.kc);
 #pragma unroll
     for (int i = 0; i < kAChunks; i++) {
       const uint32_t r = (i * kThreads + tid) >> 2;
@@ -247,8 +257,8 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
       a_voff[i] = (m - m_tile * kBM) * p.input_stride + a_chunk[i] * 16;
     }
     // fragment F = i * 8 + wave: channel block nb0 + i * 4 + (wave >> 1), K block (wave & 1) of the tile's two
-    w_base = reinterpret_cast<const uint8_t*>(p.packed_w) + static_cast<uint64_t>(g) * nblocks * kblocks * 1024 +
-        (static_cast<uint64_t>(nb0 + (wave >> 1)) * kblocks + (wave & 1u)) * 1024;
+    w_base = scalar_ptr(reinterpret_cast<const uint8_t*>(p.packed_w) + static_cast<uint64_t>(g) * nblocks * kblocks * 1024 +
+        (static_cast<uint64_t>(nb0 + (wave >> 1)) * kblocks + (wave & 1u)) * 1024);
 #pragma unroll
     for (int i = 0; i < kWFrags; i++) w_voff[i] = lane * 16 + static_cast<uint32_t>(i) * (kWM * kWN / 2) * kblocks * 1024;
   }
@@ -311,6 +321,13 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 
   // Accumulators start at the folded bias (the MFMAs add into them): the loads ride under the prologue's DMA
   // wait instead of sitting exposed after the main loop, and the epilogue saves one add per value.
+  // (lean flavour, whole-line stores: where the lane forms of the requantization apply, from the bias + 2^31 half of
+  //  the pair table, and the epilogue spends no add on the row term either -- requant.hip.h)
+  bool lane_rq = false;
+  if constexpr (LEAN) {
+    lane_rq = p.store_mode == 2 && p.bias2u != nullptr && (p.lane.kind == 1 || (p.lane.kind == 2 && p.rq.full_range != 0));
+  }
+  const int32_t* bias_tab = lane_rq ? p.bias2u : p.bias2;
   v16i acc[kTM][kTN];
 #pragma unroll
   for (int tn = 0; tn < kTN; tn++) {
@@ -319,7 +336,7 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) {
       const uint32_t ncol = nbb * 32 + rg * 8 + (lane >> 5) * 4;
-      const int4 b = *reinterpret_cast<const int4*>(p.bias2 + static_cast<uint64_t>(g) * p.n_pad + ncol);
+      const int4 b = *reinterpret_cast<const int4*>(bias_tab + static_cast<uint64_t>(g) * p.n_pad + ncol);
 #pragma unroll
       for (int tm = 0; tm < kTM; tm++) {
         acc[tm][tn][rg * 4 + 0] = b.x;
@@ -727,6 +744,52 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
 
   // ---- fused epilogue (igemm_epilogue.hip.h); the requantization flavour is chosen once ----
   const uint32_t raw_to_centred = 128u * p.k_pad;      // sum(a') = sum(a) - 128 * k_pad
+  if constexpr (LEAN) {
+    if (lane_rq) {
+      // the store_mode 2 branch below with the lane forms: the row term enters as the multiply-add's addend
+      auto epilogue_lane = [&](auto seq_c, auto full_c) __attribute__((always_inline)) {
+        constexpr int kSeq = decltype(seq_c)::value;
+        constexpr bool kFull = decltype(full_c)::value;
+        constexpr uint32_t kPitch = kTN * 32 + 16;
+        uint8_t* image = lds + wave * (kTM * 32 * kPitch);
+        uint64_t row_addend[kTM];
+#pragma unroll
+        for (int tm = 0; tm < kTM; tm++) {
+          const uint32_t row = frag_row0 + tm * 32;
+          row_addend[tm] = lane_addend(p.row_coeff * static_cast<int32_t>(
+              static_cast<uint32_t>(lds_rowsum[row]) + static_cast<uint32_t>(lds_rowsum[kBM + row]) - raw_to_centred), p.lane);
+        }
+#pragma unroll
+        for (int tn = 0; tn < kTN; tn++) {
+#pragma unroll
+          for (int tm = 0; tm < kTM; tm++) {
+            igemm_stage_tile_lane<kSeq, kFull>(acc[tm][tn], row_addend[tm], image + (tm * 32 + (lane & 31u)) * kPitch, tn * 32, frag_khalf, p);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
+        const uint32_t m0 = m_tile * kBM + wm * (kTM * 32);
+        const uint32_t n0 = (nb0 + wn * kTN) * 32;
+        uint8_t* out0 = p.output + static_cast<uint64_t>(m0) * p.output_stride + static_cast<uint64_t>(g) * p.n + n0;
+#pragma unroll
+        for (int i = 0; i < (kTM * 32 * kTN * 2) / 64; i++) {
+          const uint32_t idx = i * 64 + lane;
+          const uint32_t r = idx / (kTN * 2);
+          const uint32_t c = idx % (kTN * 2);
+          const uint4 v = *reinterpret_cast<const uint4*>(image + r * kPitch + c * 16);
+          if (m0 + r < p.rows && n0 + c * 16 < p.n) {
+            *reinterpret_cast<uint4*>(out0 + static_cast<uint64_t>(r) * p.output_stride + c * 16) = v;
+          }
+        }
+      };
+      if (p.lane.kind == 1) {
+        if (p.rq.full_range) epilogue_lane(std::integral_constant<int, kRqShift0Lane>{}, std::true_type{});
+        else epilogue_lane(std::integral_constant<int, kRqShift0Lane>{}, std::false_type{});
+      } else {
+        epilogue_lane(std::integral_constant<int, kRqBoundedLane>{}, std::true_type{});
+      }
+      return;
+    }
+  }
   requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
     // (+ 2^31 for the offset rounding sequences, requant.hip.h: rides on the row term)
     constexpr int kSeq = decltype(shift0)::value;
