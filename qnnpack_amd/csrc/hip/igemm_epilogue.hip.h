@@ -133,10 +133,10 @@ __device__ __forceinline__ void igemm_store_pk4(
 
 /* The same for the lane forms of the requantization (requant.hip.h): the accumulators started from the bias table
  * that carries 2^31, `addend` = lane_addend(row term of this lane's row). */
-template <int SEQ, bool FULL_RANGE>
+template <int SEQ, bool FULL_RANGE, bool RESIDUAL = false>
 __device__ __forceinline__ void igemm_store_tile_lane(
     const epi_v16i& acc, uint64_t addend, uint8_t* out_row, uint32_t ncol0, uint32_t khalf, bool row_ok,
-    const IgemmParams& p)
+    const IgemmParams& p, const uint8_t* res_row = nullptr, const qnnp_hip_add_params* add = nullptr)
 {
   uint32_t pk[4];
 #pragma unroll
@@ -144,6 +144,10 @@ __device__ __forceinline__ void igemm_store_tile_lane(
     pk[rg] = q31_requantize_pack4_lane<SEQ, FULL_RANGE>(
         static_cast<uint32_t>(acc[rg * 4 + 0]), static_cast<uint32_t>(acc[rg * 4 + 1]),
         static_cast<uint32_t>(acc[rg * 4 + 2]), static_cast<uint32_t>(acc[rg * 4 + 3]), addend, p.lane, p.rq);
+    if constexpr (RESIDUAL) {                                  // (as igemm_store_tile)
+      const uint32_t c = ncol0 + rg * 8 + khalf * 4;
+      if (c < p.n) pk[rg] = add_quantize4(*reinterpret_cast<const uint32_t*>(res_row + c), pk[rg], *add);
+    }
   }
   igemm_store_pk4(pk, out_row, ncol0, khalf, row_ok, p);
 }

@@ -81,10 +81,14 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
     }
     uint8_t* lds_bias = lds + frags * 1024;
     const uint32_t bias_chunks = p.n_pad / 4;             // 16-byte pieces; n_pad is a multiple of 32
+    // (where the lane forms of the requantization apply -- requant_dispatch_lane below -- the accumulators start from
+    //  bias + 2^31, the second half of the pair table)
+    const bool lane_rq = p.bias2u != nullptr && (p.lane.kind == 1 || (p.lane.kind == 2 && p.rq.full_range != 0));
+    const int32_t* bias_src = lane_rq ? p.bias2u : p.bias2;
     for (uint32_t c0 = wave * 64; c0 < bias_chunks; c0 += kThreads) {
       const uint32_t c = min(c0 + lane, bias_chunks - 1); // the tail lanes repeat the last piece (same bytes)
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(p.bias2) + c * 16),
+          (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(bias_src) + c * 16),
           (__attribute__((address_space(3))) void*) (lds_bias + c0 * 16), 16, 0, 0);
     }
     // (no wait here: the first row block's loads are issued first, so both latencies overlap)
@@ -134,7 +138,8 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // weights + bias are in LDS (and the first rows landed)
   __syncthreads();
 
-  requant_dispatch_ofs(p.rq, [&](auto shift0, auto full) {
+  requant_dispatch_lane(p.rq, p.lane, [&](auto shift0, auto full) {
+    constexpr int kSeq = decltype(shift0)::value;
     for (; unit < units; unit += unit_stride) {
       v4i a[KB];
 #pragma unroll
@@ -157,6 +162,8 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
       rs += __shfl_xor(rs, 32);                           // the other K half of the same row
       // (+ 2^31 for the offset rounding sequences, requant.hip.h: the accumulators start from bias + this)
       const int32_t rowterm = with_rq_offset<decltype(shift0)::value>(p.row_coeff * static_cast<int32_t>(rs - raw_to_centred));
+      uint64_t row_addend = 0;                            // lane forms: the row term as the multiply-add's addend
+      if constexpr (rq_is_lane<kSeq>()) row_addend = lane_addend(rowterm, p.lane);
 
       const uint32_t m = unit * 32u + row_in_block;
       uint8_t* out_row = p.output + static_cast<uint64_t>(m) * p.output_stride;
@@ -217,18 +224,31 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
           const uint32_t py = phase / p.d2s_sw;
           const uint32_t px = phase - py * p.d2s_sw;
           uint8_t* phase_row = out_row + (static_cast<uint64_t>(py) * (p.d2s_in_w * p.d2s_sw) + px) * p.output_stride;
-          igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 2>(
-              acc, bias4, rowterm, phase_row, (nb - phase * p.d2s_nbpp) * 32, khalf, row_ok, p);
+          if constexpr (rq_is_lane<kSeq>()) {
+            igemm_store_tile_lane<kSeq, decltype(full)::value>(
+                acc, row_addend, phase_row, (nb - phase * p.d2s_nbpp) * 32, khalf, row_ok, p);
+          } else {
+            igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 2>(
+                acc, bias4, rowterm, phase_row, (nb - phase * p.d2s_nbpp) * 32, khalf, row_ok, p);
+          }
           continue;
         }
         if constexpr (RES) {                              // project layer with its residual add folded in
           const uint8_t* res_row = p.residual + static_cast<uint64_t>(row_ok ? m : 0u) * p.residual_stride;
-          igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 2, true>(
-              acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p, res_row, &p.add);
+          if constexpr (rq_is_lane<kSeq>()) {
+            igemm_store_tile_lane<kSeq, decltype(full)::value, true>(acc, row_addend, out_row, nb * 32, khalf, row_ok, p, res_row, &p.add);
+          } else {
+            igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 2, true>(
+                acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p, res_row, &p.add);
+          }
           continue;
         }
-        igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 2>(
-            acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p);
+        if constexpr (rq_is_lane<kSeq>()) {
+          igemm_store_tile_lane<kSeq, decltype(full)::value>(acc, row_addend, out_row, nb * 32, khalf, row_ok, p);
+        } else {
+          igemm_store_tile<decltype(shift0)::value, decltype(full)::value, false, 2>(
+              acc, bias4, rowterm, out_row, nb * 32, khalf, row_ok, p);
+        }
       }
     }
   });
