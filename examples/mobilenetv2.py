@@ -255,18 +255,31 @@ class DeviceNetwork:
                     i += 1
             self.schedule = schedule
 
+    # Every operator's output is the next operator's input: keep the outputs cacheable. The library's default marks
+    # whole-line output stores as streaming ("streaming_stores" = 1), which is right for an operator run on its own --
+    # the per-layer sweep gains 4-5 % -- and costs a chained network about 1 %: the consumer finds nothing of a streamed
+    # tensor in the last-level cache. The option is read at launch time, i.e. while recording.
+    def _launch_all(self, record_names: bool):
+        self.lib.set_option("streaming_stores", 0)
+        try:
+            for name, h in self.schedule:
+                self.lib.run_operator(h)
+                if record_names:
+                    self.kernels[name] = self.lib.operator_kernel(h)
+        finally:
+            self.lib.set_option("streaming_stores", 1)
+
     def run(self):
         """One forward pass, operator by operator."""
-        for name, h in self.schedule:
-            self.lib.run_operator(h)
-            self.kernels[name] = self.lib.operator_kernel(h)
+        self._launch_all(True)
 
     def capture(self):
         """Record the whole forward pass into one hipGraph (device pointers only; nothing runs yet)."""
         self.lib.graph_begin()
-        for _, h in self.schedule:
-            self.lib.run_operator(h)
-        self.graph = self.lib.graph_end()
+        try:
+            self._launch_all(False)
+        finally:
+            self.graph = self.lib.graph_end()
         return self.graph
 
     def replay(self):

@@ -140,6 +140,11 @@ int qnnp_gfx950_operator_residual_folded(qnnp_operator_t op);
  *                    6 = column-sliding register window (3x3, stride 1 | 2): tap pairs shared between output rows
  *   "timing_graph":  1 (default) = qnnp_gfx950_time_operator* time a hipGraph replay of the launches (kernel
  *                    time without per-launch dispatch gaps); 0 = a plain back-to-back launch loop
+ *   "streaming_stores": 1 (default) = kernels whose waves write whole cache lines exactly once (pointwise / fully
+ *                    connected outputs, the 4096^3-class GEMM, the element-wise add) mark those stores as streaming:
+ *                    right for an operator that runs on its own (per-layer sweep +4-5 %, GEMM +2 %); 0 = plain stores,
+ *                    for callers that chain operators -- a streamed tensor is not in the last-level cache when its
+ *                    consumer starts (whole MobileNetV2: -1 % with the hint). Read at launch (or graph-capture) time.
  * Unknown key -> invalid_parameter. Kernel choices apply to operators set up afterwards. */
 enum qnnp_status qnnp_gfx950_set_option(const char* key, int value);
 

@@ -80,6 +80,7 @@ struct IgemmParams {
   // lane forms of the requantization (requant.hip.h; the kernels instantiated for kRqShift0Lane / kRqBoundedLane only)
   qnnp_requant_lane lane;
   const int32_t* bias2u;     // bias2 + 2^31, laid out like bias2 (bias-pair.h), or NULL (then lane.kind == 0)
+  uint32_t stream_out;       // 1: whole-line stores that write a line exactly once carry the streaming hint ("streaming_stores")
 };
 
 /* convolution geometry for the LDS-tiled direct-convolution kernel */

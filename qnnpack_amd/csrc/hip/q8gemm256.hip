@@ -777,7 +777,15 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
           const uint32_t c = idx % (kTN * 2);
           const uint4 v = *reinterpret_cast<const uint4*>(image + r * kPitch + c * 16);
           if (m0 + r < p.rows && n0 + c * 16 < p.n) {
-            *reinterpret_cast<uint4*>(out0 + static_cast<uint64_t>(r) * p.output_stride + c * 16) = v;
+            typedef int nt_v4i __attribute__((ext_vector_type(4)));     // whole lines, written once: streaming hint
+            const nt_v4i x = {static_cast<int>(v.x), static_cast<int>(v.y), static_cast<int>(v.z), static_cast<int>(v.w)};
+            nt_v4i* dst = reinterpret_cast<nt_v4i*>(out0 + static_cast<uint64_t>(r) * p.output_stride + c * 16);
+            if (p.stream_out) {                                    // ("streaming_stores", igemm_params.h)
+              // (as an instruction: with the builtin, hipcc merges the two stores of this branch and drops the hint)
+              asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dst), "v"(x) : "memory");
+            } else {
+              *dst = x;
+            }
           }
         }
       };

@@ -28,18 +28,26 @@ constexpr int kThreads = 256;
 /* dense, 16-byte aligned tensors: one flat run of `vectors` uint4 */
 __global__ __launch_bounds__(kThreads)
 void q8_vadd_flat_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ sum,
-                         const uint64_t vectors, const qnnp_hip_add_params q)
+                         const uint64_t vectors, const qnnp_hip_add_params q, const uint32_t streaming)
 {
   const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kThreads;
   for (uint64_t v = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x; v < vectors; v += stride) {
-    const uint4 x = a[v];
-    const uint4 y = b[v];
-    uint4 r;
+    // a pure stream -- every line read or written exactly once: streaming hints (a plain copy kernel gains 12 % from
+    // them, tools/ubench_copy.hip; kernels that touch their lines again lose)
+    typedef unsigned int nt_v4u __attribute__((ext_vector_type(4)));
+    const nt_v4u x = __builtin_nontemporal_load(reinterpret_cast<const nt_v4u*>(a + v));
+    const nt_v4u y = __builtin_nontemporal_load(reinterpret_cast<const nt_v4u*>(b + v));
+    nt_v4u r;
     r.x = add_quantize4(x.x, y.x, q);
     r.y = add_quantize4(x.y, y.y, q);
     r.z = add_quantize4(x.z, y.z, q);
     r.w = add_quantize4(x.w, y.w, q);
-    sum[v] = r;
+    if (streaming) {                                                                        // ("streaming_stores")
+      // (as an instruction: with the builtin, hipcc merges the two stores of this branch and drops the hint)
+      asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(sum + v), "v"(r) : "memory");
+    } else {
+      *reinterpret_cast<nt_v4u*>(sum + v) = r;
+    }
   }
 }
 
@@ -175,7 +183,8 @@ extern "C" int qnnp_hip_vadd_run(const struct qnnp_hip_vadd_args* a, const char*
     const uint64_t vectors = bytes / 16;
     hipLaunchKernelGGL(q8_vadd_flat_kernel, dim3(grid_for(vectors, device_cus())), dim3(kThreads), 0, stream,
                        reinterpret_cast<const uint4*>(a->a), reinterpret_cast<const uint4*>(a->b),
-                       reinterpret_cast<uint4*>(a->sum), vectors, a->params);
+                       reinterpret_cast<uint4*>(a->sum), vectors, a->params,
+                       qnnp_hip_streaming_stores() != 0 ? 1u : 0u);
     if (kernel_name != nullptr) *kernel_name = "q8_vadd_flat";
   } else {
     hipLaunchKernelGGL(q8_vadd_strided_kernel, dim3(grid_for(bytes, device_cus())), dim3(kThreads), 0, stream, *a);

@@ -57,6 +57,8 @@ int qnnp_hip_enter(int device);
 void qnnp_hip_leave(int token);
 int qnnp_hip_device_info(char* arch, size_t arch_len, int* cus, int* clock_khz, size_t* mem_bytes);
 int qnnp_hip_compute_units(void);
+void qnnp_hip_set_streaming_stores(int on);   /* see qnnp_gfx950_set_option("streaming_stores") */
+int qnnp_hip_streaming_stores(void);
 void qnnp_hip_set_stream(void* stream);
 void* qnnp_hip_get_stream(void);         /* the stream a launch of this thread goes to (its capture stream while recording) */
 void qnnp_hip_set_async(int async);

@@ -277,6 +277,12 @@ const uint8_t* qnnp_hip_fill_table(void)
   return c != nullptr ? c->fill_table : nullptr;
 }
 
+/* "streaming_stores" (qnnp_gfx950_set_option): 1 (default) = kernels that write whole lines exactly once mark them
+ * as streaming; 0 = plain stores, for callers that chain operators and want each output cacheable for its consumer */
+static std::atomic<int> g_streaming_stores{1};
+void qnnp_hip_set_streaming_stores(int on) { g_streaming_stores.store(on != 0 ? 1 : 0, std::memory_order_relaxed); }
+int qnnp_hip_streaming_stores(void) { return g_streaming_stores.load(std::memory_order_relaxed); }
+
 void qnnp_hip_set_stream(void* stream)
 {
   DeviceCtx* c = ctx();

@@ -177,6 +177,10 @@ enum qnnp_status qnnp_gfx950_set_option(const char* key, int value)
     qnnp_state.opt_timing_graph = value;
     return qnnp_status_success;
   }
+  if (strcmp(key, "streaming_stores") == 0 && (value == 0 || value == 1)) {
+    qnnp_hip_set_streaming_stores(value);
+    return qnnp_status_success;
+  }
   if (strcmp(key, "dwconv_kernel") == 0 && value >= 0 && value <= 6) {
     qnnp_state.opt_dwconv_kernel = value;
     return qnnp_status_success;

@@ -42,6 +42,9 @@ int qnnp_hip_device_info(char* arch, size_t arch_len, int* cus, int* clock_khz, 
   return QNNP_HIP_OK;
 }
 int qnnp_hip_compute_units(void) { return 256; }
+static int g_streaming = 1;
+void qnnp_hip_set_streaming_stores(int on) { g_streaming = on != 0; }
+int qnnp_hip_streaming_stores(void) { return g_streaming; }
 void qnnp_hip_set_stream(void* stream) { g_stream = stream; }
 void* qnnp_hip_get_stream(void) { return g_stream; }
 void qnnp_hip_set_async(int async) { g_async = async != 0; }
