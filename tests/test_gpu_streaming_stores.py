@@ -1,0 +1,54 @@
+"""GPU tier: the "streaming_stores" option (include/qnnpack_gfx950.h). The kernels that write whole lines exactly once --
+the staged and long-K pointwise kernels' copy-out (whole dense blocks and row chunks, with and without a channel
+split), the lean GEMM's copy-out, the element-wise add -- take a different store instruction with the option on (the
+default) and off; the bytes must be the oracle's either way. The option is read at launch time."""
+import numpy as np
+import pytest
+
+import _pointwise as pw
+from _cases import FcCase
+from _gpu import from_device, to_device
+from _runner import assert_bytes_equal, fc_expected, fc_run
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=[1, 0], ids=["streaming", "plain"])
+def stores(qnnp, request):
+    qnnp.set_option("streaming_stores", request.param)
+    yield qnnp
+    qnnp.set_option("streaming_stores", 1)
+    qnnp.set_option("gemm_kernel", 0)
+
+
+@pytest.mark.parametrize("case,variant,kernel", [
+    (FcCase("ss_dense_whole", 4100, 32, 96), 5, "q8_pw_stream_mfma"),                 # whole dense 32-row blocks
+    (FcCase("ss_dense_tail", 1000, 64, 144), 5, "q8_pw_stream_mfma"),                 # a partly filled last block
+    (FcCase("ss_strided_chunks", 2050, 48, 80, output_stride=96), 5, "q8_pw_stream_mfma"),   # row chunks
+    (FcCase("ss_split_columns", 300, 96, 576), 5, "q8_pw_stream_mfma"),               # channel columns: chunks of a row
+    (FcCase("ss_longk", 900, 384, 96), 9, "q8_pw_stream_longk_mfma"),
+    (FcCase("ss_lean_gemm", 520, 704, 512), 15, "q8_gemm_mfma_256x256_lean"),
+], ids=lambda v: v.name if isinstance(v, FcCase) else None)
+def test_outputs_do_not_depend_on_the_store_flavour(stores, case, variant, kernel):
+    stores.set_option("gemm_kernel", variant)
+    expected, quant = fc_expected(case)
+    out, kname = fc_run(stores, case, quant, to_device=to_device, from_device=from_device)
+    assert kname == kernel, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+def test_add_does_not_depend_on_the_store_flavour(stores):
+    flat = 0
+    for case in pw.add_cases():
+        a, b, _ = pw.add_tensors(case)
+        got, kname = pw.add_run(stores, case, a, b, to_device=to_device, from_device=from_device)
+        flat += kname == "q8_vadd_flat"
+        assert np.array_equal(got, pw.add_expected(case, a, b)), case.name
+    assert flat > 0
+
+
+def test_option_values(qnnp):
+    from qnnpack_amd.binding import QnnpackError
+    with pytest.raises(QnnpackError):
+        qnnp.set_option("streaming_stores", 2)
+    qnnp.set_option("streaming_stores", 1)
