@@ -137,3 +137,30 @@ def test_lean_gemm_is_the_only_writer_of_m0_in_its_kernels(tmp_path):
             dma = [ln.strip() for ln in body.split("\n") if "global_load_lds" in ln]
             assert dma and all(re.match(r"global_load_lds_dwordx4 v\d+, s\[\d+:\d+\]", ln) for ln in dma), (name, dma[:3])
     assert seen == 2, seen          # the 8-wave flavour and the 4-wave A/B flavour
+
+
+def test_streaming_store_flavours_survive_the_compiler(tmp_path):
+    """"streaming_stores" (include/qnnpack_gfx950.h): the kernels that write whole lines once choose between a plain and
+    an `nt` 16-byte store at run time. Written with the builtin in one arm of the branch, hipcc merged the two stores
+    and dropped the hint without a word (every measurement then showed "no effect"); they are inline-asm instructions
+    now, and this test looks for both flavours in the disassembly of each kernel family that has them."""
+    if not os.path.exists(LIB):
+        pytest.skip("library not built")
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    blob = open(LIB, "rb").read()
+    want = {"q8_pw_stream_staged_kernel": 0, "q8_pw_stream_longk_kernel": 0, "q8_vadd_flat_kernel": 0,
+            "q8_gemm_mfma_256x256_kernelILb0ELi4ELi256ELi0ELb0ELb1E": 0}
+    for k, elf in enumerate(_code_objects(blob)):
+        path = tmp_path / f"co{k}.elf"
+        path.write_bytes(elf)
+        dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", str(path)], capture_output=True, text=True, check=True).stdout
+        for m in re.finditer(r"^[0-9a-f]+ <(\S+)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", dis, re.S | re.M):
+            name, body = m.group(1), m.group(2)
+            for frag in want:
+                if frag in name:
+                    stores = [ln for ln in body.split("\n") if "global_store_dwordx4" in ln]
+                    hinted = [ln for ln in stores if re.search(r"\bnt\b", ln)]
+                    assert hinted and len(hinted) < len(stores), (name, len(hinted), len(stores))
+                    want[frag] += 1
+    assert all(v > 0 for v in want.values()), want
