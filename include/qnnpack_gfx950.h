@@ -144,7 +144,9 @@ int qnnp_gfx950_operator_residual_folded(qnnp_operator_t op);
  *                    connected outputs, the 4096^3-class GEMM, the element-wise add) mark those stores as streaming:
  *                    right for an operator that runs on its own (per-layer sweep +4-5 %, GEMM +2 %); 0 = plain stores,
  *                    for callers that chain operators -- a streamed tensor is not in the last-level cache when its
- *                    consumer starts (whole MobileNetV2: -1 % with the hint). Read at launch (or graph-capture) time.
+ *                    consumer starts (whole MobileNetV2: -1 % with the hint). Read at launch (or graph-capture) time;
+ *                    process-wide like the other options (a thread that flips it affects launches of other threads --
+ *                    only their speed, never their bytes).
  * Unknown key -> invalid_parameter. Kernel choices apply to operators set up afterwards. */
 enum qnnp_status qnnp_gfx950_set_option(const char* key, int value);
 
