@@ -81,6 +81,7 @@ struct DwParams {
   uint32_t abl;          // measurement builds only: bit 0 = no stores, bit 1 = no global loads (kernel F)
   unsigned long long* trace;   // measurement builds only (QNNP_ENABLE_ABLATION + env QNNP_GFX950_TRACE)
   qnnp::RequantDev rq;
+  uint32_t stream_out;       // 1: the column-walk kernels mark their output stores as streaming ("streaming_stores")
 };
 
 #ifdef QNNP_ENABLE_ABLATION
@@ -769,7 +770,10 @@ __device__ __forceinline__ void dwconv_col3x3_body(
     auto finish = [&](int32_t (&acc)[4]) __attribute__((always_inline)) {
       const uint32_t packed = qnnp::q31_requantize_pack4<SEQ, FULL>(
           acc[0], acc[1], acc[2], acc[3], p.rq);
-      __builtin_amdgcn_raw_buffer_store_b32(packed, out_rsrc, out_voff, out_soff, 0);
+      // (a wave's 64 dwords of an output row are contiguous: whole lines, written once -- the streaming hint, under the
+      //  "streaming_stores" option; the two builtins differ in an immediate, so hipcc cannot merge them)
+      if (p.stream_out) __builtin_amdgcn_raw_buffer_store_b32(packed, out_rsrc, out_voff, out_soff, 2);
+      else __builtin_amdgcn_raw_buffer_store_b32(packed, out_rsrc, out_voff, out_soff, 0);
       out_soff += out_step;
     };
     const uint32_t steps = oy1 - oy0;
@@ -1394,7 +1398,8 @@ __device__ __forceinline__ void dwconv_col5x5_body(
       acc[c] = __builtin_amdgcn_sdot4(static_cast<int32_t>(e_new), static_cast<int32_t>(w5[c]), acc[c], false);
     }
     const uint32_t packed = qnnp::q31_requantize_pack4<SEQ, FULL>(acc[0], acc[1], acc[2], acc[3], p.rq);
-    __builtin_amdgcn_raw_buffer_store_b32(packed, out_rsrc, out_voff, out_soff, 0);
+    if (p.stream_out) __builtin_amdgcn_raw_buffer_store_b32(packed, out_rsrc, out_voff, out_soff, 2);   // ("streaming_stores", as kernel G)
+    else __builtin_amdgcn_raw_buffer_store_b32(packed, out_rsrc, out_voff, out_soff, 0);
     out_soff += out_step;
     slide(V, e_new);
     t++;
@@ -2155,6 +2160,7 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
   p.izp = a->input_zero_point & 0xFFu;
   p.CS = p.TOH = p.IR = p.IC = p.PP = p.bands = p.slabs = 0;
   p.rq = qnnp::make_requant_dev(a->rq);
+  p.stream_out = qnnp_hip_streaming_stores() != 0 ? 1u : 0u;
   p.trace = nullptr;
   p.abl = 0;
 #ifdef QNNP_ENABLE_ABLATION

@@ -1,14 +1,14 @@
 """GPU tier: the "streaming_stores" option (include/qnnpack_gfx950.h). The kernels that write whole lines exactly once --
 the staged and long-K pointwise kernels' copy-out (whole dense blocks and row chunks, with and without a channel
-split), the lean GEMM's copy-out, the element-wise add -- take a different store instruction with the option on (the
+split), the lean GEMM's copy-out, the depthwise column walks (3x3 and 5x5), the element-wise add -- take a different store instruction with the option on (the
 default) and off; the bytes must be the oracle's either way. The option is read at launch time."""
 import numpy as np
 import pytest
 
 import _pointwise as pw
-from _cases import FcCase
+from _cases import ConvCase, FcCase, conv_tensors
 from _gpu import from_device, to_device
-from _runner import assert_bytes_equal, fc_expected, fc_run
+from _runner import assert_bytes_equal, conv_expected, conv_run, fc_expected, fc_run
 
 pytestmark = pytest.mark.gpu
 
@@ -19,6 +19,7 @@ def stores(qnnp, request):
     yield qnnp
     qnnp.set_option("streaming_stores", 1)
     qnnp.set_option("gemm_kernel", 0)
+    qnnp.set_option("dwconv_kernel", 0)
 
 
 @pytest.mark.parametrize("case,variant,kernel", [
@@ -34,6 +35,26 @@ def test_outputs_do_not_depend_on_the_store_flavour(stores, case, variant, kerne
     expected, quant = fc_expected(case)
     out, kname = fc_run(stores, case, quant, to_device=to_device, from_device=from_device)
     assert kname == kernel, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+def _dw(name, hw, c, k=3, **kw):
+    pad = kw.pop("padding", (k // 2,) * 4)
+    return ConvCase(name, hw, (k, k), pad, groups=c, gic=1, goc=1, **kw)
+
+
+@pytest.mark.parametrize("case,prefix", [
+    (_dw("ss_dw_c32_56", (56, 56), 32, batch=2), "q8_dwconv_col_3x3"),                      # several row segments
+    (_dw("ss_dw_c144_s2", (29, 31), 144, subsampling=(2, 2)), "q8_dwconv_col_3x3"),
+    (_dw("ss_dw_c260_ragged", (7, 7), 260, batch=3), "q8_dwconv_col_3x3"),                  # partly filled last wave
+    (_dw("ss_dw_strided_pixels", (11, 12), 32, input_pixel_stride=40, output_pixel_stride=36), "q8_dwconv_col_3x3"),
+    (_dw("ss_dw5_c72_s2", (28, 28), 72, k=5, subsampling=(2, 2), batch=2), "q8_dwconv_col_5x5"),
+], ids=lambda v: v.name if isinstance(v, ConvCase) else None)
+def test_depthwise_column_walks_do_not_depend_on_the_store_flavour(stores, case, prefix):
+    inp, kernel, bias = conv_tensors(case)
+    expected, quant, out_hw = conv_expected(case, inp, kernel, bias)
+    out, kname = conv_run(stores, case, quant, out_hw, inp, kernel, bias, to_device, from_device)
+    assert kname.startswith(prefix), kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 
 
