@@ -133,7 +133,13 @@ int qnnp_gfx950_operator_residual_folded(qnnp_operator_t op);
  *                    7 = its 3-channel-image convolution flavour (first layers; in-register tap gather),
  *                    8 = wave-per-8x8-block direct-convolution MFMA kernel (small windows, <= 64 channels, dense output),
  *                    9 = long-K flavour of the streaming kernel (256 < K <= 1024, 16-byte aligned rows both sides:
- *                        a channel column's weights in LDS, every K block of a unit's rows in flight at once)
+ *                        a channel column's weights in LDS, every K block of a unit's rows in flight at once),
+ *                    10 = 128x256 tiles of the LDS-DMA kernel, two workgroups per CU; 11 = its ping-pong schedule;
+ *                    12 = the round-2 register-path flavour of kernel 8; 13 = stride-2 deconvolution streaming kernel
+ *                    forced (1 keeps deconvolutions on the phase-table GEMMs); 14 = first-layer row-slot kernel;
+ *                    15 = the lean flavour of kernel 2 (what auto picks when K % 64 == 0 and N % 256 == 0; 2 keeps the
+ *                    general flavour), 16 = the lean flavour of kernel 4. A forced kernel refuses what it cannot take
+ *                    (unsupported_parameter at run) instead of rerouting.
  *   "dwconv_kernel": 0 = auto, 1 = generic direct kernel, 2 = LDS-tiled kernel, 3 = register sliding-window kernel (3x3),
  *                    4 = matrix-core kernel (diagonal MFMA operands; 3x3, channels % 16 == 0), tap operands gathered
  *                        from global memory, 5 = the same with the input band staged in LDS first,
