@@ -201,3 +201,10 @@ void qnnp_debug_pack_igemm_w_slots(
 {
   qnnp_pack_igemm_w_slots(groups, n, ks, kc, kc_slot, n_pad, k_pad, izp, kzp, kernel, bias, packed, bias2);
 }
+
+void qnnp_debug_pack_igemm_w_centred127(
+    uint32_t n, uint32_t k_total, uint32_t n_pad, uint8_t izp, const uint8_t* kernel, const int32_t* bias,
+    int8_t* packed, int32_t* biasc)
+{
+  qnnp_pack_igemm_w_centred127(n, k_total, n_pad, izp, kernel, bias, packed, biasc);
+}

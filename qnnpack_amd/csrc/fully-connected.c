@@ -124,6 +124,23 @@ static enum qnnp_status qnnp_create_fully_connected_nc_q8_impl(
     qnnp_log_error("failed to place %zu bytes of packed weights on the device", w_bytes + 2 * b_bytes);
     goto error;
   }
+  /* The big GEMM kernel's zero-point-centred image (pack.h, hip/q8gemm256c.hip): kernel zero point 128 IS the
+   * standard image; 127 (the reference benchmarks' value, bench/q8gemm.cc:60-64) gets its own, for the shapes that
+   * kernel takes (no K padding, channel blocks of 256, MFMA-bound sizes). */
+  if (kernel_zero_point == 128) {
+    op->centre_flip = 0x80;
+  } else if (kernel_zero_point == 127 && k_pad == input_channels && n_pad % 256 == 0 && input_channels >= 512) {
+    qnnp_pack_igemm_w_centred127((uint32_t) output_channels, (uint32_t) input_channels, n_pad,
+        input_zero_point, kernel, bias, host_weights, host_bias);
+    op->d_weights_centred = qnnp_hip_alloc(w_bytes);
+    op->d_bias_centred = qnnp_upload_bias_pair(host_bias, n_pad);
+    if (op->d_weights_centred == NULL || op->d_bias_centred == NULL ||
+        qnnp_hip_h2d(op->d_weights_centred, host_weights, w_bytes, 0) != QNNP_HIP_OK) {
+      qnnp_log_error("failed to place %zu bytes of centred weights on the device", w_bytes + 2 * b_bytes);
+      goto error;
+    }
+    op->centre_flip = 0x7F;
+  }
   free(host_weights);
   free(host_bias);
   host_weights = NULL;
@@ -189,6 +206,8 @@ static enum qnnp_status qnnp_setup_fully_connected_nc_q8_impl(
 
   /* reference fully-connected.c:149-158: the batch becomes the row dimension */
   op->setup_valid = 0;   /* until every check, allocation and upload below has succeeded */
+  op->residual = NULL;   /* an attached residual add belongs to the previous binding (residual.c), as in convolution.c */
+  op->residual_folded = 0;
   op->batch_size = 1;
   op->input_height = batch_size;
   op->input_width = 1;

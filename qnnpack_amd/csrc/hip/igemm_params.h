@@ -81,6 +81,8 @@ struct IgemmParams {
   qnnp_requant_lane lane;
   const int32_t* bias2u;     // bias2 + 2^31, laid out like bias2 (bias-pair.h), or NULL (then lane.kind == 0)
   uint32_t stream_out;       // 1: whole-line stores that write a line exactly once carry the streaming hint ("streaming_stores")
+  uint32_t a_flip;           // q8gemm256c.hip only: the activation recentring mask, 0x80808080 (image centred on 128) or
+                             // 0x7F7F7F7F (on 127); 0 = the operator has no centred image
 };
 
 /* convolution geometry for the LDS-tiled direct-convolution kernel */
@@ -111,6 +113,10 @@ int pwstream_gw_launch(const IgemmParams& p, hipStream_t stream, const char** na
 /* q8convc3.hip */
 bool conv_c3rows_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, const int8_t* w_rows16, uint32_t real_kc);
 int conv_c3rows_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_rows16, hipStream_t stream, const char** name);
+
+/* q8gemm256c.hip: the zero-point-centred flavour (p carries the centred image, its bias pair table and a_flip) */
+bool gemm256c_supported(const IgemmParams& p, uint32_t vec, uint32_t ring);
+int gemm256c_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, uint32_t ring, uint32_t tail);
 
 /* q8gemm256.hip */
 bool gemm256_supported(const IgemmParams& p, uint32_t vec);

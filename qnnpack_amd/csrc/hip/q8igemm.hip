@@ -534,6 +534,7 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   p.bias2u = a->bias2_pair != 0 ? a->bias2 + static_cast<size_t>(a->groups) * a->n_pad : nullptr;
   if (p.bias2u == nullptr) p.lane.kind = 0;      // no table to start from: the offset forms
   p.stream_out = qnnp_hip_streaming_stores() != 0 ? 1u : 0u;
+  p.a_flip = 0;
   p.fill_table = qnnp_hip_fill_table();
   p.trace = nullptr;
 #ifdef QNNP_ENABLE_ABLATION
@@ -674,6 +675,29 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   const bool big_forced = a->variant == 2 || a->variant == 4 || a->variant == 10 || a->variant == 11 || a->variant == 15 || a->variant == 16;   // 10: 128 x 256 tiles, two workgroups per CU; 11: ping-pong schedule; 15: lean flavour
   if (big_forced && !big_ok) return QNNP_HIP_EINVAL;
   int rc;
+  // Operators with a zero-point-centred weight image (kernel zero point 127 or 128, q8gemm256c.hip): no row term at all.
+  // "gemm_kernel" 20..23 force it (ring of 4 / 5 stages, without / with the skewed tail); auto takes 5 stages + skew.
+  const bool c_forced = a->variant >= 20 && a->variant <= 23;
+  if (c_forced || (a->variant == 0 && big_auto && a->centre_flip != 0)) {
+    qnnp::IgemmParams pc = p;
+    const uint32_t ring = c_forced ? ((a->variant & 1) ? 5u : 4u) : 5u;
+    const uint32_t tail = c_forced ? ((a->variant >= 22) ? 1u : 0u) : 1u;
+    bool c_ok = a->centre_flip != 0 && a->packed_w_centred != nullptr && a->bias2_centred != nullptr && a->bias2_pair != 0;
+    if (c_ok) {
+      pc.packed_w = a->packed_w_centred;
+      pc.bias2 = a->bias2_centred;
+      pc.bias2u = a->bias2_centred + static_cast<size_t>(a->groups) * a->n_pad;
+      pc.a_flip = (a->centre_flip & 0xFFu) * 0x01010101u;
+      pc.row_coeff = 0;
+      c_ok = big_ok && qnnp::gemm256c_supported(pc, vec, ring);
+    }
+    if (c_ok) {
+      rc = qnnp::gemm256c_launch(pc, a->groups, stream, &name, ring, tail);
+      if (kernel_name != nullptr) *kernel_name = name;
+      return rc;
+    }
+    if (c_forced) return QNNP_HIP_EINVAL;
+  }
   if (big_ok && (big_forced || (a->variant == 0 && big_auto))) {
     rc = qnnp::gemm256_launch(p, a->groups, stream, &name, a->variant == 4 || a->variant == 16, a->variant == 10, a->variant == 11,
                                (a->variant == 15 || a->variant == 16) ? 2 : (a->variant == 0 ? 1 : 0));   // 16: the 4-wave flavour, lean;   // ("gemm_kernel" = 2 keeps the general flavour for A/B)

@@ -185,6 +185,12 @@ struct qnnp_hip_igemm_args {
    * kernels that use the lane forms of the requantization start their accumulators from. 0: those kernels keep the
    * offset forms. */
   uint32_t bias2_pair;
+  /* optional zero-point-centred weight image (pack.h qnnp_pack_igemm_w_centred; q8gemm256c.hip): same fragment layout
+   * as packed_w with w'' = (w ^ centre_flip) as int8, and its folded bias as a pair table (bias-pair.h). centre_flip =
+   * 0x80 (kernel zero point 128: the two pointers may simply repeat packed_w / bias2) or 0x7F (127); 0 = none. */
+  const int8_t* packed_w_centred;
+  const int32_t* bias2_centred;
+  uint32_t centre_flip;
 };
 int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* args, const char** kernel_name);
 

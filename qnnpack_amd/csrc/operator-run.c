@@ -262,6 +262,10 @@ static int launch_kernel(struct qnnp_operator* op, const void* input, const void
         .residual_stride = (uint32_t) op->residual_pixel_stride,
         .residual_add = &op->residual_params,
         .residual_folded = &op->residual_folded,
+        /* zero-point-centred image (fully-connected.c): its own, or the standard one when that is centred already */
+        .packed_w_centred = (const int8_t*) (op->d_weights_centred != NULL ? op->d_weights_centred : op->d_weights),
+        .bias2_centred = op->d_bias_centred != NULL ? op->d_bias_centred : op->d_bias,
+        .centre_flip = is_conv ? 0u : op->centre_flip,
       };
       return qnnp_hip_igemm_run(&args, &op->kernel_name);
     }

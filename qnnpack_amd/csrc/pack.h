@@ -154,6 +154,45 @@ static inline void qnnp_pack_igemm_w(
 }
 
 /*
+ * Zero-point-centred GEMM image (hip/q8gemm256c.hip) for kernel zero point 127: same fragment geometry as
+ * qnnp_pack_igemm_w, element w'' = 127 - w (= w ^ 0x7F read as int8: always in [-128, 127]). The kernel recentres
+ * the activations with the same mask, a'' = a ^ 0x7F = 127 - a, so a'' w'' = (a - 127)(w - 127) and
+ *   bias + sum (a - izp)(w - 127) = biasc + sum a'' w'',   biasc[n] = bias[n] + (127 - izp) * sum_k (w(n,k) - 127)
+ * -- no per-row kernel-zero-point term (the reference folds only the INPUT zero point into its packed bias,
+ * src/qnnpack/pack.h:24-43; here both zero points end up in the weights' image and the bias).
+ * Single group, no K padding (k_total == k_pad); padding columns hold zero weights and a zero bias.
+ * (Kernel zero point 128 needs nothing of its own: qnnp_pack_igemm_w's image w ^ 0x80 = w - 128 is the centred one and
+ *  its bias2 has no kernel-zero-point part.)
+ */
+static inline void qnnp_pack_igemm_w_centred127(
+    uint32_t n, uint32_t k_total, uint32_t n_pad,
+    uint8_t izp,
+    const uint8_t* kernel, const int32_t* bias,
+    int8_t* packed, int32_t* biasc)
+{
+  const uint32_t kblocks = k_total / 32;
+  memset(packed, 0, (size_t) n_pad * k_total);
+  const uint32_t a_off = (uint32_t) (127 - (int32_t) izp);
+  for (uint32_t col = 0; col < n_pad; col++) {
+    uint32_t b = 0;
+    if (col < n) {
+      const uint8_t* src = kernel + (size_t) col * k_total;
+      const uint32_t nb = col / 32;
+      const uint32_t lane_lo = col % 32;
+      uint32_t wsum = 0;                                   /* sum (w - 127), mod 2^32 */
+      for (uint32_t kk = 0; kk < k_total; kk++) {
+        wsum += (uint32_t) ((int32_t) src[kk] - 127);
+        const uint32_t kb = kk / 32;
+        const uint32_t lane = lane_lo + 32 * ((kk % 32) / 16);
+        packed[((((size_t) nb * kblocks + kb) * 64) + lane) * 16 + (kk % 16)] = (int8_t) (127 - (int32_t) src[kk]);
+      }
+      b = (uint32_t) bias[col] + a_off * wsum;
+    }
+    biasc[col] = (int32_t) b;
+  }
+}
+
+/*
  * depthwise image: wadj[tap][c] = w[c][ky][kx] - kzp as int16, tap = ky*kw + kx,
  * row length c_pad (zero padded); bias1[c] = bias[c] + taps*izp*kzp - izp*sum_taps w
  * -- the folding of pack_q8dw_w (src/qnnpack/pack.h:146,151,159), so the kernel

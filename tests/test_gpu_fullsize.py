@@ -13,14 +13,17 @@ from oracle import o1
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant,kernel", [(0, "q8_gemm_mfma_256x256_lean"), (2, "q8_gemm_mfma_256x256"),
+@pytest.mark.parametrize("variant,kernel", [(0, "q8_gemm_mfma_256x256_c5_skew"), (20, "q8_gemm_mfma_256x256_c4"),
+                                            (21, "q8_gemm_mfma_256x256_c5"), (22, "q8_gemm_mfma_256x256_c4_skew"),
+                                            (15, "q8_gemm_mfma_256x256_lean"), (2, "q8_gemm_mfma_256x256"),
                                             (10, "q8_gemm_mfma_128x256"), (11, "q8_gemm_mfma_256x256_pp"),
                                             (16, "q8_gemm_mfma_256x256_w4_lean")],
-                         ids=["auto", "general", "rows128", "pingpong", "w4_lean"])
+                         ids=["auto", "c4", "c5", "c4_skew", "lean", "general", "rows128", "pingpong", "w4_lean"])
 def test_c2_q8gemm_4096_cubed(qnnp, variant, kernel):
-    """configs[1]: q8gemm M=N=K=4096 through qnnp_fully_connected_nc_q8 -- the shipped kernel (the lean flavour of the
-    256 x 256 kernel is what "auto" picks for this shape), the general flavour it came from, and the two A/B structures of
-    round 3 (128 x 256 tiles with two workgroups per CU; the ping-pong schedule)."""
+    """configs[1]: q8gemm M=N=K=4096 through qnnp_fully_connected_nc_q8 -- the shipped kernel (round 4: the
+    zero-point-centred flavour, q8gemm256c.hip, is what "auto" picks for this shape and these zero points) and its three
+    sibling structures, the lean and general flavours of the kernel it came from (what other zero points run on), and the
+    A/B structures of round 3 (128 x 256 tiles with two workgroups per CU; the ping-pong schedule)."""
     import torch
     qnnp.set_option("gemm_kernel", variant)
     M = N = K = 4096
@@ -190,8 +193,11 @@ def test_c5_mobilenetv2_first_layer(qnnp):
         qnnp.delete_operator(op)
 
 
-def test_c2_q8gemm_4096_cubed_full_output_vs_compiled_reference(qnnp):
-    """configs[1], every one of the 16.8 M output bytes: the compiled REFERENCE (oracle/_ref, its SSE2 q8gemm under
+@pytest.mark.parametrize("kzp,kernel", [(127, "q8_gemm_mfma_256x256_c5_skew"), (128, "q8_gemm_mfma_256x256_c5_skew"),
+                                        (126, "q8_gemm_mfma_256x256_lean")], ids=["kzp127", "kzp128", "kzp126"])
+def test_c2_q8gemm_4096_cubed_full_output_vs_compiled_reference(qnnp, kzp, kernel):
+    """(both centring classes of the shipped kernel, and a zero point that keeps the lean flavour)
+    configs[1], every one of the 16.8 M output bytes: the compiled REFERENCE (oracle/_ref, its SSE2 q8gemm under
     qnnp_fully_connected_nc_q8, all host threads) computes the same 4096^3 problem with bench.py's quantization
     (bench/q8gemm.cc:103: zero points 127, scale 0.75, clamp [1, 254]) in well under a minute; the device output
     must equal it byte for byte. Where the prebuilt reference did not travel, the oracle restatement (O1, pinned to it)
@@ -202,20 +208,20 @@ def test_c2_q8gemm_4096_cubed_full_output_vs_compiled_reference(qnnp):
     a = rng.integers(0, 256, size=(M, K), dtype=np.uint8)
     w = rng.integers(0, 256, size=(N, K), dtype=np.uint8)
     bias = rng.integers(-10000, 10001, size=N, dtype=np.int32)
-    op = qnnp.create_fully_connected_nc_q8(K, N, 127, 0.75, 127, 1.0, w, bias, 127, 1.0, 1, 254)
+    op = qnnp.create_fully_connected_nc_q8(K, N, 127, 0.75, kzp, 1.0, w, bias, 127, 1.0, 1, 254)
     try:
         d_a = to_device(a.reshape(-1))
         d_c = to_device(np.full(M * N, FILL, np.uint8))
         qnnp.setup_fully_connected_nc_q8(op, M, d_a, K, d_c, N)
         qnnp.run_operator(op)
-        assert qnnp.operator_kernel(op) == "q8_gemm_mfma_256x256_lean", qnnp.operator_kernel(op)
+        assert qnnp.operator_kernel(op) == kernel, qnnp.operator_kernel(op)
         got = from_device(d_c).reshape(M, N)
     finally:
         qnnp.delete_operator(op)
     if ref.available():
         rlib = ref.lib()
         want = np.full(M * N, FILL, np.uint8)
-        rop = rlib.create_fully_connected_nc_q8(K, N, 127, 0.75, 127, 1.0, w, bias, 127, 1.0, 1, 254)
+        rop = rlib.create_fully_connected_nc_q8(K, N, 127, 0.75, kzp, 1.0, w, bias, 127, 1.0, 1, 254)
         pool = rlib.threadpool(16)
         rlib.setup_fully_connected_nc_q8(rop, M, a.reshape(-1), K, want, N)
         rlib.run_operator(rop, pool)
@@ -225,7 +231,7 @@ def test_c2_q8gemm_4096_cubed_full_output_vs_compiled_reference(qnnp):
     else:
         rows = np.arange(0, M, 8)
         o1.set_threads(8)
-        acc = o1.gemm_acc(np.ascontiguousarray(a[rows]), w, bias, 127, 127)
+        acc = o1.gemm_acc(np.ascontiguousarray(a[rows]), w, bias, 127, kzp)
         want = o1.requantize_rows(acc, np.float32(0.75), 127, 1, 254)
         o1.set_threads(1)
         assert_bytes_equal(got[rows].reshape(-1), want.reshape(-1), "4096^3 every 8th row vs oracle (no prebuilt reference here)")

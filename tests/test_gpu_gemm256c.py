@@ -1,0 +1,144 @@
+"""GPU tier: the zero-point-centred 256x256 GEMM kernel (qnnpack_amd/csrc/hip/q8gemm256c.hip; what auto picks for
+BASELINE configs[1]) against the scalar oracle, in its four structures ("gemm_kernel" 20..23: ring of 4 / 5 LDS stages,
+tail without / with the priority skew): every prologue / steady-state / tail length in K, row edges, padded channel
+counts, both centring classes (kernel zero point 127 and 128), every requantization flavour the launcher can pick
+(shift 0 / bounded shift >= 1 / general, saturating clamp and explicit clamp), strided rows, and what it must refuse."""
+import numpy as np
+import pytest
+
+from _cases import FcCase
+from _gpu import from_device, to_device
+from oracle import o1
+from qnnpack_amd.binding import QnnpackError
+from _runner import assert_bytes_equal, fc_expected, fc_run
+
+pytestmark = pytest.mark.gpu
+
+_NAME = {20: "q8_gemm_mfma_256x256_c4", 21: "q8_gemm_mfma_256x256_c5", 22: "q8_gemm_mfma_256x256_c4_skew",
+         23: "q8_gemm_mfma_256x256_c5_skew"}
+_MIN_K = {20: 512, 21: 640, 22: 512, 23: 640}
+
+
+@pytest.fixture(params=sorted(_NAME), ids=lambda v: _NAME[v].replace("q8_gemm_mfma_256x256_", ""))
+def centred(qnnp, request):
+    qnnp.set_option("gemm_kernel", request.param)
+    qnnp._kname = _NAME[request.param]
+    qnnp._min_k = _MIN_K[request.param]
+    yield qnnp
+    qnnp.set_option("gemm_kernel", 0)
+
+
+def _fc(lib, case):
+    expected, quant = fc_expected(case)
+    out, kname = fc_run(lib, case, quant, to_device=to_device, from_device=from_device)
+    assert kname == lib._kname, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+# 8 ... 21 K tiles: the unrolled steady state runs 0, 1 or 2 times, the run-time-slot steady state 0 ... 4 times
+@pytest.mark.parametrize("k", [512, 576, 640, 704, 768, 832, 896, 960, 1024, 1088, 1152, 1344])
+@pytest.mark.parametrize("m", [1, 255, 257, 1000])
+def test_m_and_k(centred, m, k):
+    if k < centred._min_k:
+        pytest.skip("fewer K tiles than twice the ring")
+    _fc(centred, FcCase(f"c_m{m}_k{k}", m, k, 256))
+
+
+@pytest.mark.parametrize("n", [256, 1000, 768])
+@pytest.mark.parametrize("kw", [dict(), dict(kzp=128), dict(izp=0, kzp=128), dict(izp=255), dict(izp=3, kzp=128), dict(qmin=128),
+                                dict(qmax=128, kzp=128)],
+                         ids=lambda d: "_".join(f"{k}{v}" for k, v in d.items()) or "default")
+def test_n_and_quantization(centred, n, kw):
+    _fc(centred, FcCase(f"c_n{n}_" + "_".join(f"{k}{v}" for k, v in kw.items()), 520, 704, n, **kw))
+
+
+def test_strided_rows(centred):
+    _fc(centred, FcCase("c_strided", 300, 640, 256, input_stride=656, output_stride=272))
+
+
+@pytest.mark.parametrize("kw", [dict(kzp=126), dict(kzp=0), dict(kzp=129)], ids=lambda d: f"kzp{d['kzp']}")
+def test_other_zero_points_have_no_centred_image(centred, kw):
+    case = FcCase("c_refused_kzp", 300, 640, 256, **kw)
+    _, quant = fc_expected(case)
+    with pytest.raises(QnnpackError):
+        fc_run(centred, case, quant, to_device=to_device, from_device=from_device)
+
+
+@pytest.mark.parametrize("k,n,stride", [(448, 256, 0), (640, 260, 0), (648, 256, 0), (640, 256, 260)])
+def test_refuses_what_it_cannot_take(centred, k, n, stride):
+    case = FcCase(f"c_refused_k{k}_n{n}", 300, k, n, output_stride=stride)
+    _, quant = fc_expected(case)
+    with pytest.raises(QnnpackError):
+        fc_run(centred, case, quant, to_device=to_device, from_device=from_device)
+
+
+SCALES = [float.fromhex("0x1.FFFFFEp-1"), float.fromhex("0x1.FFFFFCp-1"), 0.75, 0.5, 1 / 255.0, 0.0031, 2.0 ** -22,
+          2.0 ** -24, 2.0 ** -32]
+QUANT = [(0, 0, 255), (127, 0, 255), (255, 0, 255), (200, 1, 254), (100, 128, 255), (7, 5, 9)]
+
+
+def _accumulators(n):
+    rng = np.random.default_rng(5)
+    acc = rng.integers(-2**31, 2**31, size=n).astype(np.int64)
+    edge = [-2**31, 2**31 - 1, 0, -1, 1, -2**30, 2**30, -2**31 + 1, 2**31 - 2, 2**31 - 129, 2**31 - 257]
+    acc[:len(edge)] = edge
+    ties = []
+    for s in range(1, 24):
+        for k in (-3, -1, 0, 1, 2, 100):
+            ties += [(k << s) + (1 << (s - 1)) + d for d in (-1, 0, 1)]
+    acc[len(edge):len(edge) + len(ties)] = ties[:n - len(edge)]
+    small = rng.integers(-70000, 70000, size=n // 4)
+    acc[-small.size:] = small
+    return np.clip(acc, -2**31, 2**31 - 1).astype(np.int32)
+
+
+@pytest.mark.parametrize("kzp", [127, 128])
+@pytest.mark.parametrize("scale", SCALES, ids=lambda s: f"{s:.3e}")
+def test_epilogue_corners(qnnp, scale, kzp):
+    """Accumulators driven by the bias alone (activations on their zero point): +-2^31, ties of both roundings, the
+    unfolded zero-point corners -- through the offset / general sequences of the centred kernel."""
+    N, K, M = 1024, 640, 260
+    acc = _accumulators(N)
+    kernel = np.random.default_rng(9).integers(0, 256, size=(N, K), dtype=np.uint8)
+    inp = np.full(M * K, 77, np.uint8)
+    qnnp.set_option("gemm_kernel", 23)
+    try:
+        for zp, qmin, qmax in QUANT:
+            op = qnnp.create_fully_connected_nc_q8(K, N, 77, 1.0, kzp, float(scale), kernel, acc, zp, 1.0, qmin, qmax, 0)
+            try:
+                d_in, d_out = to_device(inp), to_device(np.zeros(M * N, np.uint8))
+                qnnp.setup_fully_connected_nc_q8(op, M, d_in, K, d_out, N)
+                qnnp.run_operator(op)
+                assert qnnp.operator_kernel(op) == "q8_gemm_mfma_256x256_c5_skew"
+                out = from_device(d_out).reshape(M, N)
+            finally:
+                qnnp.delete_operator(op)
+            exp = o1.q31_requantize(acc, np.float32(scale), zp, qmin, qmax)
+            for m in (0, 131, M - 1):
+                bad = np.flatnonzero(out[m] != exp)
+                assert bad.size == 0, (scale, zp, qmin, qmax, acc[bad[:4]].tolist(), out[m][bad[:4]].tolist(), exp[bad[:4]].tolist())
+    finally:
+        qnnp.set_option("gemm_kernel", 0)
+
+
+@pytest.mark.parametrize("kzp,k,n,kernel", [(127, 1088, 2048, "q8_gemm_mfma_256x256_c5_skew"),
+                                            (128, 1088, 2048, "q8_gemm_mfma_256x256_c5_skew"),
+                                            (126, 1088, 2048, "q8_gemm_mfma_256x256_lean"),
+                                            (127, 576, 2048, "q8_gemm_mfma_256x256_lean"),      # 9 K tiles: below twice the ring
+                                            (127, 1088, 2080, "q8_gemm_mfma_256x256")])
+def test_auto_takes_the_centred_flavour_where_it_applies(qnnp, kzp, k, n, kernel):
+    case = FcCase(f"auto_kzp{kzp}_k{k}_n{n}", 3328, k, n, kzp=kzp)
+    expected, quant = fc_expected(case)
+    out, kname = fc_run(qnnp, case, quant, to_device=to_device, from_device=from_device)
+    assert kname == kernel, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+def test_repeated_launches_are_stable(qnnp):
+    """The barrier-free tail and the image slots race with nothing: 20 launches of one operator, identical bytes."""
+    case = FcCase("c_repeat", 2048, 1280, 1024)
+    expected, quant = fc_expected(case)
+    for _ in range(20):
+        out, kname = fc_run(qnnp, case, quant, to_device=to_device, from_device=from_device)
+        assert kname == "q8_gemm_mfma_256x256_c5_skew", kname
+        assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")

@@ -50,6 +50,36 @@ def test_fully_connected_host_images(hooks, case):
     assert_bytes_equal(out, expected, f"host images replay vs oracle [{case.name}]")
 
 
+@pytest.mark.parametrize("izp", [0, 3, 127, 128, 255])
+@pytest.mark.parametrize("n,k", [(256, 512), (1000, 640), (300, 64)])
+def test_centred_gemm_image_replays_the_oracle(debug_hooks, izp, n, k):
+    """pack.h qnnp_pack_igemm_w_centred127 + the arithmetic of hip/q8gemm256c.hip for kernel zero point 127: both
+    operands recentred with ^ 0x7F (a'' = 127 - a, w'' = 127 - w), no row term, bias folded for both zero points.
+    (Kernel zero point 128 is the standard image with a zero row coefficient: test_fully_connected_host_images.)"""
+    import ctypes
+    L = debug_hooks.lib
+    L.qnnp_debug_pack_igemm_w_centred127.restype = None
+    L.qnnp_debug_pack_igemm_w_centred127.argtypes = [ctypes.c_uint32] * 3 + [ctypes.c_uint8] + [ctypes.c_void_p] * 4
+    rng = np.random.default_rng(n * 7 + k + izp)
+    m = 37
+    a = rng.integers(0, 256, size=(m, k), dtype=np.uint8)
+    w = rng.integers(0, 256, size=(n, k), dtype=np.uint8)
+    w[0, :] = 255; w[1, :] = 0; a[0, :] = 255; a[1, :] = 0           # the corners of both ranges
+    bias = rng.integers(-10000, 10001, size=n).astype(np.int32)
+    bias[2] = 2**31 - 1; bias[3] = -2**31                               # folding wraps like the reference's int32
+    n_pad = em.round_up(n, 32)
+    packed = np.empty(n_pad * k, dtype=np.int8)
+    biasc = np.empty(n_pad, dtype=np.int32)
+    L.qnnp_debug_pack_igemm_w_centred127(n, k, n_pad, izp, w.ctypes.data, bias.ctypes.data, packed.ctypes.data, biasc.ctypes.data)
+    wc = em.unpack_fragments(packed, 1, n_pad, k)[0]                   # what the MFMA sees
+    assert np.array_equal(wc[:n], 127 - w.astype(np.int64)) and not wc[n:].any() and not biasc[n:].any()
+    assert np.array_equal(wc[:n].astype(np.int8), (w ^ 0x7F).view(np.int8))
+    a_c = (a ^ 0x7F).view(np.int8).astype(np.int64)                    # the kernel's v_xor with 0x7F7F7F7F
+    assert np.array_equal(a_c, 127 - a.astype(np.int64))
+    acc = em.wrap32(a_c @ wc[:n].T + biasc[None, :n].astype(np.int64))
+    assert np.array_equal(acc, o1.gemm_acc(a, w, bias, izp, 127).astype(np.int64))
+
+
 @pytest.mark.parametrize("case", SMALL_CONV, ids=lambda c: c.name)
 def test_convolution_host_images(hooks, case):
     inp, kernel, bias = conv_tensors(case)
