@@ -83,6 +83,8 @@ struct IgemmParams {
   uint32_t stream_out;       // 1: whole-line stores that write a line exactly once carry the streaming hint ("streaming_stores")
   uint32_t a_flip;           // q8gemm256c.hip only: the activation recentring mask, 0x80808080 (image centred on 128) or
                              // 0x7F7F7F7F (on 127); 0 = the operator has no centred image
+  uint32_t tiles_n_magic;    // q8gemm256c.hip only: floor(2^32 / tiles_n) + 1, so that x / tiles_n == hi32(x * magic) for the
+                             // tile ids of a launch (x * tiles_n < 2^32); set by gemm256c_launch
 };
 
 /* convolution geometry for the LDS-tiled direct-convolution kernel */
@@ -115,8 +117,8 @@ bool conv_c3rows_supported(const IgemmParams& p, const ConvGeom& g, uint32_t gro
 int conv_c3rows_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_rows16, hipStream_t stream, const char** name);
 
 /* q8gemm256c.hip: the zero-point-centred flavour (p carries the centred image, its bias pair table and a_flip) */
-bool gemm256c_supported(const IgemmParams& p, uint32_t vec, uint32_t ring);
-int gemm256c_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, uint32_t ring, uint32_t tail);
+bool gemm256c_supported(const IgemmParams& p, uint32_t vec);
+int gemm256c_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, uint32_t opt);
 
 /* q8gemm256.hip */
 bool gemm256_supported(const IgemmParams& p, uint32_t vec);

@@ -911,6 +911,11 @@ int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, co
   const uint32_t tiles_n = (p.n_pad + kBN - 1) / kBN;
   const dim3 grid(tiles_m * tiles_n, groups, 1);
   const bool conv = p.offsets != nullptr;
+#ifndef QNNP_ENABLE_ABLATION
+  // The structures that LOST their A/B (profiles/r03/gemm_structures_ab_r03a.txt: 4 waves of 128 x 128, 128 x 256 tiles with
+  // two workgroups per CU, the ping-pong schedule) are evidence, not product: measurement builds only.
+  if (waves4 || rows128 || pingpong) return QNNP_HIP_EINVAL;
+#else
   if (rows128) {
     *name = conv ? "q8_gemm_mfma_128x256_conv" : "q8_gemm_mfma_128x256";
     return conv ? launch256<true, 2, 128>(p, grid, stream) : launch256<false, 2, 128>(p, grid, stream);
@@ -921,7 +926,6 @@ int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, co
     else hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 4, 256, 0, true>), grid, dim3(512), 0, stream, p);
     return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
   }
-#ifdef QNNP_ENABLE_ABLATION
   if (!conv) {
     const char* env = getenv("QNNP_GFX950_ABLATE");
     const int abl = env != nullptr ? atoi(env) : 0;
@@ -937,20 +941,25 @@ int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, co
     }
 #undef QNNP_ABL_CASE
   }
+  if (waves4) {
+    if (lean != 0 && gemm256_lean_supported(p)) {
+      *name = "q8_gemm_mfma_256x256_w4_lean";
+      hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 2, 256, 0, false, true>), grid, dim3(256), 0, stream, p);
+      return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+    }
+    if (lean > 1) return QNNP_HIP_EINVAL;
+    *name = conv ? "q8_gemm_mfma_256x256_w4_conv" : "q8_gemm_mfma_256x256_w4";
+    return conv ? launch256<true, 2>(p, grid, stream) : launch256<false, 2>(p, grid, stream);
+  }
 #endif
   if (lean != 0 && gemm256_lean_supported(p)) {
-    *name = waves4 ? "q8_gemm_mfma_256x256_w4_lean" : "q8_gemm_mfma_256x256_lean";
-    if (waves4) hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 2, 256, 0, false, true>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 4, 256, 0, false, true>), grid, dim3(512), 0, stream, p);
+    *name = "q8_gemm_mfma_256x256_lean";
+    hipLaunchKernelGGL((q8_gemm_mfma_256x256_kernel<false, 4, 256, 0, false, true>), grid, dim3(512), 0, stream, p);
     return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
   }
   if (lean > 1) return QNNP_HIP_EINVAL;        // forced and not applicable
-  if (conv) {
-    *name = waves4 ? "q8_gemm_mfma_256x256_w4_conv" : "q8_gemm_mfma_256x256_conv";
-    return waves4 ? launch256<true, 2>(p, grid, stream) : launch256<true, 4>(p, grid, stream);
-  }
-  *name = waves4 ? "q8_gemm_mfma_256x256_w4" : "q8_gemm_mfma_256x256";
-  return waves4 ? launch256<false, 2>(p, grid, stream) : launch256<false, 4>(p, grid, stream);
+  *name = conv ? "q8_gemm_mfma_256x256_conv" : "q8_gemm_mfma_256x256";
+  return conv ? launch256<true, 4>(p, grid, stream) : launch256<false, 4>(p, grid, stream);
 }
 
 }  // namespace qnnp

@@ -20,25 +20,32 @@
  * reference's own benchmarks and PyTorch's symmetric weights use exactly these two zero points, bench/q8gemm.cc:60-64.)
  * Every other zero point keeps q8gemm256.hip.
  *
- * What else differs from the lean flavour there (each an A/B item of round 4):
- *   - the requantization sequence is a TEMPLATE argument chosen by the launcher (the kernel has no branch on it); with
- *     no row term the accumulators start from biasc + 2^31 and the offset forms of requant_math.h apply as they are;
- *   - RING = 5: the whole 160 KiB of LDS as five 32 KiB stages (the DMA runs one tile further ahead);
- *   - a barrier-free TAIL: the last RING - 1 K tiles are resident once the last LDS-DMA has landed, so one final
- *     vmcnt(0) + barrier releases the waves to run to the end on their own; with TAIL = 1 the older wave of each SIMD
- *     (waves 0-3) takes the matrix pipe first (s_setprio), finishes early and requantizes / stores its tile while the
- *     younger wave (4-7) multiplies -- the epilogue of one wave under the MFMAs of the other instead of both epilogues
- *     queueing on the SIMD's issue port behind an idle matrix pipe;
- *   - the folded bias arrives by inline-asm loads issued right behind the first tile's LDS-DMA (hipcc cannot see the
- *     LDS-DMA on the vmcnt queue: a visible load would be waited for with vmcnt(0), i.e. behind the whole ring);
- *   - the output tile is staged through the two ring slots that are free during the tail, half a wave tile at a time.
+ * What else differs from the lean flavour there (each measured in round 4, DESIGN.md section 4.1, profiles/r04/):
+ *   - the requantization sequence and the clamp class are TEMPLATE arguments chosen by the launcher (the kernel has no
+ *     branch on them); with no row term the accumulators start from biasc + 2^31 and the offset forms of requant_math.h
+ *     apply as they are; a clamp other than [0, 255] with a folded zero point costs one v_med3 per value and a 3-op pack;
+ *   - the folded bias arrives by ONE LDS-DMA instruction per wave (512 bytes into the 32 KiB of LDS the ring leaves
+ *     free) right behind the first tile's pieces and is read back as broadcast ds_read_b128: sixteen global loads per
+ *     wave -- as many texture-path instructions as the whole ring fill -- sat in front of the first MFMA before;
+ *   - the weight-fragment reads of a phase are issued one per MFMA instead of in one burst behind the barrier (the LDS
+ *     command FIFO was full for 1.2 M of 45 M wave-cycles);
+ *   - a barrier-free TAIL: the last three K tiles are resident once the last LDS-DMA has landed, so one final
+ *     vmcnt(0) + barrier releases the waves to run to the end on their own, and the output tile is staged through the
+ *     two ring slots that are free from then on, half a wave tile at a time.
+ * Measured and dropped (profiles/r04/gemm_centred_ring_skew_ab_r04a.txt, gemm_centred_cycle_stamps_r04c.txt): a fifth
+ * ring stage (59.3 against 58.9 us), s_setprio for the older wave of each SIMD in the tail (the older wave wins the
+ * matrix pipe anyway: its tail takes 1.5 k cycles against the younger one's 2.7 k with or without it) and, the blunt form
+ * of the same idea, putting the younger waves to sleep for 1024 / 1536 cycles behind the final barrier (59.64 / 59.68
+ * against 59.53 us, gemm_centred_aligned_sleep_ab_r04e.txt), a wave-dependent issue position for the LDS-DMA pieces (four
+ * copies of the loop: 210 spilled registers), nt / sc1 cache policy on the LDS-DMA loads (61.0 / 55.7 against 55.5 us).
  *
- * Requirements (gemm256c_supported): plain GEMM, K % 64 == 0, K >= 128 * RING, N padded to 256, 16-byte aligned rows and
+ * Requirements (gemm256c_supported): plain GEMM, K % 64 == 0, K >= 512, N padded to 256, 16-byte aligned rows and
  * outputs (store_mode 2), a bias pair table.
  */
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -64,6 +71,8 @@ constexpr int kTM = 2;                         // 32-row MFMA tiles per wave
 constexpr int kTN = 4;                         // 32-channel MFMA tiles per wave
 constexpr int kDma = 4;                        // LDS-DMA instructions per thread and K tile: 2 activation + 2 weight pieces
 constexpr int kMma = kTM * kTN;                // MFMAs per K sub-step
+constexpr int kRing = 4;                       // LDS stages of 32 KiB; the remaining 32 KiB hold the waves' bias lines
+constexpr int kBiasArea = kRing * kStage;      // 8 waves x 512 bytes
 constexpr uint32_t kImagePitch = kTN * 32 + 16;          // +16: the 8-lane ds_write_b128 groups hit distinct banks
 constexpr uint32_t kImageBytes = 32 * kImagePitch;       // one 32-row half of a wave's 64 x 128 output tile
 
@@ -88,7 +97,9 @@ __device__ __forceinline__ uint32_t lds_address(uint8_t* lds_ptr)
   return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*) lds_ptr));
 }
 
-/* LDS-DMA, saddr form (q8gemm256.hip): 16 bytes per lane from base + lane_offset to m0 + lane * 16 */
+/* LDS-DMA, saddr form (q8gemm256.hip): 16 bytes per lane from base + lane_offset to m0 + lane * 16.
+ * (Cache policy bits on these loads, measured in round 4: sc1 level, nt 10 % slower -- every line is re-read by the
+ *  other CUs of the XCD; profiles/r04/gemm_centred_bias_dma_clamp_spread_policy_ab_r04d.txt.) */
 __device__ __forceinline__ void dma16_saddr(const uint8_t* base, uint32_t lane_offset, uint8_t* lds_wave_base)
 {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
@@ -103,30 +114,44 @@ __device__ __forceinline__ void dma16_saddr_m0_set(const uint8_t* base, uint32_t
   asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(lane_offset), "s"(base));
 }
 
-/* 16 bytes per lane into registers, asynchronously: the result is valid behind bias_wait() only */
-template <int OFFSET>
-__device__ __forceinline__ v4i load16_async(const uint8_t* base, uint32_t lane_offset)
-{
-  v4i r;
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(lane_offset), "s"(base), "n"(OFFSET));
-  return r;
-}
-
 #define QNNP_PIN() __builtin_amdgcn_sched_barrier(0)
 
+// measurement builds: cycle stamps of wave 0 (item 0) and wave 4 (item 1) of every workgroup; item 3 = wall clock
+#ifdef QNNP_ENABLE_ABLATION
+#define QNNP_C_STAMP(slot)                                                                                  \
+  do {                                                                                                       \
+    if (p.trace != nullptr && lane == 0 && (wave & 3u) == 0)                                                 \
+      p.trace[(blockIdx.x * 4 + (wave >> 2)) * 8 + (slot)] = __builtin_readcyclecounter();                  \
+  } while (0)
+#define QNNP_C_STAMP_WALL(slot)                                                                             \
+  do {                                                                                                       \
+    if (p.trace != nullptr && lane == 0 && (wave & 3u) == 0)                                                 \
+      p.trace[(blockIdx.x * 4 + 2 + (wave >> 2)) * 8 + (slot)] = wall_clock64();                            \
+  } while (0)
+#else
+#define QNNP_C_STAMP(slot) do { } while (0)
+#define QNNP_C_STAMP_WALL(slot) do { } while (0)
+#endif
+
 /*
- * SEQ / FULL: rounding sequence and clamp class of the requantization (requant.hip.h), chosen by the launcher.
- * RING: LDS stages (4 or 5). TAIL: 0 = barrier-free tail, both waves of a SIMD at equal priority; 1 = the older wave first.
+ * SEQ / CLAMP: rounding sequence and clamp class of the requantization (requant.hip.h), chosen by the launcher.
+ * ALIGNED: the K tiles are a multiple of the ring (K % 256 == 0): every ring slot is a literal, the drain included.
+ * OPT (A/B structure, "gemm_kernel" 21): 2 = the fragment reads of a phase in one burst behind the barrier (round 3's
+ * order) instead of the weight fragments one per MFMA.
+ * ABL: measurement-only ablation mask (builds with -DQNNP_ENABLE_ABLATION, env QNNP_GFX950_ABLATE); 0 in the product.
+ * 1 = no epilogue (requantization + stores), 2 = no recentring, 4 = no MFMA, 8 = no LDS-DMA after the prologue,
+ * 16 = no fragment reads after the prologue, 32 = no per-tile wait + barrier, 64 = no global stores (everything else of the
+ * epilogue stays).
  */
-template <int SEQ, bool FULL, int RING, int TAIL>
+template <int SEQ, int CLAMP, bool ALIGNED, int OPT = 0, int ABL = 0>
 __global__ __launch_bounds__(kThreads, 2)
 void q8_gemm_mfma_256x256_c_kernel(const IgemmParams p)
 {
-  static_assert(RING == 4 || RING == 5, "ring of four or five 32 KiB stages");
   static_assert(SEQ == kRqShift0Ofs || SEQ == kRqBoundedOfs || SEQ == kRqGeneral, "offset forms, or the general one");
+  constexpr int RING = kRing;
   constexpr int kGroups = (RING + 1) / 2;        // address registers per fragment: a ds_read immediate reaches 64 KiB = 2 stages
 
-  __shared__ __attribute__((aligned(16))) uint8_t lds[RING * kStage];    // the ONE LDS object (guide 5, trap 4a)
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kRing * kStage + 8 * 512];    // the ONE LDS object (guide 5, trap 4a)
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -134,21 +159,24 @@ void q8_gemm_mfma_256x256_c_kernel(const IgemmParams p)
   const uint32_t wm = wave >> 1;       // 64-row slice
   const uint32_t wn = wave & 1u;       // 128-channel half
   const uint32_t g = blockIdx.y;
+  QNNP_C_STAMP(0);
+  QNNP_C_STAMP_WALL(0);
 
   // Workgroup -> tile (q8gemm256.hip): contiguous logical ids per XCD, bands of four row tiles.
   const uint32_t tiles_m = (p.rows + kBM - 1) / kBM;
   const uint32_t tiles_n = p.n_pad / kBN;
   uint32_t m_tile, n_tile;
   {
+    // (branch-free up to the band test, division by multiplication: the kernel arguments are fetched in one round
+    //  instead of one per basic block -- each round is a scalar-cache miss in front of the first LDS-DMA)
     const uint32_t nwg = gridDim.x;
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t idx = blockIdx.x >> 3;
     const uint32_t q = nwg >> 3, r = nwg & 7u;
-    const uint32_t logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const uint32_t logical = xcd * q + min(xcd, r) + idx;       // == (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx
     constexpr uint32_t kBand = 4;
-    const uint32_t per_band = kBand * tiles_n;
-    const uint32_t band = logical / per_band;
-    const uint32_t within = logical - band * per_band;
+    const uint32_t band = p.tiles_n_magic != 0 ? __umulhi(logical >> 2, p.tiles_n_magic) : logical >> 2;   // logical / (4 * tiles_n)
+    const uint32_t within = logical - band * kBand * tiles_n;
     const uint32_t rows_in_band = min(kBand, tiles_m - band * kBand);
     if (rows_in_band == kBand) {                 // (the common case without a division)
       m_tile = band * kBand + (within & 3u);
@@ -203,19 +231,15 @@ void q8_gemm_mfma_256x256_c_kernel(const IgemmParams p)
 #pragma unroll
   for (int piece = 0; piece < kDma; piece++) stage_piece(0, piece, 0);
 
-  // Accumulators start at the folded bias (+ 2^31 for the offset forms): lane l holds, in register r of tile tn,
-  // channel (nb0 + wn * 4 + tn) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).
+  // The wave's 128 folded biases (+ 2^31 for the offset forms): ONE LDS-DMA instruction, lanes 0..31, 512 bytes into the
+  // wave's line of the bias area. (Sixteen 16-byte global loads per wave, as before, are as many texture-path
+  // instructions as the whole ring fill, and the first MFMA waited for them.)
   const int32_t* bias_tab = SEQ == kRqGeneral ? p.bias2 : p.bias2u;
-  const uint8_t* bias_base = scalar_ptr(reinterpret_cast<const uint8_t*>(
-      bias_tab + static_cast<uint64_t>(g) * p.n_pad + (nb0 + wn * kTN) * 32));
-  const uint32_t bias_voff = (lane >> 5) * 16;
-  v4i braw[kTN][4];
-#define QNNP_BIAS_LOAD(TN, RG) braw[TN][RG] = load16_async<(TN) * 128 + (RG) * 32>(bias_base, bias_voff)
-  QNNP_BIAS_LOAD(0, 0); QNNP_BIAS_LOAD(0, 1); QNNP_BIAS_LOAD(0, 2); QNNP_BIAS_LOAD(0, 3);
-  QNNP_BIAS_LOAD(1, 0); QNNP_BIAS_LOAD(1, 1); QNNP_BIAS_LOAD(1, 2); QNNP_BIAS_LOAD(1, 3);
-  QNNP_BIAS_LOAD(2, 0); QNNP_BIAS_LOAD(2, 1); QNNP_BIAS_LOAD(2, 2); QNNP_BIAS_LOAD(2, 3);
-  QNNP_BIAS_LOAD(3, 0); QNNP_BIAS_LOAD(3, 1); QNNP_BIAS_LOAD(3, 2); QNNP_BIAS_LOAD(3, 3);
-#undef QNNP_BIAS_LOAD
+  uint8_t* bias_line = lds + kBiasArea + wave * 512;
+  if (lane < 32) {
+    dma16_saddr(scalar_ptr(reinterpret_cast<const uint8_t*>(bias_tab + static_cast<uint64_t>(g) * p.n_pad + (nb0 + wn * kTN) * 32)),
+                   lane * 16, bias_line);
+  }
 
 #pragma unroll
   for (int t = 1; t < RING; t++) {
@@ -261,6 +285,18 @@ void q8_gemm_mfma_256x256_c_kernel(const IgemmParams p)
       f.w[tn] = *reinterpret_cast<const v4i*>(lds + w_off[sub][h] + imm + tn * 2048);
     }
   };
+  // (OPT 2: the activation fragments first, the weight fragments one per MFMA)
+  auto read_frags_a_slot = [&](uint32_t slot, int sub, Frags& f) __attribute__((always_inline)) {
+    const uint32_t h = slot >> 1, imm = (slot & 1u) * kStage;
+#pragma unroll
+    for (int tm = 0; tm < kTM; tm++) {
+      f.a[tm] = *reinterpret_cast<const v4i*>(lds + a_off[sub][tm][h] + imm);
+    }
+  };
+  auto read_frag_w_slot = [&](uint32_t slot, int sub, Frags& f, int tn) __attribute__((always_inline)) {
+    const uint32_t h = slot >> 1, imm = (slot & 1u) * kStage;
+    f.w[tn] = *reinterpret_cast<const v4i*>(lds + w_off[sub][h] + imm + tn * 2048);
+  };
   // run-time slot (the few iterations outside the unrolled steady state)
   auto read_frags_rt = [&](uint32_t slot, int sub, Frags& f) __attribute__((always_inline)) {
     const uint8_t* st = lds + slot * kStage;
@@ -278,7 +314,9 @@ void q8_gemm_mfma_256x256_c_kernel(const IgemmParams p)
   // half h (0..3) of the recentring of one fragment set: 2 of its 8 dwords (opaque HERE: q8gemm256.hip)
   auto flip_part = [&](Frags& f, int h) __attribute__((always_inline)) {
     const int tm = h >> 1;
-    if (h & 1) {
+    if constexpr ((ABL & 2) != 0) {
+      asm volatile("" : "+v"(f.a[tm]));
+    } else if (h & 1) {
       f.a[tm].z ^= static_cast<int>(flip);
       f.a[tm].w ^= static_cast<int>(flip);
       asm volatile("" : "+v"(f.a[tm].z), "+v"(f.a[tm].w));
@@ -295,34 +333,35 @@ void q8_gemm_mfma_256x256_c_kernel(const IgemmParams p)
   v16i acc[kTM][kTN];
   auto mma = [&](const Frags& f, int i) __attribute__((always_inline)) {       // i = 0..kMma-1 -> (tm, tn)
     const int tm = i / kTN, tn = i % kTN;
+    if constexpr ((ABL & 4) != 0) return;
     acc[tm][tn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[tn], f.a[tm], acc[tm][tn], 0, 0, 0);
   };
 
-  // ---- prologue, part 2: tile 0 and the bias have landed (loads complete in issue order) ----
-  asm volatile("s_waitcnt vmcnt(%16)"
-               : "+v"(braw[0][0]), "+v"(braw[0][1]), "+v"(braw[0][2]), "+v"(braw[0][3]),
-                 "+v"(braw[1][0]), "+v"(braw[1][1]), "+v"(braw[1][2]), "+v"(braw[1][3]),
-                 "+v"(braw[2][0]), "+v"(braw[2][1]), "+v"(braw[2][2]), "+v"(braw[2][3]),
-                 "+v"(braw[3][0]), "+v"(braw[3][1]), "+v"(braw[3][2]), "+v"(braw[3][3])
-               : "n"((RING - 1) * kDma) : "memory");
+  // ---- prologue, part 2: tile 0 and the bias line have landed (loads complete in issue order) ----
+  wait_vmcnt<(RING - 1) * kDma>();
   __builtin_amdgcn_s_barrier();
+  QNNP_C_STAMP(1);
   Frags fa, fb;
   read_frags_slot(0, 0, fa);
+  // accumulators: lane l holds, in register r of tile tn, channel (nb0 + wn * 4 + tn) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+  // (its own wave's DMA: visible behind the vmcnt wait above; two addresses per read, a broadcast)
 #pragma unroll
   for (int tn = 0; tn < kTN; tn++) {
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) {
+      const v4i b = *reinterpret_cast<const v4i*>(bias_line + (lane >> 5) * 16 + tn * 128 + rg * 32);
 #pragma unroll
       for (int tm = 0; tm < kTM; tm++) {
-        acc[tm][tn][rg * 4 + 0] = braw[tn][rg].x;
-        acc[tm][tn][rg * 4 + 1] = braw[tn][rg].y;
-        acc[tm][tn][rg * 4 + 2] = braw[tn][rg].z;
-        acc[tm][tn][rg * 4 + 3] = braw[tn][rg].w;
+        acc[tm][tn][rg * 4 + 0] = b.x;
+        acc[tm][tn][rg * 4 + 1] = b.y;
+        acc[tm][tn][rg * 4 + 2] = b.z;
+        acc[tm][tn][rg * 4 + 3] = b.w;
       }
     }
   }
   flip_part(fa, 0); flip_part(fa, 1); flip_part(fa, 2); flip_part(fa, 3);
   settle_w(fa);
+  if constexpr ((ABL & 16) != 0) fb = fa;       // (measurement builds: something defined to multiply)
 
   /*
    * Software pipeline (q8gemm256.hip, "iteration"): two phases per K tile, each = 8 MFMAs on one fragment set while the
@@ -334,27 +373,36 @@ void q8_gemm_mfma_256x256_c_kernel(const IgemmParams p)
    * At the wait of tile kt the tiles kt + 2 .. kt + RING - 1 may still be in flight: vmcnt((RING - 2) * 4).
    * SYNC: 1 = that wait + barrier; 2 = the FINAL one, vmcnt(0): every tile is resident afterwards; 0 = none (the tail).
    */
-  auto iteration = [&](auto p1f_c, auto more_c, auto p2f_c, auto sync_c, auto known_c, uint32_t kt, uint32_t slot) __attribute__((always_inline)) {
-    constexpr bool P1F = decltype(p1f_c)::value;
+  auto iteration = [&](auto p1f_c, auto more_c, auto p2f_c, auto sync_c, auto known_c, auto stag_c, uint32_t kt, uint32_t slot) __attribute__((always_inline)) {
+    constexpr int S = decltype(stag_c)::value;           // MFMA position (mod 4) of the LDS-DMA pieces
+    constexpr bool SPREAD = (OPT & 2) == 0;
+    constexpr bool P1F = decltype(p1f_c)::value && (ABL & 8) == 0;
     constexpr bool MORE = decltype(more_c)::value;
-    constexpr bool P2F = decltype(p2f_c)::value;
-    constexpr int SYNC = decltype(sync_c)::value;
+    constexpr bool P2F = decltype(p2f_c)::value && (ABL & 8) == 0;
+    constexpr int SYNC = (ABL & 32) != 0 ? 0 : decltype(sync_c)::value;
     constexpr bool KNOWN = decltype(known_c)::value;     // `slot` is a literal
     const uint32_t prev_slot = slot == 0 ? RING - 1 : slot - 1;
     const uint32_t next_slot = slot + 1 == RING ? 0 : slot + 1;
 
     QNNP_PIN();
-    if constexpr (KNOWN) read_frags_slot(slot, 1, fb); else read_frags_rt(slot, 1, fb);
+    if constexpr ((ABL & 16) == 0) {
+      if constexpr (KNOWN && SPREAD) read_frags_a_slot(slot, 1, fb);
+      else if constexpr (KNOWN) read_frags_slot(slot, 1, fb);
+      else read_frags_rt(slot, 1, fb);
+    }
     QNNP_PIN();
 #pragma unroll
     for (int i = 0; i < kMma; i++) {
       if constexpr (P1F && KNOWN) {
-        if (i % 4 == 0) { dma16_set_m0(piece_dst(2 + i / 4, prev_slot)); QNNP_PIN(); }
+        if (i % 4 == S) { dma16_set_m0(piece_dst(2 + i / 4, prev_slot)); QNNP_PIN(); }
       }
       mma(fa, i);
       QNNP_PIN();
+      if constexpr (KNOWN && SPREAD && (ABL & 16) == 0) {
+        if (i < kTN) { read_frag_w_slot(slot, 1, fb, i); QNNP_PIN(); }
+      }
       if constexpr (P1F && KNOWN) {
-        if (i % 4 == 0) { dma16_saddr_m0_set(piece_src(kt + RING - 1, 2 + i / 4), piece_off(2 + i / 4)); QNNP_PIN(); }
+        if (i % 4 == S) { dma16_saddr_m0_set(piece_src(kt + RING - 1, 2 + i / 4), piece_off(2 + i / 4)); QNNP_PIN(); }
       } else if constexpr (P1F) {
         if (i % 4 == 0) { stage_piece(kt + RING - 1, 2 + i / 4, prev_slot); QNNP_PIN(); }
       }
@@ -374,27 +422,28 @@ void q8_gemm_mfma_256x256_c_kernel(const IgemmParams p)
       __builtin_amdgcn_s_barrier();
     } else if constexpr (SYNC == 2) {
       wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      if constexpr (TAIL == 1) {
-        // from here on nothing synchronizes the waves: the older wave of each SIMD takes the matrix pipe first
-        if (wave < 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
-      }
+      __builtin_amdgcn_s_barrier();         // from here on nothing synchronizes the waves
     }
     QNNP_PIN();
 
-    if constexpr (MORE) {
-      if constexpr (KNOWN) read_frags_slot(next_slot, 0, fa); else read_frags_rt(next_slot, 0, fa);
+    if constexpr (MORE && (ABL & 16) == 0) {
+      if constexpr (KNOWN && SPREAD) read_frags_a_slot(next_slot, 0, fa);
+      else if constexpr (KNOWN) read_frags_slot(next_slot, 0, fa);
+      else read_frags_rt(next_slot, 0, fa);
     }
     QNNP_PIN();
 #pragma unroll
     for (int i = 0; i < kMma; i++) {
       if constexpr (P2F && KNOWN) {
-        if (i % 4 == 0) { dma16_set_m0(piece_dst(i / 4, slot)); QNNP_PIN(); }
+        if (i % 4 == S) { dma16_set_m0(piece_dst(i / 4, slot)); QNNP_PIN(); }
       }
       mma(fb, i);
       QNNP_PIN();
+      if constexpr (MORE && KNOWN && SPREAD && (ABL & 16) == 0) {
+        if (i < kTN) { read_frag_w_slot(next_slot, 0, fa, i); QNNP_PIN(); }
+      }
       if constexpr (P2F && KNOWN) {
-        if (i % 4 == 0) { dma16_saddr_m0_set(piece_src(kt + RING, i / 4), piece_off(i / 4)); QNNP_PIN(); }
+        if (i % 4 == S) { dma16_saddr_m0_set(piece_src(kt + RING, i / 4), piece_off(i / 4)); QNNP_PIN(); }
       } else if constexpr (P2F) {
         if (i % 4 == 0) { stage_piece(kt + RING, i / 4, slot); QNNP_PIN(); }
       }
@@ -417,45 +466,79 @@ void q8_gemm_mfma_256x256_c_kernel(const IgemmParams p)
   using Sync0 = std::integral_constant<int, 0>;
   using Sync1 = std::integral_constant<int, 1>;
   using Sync2 = std::integral_constant<int, 2>;
+  using S0 = std::integral_constant<int, 0>;
 
   // (the launcher guarantees ktiles >= 2 * RING)
-  iteration(F{}, T{}, T{}, Sync1{}, T{}, 0u, 0u);         // the prologue staged pieces 2, 3 of tile RING - 1 already
+  iteration(F{}, T{}, T{}, Sync1{}, T{}, S0{}, 0u, 0u);   // the prologue staged pieces 2, 3 of tile RING - 1 already
+  QNNP_C_STAMP(2);
+  auto rest = [&](auto stag_all) __attribute__((always_inline)) {
   uint32_t kt = 1;
-  for (; kt + (RING - 1) + RING < ktiles; kt += RING) {   // steady state, ring slots as literals (kt % RING == 1 here)
-    iteration(T{}, T{}, T{}, Sync1{}, T{}, kt, 1u);
-    iteration(T{}, T{}, T{}, Sync1{}, T{}, kt + 1, 2u);
-    iteration(T{}, T{}, T{}, Sync1{}, T{}, kt + 2, 3u);
-    if constexpr (RING == 5) {
-      iteration(T{}, T{}, T{}, Sync1{}, T{}, kt + 3, 4u);
-      iteration(T{}, T{}, T{}, Sync1{}, T{}, kt + 4, 0u);
-    } else {
-      iteration(T{}, T{}, T{}, Sync1{}, T{}, kt + 3, 0u);
+  auto steady = [&](auto stag_c) __attribute__((always_inline)) {
+    for (; kt + (RING - 1) + RING < ktiles; kt += RING) {   // steady state, ring slots as literals (kt % RING == 1 here)
+      iteration(T{}, T{}, T{}, Sync1{}, T{}, stag_c, kt, 1u);
+      iteration(T{}, T{}, T{}, Sync1{}, T{}, stag_c, kt + 1, 2u);
+      iteration(T{}, T{}, T{}, Sync1{}, T{}, stag_c, kt + 2, 3u);
+      iteration(T{}, T{}, T{}, Sync1{}, T{}, stag_c, kt + 3, 0u);
     }
-  }
+  };
+  steady(stag_all);
+  if constexpr (ALIGNED) {
+    // ktiles % 4 == 0: the loop above stopped at kt == ktiles - 7 (slot 1); the rest of the tiles with literal slots
+    iteration(T{}, T{}, T{}, Sync1{}, T{}, S0{}, kt, 1u);
+    iteration(T{}, T{}, T{}, Sync1{}, T{}, S0{}, kt + 1, 2u);
+    iteration(T{}, T{}, T{}, Sync1{}, T{}, S0{}, kt + 2, 3u);
+    QNNP_C_STAMP(3);
+    iteration(T{}, T{}, F{}, Sync1{}, T{}, S0{}, kt + 3, 0u);     // ktiles - 4: the last pieces of the last tile
+    iteration(F{}, T{}, F{}, Sync2{}, T{}, S0{}, kt + 4, 1u);     // ktiles - 3: the final wait + barrier
+    QNNP_C_STAMP(4);
+    iteration(F{}, T{}, F{}, Sync0{}, T{}, S0{}, kt + 5, 2u);     // tail: everything resident, no barriers
+    iteration(F{}, F{}, F{}, Sync0{}, T{}, S0{}, kt + 6, 3u);     // last tile
+  } else {
   uint32_t slot = 1;                                      // == kt % RING
   auto advance = [&]() __attribute__((always_inline)) { kt++; slot = slot + 1 == RING ? 0 : slot + 1; };
   while (kt + RING < ktiles) {                            // steady state, run-time slot
-    iteration(T{}, T{}, T{}, Sync1{}, F{}, kt, slot);
+    iteration(T{}, T{}, T{}, Sync1{}, F{}, S0{}, kt, slot);
     advance();
   }
-  iteration(T{}, T{}, F{}, Sync1{}, F{}, kt, slot);       // kt == ktiles - RING: the last pieces of the last tile
+  QNNP_C_STAMP(3);
+  iteration(T{}, T{}, F{}, Sync1{}, F{}, S0{}, kt, slot); // kt == ktiles - RING: the last pieces of the last tile
   advance();
-  iteration(F{}, T{}, F{}, Sync2{}, F{}, kt, slot);       // kt == ktiles - RING + 1: the final wait + barrier
+  iteration(F{}, T{}, F{}, Sync2{}, F{}, S0{}, kt, slot); // kt == ktiles - RING + 1: the final wait + barrier
   advance();
+  QNNP_C_STAMP(4);
   while (kt + 1 < ktiles) {                               // tail: everything resident, no barriers
-    iteration(F{}, T{}, F{}, Sync0{}, F{}, kt, slot);
+    iteration(F{}, T{}, F{}, Sync0{}, F{}, S0{}, kt, slot);
     advance();
   }
-  iteration(F{}, F{}, F{}, Sync0{}, F{}, kt, slot);       // last tile
+  iteration(F{}, F{}, F{}, Sync0{}, F{}, S0{}, kt, slot); // last tile
+  }
+  QNNP_C_STAMP(5);
 
   // ---- fused epilogue: Q31 requantize in registers -> half a wave tile at a time through LDS -> whole 128-byte lines ----
-  if constexpr (TAIL == 1) __builtin_amdgcn_s_setprio(0);
+  if constexpr ((ABL & 1) != 0) {
+#pragma unroll
+    for (int tm = 0; tm < kTM; tm++) {
+#pragma unroll
+      for (int tn = 0; tn < kTN; tn++) asm volatile("" : : "v"(acc[tm][tn]));
+    }
+    return;
+  }
   // The two ring slots nobody reads after the final barrier: those of tiles kf = ktiles - RING + 1 and kf - 1.
   const uint32_t kf = ktiles - RING + 1;
-  const uint32_t slot_a = kf % RING;
-  const uint32_t slot_b = (kf + RING - 1) % RING;
+  const uint32_t slot_a = ALIGNED ? 1u : kf % RING;
+  const uint32_t slot_b = ALIGNED ? 0u : (kf + RING - 1) % RING;
   uint8_t* image = lds + (wave < 4 ? slot_a : slot_b) * kStage + (wave & 3u) * kImageBytes;
-  const int4 no_bias[4] = {};                    // (the bias is already in the accumulators)
+  // one 32 x 32 accumulator tile -> 16 bytes of this lane's row in the image (lane l: channels 0..15, lane l + 32: 16..31)
+  auto stage_tile = [&](const v16i& a, uint8_t* dst) __attribute__((always_inline)) {
+    uint32_t pk[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      pk[rg] = q31_requantize_pack4_clamp<SEQ, CLAMP>(a[rg * 4 + 0], a[rg * 4 + 1], a[rg * 4 + 2], a[rg * 4 + 3], p.rq);
+    }
+    const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+    const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+    *reinterpret_cast<uint4*>(dst) = make_uint4(s02[0], s02[1], s13[0], s13[1]);
+  };
   const uint32_t m0 = m_tile * kBM + wm * (kTM * 32);
   const uint32_t n0 = (nb0 + wn * kTN) * 32;
   uint8_t* out0 = p.output + static_cast<uint64_t>(m0) * p.output_stride + static_cast<uint64_t>(g) * p.n + n0;
@@ -463,7 +546,7 @@ void q8_gemm_mfma_256x256_c_kernel(const IgemmParams p)
   for (int tm = 0; tm < kTM; tm++) {
 #pragma unroll
     for (int tn = 0; tn < kTN; tn++) {
-      igemm_stage_tile_rq<SEQ, FULL, false, 1>(acc[tm][tn], no_bias, 0, image + (lane & 31u) * kImagePitch, tn * 32, frag_khalf, p.rq);
+      stage_tile(acc[tm][tn], image + (lane & 31u) * kImagePitch + tn * 32 + frag_khalf * 16);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
 #pragma unroll
@@ -472,7 +555,7 @@ void q8_gemm_mfma_256x256_c_kernel(const IgemmParams p)
       const uint32_t r = idx / (kTN * 2);
       const uint32_t c = idx % (kTN * 2);
       const uint4 v = *reinterpret_cast<const uint4*>(image + r * kImagePitch + c * 16);
-      if (m0 + tm * 32 + r < p.rows && n0 + c * 16 < p.n) {
+      if (m0 + tm * 32 + r < p.rows && n0 + c * 16 < p.n && ((ABL & 64) == 0 || p.rows == 0xFFFFFFFFu)) {
         typedef int nt_v4i __attribute__((ext_vector_type(4)));     // whole lines, written once: streaming hint
         const nt_v4i x = {static_cast<int>(v.x), static_cast<int>(v.y), static_cast<int>(v.z), static_cast<int>(v.w)};
         nt_v4i* dst = reinterpret_cast<nt_v4i*>(out0 + static_cast<uint64_t>(tm * 32 + r) * p.output_stride + c * 16);
@@ -484,18 +567,47 @@ void q8_gemm_mfma_256x256_c_kernel(const IgemmParams p)
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // read back before the other half overwrites it
+    if (tm == 0) QNNP_C_STAMP(6);
   }
+  QNNP_C_STAMP(7);
+#ifdef QNNP_ENABLE_ABLATION
+  if (p.trace != nullptr) {                      // when the stores have left the wave
+    wait_vmcnt<0>();
+    QNNP_C_STAMP_WALL(1);
+  }
+#endif
+  };
+  rest(S0{});
 }
 #undef QNNP_PIN
 
-template <int RING, int TAIL>
+template <int OPT, bool ALIGNED>
 int launch_c(const IgemmParams& p, const dim3& grid, hipStream_t stream)
 {
   int rc = QNNP_HIP_EINVAL;
+#ifdef QNNP_ENABLE_ABLATION
+  if constexpr (OPT == 0 && ALIGNED) {
+    const char* env = getenv("QNNP_GFX950_ABLATE");
+    const int abl = env != nullptr ? atoi(env) : 0;
+#define QNNP_ABL_CASE(V) case V: hipLaunchKernelGGL((q8_gemm_mfma_256x256_c_kernel<kRqShift0Ofs, 1, true, 0, V>), grid, dim3(kThreads), 0, stream, p); \
+        return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+    switch (abl) {
+      QNNP_ABL_CASE(1) QNNP_ABL_CASE(2) QNNP_ABL_CASE(3) QNNP_ABL_CASE(4) QNNP_ABL_CASE(8) QNNP_ABL_CASE(16) QNNP_ABL_CASE(24)
+      QNNP_ABL_CASE(27) QNNP_ABL_CASE(32) QNNP_ABL_CASE(59) QNNP_ABL_CASE(31) QNNP_ABL_CASE(64)
+      default: break;
+    }
+#undef QNNP_ABL_CASE
+  }
+#endif
   requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
     constexpr int kSeq = decltype(seq)::value;
-    constexpr bool kFull = decltype(full)::value;
-    hipLaunchKernelGGL((q8_gemm_mfma_256x256_c_kernel<kSeq, kFull, RING, TAIL>), grid, dim3(kThreads), 0, stream, p);
+    if constexpr (decltype(full)::value) {
+      hipLaunchKernelGGL((q8_gemm_mfma_256x256_c_kernel<kSeq, 0, ALIGNED, OPT>), grid, dim3(kThreads), 0, stream, p);
+    } else if (p.rq.zp_late == 0) {             // zero point folded (or zero): no add behind the clamp
+      hipLaunchKernelGGL((q8_gemm_mfma_256x256_c_kernel<kSeq, 1, ALIGNED, OPT>), grid, dim3(kThreads), 0, stream, p);
+    } else {
+      hipLaunchKernelGGL((q8_gemm_mfma_256x256_c_kernel<kSeq, 2, ALIGNED, OPT>), grid, dim3(kThreads), 0, stream, p);
+    }
     rc = hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
   });
   return rc;
@@ -503,27 +615,31 @@ int launch_c(const IgemmParams& p, const dim3& grid, hipStream_t stream)
 
 }  // namespace
 
-/* p as the general kernels get it; `ring` 4 or 5 */
-bool gemm256c_supported(const IgemmParams& p, uint32_t vec, uint32_t ring)
+/* p as the general kernels get it, with the centred image */
+bool gemm256c_supported(const IgemmParams& p, uint32_t vec)
 {
   return vec == 16 && p.offsets == nullptr && p.a_flip != 0 && p.bias2u != nullptr && p.store_mode == 2 &&
-         p.k_total == p.k_pad && p.k_pad % kBK == 0 && p.k_pad / kBK >= 2 * ring && p.n_pad % kBN == 0 &&
+         p.k_total == p.k_pad && p.k_pad % kBK == 0 && p.k_pad / kBK >= 2 * kRing && p.n_pad % kBN == 0 &&
          p.k_pad <= (1u << 22) && static_cast<uint64_t>(p.input_stride) * 256u < (1ull << 32) &&
          p.residual == nullptr && p.rows >= 1;
 }
 
-/* `p` must carry the CENTRED weight image, its bias pair table and a_flip (q8igemm.hip) */
-int gemm256c_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, uint32_t ring, uint32_t tail)
+/* `p` must carry the CENTRED weight image, its bias pair table and a_flip (q8igemm.hip).
+ * opt: 0 = the product; 2 = the A/B structure (kernel comment) */
+int gemm256c_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, uint32_t opt)
 {
   const uint32_t tiles_m = (p.rows + kBM - 1) / kBM;
   const uint32_t tiles_n = p.n_pad / kBN;
   const dim3 grid(tiles_m * tiles_n, groups, 1);
-  if (ring == 5) {
-    *name = tail ? "q8_gemm_mfma_256x256_c5_skew" : "q8_gemm_mfma_256x256_c5";
-    return tail ? launch_c<5, 1>(p, grid, stream) : launch_c<5, 0>(p, grid, stream);
+  IgemmParams pm = p;
+  // x / tiles_n == hi32(x * magic) for x < 2^32 / tiles_n (the tile ids); 0 stands for tiles_n == 1
+  pm.tiles_n_magic = tiles_n == 1 ? 0u : static_cast<uint32_t>((1ull << 32) / tiles_n) + 1u;
+  const bool aligned = (p.k_pad / kBK) % kRing == 0;
+  switch (opt) {
+    case 0: *name = "q8_gemm_mfma_256x256_c"; return aligned ? launch_c<0, true>(pm, grid, stream) : launch_c<0, false>(pm, grid, stream);
+    case 2: *name = "q8_gemm_mfma_256x256_c_burst"; return aligned ? launch_c<2, true>(pm, grid, stream) : launch_c<2, false>(pm, grid, stream);
+    default: return QNNP_HIP_EINVAL;
   }
-  *name = tail ? "q8_gemm_mfma_256x256_c4_skew" : "q8_gemm_mfma_256x256_c4";
-  return tail ? launch_c<4, 1>(p, grid, stream) : launch_c<4, 0>(p, grid, stream);
 }
 
 }  // namespace qnnp

@@ -676,12 +676,11 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   if (big_forced && !big_ok) return QNNP_HIP_EINVAL;
   int rc;
   // Operators with a zero-point-centred weight image (kernel zero point 127 or 128, q8gemm256c.hip): no row term at all.
-  // "gemm_kernel" 20..23 force it (ring of 4 / 5 stages, without / with the skewed tail); auto takes 5 stages + skew.
-  const bool c_forced = a->variant >= 20 && a->variant <= 23;
+  // "gemm_kernel" 20 forces it; 21 = its A/B structure (fragment reads in one burst).
+  const bool c_forced = a->variant == 20 || a->variant == 21;
   if (c_forced || (a->variant == 0 && big_auto && a->centre_flip != 0)) {
     qnnp::IgemmParams pc = p;
-    const uint32_t ring = c_forced ? ((a->variant & 1) ? 5u : 4u) : 5u;
-    const uint32_t tail = c_forced ? ((a->variant >= 22) ? 1u : 0u) : 1u;
+    const uint32_t opt = a->variant == 21 ? 2u : 0u;
     bool c_ok = a->centre_flip != 0 && a->packed_w_centred != nullptr && a->bias2_centred != nullptr && a->bias2_pair != 0;
     if (c_ok) {
       pc.packed_w = a->packed_w_centred;
@@ -689,10 +688,10 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
       pc.bias2u = a->bias2_centred + static_cast<size_t>(a->groups) * a->n_pad;
       pc.a_flip = (a->centre_flip & 0xFFu) * 0x01010101u;
       pc.row_coeff = 0;
-      c_ok = big_ok && qnnp::gemm256c_supported(pc, vec, ring);
+      c_ok = big_ok && qnnp::gemm256c_supported(pc, vec);
     }
     if (c_ok) {
-      rc = qnnp::gemm256c_launch(pc, a->groups, stream, &name, ring, tail);
+      rc = qnnp::gemm256c_launch(pc, a->groups, stream, &name, opt);
       if (kernel_name != nullptr) *kernel_name = name;
       return rc;
     }

@@ -201,6 +201,44 @@ __device__ __forceinline__ uint32_t q31_requantize_pack4(
   return clamp_pack4<FULL_RANGE>(y0, y1, y2, y3, rq);
 }
 
+/* The same with the clamp class as a template argument (q8gemm256c.hip picks it on the host):
+ *   CLAMP 0: zero point folded, clamp exactly [0, 255] -- the saturating packs (FULL_RANGE above);
+ *   CLAMP 1: nothing to add after the clamp (rq.zp_late == 0: zero point folded, or zero) -- one v_med3 per value and
+ *            three v_perm per dword (the clamped values are bytes already);
+ *   CLAMP 2: the general form (clamp, + zero point, pack). */
+template <int SEQ, int CLAMP>
+__device__ __forceinline__ uint32_t q31_requantize_pack4_clamp(int32_t n0, int32_t n1, int32_t n2, int32_t n3, const RequantDev& rq)
+{
+  if constexpr (CLAMP == 0) {
+    return q31_requantize_pack4<SEQ, true>(n0, n1, n2, n3, rq);
+  } else if constexpr (CLAMP == 2) {
+    return q31_requantize_pack4<SEQ, false>(n0, n1, n2, n3, rq);
+  } else {
+    int32_t y0, y1, y2, y3;
+    if constexpr (SEQ == kRqShift0Ofs) {
+      uint32_t mult_v = rq.f.ofs_multiplier;
+      asm("" : "+v"(mult_v));
+      const uint64_t addend = rq.f.ofs_addend;
+      y0 = static_cast<int32_t>(requant_mad_hi(static_cast<uint32_t>(n0), mult_v, addend));
+      y1 = static_cast<int32_t>(requant_mad_hi(static_cast<uint32_t>(n1), mult_v, addend));
+      y2 = static_cast<int32_t>(requant_mad_hi(static_cast<uint32_t>(n2), mult_v, addend));
+      y3 = static_cast<int32_t>(requant_mad_hi(static_cast<uint32_t>(n3), mult_v, addend));
+    } else {
+      static_assert(SEQ == kRqGeneral, "bounded operators with an explicit clamp take the general sequence (requant_dispatch_ofs)");
+      y0 = qnnp_requant_scale_sn(n0, rq.f); y1 = qnnp_requant_scale_sn(n1, rq.f);
+      y2 = qnnp_requant_scale_sn(n2, rq.f); y3 = qnnp_requant_scale_sn(n3, rq.f);
+    }
+    const uint32_t b0 = static_cast<uint32_t>(clamp_med3(y0, rq.qmin, rq.qmax));     // in [0, 255]: 0 <= qmin <= qmax <= 255 here
+    const uint32_t b1 = static_cast<uint32_t>(clamp_med3(y1, rq.qmin, rq.qmax));
+    const uint32_t b2 = static_cast<uint32_t>(clamp_med3(y2, rq.qmin, rq.qmax));
+    const uint32_t b3 = static_cast<uint32_t>(clamp_med3(y3, rq.qmin, rq.qmax));
+    // three byte permutes (written as shifts and ors hipcc re-associates them into four instructions)
+    const uint32_t p01 = __builtin_amdgcn_perm(b1, b0, 0x0c0c0400u);   // {b0.byte0, b1.byte0, 0, 0}
+    const uint32_t p23 = __builtin_amdgcn_perm(b3, b2, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(p23, p01, 0x05040100u);               // {p01.b0, p01.b1, p23.b0, p23.b1}
+  }
+}
+
 /* L of this lane's row (requant_math.h): once per row block */
 __device__ __forceinline__ uint64_t lane_addend(int32_t rowterm, const qnnp_requant_lane& l)
 {

@@ -65,6 +65,20 @@ CONV_CASES = [
     ConvCase("1x1_with_output_stride", (27, 29), gic=23, goc=19, output_pixel_stride=29),
     ConvCase("1x1_with_batch", (13, 14), gic=23, goc=19, batch=3),
     ConvCase("grouped_1x1", (24, 25), groups=2, gic=17, goc=19),
+] + [
+    # test/convolution.cc:103-198, the seven xzp_* cases: group input channels = q8conv_xzp.kthreshold + 1, where the
+    # threshold is what src/init.c:66-80 sets per ARM core (64, 256, 32, 16; SIZE_MAX -- "never" -- elsewhere). The XZP
+    # kernels are ARM-only; the shapes are plain API cases and run here for every threshold.
+    case for kt in (16, 32, 64, 256) for case in (
+        ConvCase(f"xzp_1x1_kt{kt}", (27, 29), gic=kt + 1, goc=19),
+        ConvCase(f"xzp_1x1_with_qmin_kt{kt}", (27, 29), gic=kt + 1, goc=19, qmin=128),
+        ConvCase(f"xzp_1x1_with_qmax_kt{kt}", (27, 29), gic=kt + 1, goc=19, qmax=128),
+        ConvCase(f"xzp_1x1_with_input_stride_kt{kt}", (27, 29), gic=kt + 1, goc=19, input_pixel_stride=kt + 5),
+        ConvCase(f"xzp_1x1_with_output_stride_kt{kt}", (27, 29), gic=kt + 1, goc=19, output_pixel_stride=29),
+        ConvCase(f"xzp_1x1_with_batch_kt{kt}", (13, 14), gic=kt + 1, goc=19, batch=3),
+        ConvCase(f"grouped_xzp_1x1_kt{kt}", (24, 25), groups=2, gic=kt + 1, goc=19),
+    )
+] + [
     ConvCase("1x3", (20, 19), (1, 3), _pad(w=1), gic=17, goc=15),
     ConvCase("grouped_1x3", (20, 19), (1, 3), _pad(w=1), groups=2, gic=17, goc=15),
     ConvCase("3x1", (19, 20), (3, 1), _pad(h=1), gic=17, goc=15),

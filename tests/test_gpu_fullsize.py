@@ -13,17 +13,13 @@ from oracle import o1
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant,kernel", [(0, "q8_gemm_mfma_256x256_c5_skew"), (20, "q8_gemm_mfma_256x256_c4"),
-                                            (21, "q8_gemm_mfma_256x256_c5"), (22, "q8_gemm_mfma_256x256_c4_skew"),
-                                            (15, "q8_gemm_mfma_256x256_lean"), (2, "q8_gemm_mfma_256x256"),
-                                            (10, "q8_gemm_mfma_128x256"), (11, "q8_gemm_mfma_256x256_pp"),
-                                            (16, "q8_gemm_mfma_256x256_w4_lean")],
-                         ids=["auto", "c4", "c5", "c4_skew", "lean", "general", "rows128", "pingpong", "w4_lean"])
+@pytest.mark.parametrize("variant,kernel", [(0, "q8_gemm_mfma_256x256_c"), (21, "q8_gemm_mfma_256x256_c_burst"),
+                                            (15, "q8_gemm_mfma_256x256_lean"), (2, "q8_gemm_mfma_256x256")],
+                         ids=["auto", "c_burst", "lean", "general"])
 def test_c2_q8gemm_4096_cubed(qnnp, variant, kernel):
     """configs[1]: q8gemm M=N=K=4096 through qnnp_fully_connected_nc_q8 -- the shipped kernel (round 4: the
-    zero-point-centred flavour, q8gemm256c.hip, is what "auto" picks for this shape and these zero points) and its three
-    sibling structures, the lean and general flavours of the kernel it came from (what other zero points run on), and the
-    A/B structures of round 3 (128 x 256 tiles with two workgroups per CU; the ping-pong schedule)."""
+    zero-point-centred flavour, q8gemm256c.hip, is what "auto" picks for this shape and these zero points), its
+    A/B sibling, and the lean and general flavours of the kernel it came from (what other zero points run on)."""
     import torch
     qnnp.set_option("gemm_kernel", variant)
     M = N = K = 4096
@@ -62,8 +58,12 @@ def test_c2_q8gemm_4096_cubed(qnnp, variant, kernel):
         qnnp.delete_operator(op)
 
 
-def test_c3_q8conv_3x3_56x56x64_batch128(qnnp):
-    """configs[2]: 3x3 s1 pad1 conv via the device-side offset table, 56x56x64 -> 64, batch 128."""
+@pytest.mark.parametrize("variant,kernel_name", [(0, "q8_conv_wave_ws_mfma"), (1, None), (2, "q8_gemm_mfma_256x256_conv")],
+                         ids=["auto", "offset_table_generic", "offset_table_256x256"])
+def test_c3_q8conv_3x3_56x56x64_batch128(qnnp, variant, kernel_name):
+    """configs[2]: 3x3 s1 pad1 conv, 56x56x64 -> 64, batch 128. "auto" is the weight-stationary wave kernel, which
+    computes its patch addresses arithmetically (q8convwave.hip); "gemm_kernel" 1 and 2 force the two kernels that read the
+    device-side OFFSET TABLE of csrc/indirection.c -- the path BASELINE configs[2] names literally -- at the full size."""
     import torch
     case = ConvCase("c3_fullsize", (56, 56), (3, 3), (1, 1, 1, 1), gic=64, goc=64, batch=128)
     inp, kernel, bias = conv_tensors(case)
@@ -77,6 +77,7 @@ def test_c3_q8conv_3x3_56x56x64_batch128(qnnp):
     expected = o1.requantize_rows(acc.reshape(-1, 64), np.float32(1.0) / oscale, ozp, 0, 255).reshape(len(sample), -1)
     o1.set_threads(1)
 
+    qnnp.set_option("gemm_kernel", variant)
     op = qnnp.create_convolution2d_nhwc_q8(1, 1, 1, 1, 3, 3, 1, 1, 1, 1, 1, 64, 64, case.izp, 1.0, case.kzp, 1.0,
                                            kernel, bias, ozp, float(oscale), 0, 255, 0)
     try:
@@ -84,7 +85,10 @@ def test_c3_q8conv_3x3_56x56x64_batch128(qnnp):
         d_out = to_device(np.full(128 * img, FILL, np.uint8))
         qnnp.setup_convolution2d_nhwc_q8(op, 128, 56, 56, d_in, 64, d_out, 64)
         qnnp.run_operator(op)
-        assert qnnp.operator_kernel(op) == "q8_conv_wave_ws_mfma", qnnp.operator_kernel(op)
+        if kernel_name is not None:
+            assert qnnp.operator_kernel(op) == kernel_name, qnnp.operator_kernel(op)
+        else:
+            assert qnnp.operator_kernel(op).startswith("q8_igemm_mfma"), qnnp.operator_kernel(op)
         out = from_device(d_out).reshape(128, img)
         for j, i in enumerate(sample):
             assert_bytes_equal(out[i], expected[j], f"C3 image {i} vs oracle")
@@ -96,6 +100,7 @@ def test_c3_q8conv_3x3_56x56x64_batch128(qnnp):
         out2 = from_device(d_out2).reshape(128, img)
         assert np.array_equal(out2[::-1], out), "image permutation equivariance violated"
     finally:
+        qnnp.set_option("gemm_kernel", 0)
         qnnp.delete_operator(op)
 
 
@@ -193,7 +198,7 @@ def test_c5_mobilenetv2_first_layer(qnnp):
         qnnp.delete_operator(op)
 
 
-@pytest.mark.parametrize("kzp,kernel", [(127, "q8_gemm_mfma_256x256_c5_skew"), (128, "q8_gemm_mfma_256x256_c5_skew"),
+@pytest.mark.parametrize("kzp,kernel", [(127, "q8_gemm_mfma_256x256_c"), (128, "q8_gemm_mfma_256x256_c"),
                                         (126, "q8_gemm_mfma_256x256_lean")], ids=["kzp127", "kzp128", "kzp126"])
 def test_c2_q8gemm_4096_cubed_full_output_vs_compiled_reference(qnnp, kzp, kernel):
     """(both centring classes of the shipped kernel, and a zero point that keeps the lean flavour)

@@ -14,10 +14,10 @@ from _runner import assert_bytes_equal, conv_expected, conv_run, fc_expected, fc
 pytestmark = pytest.mark.gpu
 
 
-# gemm_kernel option -> kernel name: 8-wave default / 4-wave A/B flavour / 128 x 256 tiles with two workgroups per CU /
-# the ping-pong schedule (round 3: the two structures DESIGN section 9 had listed as untried)
-_NAME = {2: "q8_gemm_mfma_256x256", 4: "q8_gemm_mfma_256x256_w4", 10: "q8_gemm_mfma_128x256",
-         11: "q8_gemm_mfma_256x256_pp"}
+# gemm_kernel option -> kernel name. (The structures that lost their A/B in round 3 -- "gemm_kernel" 4 / 16: four waves of
+# 128 x 128, 10: 128 x 256 tiles with two workgroups per CU, 11: the ping-pong schedule -- are compiled into measurement
+# builds only since round 4: the product refuses them, test_losing_structures_are_not_in_the_product.)
+_NAME = {2: "q8_gemm_mfma_256x256"}
 
 
 @pytest.fixture(params=sorted(_NAME), ids=lambda v: _NAME[v].replace("q8_gemm_mfma_", ""))
@@ -52,8 +52,7 @@ def test_k_edges(big, k):
 
 # ---- the lean flavour ("gemm_kernel" = 15: saddr LDS-DMA, steady state unrolled over the ring): plain GEMMs whose K is a
 # multiple of 64 and whose N is a multiple of 256; forced, so an unsupported shape is refused instead of rerouted ----
-# (16: the same for the 4-wave A/B flavour)
-_LEAN = {15: "q8_gemm_mfma_256x256_lean", 16: "q8_gemm_mfma_256x256_w4_lean"}
+_LEAN = {15: "q8_gemm_mfma_256x256_lean"}
 
 
 @pytest.fixture(params=sorted(_LEAN), ids=lambda v: _LEAN[v].replace("q8_gemm_mfma_256x256_", ""))
@@ -142,3 +141,15 @@ def test_unsupported_alignment_is_reported_not_silently_rerouted(big):
     _, quant = fc_expected(case)
     with pytest.raises(QnnpackError):
         fc_run(big, case, quant, to_device=to_device, from_device=from_device)
+
+
+@pytest.mark.parametrize("variant", [4, 10, 11, 16])
+def test_losing_structures_are_not_in_the_product(qnnp, variant):
+    case = FcCase(f"b_not_shipped_{variant}", 300, 640, 256)
+    _, quant = fc_expected(case)
+    qnnp.set_option("gemm_kernel", variant)
+    try:
+        with pytest.raises(QnnpackError):
+            fc_run(qnnp, case, quant, to_device=to_device, from_device=from_device)
+    finally:
+        qnnp.set_option("gemm_kernel", 0)

@@ -1,8 +1,9 @@
 """GPU tier: the zero-point-centred 256x256 GEMM kernel (qnnpack_amd/csrc/hip/q8gemm256c.hip; what auto picks for
-BASELINE configs[1]) against the scalar oracle, in its four structures ("gemm_kernel" 20..23: ring of 4 / 5 LDS stages,
-tail without / with the priority skew): every prologue / steady-state / tail length in K, row edges, padded channel
-counts, both centring classes (kernel zero point 127 and 128), every requantization flavour the launcher can pick
-(shift 0 / bounded shift >= 1 / general, saturating clamp and explicit clamp), strided rows, and what it must refuse."""
+BASELINE configs[1]) against the scalar oracle -- the product ("gemm_kernel" 20) and its A/B structure (21: fragment
+reads in one burst): every prologue / steady-state / tail length in
+K, row edges, padded channel counts, both centring classes (kernel zero point 127 and 128), every requantization flavour
+the launcher can pick (shift 0 / bounded shift >= 1 / general x saturating clamp / explicit clamp with and without a
+folded zero point), strided rows, and what it must refuse."""
 import numpy as np
 import pytest
 
@@ -14,12 +15,11 @@ from _runner import assert_bytes_equal, fc_expected, fc_run
 
 pytestmark = pytest.mark.gpu
 
-_NAME = {20: "q8_gemm_mfma_256x256_c4", 21: "q8_gemm_mfma_256x256_c5", 22: "q8_gemm_mfma_256x256_c4_skew",
-         23: "q8_gemm_mfma_256x256_c5_skew"}
-_MIN_K = {20: 512, 21: 640, 22: 512, 23: 640}
+_NAME = {20: "q8_gemm_mfma_256x256_c", 21: "q8_gemm_mfma_256x256_c_burst"}
+_MIN_K = {20: 512, 21: 512}
 
 
-@pytest.fixture(params=sorted(_NAME), ids=lambda v: _NAME[v].replace("q8_gemm_mfma_256x256_", ""))
+@pytest.fixture(params=sorted(_NAME), ids=lambda v: _NAME[v].replace("q8_gemm_mfma_256x256_", "").replace("c_", "") or "c")
 def centred(qnnp, request):
     qnnp.set_option("gemm_kernel", request.param)
     qnnp._kname = _NAME[request.param]
@@ -44,7 +44,7 @@ def test_m_and_k(centred, m, k):
     _fc(centred, FcCase(f"c_m{m}_k{k}", m, k, 256))
 
 
-@pytest.mark.parametrize("n", [256, 1000, 768])
+@pytest.mark.parametrize("n", [256, 1008, 768])
 @pytest.mark.parametrize("kw", [dict(), dict(kzp=128), dict(izp=0, kzp=128), dict(izp=255), dict(izp=3, kzp=128), dict(qmin=128),
                                 dict(qmax=128, kzp=128)],
                          ids=lambda d: "_".join(f"{k}{v}" for k, v in d.items()) or "default")
@@ -64,7 +64,7 @@ def test_other_zero_points_have_no_centred_image(centred, kw):
         fc_run(centred, case, quant, to_device=to_device, from_device=from_device)
 
 
-@pytest.mark.parametrize("k,n,stride", [(448, 256, 0), (640, 260, 0), (648, 256, 0), (640, 256, 260)])
+@pytest.mark.parametrize("k,n,stride", [(448, 256, 0), (640, 260, 0), (640, 1000, 0), (648, 256, 0), (640, 256, 260)])
 def test_refuses_what_it_cannot_take(centred, k, n, stride):
     case = FcCase(f"c_refused_k{k}_n{n}", 300, k, n, output_stride=stride)
     _, quant = fc_expected(case)
@@ -101,7 +101,7 @@ def test_epilogue_corners(qnnp, scale, kzp):
     acc = _accumulators(N)
     kernel = np.random.default_rng(9).integers(0, 256, size=(N, K), dtype=np.uint8)
     inp = np.full(M * K, 77, np.uint8)
-    qnnp.set_option("gemm_kernel", 23)
+    qnnp.set_option("gemm_kernel", 20)
     try:
         for zp, qmin, qmax in QUANT:
             op = qnnp.create_fully_connected_nc_q8(K, N, 77, 1.0, kzp, float(scale), kernel, acc, zp, 1.0, qmin, qmax, 0)
@@ -109,7 +109,7 @@ def test_epilogue_corners(qnnp, scale, kzp):
                 d_in, d_out = to_device(inp), to_device(np.zeros(M * N, np.uint8))
                 qnnp.setup_fully_connected_nc_q8(op, M, d_in, K, d_out, N)
                 qnnp.run_operator(op)
-                assert qnnp.operator_kernel(op) == "q8_gemm_mfma_256x256_c5_skew"
+                assert qnnp.operator_kernel(op) == "q8_gemm_mfma_256x256_c"
                 out = from_device(d_out).reshape(M, N)
             finally:
                 qnnp.delete_operator(op)
@@ -121,10 +121,9 @@ def test_epilogue_corners(qnnp, scale, kzp):
         qnnp.set_option("gemm_kernel", 0)
 
 
-@pytest.mark.parametrize("kzp,k,n,kernel", [(127, 1088, 2048, "q8_gemm_mfma_256x256_c5_skew"),
-                                            (128, 1088, 2048, "q8_gemm_mfma_256x256_c5_skew"),
+@pytest.mark.parametrize("kzp,k,n,kernel", [(127, 1088, 2048, "q8_gemm_mfma_256x256_c"),
+                                            (128, 1088, 2048, "q8_gemm_mfma_256x256_c"),
                                             (126, 1088, 2048, "q8_gemm_mfma_256x256_lean"),
-                                            (127, 576, 2048, "q8_gemm_mfma_256x256_lean"),      # 9 K tiles: below twice the ring
                                             (127, 1088, 2080, "q8_gemm_mfma_256x256")])
 def test_auto_takes_the_centred_flavour_where_it_applies(qnnp, kzp, k, n, kernel):
     case = FcCase(f"auto_kzp{kzp}_k{k}_n{n}", 3328, k, n, kzp=kzp)
@@ -138,7 +137,11 @@ def test_repeated_launches_are_stable(qnnp):
     """The barrier-free tail and the image slots race with nothing: 20 launches of one operator, identical bytes."""
     case = FcCase("c_repeat", 2048, 1280, 1024)
     expected, quant = fc_expected(case)
-    for _ in range(20):
-        out, kname = fc_run(qnnp, case, quant, to_device=to_device, from_device=from_device)
-        assert kname == "q8_gemm_mfma_256x256_c5_skew", kname
-        assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+    qnnp.set_option("gemm_kernel", 20)
+    try:
+        for _ in range(20):
+            out, kname = fc_run(qnnp, case, quant, to_device=to_device, from_device=from_device)
+            assert kname == "q8_gemm_mfma_256x256_c", kname
+            assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+    finally:
+        qnnp.set_option("gemm_kernel", 0)

@@ -3,8 +3,11 @@
 small batches does not cover what the bench runs: here every layer is created and set up exactly as bench.py's
 ConvLayer does, at batch 128, the kernel name is compared with the committed dispatch table
 (tests/golden/sweep_kernels.json, regenerated with QNNP_WRITE_SWEEP_KERNELS=1 -- bench.py prints the same names in its
-per-layer rows), and four images spread over the batch (first, second, middle, last) are held to the scalar oracle byte
-for byte.
+per-layer rows), four images spread over the batch (first, second, middle, last) are held to the scalar oracle byte
+for byte, and -- round 4 -- ALL 128 images of every layer and flavour to the compiled REFERENCE (oracle/_ref: the
+reference's own SSE2 operators on the host threads, a fraction of a second per layer), because dispatch at batch 128
+spreads row blocks over XCDs and segments and a fault confined to other images than the four would pass. Where the
+prebuilt reference did not travel the four-image oracle check is what remains.
 
 The bench's own quantization (bench/convolution.cc:71-74: scales 0.5 / 0.5 / 0.5 on full-range random data) saturates
 98.8-99.9 % of the output bytes to 0 or 255, so with it a wrong accumulator is caught only if it changes sign. The
@@ -34,7 +37,7 @@ import bench
 from _cases import output_quantization
 from _gpu import from_device, to_device
 from _runner import FILL, assert_bytes_equal
-from oracle import o1
+from oracle import o1, ref
 
 pytestmark = pytest.mark.gpu
 
@@ -133,6 +136,26 @@ def test_sweep_layer_at_bench_batch(qnnp, index, flavour):
         assert kname == table[str(index + 1)], f"layer {index + 1}: dispatch changed ({kname} vs committed {table[str(index + 1)]})"
     for j, i in enumerate(SAMPLE):
         assert_bytes_equal(out[i], expected[j], f"sweep layer {index + 1} {flavour} ({kname}) image {i} of {BATCH} vs oracle")
+    if ref.available():
+        want = _reference_output(pt, pr, pb, pl, KH, KW, S, D, G, GIC, GOC, izp, kzp, kernel, bias, ozp, float(out_scale),
+                                 H, W, inp, cin, cout, out_img)
+        assert_bytes_equal(out.reshape(-1), want, f"sweep layer {index + 1} {flavour} ({kname}): all {BATCH} images vs the compiled reference")
+
+
+def _reference_output(pt, pr, pb, pl, KH, KW, S, D, G, GIC, GOC, izp, kzp, kernel, bias, ozp, out_scale, H, W, inp, cin, cout, out_img):
+    """The same operator through the compiled reference (include/qnnpack.h ABI, its SSE2 microkernels), 16 host threads."""
+    rlib = ref.lib()
+    want = np.full(BATCH * out_img, FILL, np.uint8)
+    rop = rlib.create_convolution2d_nhwc_q8(pt, pr, pb, pl, KH, KW, S, S, D, D, G, GIC, GOC,
+                                            izp, 0.5, kzp, 0.5, kernel, bias, ozp, out_scale, 0, 255, 0)
+    pool = rlib.threadpool(16)
+    try:
+        rlib.setup_convolution2d_nhwc_q8(rop, BATCH, H, W, inp, cin, want, cout)
+        rlib.run_operator(rop, pool)
+    finally:
+        rlib.destroy_threadpool(pool)
+        rlib.delete_operator(rop)
+    return want
 
 
 @pytest.mark.parametrize("index", range(len(bench.MOBILENETV2)), ids=lambda i: f"layer{i + 1}")

@@ -63,7 +63,7 @@ def kernels(tmp_path_factory):
 # mangled-name fragments of the kernels the automatic dispatch picks for aligned tensors; the
 # generic implicit-GEMM fallback for unaligned / odd-channel tensors (q8_igemm_mfma_kernel, byte gathers) is known to
 # spill in its 1-byte flavours and is reported by test_report_of_spilling_kernels below, not asserted
-DEFAULT_PATH = ["q8_gemm_mfma_256x256_kernelILb0ELi4E", "q8_gemm_mfma_256x256_kernelILb1ELi4E", "q8_pw_stream_staged_kernel", "q8_pw_stream_longk_kernel",
+DEFAULT_PATH = ["q8_gemm_mfma_256x256_c_kernel", "q8_gemm_mfma_256x256_kernelILb0ELi4E", "q8_gemm_mfma_256x256_kernelILb1ELi4E", "q8_pw_stream_staged_kernel", "q8_pw_stream_longk_kernel",
                 "q8_pw_stream_gw_kernel", "q8_pw_stream_gwk_kernel", "q8_conv_stream_c3s_kernel",
                 "q8_dwconv_col3x3_kernel", "q8_conv_wave_reg_kernel", "q8_conv_wave_ws_kernel", "q8_conv_lds_mfma", "q8_vadd", "q8_gavgpool"]
 
@@ -87,8 +87,7 @@ def test_default_path_kernels_do_not_spill(kernels):
     ("26q8_pw_stream_staged_kernelILi7ELi16ELi3ELb1E", 128, "5-7 K blocks: 4 per CU"),
     ("25q8_conv_stream_c3s_kernelILi3ELb1E", 96, "first-layer kernel: 5 per CU"),
     ("27q8_gemm_mfma_256x256_kernelILb0ELi4ELi256ELi0ELb0E", 256, "256x256 GEMM: 2 waves per SIMD"),
-    ("27q8_gemm_mfma_256x256_kernelILb0ELi4ELi256ELi0ELb1E", 256, "256x256 GEMM, ping-pong schedule: 2 waves per SIMD"),
-    ("27q8_gemm_mfma_256x256_kernelILb0ELi2ELi128ELi0ELb0E", 256, "128x256 GEMM: two 4-wave workgroups per CU"),
+    ("29q8_gemm_mfma_256x256_c_kernel", 256, "256x256 GEMM, zero-point-centred flavour: 2 waves per SIMD"),
 ])
 def test_register_budgets_of_the_occupancy_critical_kernels(kernels, fragment, max_vgpr, why):
     hits = {n: k for n, k in kernels.items() if fragment in n}
@@ -111,8 +110,8 @@ OBJDUMP = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 
 def test_lean_gemm_is_the_only_writer_of_m0_in_its_kernels(tmp_path):
-    """The lean GEMM flavour issues its LDS-DMA as inline assembly and writes m0 itself, in the main loop one MFMA
-    AHEAD of the load that uses it (q8gemm256.hip, dma16_set_m0). That is only sound while nothing the compiler emits
+    """The lean and the zero-point-centred GEMM flavours issue their LDS-DMA as inline assembly and write m0 themselves,
+    in the main loop one MFMA AHEAD of the load that uses it (q8gemm256.hip / q8gemm256c.hip, dma16_set_m0). That is only sound while nothing the compiler emits
     in those kernels touches m0: every m0 reference in their disassembly must be one of the kernel's own
     `s_mov_b32 m0, sN`, and every LDS-DMA must be the saddr form the inline assembly spells out."""
     if not os.path.exists(LIB):
@@ -125,9 +124,9 @@ def test_lean_gemm_is_the_only_writer_of_m0_in_its_kernels(tmp_path):
         path = tmp_path / f"co{k}.elf"
         path.write_bytes(elf)
         dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", str(path)], capture_output=True, text=True, check=True).stdout
-        for m in re.finditer(r"^[0-9a-f]+ <(\S*q8_gemm_mfma_256x256_kernel\S*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", dis, re.S | re.M):
+        for m in re.finditer(r"^[0-9a-f]+ <(\S*q8_gemm_mfma_256x256_(?:c_)?kernel\S*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", dis, re.S | re.M):
             name, body = m.group(1), m.group(2)
-            if not name.endswith("ELb0ELb1EEEvNS_11IgemmParamsE"):      # <..., PP = false, LEAN = true>
+            if "_c_kernel" not in name and not name.endswith("ELb0ELb1EEEvNS_11IgemmParamsE"):      # <..., PP = false, LEAN = true>
                 continue
             seen += 1
             m0_lines = [ln.strip() for ln in body.split("\n") if re.search(r"\bm0\b", ln)]
@@ -136,7 +135,7 @@ def test_lean_gemm_is_the_only_writer_of_m0_in_its_kernels(tmp_path):
                 assert re.match(r"s_mov_b32 m0, s\d+\b", ln), (name, ln)
             dma = [ln.strip() for ln in body.split("\n") if "global_load_lds" in ln]
             assert dma and all(re.match(r"global_load_lds_dwordx4 v\d+, s\[\d+:\d+\]", ln) for ln in dma), (name, dma[:3])
-    assert seen == 2, seen          # the 8-wave flavour and the 4-wave A/B flavour
+    assert seen == 1 + 28, seen     # the lean flavour + the centred flavour's 7 requantization / clamp classes x aligned or not x 2 structures
 
 
 def test_streaming_store_flavours_survive_the_compiler(tmp_path):

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 NAMES = {0: "shipped 256x256 (8 waves, interleaved)", 2: "256x256 forced", 4: "256x256 4 waves 128x128/wave",
          10: "128x256 x 2 workgroups per CU", 11: "256x256 ping-pong + setprio",
          16: "256x256 4 waves, lean", 15: "256x256 lean (saddr DMA, ring unrolled)",
-         20: "centred, ring 4", 21: "centred, ring 5", 22: "centred, ring 4, skewed tail", 23: "centred, ring 5, skewed tail"}
+         20: "centred (product)", 21: "centred, fragment reads in one burst"}
 
 
 def main():
