@@ -189,35 +189,70 @@ def test_status_codes_and_detach(qnnp):
     add = qnnp.create_add_nc_q8(16, 1, 1.0, 5, 1.0, 6, 2.0, 0, 255, 0)
     add8 = qnnp.create_add_nc_q8(8, 1, 1.0, 5, 1.0, 6, 2.0, 0, 255, 0)
     buf = to_device(np.zeros(1 << 16, np.uint8))
+    out = to_device(np.zeros(1 << 12, np.uint8))
+    res = to_device(np.zeros(1 << 12, np.uint8))
     host = np.zeros(1 << 16, np.uint8)
     try:
-        assert qnnp.attach_residual_add_status(conv, add, buf, 16) == Status.invalid_parameter       # before any setup
-        qnnp.setup_convolution2d_nhwc_q8(conv, 1, 8, 8, buf, 32, buf, 16)
-        assert qnnp.attach_residual_add_status(None, add, buf, 16) == Status.invalid_parameter
-        assert qnnp.attach_residual_add_status(conv, None, buf, 16) == Status.invalid_parameter
-        assert qnnp.attach_residual_add_status(conv, conv, buf, 16) == Status.invalid_parameter      # not an add operator
-        assert qnnp.attach_residual_add_status(add, add, buf, 16) == Status.invalid_parameter        # not a convolution
-        assert qnnp.attach_residual_add_status(conv, add8, buf, 16) == Status.invalid_parameter      # channel mismatch
-        assert qnnp.attach_residual_add_status(conv, add, buf, 15) == Status.invalid_parameter       # stride < channels
+        assert qnnp.attach_residual_add_status(conv, add, res, 16) == Status.invalid_parameter       # before any setup
+        qnnp.setup_convolution2d_nhwc_q8(conv, 1, 8, 8, buf, 32, out, 16)
+        assert qnnp.attach_residual_add_status(None, add, res, 16) == Status.invalid_parameter
+        assert qnnp.attach_residual_add_status(conv, None, res, 16) == Status.invalid_parameter
+        assert qnnp.attach_residual_add_status(conv, conv, res, 16) == Status.invalid_parameter      # not an add operator
+        assert qnnp.attach_residual_add_status(add, add, res, 16) == Status.invalid_parameter        # not a convolution
+        assert qnnp.attach_residual_add_status(conv, add8, res, 16) == Status.invalid_parameter      # channel mismatch
+        assert qnnp.attach_residual_add_status(conv, add, res, 15) == Status.invalid_parameter       # stride < channels
         assert qnnp.attach_residual_add_status(conv, add, None, 16) == Status.invalid_parameter
         assert qnnp.attach_residual_add_status(conv, add, host, 16) == Status.unsupported_parameter  # host residual
+        assert qnnp.attach_residual_add_status(conv, add, out, 16) == Status.invalid_parameter       # residual overlaps the output
         assert qnnp.operator_residual_folded(conv) == -1
-        assert qnnp.attach_residual_add_status(conv, add, buf, 16) == Status.success
+        assert qnnp.attach_residual_add_status(conv, add, res, 16) == Status.success
         assert qnnp.operator_residual_folded(conv) == 0
         qnnp.run_operator(conv)
         # the next setup detaches
-        qnnp.setup_convolution2d_nhwc_q8(conv, 1, 8, 8, buf, 32, buf, 16)
+        qnnp.setup_convolution2d_nhwc_q8(conv, 1, 8, 8, buf, 32, out, 16)
         assert qnnp.operator_residual_folded(conv) == -1
         # host endpoints keep the two-operator form
-        qnnp.setup_convolution2d_nhwc_q8(conv, 1, 8, 8, host, 32, buf, 16)
-        assert qnnp.attach_residual_add_status(conv, add, buf, 16) == Status.unsupported_parameter
+        qnnp.setup_convolution2d_nhwc_q8(conv, 1, 8, 8, host, 32, out, 16)
+        assert qnnp.attach_residual_add_status(conv, add, res, 16) == Status.unsupported_parameter
         # refused while a graph is being captured
-        qnnp.setup_convolution2d_nhwc_q8(conv, 1, 8, 8, buf, 32, buf, 16)
+        qnnp.setup_convolution2d_nhwc_q8(conv, 1, 8, 8, buf, 32, out, 16)
         qnnp.graph_begin()
         try:
-            assert qnnp.attach_residual_add_status(conv, add, buf, 16) == Status.invalid_parameter
+            assert qnnp.attach_residual_add_status(conv, add, res, 16) == Status.invalid_parameter
         finally:
             qnnp.graph_destroy(qnnp.graph_end())
     finally:
         for h in (conv, add, add8):
             qnnp.delete_operator(h)
+
+
+def test_fully_connected_setup_detaches_a_stale_residual(qnnp):
+    """qnnp_gfx950_attach_residual_add accepts fully connected operators; like the convolution's, the next setup of the
+    operator detaches the residual (it belongs to the previous binding: a new batch would read past its end)."""
+    from qnnpack_amd import Status
+    rng = np.random.default_rng(11)
+    K, N = 64, 32
+    w = rng.integers(0, 256, size=(N, K), dtype=np.uint8)
+    b = rng.integers(-1000, 1000, size=N).astype(np.int32)
+    fc = qnnp.create_fully_connected_nc_q8(K, N, 127, 0.5, 127, 0.5, w, b, 127, 40.0, 0, 255, 0)
+    add = qnnp.create_add_nc_q8(N, 3, 1.0, 5, 1.0, 6, 2.0, 0, 255, 0)
+    try:
+        a4 = to_device(rng.integers(0, 256, size=4 * K, dtype=np.uint8))
+        out4 = to_device(np.zeros(4 * N, np.uint8))
+        res4 = to_device(rng.integers(0, 256, size=4 * N, dtype=np.uint8))
+        qnnp.setup_fully_connected_nc_q8(fc, 4, a4, K, out4, N)
+        assert qnnp.attach_residual_add_status(fc, add, res4, N) == Status.success
+        qnnp.run_operator(fc)
+        with_add = from_device(out4).copy()
+        # a new binding with MORE rows than the residual has: the stale residual must be gone
+        a64 = to_device(np.tile(from_device(a4), 16))
+        out64 = to_device(np.zeros(64 * N, np.uint8))
+        qnnp.setup_fully_connected_nc_q8(fc, 64, a64, K, out64, N)
+        assert qnnp.operator_residual_folded(fc) == -1
+        qnnp.run_operator(fc)
+        plain = from_device(out64).reshape(16, 4 * N)
+        assert (plain == plain[0]).all()                       # 16 repeats of the 4 rows, no add anywhere
+        assert not np.array_equal(plain[0], with_add)          # ... and different from the run that had the add
+    finally:
+        qnnp.delete_operator(fc)
+        qnnp.delete_operator(add)
