@@ -208,3 +208,17 @@ void qnnp_debug_pack_igemm_w_centred127(
 {
   qnnp_pack_igemm_w_centred127(n, k_total, n_pad, izp, kernel, bias, packed, biasc);
 }
+
+void qnnp_debug_strip_pointwise_images(
+    const int8_t* std_w, const int32_t* std_bias2, uint32_t k_pad_std, uint32_t n, uint32_t k, uint8_t izp, uint8_t kzp,
+    int offset_form, int8_t* frags, int32_t* biasc)
+{
+  qnnp_strip_pointwise_images(std_w, std_bias2, k_pad_std, n, k, izp, kzp, offset_form, frags, biasc);
+}
+
+void qnnp_debug_strip_depthwise_images(
+    const int16_t* wadj, const int32_t* bias1, uint32_t c_pad, uint32_t ch, uint32_t hidden_pad, uint8_t izp, uint8_t kzp,
+    int offset_form, int8_t* w2, int32_t* biasc)
+{
+  qnnp_strip_depthwise_images(wadj, bias1, c_pad, ch, hidden_pad, izp, kzp, offset_form, w2, biasc);
+}

@@ -13,6 +13,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <qnnpack.h>
 #include <qnnpack_gfx950.h>
@@ -20,6 +21,7 @@
 #include "hip/qnnp_hip.h"
 #include "log.h"
 #include "operator.h"
+#include "pack.h"
 #include "state.h"
 
 static int is_pointwise(const struct qnnp_operator* op)
@@ -75,6 +77,145 @@ static struct qnnp_hip_fused_args fused_args(const struct qnnp_operator* op, con
   return a;
 }
 
+/* ---- the strip kernel's images (hip/q8fusedstrip.hip) -------------------------------------------------------------
+ * Everything is derived from what the stand-alone operators already hold on the device (the caller's kernel / bias
+ * arrays are gone by now): the standard fragment image w' = w - 128 and its folded bias2 (pack.h qnnp_pack_igemm_w), the
+ * depthwise int16 image w - kzp and its bias1 (qnnp_pack_dwconv_w). Centred element: w ^ flip with flip = 0x80 for
+ * kernel zero point 128 (= w') and 0x7F for 127 (= ~w' = 127 - w); padding positions stay zero weights.
+ *   bias       = bias2 - (128 - izp) * sum w' - K (128 - izp)(128 - kzp)                  (undoing pack.h's folding)
+ *   biasc[n]   = bias + (kzp - izp) * sum_k (w - kzp)   [+ 2^31 where the stage's rounding sequence is an offset form]
+ * so that  bias + sum (a - izp)(w - kzp) = biasc + sum (a ^ flip)(w ^ flip)  with both factors valid int8. */
+static uint32_t round_up32(uint32_t x) { return (x + 31u) / 32u * 32u; }
+
+/* one pointwise stage (pack.h qnnp_strip_pointwise_images does the arithmetic on host copies of the device images) */
+static int strip_pointwise(const struct qnnp_operator* op, uint32_t n, uint32_t k, int8_t* frags, int32_t* biasc)
+{
+  const size_t w_bytes = (size_t) op->n_pad * op->k_pad;
+  int8_t* std_w = (int8_t*) malloc(w_bytes);
+  int32_t* std_b = (int32_t*) malloc(sizeof(int32_t) * op->n_pad);
+  const int ok = std_w != NULL && std_b != NULL &&
+      qnnp_hip_d2h(std_w, op->d_weights, w_bytes, 0) == QNNP_HIP_OK &&
+      qnnp_hip_d2h(std_b, op->d_bias, sizeof(int32_t) * op->n_pad, 0) == QNNP_HIP_OK;
+  if (ok) {
+    qnnp_strip_pointwise_images(std_w, std_b, op->k_pad, n, k, op->input_zero_point, op->kernel_zero_point,
+        qnnp_hip_fused_strip_bias_offset(&op->requant), frags, biasc);
+  }
+  free(std_w);
+  free(std_b);
+  return ok;
+}
+
+static int strip_depthwise(const struct qnnp_operator* dw, uint32_t ch, uint32_t hidden_pad, int8_t* w2, int32_t* biasc)
+{
+  const size_t w_elems = (size_t) 9 * dw->c_pad;
+  int16_t* wadj = (int16_t*) malloc(sizeof(int16_t) * w_elems);
+  int32_t* bias1 = (int32_t*) malloc(sizeof(int32_t) * dw->c_pad);
+  const int ok = wadj != NULL && bias1 != NULL &&
+      qnnp_hip_d2h(wadj, dw->d_weights, sizeof(int16_t) * w_elems, 0) == QNNP_HIP_OK &&
+      qnnp_hip_d2h(bias1, dw->d_bias, sizeof(int32_t) * dw->c_pad, 0) == QNNP_HIP_OK;
+  if (ok) {
+    qnnp_strip_depthwise_images(wadj, bias1, dw->c_pad, ch, hidden_pad, dw->input_zero_point, dw->kernel_zero_point,
+        qnnp_hip_fused_strip_bias_offset(&dw->requant), w2, biasc);
+  }
+  free(wadj);
+  free(bias1);
+  return ok;
+}
+
+static int centred_zero_point(const struct qnnp_operator* op)
+{
+  return op == NULL || op->kernel_zero_point == 127 || op->kernel_zero_point == 128;
+}
+
+/* builds op->d_strip; leaves it NULL (no error) when the block is outside the strip kernel's arithmetic */
+static void build_strip_images(struct qnnp_operator* op)
+{
+  const struct qnnp_operator* ex = op->fused_expand;
+  const struct qnnp_operator* dw = op->fused_depthwise;
+  const struct qnnp_operator* pr = op->fused_project;
+  if (!centred_zero_point(ex) || !centred_zero_point(dw) || !centred_zero_point(pr)) return;
+  const uint32_t ch = dw->groups;
+  const uint32_t cin = ex != NULL ? (uint32_t) ex->group_input_channels : ch;
+  const uint32_t cout = (uint32_t) pr->group_output_channels;
+  if (cin > 160 || ch % 4 != 0 || cin % 4 != 0 || cout % 4 != 0) return;
+  const uint32_t hidden_pad = round_up32(ch), output_pad = round_up32(cout);
+  const uint32_t kb1 = (cin + 31u) / 32u, nb1 = hidden_pad / 32u, nb3 = output_pad / 32u;
+  const size_t w1_bytes = ex != NULL ? (size_t) nb1 * kb1 * 1024u : 0, w3_bytes = (size_t) nb3 * nb1 * 1024u;
+  const size_t w2_bytes = ((size_t) 9 * hidden_pad + 255u) & ~(size_t) 255u;
+  op->strip_w1 = 0;
+  op->strip_w3 = w1_bytes;
+  op->strip_w2 = op->strip_w3 + w3_bytes;
+  op->strip_b1 = op->strip_w2 + w2_bytes;
+  op->strip_b2 = op->strip_b1 + sizeof(int32_t) * hidden_pad;
+  op->strip_b3 = op->strip_b2 + sizeof(int32_t) * hidden_pad;
+  const size_t total = op->strip_b3 + sizeof(int32_t) * output_pad;
+  uint8_t* host = (uint8_t*) calloc(1, total);
+  if (host == NULL) return;
+  int ok = 1;
+  if (ex != NULL) ok = strip_pointwise(ex, ch, cin, (int8_t*) (host + op->strip_w1), (int32_t*) (host + op->strip_b1));
+  ok = ok && strip_depthwise(dw, ch, hidden_pad, (int8_t*) (host + op->strip_w2), (int32_t*) (host + op->strip_b2));
+  ok = ok && strip_pointwise(pr, cout, ch, (int8_t*) (host + op->strip_w3), (int32_t*) (host + op->strip_b3));
+  if (ok) {
+    op->d_strip = qnnp_hip_alloc(total);
+    if (op->d_strip != NULL && qnnp_hip_h2d(op->d_strip, host, total, 0) != QNNP_HIP_OK) {
+      qnnp_hip_free(op->d_strip);
+      op->d_strip = NULL;
+    }
+  }
+  free(host);
+  if (op->d_strip != NULL) {
+    op->strip_hidden_pad = hidden_pad;
+    op->strip_output_pad = output_pad;
+    op->strip_flip1 = ex != NULL && ex->kernel_zero_point == 127 ? 0x7F : 0x80;
+    op->strip_flip2 = dw->kernel_zero_point == 127 ? 0x7F : 0x80;
+    op->strip_flip3 = pr->kernel_zero_point == 127 ? 0x7F : 0x80;
+    op->strip_dw_pad = (uint8_t) (dw->input_zero_point ^ op->strip_flip2);
+  }
+}
+
+static struct qnnp_hip_fused_strip_args strip_args(const struct qnnp_operator* op, const void* input, void* output)
+{
+  const struct qnnp_operator* ex = op->fused_expand;
+  const struct qnnp_operator* dw = op->fused_depthwise;
+  const struct qnnp_operator* pr = op->fused_project;
+  const uint8_t* blob = (const uint8_t*) op->d_strip;
+  struct qnnp_hip_fused_strip_args a;
+  memset(&a, 0, sizeof(a));
+  a.input = (const uint8_t*) input;
+  a.output = (uint8_t*) output;
+  a.batch = (uint32_t) op->batch_size;
+  a.input_height = (uint32_t) op->input_height;
+  a.input_width = (uint32_t) op->input_width;
+  a.output_height = (uint32_t) op->output_height;
+  a.output_width = (uint32_t) op->output_width;
+  a.input_channels = (uint32_t) (ex != NULL ? ex->group_input_channels : dw->groups);
+  a.hidden_channels = dw->groups;
+  a.output_channels = (uint32_t) pr->group_output_channels;
+  a.input_stride = (uint32_t) op->input_pixel_stride;
+  a.output_stride = (uint32_t) op->output_pixel_stride;
+  a.stride = dw->stride_height;
+  a.has_expand = ex != NULL;
+  a.has_residual = op->fused_add != NULL;
+  a.expand_w = (const int8_t*) (blob + op->strip_w1);
+  a.expand_bias = (const int32_t*) (blob + op->strip_b1);
+  a.expand_flip = op->strip_flip1;
+  a.expand_rq = ex != NULL ? ex->requant : dw->requant;
+  a.dw_w = (const int8_t*) (blob + op->strip_w2);
+  a.dw_bias = (const int32_t*) (blob + op->strip_b2);
+  a.dw_flip = op->strip_flip2;
+  a.dw_pad = op->strip_dw_pad;
+  a.dw_rq = dw->requant;
+  a.project_w = (const int8_t*) (blob + op->strip_w3);
+  a.project_bias = (const int32_t*) (blob + op->strip_b3);
+  a.project_flip = op->strip_flip3;
+  a.project_rq = pr->requant;
+  a.hidden_pad = op->strip_hidden_pad;
+  a.output_pad = op->strip_output_pad;
+  if (op->fused_add != NULL) a.add = op->fused_add->add_params;
+  a.rows_per_strip = op->fused_rows_per_strip;
+  return a;
+}
+
 static enum qnnp_status qnnp_gfx950_create_fused_block_impl(
     qnnp_operator_t expand, qnnp_operator_t depthwise, qnnp_operator_t project, qnnp_operator_t residual_add,
     qnnp_operator_t* fused_out)
@@ -122,6 +263,7 @@ static enum qnnp_status qnnp_gfx950_create_fused_block_impl(
   op->fused_add = residual_add;
   op->channels = project->group_output_channels;
   op->ukernel_type = qnnp_ukernel_type_fused_block;
+  build_strip_images(op);                       /* (optional: without them the tile kernel is all the block has) */
   *fused_out = op;
   return qnnp_status_success;
 }
@@ -176,20 +318,33 @@ static enum qnnp_status qnnp_gfx950_setup_fused_block_impl(
       return bound;
     }
   }
-  /* does the kernel take this block (LDS plan, channel multiples, alignment)? */
-  const struct qnnp_hip_fused_args probe = fused_args(op, op->input_on_device ? input : op->d_stage_in,
-      op->output_on_device ? (void*) output : op->d_stage_out);
-  if (!qnnp_hip_fused_block_supported(&probe)) {
-    op->batch_size = 0;
-    op->input = NULL;
-    qnnp_log_info("fused block: shape outside the fused kernel range; use the stand-alone operators");
-    return qnnp_status_unsupported_parameter;
+  /* does a kernel take this block (LDS plan, channel multiples, alignment)? The strip kernel first. */
+  const void* in_dev = op->input_on_device ? input : op->d_stage_in;
+  void* out_dev = op->output_on_device ? (void*) output : op->d_stage_out;
+  op->fused_use_strip = 0;
+  op->fused_rows_per_strip = (uint32_t) qnnp_state.opt_fused_rows;
+  if (op->d_strip != NULL && qnnp_state.opt_fused_kernel != 1) {
+    const struct qnnp_hip_fused_strip_args probe = strip_args(op, in_dev, out_dev);
+    if (qnnp_hip_fused_strip_supported(&probe)) op->fused_use_strip = 1;
+  }
+  if (!op->fused_use_strip) {
+    const struct qnnp_hip_fused_args probe = fused_args(op, in_dev, out_dev);
+    if (qnnp_state.opt_fused_kernel == 2 || !qnnp_hip_fused_block_supported(&probe)) {
+      op->batch_size = 0;
+      op->input = NULL;
+      qnnp_log_info("fused block: shape outside the fused kernels' range; use the stand-alone operators");
+      return qnnp_status_unsupported_parameter;
+    }
   }
   return qnnp_status_success;
 }
 
 int qnnp_fused_block_launch(struct qnnp_operator* op, const void* input, void* output)
 {
+  if (op->fused_use_strip) {
+    const struct qnnp_hip_fused_strip_args sargs = strip_args(op, input, output);
+    return qnnp_hip_fused_strip_run(&sargs, &op->kernel_name);
+  }
   const struct qnnp_hip_fused_args args = fused_args(op, input, output);
   return qnnp_hip_fused_block_run(&args, &op->kernel_name);
 }

@@ -348,6 +348,37 @@ struct qnnp_hip_fused_args {
 int qnnp_hip_fused_block_run(const struct qnnp_hip_fused_args* args, const char** kernel_name);
 int qnnp_hip_fused_block_supported(const struct qnnp_hip_fused_args* args);
 
+/* ---- the same block, strip kernel (q8fusedstrip.hip, round 4) ------------------------------------------------------
+ * One workgroup of 16 waves owns a STRIP of output rows of one image (the whole image where it is small) and walks the
+ * hidden channels in chunks: expand (MFMA) -> requantize -> LDS, depthwise as MFMAs against diagonal weight fragments
+ * built in registers -> requantize -> LDS, project accumulated over the chunks (MFMA) -> requantize [-> + input] ->
+ * global. All three stages use zero-point-CENTRED int8 images (as q8gemm256c.hip: element w ^ flip with flip = 0x7F for
+ * kernel zero point 127, 0x80 for 128; activations recentred with the same mask), so no stage has a row term; the
+ * folded biases carry both zero points and, where the stage's rounding sequence is an offset form, the 2^31.
+ * Built by fused-block.c at create time from the stand-alone operators' device images. */
+struct qnnp_hip_fused_strip_args {
+  const uint8_t* input;
+  uint8_t* output;
+  uint32_t batch, input_height, input_width, output_height, output_width;
+  uint32_t input_channels, hidden_channels, output_channels;
+  uint32_t input_stride, output_stride;       /* bytes between pixels */
+  uint32_t stride;                            /* of the depthwise stage */
+  uint32_t has_expand, has_residual;
+  /* expand: fragments [hidden blocks][input blocks] of 1 KiB (lane l: n = l & 31, k = (l >> 5) * 16 + j), bias [hidden_pad] */
+  const int8_t* expand_w; const int32_t* expand_bias; uint32_t expand_flip; struct qnnp_hip_requant expand_rq;
+  /* depthwise: int8 [9][hidden_pad], bias [hidden_pad]; dw_pad = (input zero point ^ flip) byte of the padding taps */
+  const int8_t* dw_w; const int32_t* dw_bias; uint32_t dw_flip; uint32_t dw_pad; struct qnnp_hip_requant dw_rq;
+  /* project: fragments [output blocks][hidden blocks], bias [output_pad] */
+  const int8_t* project_w; const int32_t* project_bias; uint32_t project_flip; struct qnnp_hip_requant project_rq;
+  uint32_t hidden_pad, output_pad;            /* channel counts rounded up to 32 */
+  struct qnnp_hip_add_params add;             /* residual: output = add(a = block input, b = project output) */
+  uint32_t rows_per_strip;                    /* 0 = the kernel's own choice; else forced (A/B, tests) */
+};
+/* 1: the stage's folded bias must carry + 2^31 (its rounding sequence is an offset form); host-side twin of the kernel's choice */
+int qnnp_hip_fused_strip_bias_offset(const struct qnnp_hip_requant* rq);
+int qnnp_hip_fused_strip_supported(const struct qnnp_hip_fused_strip_args* args);
+int qnnp_hip_fused_strip_run(const struct qnnp_hip_fused_strip_args* args, const char** kernel_name);
+
 #ifdef __cplusplus
 }
 #endif

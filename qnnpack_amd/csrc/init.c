@@ -181,6 +181,14 @@ enum qnnp_status qnnp_gfx950_set_option(const char* key, int value)
     qnnp_hip_set_streaming_stores(value);
     return qnnp_status_success;
   }
+  if (strcmp(key, "fused_kernel") == 0 && value >= 0 && value <= 2) {
+    qnnp_state.opt_fused_kernel = value;
+    return qnnp_status_success;
+  }
+  if (strcmp(key, "fused_rows") == 0 && value >= 0 && value <= 4096) {
+    qnnp_state.opt_fused_rows = value;
+    return qnnp_status_success;
+  }
   if (strcmp(key, "dwconv_kernel") == 0 && value >= 0 && value <= 6) {
     qnnp_state.opt_dwconv_kernel = value;
     return qnnp_status_success;

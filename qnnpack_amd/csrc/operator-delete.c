@@ -24,6 +24,7 @@ enum qnnp_status qnnp_delete_operator(qnnp_operator_t op)
   qnnp_hip_free(op->d_weights_rows16);
   qnnp_hip_free(op->d_bias);
   qnnp_hip_free(op->d_weights_centred);
+  qnnp_hip_free(op->d_strip);
   qnnp_hip_free(op->d_bias_centred);
   qnnp_hip_free(op->d_dwm_x);
   qnnp_hip_free(op->d_dwm_bias);

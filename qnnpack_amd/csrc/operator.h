@@ -85,6 +85,14 @@ struct qnnp_operator {
   const struct qnnp_operator* fused_depthwise;
   const struct qnnp_operator* fused_project;
   const struct qnnp_operator* fused_add;        /* may be NULL */
+  /* the strip kernel's own images (hip/q8fusedstrip.hip), derived at create from the members' device images when every
+   * kernel zero point is 127 or 128: ONE device allocation, owned */
+  void* d_strip;                                /* NULL: the block only has the tile kernel (hip/q8fused.hip) */
+  size_t strip_w1, strip_b1, strip_w2, strip_b2, strip_w3, strip_b3;   /* byte offsets into d_strip */
+  uint32_t strip_hidden_pad, strip_output_pad;
+  uint8_t strip_flip1, strip_flip2, strip_flip3, strip_dw_pad;
+  int fused_use_strip;                          /* decided at setup */
+  uint32_t fused_rows_per_strip;                /* "fused_rows" option at setup: 0 = the kernel's choice */
 
   /* residual add attached to a convolution (residual.c, qnnp_gfx950_attach_residual_add): the operator then writes
    * add(a = residual pixel, b = convolution output) -- in the convolution kernel's epilogue where that kernel carries

@@ -193,6 +193,66 @@ static inline void qnnp_pack_igemm_w_centred127(
 }
 
 /*
+ * Images of the fused-block strip kernel (hip/q8fusedstrip.hip), derived from the STANDARD images above (fused-block.c
+ * reads those back from the device: the caller's kernel and bias arrays are gone by then). Centred element: w ^ flip
+ * with flip = 0x80 for kernel zero point 128 (= w' = w - 128) and 0x7F for 127 (= ~w' = 127 - w); padding positions
+ * stay zero weights. With
+ *   bias     = bias2 - (128 - izp) * sum w' - K (128 - izp)(128 - kzp)          (undoing qnnp_pack_igemm_w's folding)
+ *   biasc[n] = bias + (kzp - izp) * sum_k (w - kzp)   [+ 2^31 where the stage's rounding sequence is an offset form]
+ * bias + sum (a - izp)(w - kzp) = biasc + sum (a ^ flip)(w ^ flip), both factors valid int8 (kzp in {127, 128}).
+ * Output fragments: [ceil(n / 32)][ceil(k / 32)] of 1 KiB, the geometry of qnnp_pack_igemm_w without its K padding to 64.
+ */
+static inline void qnnp_strip_pointwise_images(
+    const int8_t* std_w, const int32_t* std_bias2, uint32_t k_pad_std,
+    uint32_t n, uint32_t k, uint8_t izp8, uint8_t kzp8, int offset_form,
+    int8_t* frags, int32_t* biasc)
+{
+  const uint32_t nb = (n + 31u) / 32u, kb = (k + 31u) / 32u;
+  const uint32_t kblocks_std = k_pad_std / 32u;
+  const uint32_t izp = izp8, kzp = kzp8;
+  const uint32_t offset = offset_form ? UINT32_C(0x80000000) : 0u;
+  memset(frags, 0, (size_t) nb * kb * 1024u);
+  memset(biasc, 0, sizeof(int32_t) * nb * 32u);
+  for (uint32_t col = 0; col < n; col++) {
+    const uint32_t b = col / 32u, lane_lo = col % 32u;
+    uint32_t wsum = 0;                                   /* sum of w' = w - 128, mod 2^32 */
+    for (uint32_t kk = 0; kk < k; kk++) {
+      const uint32_t lane = lane_lo + 32u * ((kk % 32u) / 16u);
+      const int8_t ws = std_w[(((size_t) b * kblocks_std + kk / 32u) * 64u + lane) * 16u + (kk % 16u)];
+      wsum += (uint32_t) (int32_t) ws;
+      frags[(((size_t) b * kb + kk / 32u) * 64u + lane) * 16u + (kk % 16u)] = kzp == 128 ? ws : (int8_t) ~ws;
+    }
+    const uint32_t bias = (uint32_t) std_bias2[col] - (128u - izp) * wsum - k * (128u - izp) * (128u - kzp);
+    const uint32_t wsum_c = wsum + k * (128u - kzp);     /* sum (w - kzp) */
+    biasc[col] = (int32_t) (bias + (kzp - izp) * wsum_c + offset);
+  }
+}
+
+/* the depthwise stage's: int8 [9][hidden_pad] = w - 128 or 127 - w from the int16 image w - kzp of qnnp_pack_dwconv_w,
+ * biasc[c] = bias + (kzp - izp) * sum_taps (w - kzp) with bias recovered from bias1 = bias + 9 izp kzp - izp sum w */
+static inline void qnnp_strip_depthwise_images(
+    const int16_t* wadj, const int32_t* bias1, uint32_t c_pad,
+    uint32_t ch, uint32_t hidden_pad, uint8_t izp8, uint8_t kzp8, int offset_form,
+    int8_t* w2, int32_t* biasc)
+{
+  const uint32_t izp = izp8, kzp = kzp8;
+  const uint32_t offset = offset_form ? UINT32_C(0x80000000) : 0u;
+  memset(w2, 0, (size_t) 9 * hidden_pad);
+  memset(biasc, 0, sizeof(int32_t) * hidden_pad);
+  for (uint32_t c = 0; c < ch; c++) {
+    uint32_t sum_adj = 0;                                /* sum (w - kzp) */
+    for (uint32_t t = 0; t < 9; t++) {
+      const int32_t x = wadj[(size_t) t * c_pad + c];
+      sum_adj += (uint32_t) x;
+      w2[(size_t) t * hidden_pad + c] = (int8_t) (kzp == 128 ? x : -x);     /* w - 128, or 127 - w */
+    }
+    const uint32_t sum_w = sum_adj + 9u * kzp;
+    const uint32_t bias = (uint32_t) bias1[c] - 9u * izp * kzp + izp * sum_w;
+    biasc[c] = (int32_t) (bias + (kzp - izp) * sum_adj + offset);
+  }
+}
+
+/*
  * depthwise image: wadj[tap][c] = w[c][ky][kx] - kzp as int16, tap = ky*kw + kx,
  * row length c_pad (zero padded); bias1[c] = bias[c] + taps*izp*kzp - izp*sum_taps w
  * -- the folding of pack_q8dw_w (src/qnnpack/pack.h:146,151,159), so the kernel

@@ -17,6 +17,8 @@ struct qnnp_state {
   int opt_gemm_kernel;    /* 0 auto, 1 generic, 2 big-tile */
   int opt_dwconv_kernel;  /* 0 auto, 1 generic, 2 LDS-tiled */
   int opt_timing_graph;   /* 1: qnnp_gfx950_time_operator* replay a hipGraph of the launches (default) */
+  int opt_fused_kernel;   /* fused blocks: 0 auto (strip kernel where it applies), 1 tile kernel only, 2 strip kernel only */
+  int opt_fused_rows;     /* strip kernel: output rows per strip, 0 = its own choice */
 };
 
 extern struct qnnp_state qnnp_state;

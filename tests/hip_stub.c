@@ -152,6 +152,14 @@ int qnnp_hip_gavgpool_run(const struct qnnp_hip_gavgpool_args* a, const char** k
   return QNNP_HIP_OK;
 }
 
+int qnnp_hip_fused_strip_bias_offset(const struct qnnp_hip_requant* rq) { return rq != NULL && rq->shift == 0; }
+int qnnp_hip_fused_strip_supported(const struct qnnp_hip_fused_strip_args* a) { return a != NULL && a->hidden_channels % 32 == 0; }
+int qnnp_hip_fused_strip_run(const struct qnnp_hip_fused_strip_args* a, const char** kernel_name)
+{
+  if (!qnnp_hip_fused_strip_supported(a)) return QNNP_HIP_EINVAL;
+  if (kernel_name != NULL) *kernel_name = "stub_fused_strip";
+  return QNNP_HIP_OK;
+}
 int qnnp_hip_fused_block_supported(const struct qnnp_hip_fused_args* a) { return a != NULL && a->hidden_channels % 16 == 0; }
 int qnnp_hip_fused_block_run(const struct qnnp_hip_fused_args* a, const char** kernel_name)
 {

@@ -1,8 +1,9 @@
-"""GPU tier: the fused inverted-residual block operator (qnnp_gfx950_create/setup_fused_block, hip/q8fused.hip)
-against the scalar oracle and against the stand-alone operators it is built from: every block of a MobileNetV2
-(expand / no expand, stride 1 / 2, with / without residual, 16..960 hidden channels, 112^2 .. 7^2 pixels, tile
-edges at odd sizes), bit for bit; the whole network with the blocks fused, eagerly and as one hipGraph; and the
-create / setup status codes."""
+"""GPU tier: the fused inverted-residual block operator (qnnp_gfx950_create/setup_fused_block; hip/q8fusedstrip.hip,
+round 4's strip kernel, and hip/q8fused.hip, the tile kernel it replaces where it applies) against the scalar oracle
+and against the stand-alone operators it is built from: EVERY block of a MobileNetV2 (expand / no expand, stride 1 / 2,
+with / without residual, 16..960 hidden channels, 112^2 .. 7^2 pixels, strip and tile edges at odd sizes), bit for
+bit; the whole network with the blocks fused, eagerly and as one hipGraph; forced strip heights; the bench's batch; and
+the create / setup status codes."""
 import numpy as np
 import pytest
 import torch
@@ -15,8 +16,19 @@ from test_gpu_network import oracle_forward
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("fused_kernel,rows", [(0, 0), (0, 1), (0, 3), (1, 0)], ids=["auto", "strips_of_1", "strips_of_3", "tile_kernel"])
 @pytest.mark.parametrize("input_hw,batch", [(96, 2), (224, 1), (72, 3)])
-def test_fused_network_matches_oracle(qnnp, input_hw, batch):
+def test_fused_network_matches_oracle(qnnp, input_hw, batch, fused_kernel, rows):
+    qnnp.set_option("fused_kernel", fused_kernel)
+    qnnp.set_option("fused_rows", rows)
+    try:
+        _fused_network_matches_oracle(qnnp, input_hw, batch, fused_kernel)
+    finally:
+        qnnp.set_option("fused_kernel", 0)
+        qnnp.set_option("fused_rows", 0)
+
+
+def _fused_network_matches_oracle(qnnp, input_hw, batch, fused_kernel):
     plan = mnv2.build_plan(input_hw=input_hw, classes=1000, seed=0x51A0 + input_hw)
     rng = np.random.default_rng(1000 + input_hw)
     image = rng.integers(0, 256, size=batch * input_hw * input_hw * 3, dtype=np.uint8)
@@ -27,8 +39,11 @@ def test_fused_network_matches_oracle(qnnp, input_hw, batch):
         o1.set_threads(1)
     net = mnv2.DeviceNetwork(qnnp, torch, plan, batch, quant, fuse=True)
     try:
-        # the blocks whose weights fit LDS beside the tiles take the fused kernel (b0..b9 of 17), the rest stay stand-alone
-        assert len(net.fused) >= 8, (len(net.fused), sorted(net.fused))
+        if fused_kernel == 1:
+            # the tile kernel: the blocks whose weights fit LDS beside the tiles (b0..b9 of 17), the rest stay stand-alone
+            assert len(net.fused) >= 8, (len(net.fused), sorted(net.fused))
+        else:
+            assert len(net.fused) == 17, (len(net.fused), sorted(net.fused))      # the strip kernel takes every block
         net.buffers[0].copy_(torch.from_numpy(image))
         net.run()
         hidden = set()
@@ -40,7 +55,8 @@ def test_fused_network_matches_oracle(qnnp, input_hw, batch):
             got = from_device(net.buffers[op.dst])
             bad = np.flatnonzero(got != expected[op.dst])
             assert bad.size == 0, f"{op.name}: {bad.size} of {got.size} bytes differ (first at {bad[:4].tolist()})"
-        assert any(k == "q8_fused_block" for k in net.kernels.values())
+        fused_names = {net.kernels[name] for name in net.fused}
+        assert fused_names == ({"q8_fused_block"} if fused_kernel == 1 else {"q8_fused_strip"}), fused_names
         # one hipGraph replay of the fused schedule
         net.capture()
         for t in net.buffers:
@@ -50,6 +66,47 @@ def test_fused_network_matches_oracle(qnnp, input_hw, batch):
         net.replay()
         last = plan.ops[-1].dst
         assert np.array_equal(from_device(net.buffers[last]), expected[last])
+    finally:
+        net.close()
+
+
+@pytest.mark.parametrize("rows", [0, 2], ids=["auto", "strips_of_2"])
+def test_fused_network_equals_the_unfused_one_at_the_bench_batch(qnnp, rows):
+    """Batch 128, bench.py's network and quantization (extra.mobilenetv2_network_fused): strip heights, chunk widths and
+    the workgroup count depend on the batch, so the fused chain is compared here, tensor by tensor, with the stand-alone
+    operators' chain on the same random images (those operators are held to the oracle and, at this batch, to the
+    compiled reference by tests/test_gpu_sweep_bench_batch.py)."""
+    batch = 128
+    plan = mnv2.build_plan()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(91)
+    plain = mnv2.DeviceNetwork(qnnp, torch, plan, batch)
+    try:
+        image = torch.randint(0, 256, (plain.buffers[0].numel(),), dtype=torch.uint8, device="cuda", generator=gen)
+        plain.buffers[0].copy_(image)
+        plain.run()
+        torch.cuda.synchronize()
+        want = {op.dst: plain.buffers[op.dst].clone() for op in plan.ops}
+    finally:
+        plain.close()
+    qnnp.set_option("fused_rows", rows)
+    try:
+        net = mnv2.DeviceNetwork(qnnp, torch, plan, batch, fuse=True)
+    finally:
+        qnnp.set_option("fused_rows", 0)
+    try:
+        assert len(net.fused) == 17, sorted(net.fused)
+        net.buffers[0].copy_(image)
+        net.run()
+        torch.cuda.synchronize()
+        hidden = set()
+        for first, last in net.fused.values():
+            hidden.update(plan.ops[i].dst for i in range(first, last))
+        for op in plan.ops:
+            if op.dst in hidden:
+                continue
+            assert torch.equal(net.buffers[op.dst], want[op.dst]), f"{op.name}: fused chain differs from the stand-alone chain"
+        assert {net.kernels[name] for name in net.fused} == {"q8_fused_strip"}
     finally:
         net.close()
 

@@ -473,3 +473,74 @@ def test_depthwise_dot4_walk_replay(hooks, shape, kzp):
         assert out is None
     else:
         assert_bytes_equal(out, expected, f"dot-product walk replay vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("kzps", [(127, 127, 127), (128, 128, 128), (127, 128, 127)], ids=lambda k: "kzp" + "_".join(map(str, k)))
+@pytest.mark.parametrize("cin,ch,cout,stride", [(16, 96, 24, 2), (24, 144, 24, 1), (64, 384, 64, 1)])
+def test_fused_strip_images_replay_the_oracle(hooks, debug_hooks, kzps, cin, ch, cout, stride):
+    """pack.h qnnp_strip_pointwise_images / qnnp_strip_depthwise_images (what fused-block.c derives from the stand-alone
+    operators' device images) + the arithmetic of hip/q8fusedstrip.hip, replayed in numpy for one small image: expand,
+    depthwise and project accumulators -- operands recentred with the stage's flip, padding taps = (input zero point ^ flip),
+    no row terms -- must equal the oracle's of the three stand-alone operators, every intermediate requantized by the oracle."""
+    import ctypes
+    L = debug_hooks.lib
+    L.qnnp_debug_strip_pointwise_images.restype = None
+    L.qnnp_debug_strip_pointwise_images.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_uint32] * 3 + \
+        [ctypes.c_uint8, ctypes.c_uint8, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.qnnp_debug_strip_depthwise_images.restype = None
+    L.qnnp_debug_strip_depthwise_images.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_uint32] * 3 + \
+        [ctypes.c_uint8, ctypes.c_uint8, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    rng = np.random.default_rng(cin * 1000 + ch + stride)
+    H = W = 6
+    OH = OW = (H + 2 - 3) // stride + 1
+    izp1, izp2, izp3 = 3, 200, 127
+    x = rng.integers(0, 256, size=(H * W, cin), dtype=np.uint8)
+    w1 = rng.integers(0, 256, size=(ch, cin), dtype=np.uint8); b1 = rng.integers(-5000, 5000, size=ch).astype(np.int32)
+    w2 = rng.integers(0, 256, size=(ch, 3, 3), dtype=np.uint8); b2 = rng.integers(-5000, 5000, size=ch).astype(np.int32)
+    w3 = rng.integers(0, 256, size=(cout, ch), dtype=np.uint8); b3 = rng.integers(-5000, 5000, size=cout).astype(np.int32)
+    w1[0, :] = 255; w1[1, :] = 0; w2[0] = 255; w2[1] = 0; w3[0, :] = 0; w3[1, :] = 255; x[0, :] = 255; x[1, :] = 0
+
+    def flip(k): return 0x80 if k == 128 else 0x7F
+    def s8(a, f): return (a ^ f).astype(np.uint8).view(np.int8).astype(np.int64)
+
+    def pointwise(a_u8, w, b, izp, kzp, ofs):
+        n, k = w.shape
+        packed, bias2, n_pad, k_pad = em.host_pack_igemm(hooks, 1, n, k, izp, kzp, w.reshape(1, n, k), b)
+        nb, kb = (n + 31) // 32, (k + 31) // 32
+        frags = np.empty(nb * kb * 1024, np.int8); biasc = np.empty(nb * 32, np.int32)
+        L.qnnp_debug_strip_pointwise_images(packed.ctypes.data, bias2.ctypes.data, k_pad, n, k, izp, kzp, ofs,
+                                            frags.ctypes.data, biasc.ctypes.data)
+        wc = em.unpack_fragments(frags, 1, nb * 32, kb * 32)[0]               # what the MFMA sees, [n_pad][kb * 32]
+        assert np.array_equal(wc[:n, :k], s8(w, flip(kzp))) and not wc[n:].any() and not wc[:, k:].any()
+        acc = em.wrap32(s8(a_u8, flip(kzp)) @ wc[:n, :k].T + biasc[None, :n].astype(np.int64) - (ofs << 31))
+        assert np.array_equal(acc, o1.gemm_acc(a_u8, w, b, izp, kzp).astype(np.int64))
+        return acc
+
+    kz1, kz2, kz3 = kzps
+    acc1 = pointwise(x, w1, b1, izp1, kz1, 1)
+    hid = o1.requantize_rows(acc1.astype(np.int32), np.float32(0.002), izp2, 0, 255).reshape(H, W, ch)
+    # depthwise: padded hidden image holding (pixel ^ flip2), padding cells = izp2 ^ flip2
+    c_pad = em.round_up(ch, 16)
+    wadj = np.zeros(9 * c_pad, np.int16); bias1 = np.zeros(c_pad, np.int32)
+    hooks.qnnp_debug_pack_dwconv_w(ch, c_pad, 3, 3, izp2, kz2, np.ascontiguousarray(w2).ctypes.data, b2.ctypes.data,
+                                   wadj.ctypes.data, bias1.ctypes.data)
+    hp = em.round_up(ch, 32)
+    w2c = np.empty(9 * hp, np.int8); biasc2 = np.empty(hp, np.int32)
+    L.qnnp_debug_strip_depthwise_images(wadj.ctypes.data, bias1.ctypes.data, c_pad, ch, hp, izp2, kz2, 0,
+                                        w2c.ctypes.data, biasc2.ctypes.data)
+    w2c = w2c.reshape(9, hp).astype(np.int64)
+    assert np.array_equal(w2c[:, :ch], s8(w2.reshape(ch, 9).T.copy(), flip(kz2))) and not w2c[:, ch:].any()
+    padded = np.full((H + 2, W + 2, ch), izp2, np.uint8)
+    padded[1:-1, 1:-1] = hid
+    pc = s8(padded, flip(kz2))
+    acc2 = np.zeros((OH, OW, ch), np.int64)
+    for oy in range(OH):
+        for ox in range(OW):
+            for t in range(9):
+                acc2[oy, ox] += pc[oy * stride + t // 3, ox * stride + t % 3] * w2c[t, :ch]
+    acc2 = em.wrap32(acc2 + biasc2[None, None, :ch].astype(np.int64)).reshape(OH * OW, ch)
+    shape = o1.conv_shape(1, H, W, (1, 1, 1, 1), (3, 3), (stride, stride), (1, 1), ch, 1, 1, ch)
+    want2 = o1.conv2d_acc(shape, hid.reshape(-1), w2.reshape(ch, 1, 3, 3, 1), b2, izp2, kz2).reshape(OH * OW, ch)
+    assert np.array_equal(acc2, want2.astype(np.int64))
+    dwo = o1.requantize_rows(want2.astype(np.int32), np.float32(0.001), izp3, 0, 255)
+    pointwise(dwo, w3, b3, izp3, kz3, 0)
