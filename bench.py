@@ -568,8 +568,12 @@ def main():
     try:
         # this chip's own streaming ceiling: a plain 16-byte-per-lane copy / read kernel over 1 GiB buffers
         dbg = qnnpack_amd.load_debug()       # measurement companion library, not the product
-        copy_gbs = round(dbg.copy_probe(False, 1024, 5), 1)
+        # (round 4: the ceiling is the BEST streaming form -- nt loads and stores -- and the plain form is printed beside it:
+        #  the product's layer 4 had beaten the plain copy kernel, which a ceiling must not allow)
+        plain_gbs = round(dbg.copy_probe(False, 1024, 5), 1)
+        copy_gbs = max(plain_gbs, round(dbg.copy_probe(False, 1024, 5, streaming=True), 1))
         roofline["hbm_copy_kernel_gbs"] = copy_gbs
+        roofline["hbm_copy_kernel_plain_policy_gbs"] = plain_gbs
         roofline["hbm_read_kernel_gbs"] = round(dbg.copy_probe(True, 1024, 5), 1)
     except Exception as exc:  # noqa: BLE001
         print(f"# copy probe failed: {exc}", file=sys.stderr)
@@ -667,6 +671,10 @@ def main():
             "images_per_s_by_sum_of_layers": round(my_batch / (sum_of_layers_ms * 1e-3) * world, 1),
             "hbm_gbs": round(act_bytes / (sweep_ms * 1e-3) / 1e9, 1),
             "frac_of_hbm_peak": round(act_bytes / (sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            # the whole job's %-of-roofline (north_star: images/s AND %-of-roofline at 1 / 2 / 4 / 8 GPUs): every rank moves
+            # act_bytes in the slowest rank's time against `world` x the HBM peak -- at N = 1 the line above
+            "aggregate_hbm_gbs": round(world * act_bytes / (job_sweep_ms * 1e-3) / 1e9, 1),
+            "aggregate_frac_of_hbm_peak": round(act_bytes / (job_sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
             "frac_of_copy_kernel": round(act_bytes / (sweep_ms * 1e-3) / 1e9 / copy_gbs, 4) if copy_gbs else None,
             "tops": round(total_ops / (sweep_ms * 1e-3) / 1e12, 2),
             "roofline_images_per_s_per_gpu": round(PEAK_HBM_GBS * 1e9 / (act_bytes / my_batch), 1),

@@ -172,6 +172,7 @@ class DeviceNetwork:
                         for t in plan.shapes}
         self.handles = []
         self.kernels = {}
+        self._plain_stores = set()
         quant = quant or {}
         for op in plan.ops:
             q = quant.get(op.name, Quant())
@@ -258,16 +259,16 @@ class DeviceNetwork:
     # Every operator's output is the next operator's input: keep the outputs cacheable. The library's default marks
     # whole-line output stores as streaming ("streaming_stores" = 1), which is right for an operator run on its own --
     # the per-layer sweep gains 4-5 % -- and costs a chained network about 1 %: the consumer finds nothing of a streamed
-    # tensor in the last-level cache. The option is read at launch time, i.e. while recording.
+    # tensor in the last-level cache. The hint is a property of each of THIS network's operators
+    # (qnnp_gfx950_operator_set_streaming_stores): the process-wide option, and whatever other threads launch, stay as they are.
     def _launch_all(self, record_names: bool):
-        self.lib.set_option("streaming_stores", 0)
-        try:
-            for name, h in self.schedule:
-                self.lib.run_operator(h)
-                if record_names:
-                    self.kernels[name] = self.lib.operator_kernel(h)
-        finally:
-            self.lib.set_option("streaming_stores", 1)
+        for name, h in self.schedule:
+            if h not in self._plain_stores:
+                self.lib.operator_set_streaming_stores(h, 0)
+                self._plain_stores.add(h)
+            self.lib.run_operator(h)
+            if record_names:
+                self.kernels[name] = self.lib.operator_kernel(h)
 
     def run(self):
         """One forward pass, operator by operator."""

@@ -94,9 +94,11 @@ def main(argv=None):
         got = results[d][0].reshape(count, -1)
         assert np.array_equal(got, reference[start:start + count]), f"shard of device {d} differs from the unsharded run"
     slowest = max(results[d][1] for d in range(ndev))
+    per_device = {d: round(shard_batch(args.batch, ndev, d)[1] * args.rounds / results[d][1], 1) for d in range(ndev)}
     print(f"{ndev} device(s), batch {args.batch} in shards of {[shard_batch(args.batch, ndev, d)[1] for d in range(ndev)]}: "
           f"byte-identical to the unsharded run; {args.batch * args.rounds / slowest:.0f} images/s over the timed rounds "
           f"(kernel {results[0][2]}, slowest thread {slowest * 1e3:.1f} ms, wall {wall * 1e3:.0f} ms incl. create/setup)")
+    print(f"per-device images/s (each thread's own shard over its own timed rounds): {per_device}")
     return 0
 
 

@@ -158,6 +158,12 @@ enum qnnp_status qnnp_gfx950_set_option(const char* key, int value);
 
 /* Name of the HIP kernel the operator's last setup selected (static string), or
  * NULL. Lets tests assert that the intended kernel actually ran. */
+/* The streaming-store hint ("streaming_stores" above) of ONE operator: value 1 / 0 = on / off for every later launch of
+ * `op`, -1 = follow the process-wide option again (the default). An operator whose output the next operator reads at
+ * once (a chained network) wants 0; an operator on its own, as the reference bench runs them, 1 -- both kinds can live
+ * in one process, and no launch of another thread is affected. */
+enum qnnp_status qnnp_gfx950_operator_set_streaming_stores(qnnp_operator_t op, int value);
+
 const char* qnnp_gfx950_operator_kernel(qnnp_operator_t op);
 
 /* Device properties as seen by the library: gcnArchName copied into `arch`

@@ -110,10 +110,11 @@ def load_debug():
         dbg.lib.qnnp_gfx950_copy_probe.restype = ctypes.c_int
         dbg.lib.qnnp_gfx950_copy_probe.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
 
-        def copy_probe(read_only: bool = False, mbytes: int = 1024, reps: int = 5) -> float:
-            """GB/s of a plain 16-byte-per-lane streaming kernel on this chip (copy: bytes read + written)."""
+        def copy_probe(read_only: bool = False, mbytes: int = 1024, reps: int = 5, streaming: bool = False) -> float:
+            """GB/s of a 16-byte-per-lane streaming kernel on this chip (copy: bytes read + written); streaming = the nt
+            policy on its loads and stores, the form the product's whole-line writers use."""
             gbs = ctypes.c_float(0.0)
-            rc = dbg.lib.qnnp_gfx950_copy_probe(1 if read_only else 0, mbytes, reps, ctypes.byref(gbs))
+            rc = dbg.lib.qnnp_gfx950_copy_probe(1 if read_only else (2 if streaming else 0), mbytes, reps, ctypes.byref(gbs))
             if rc != 0:
                 raise RuntimeError(f"qnnp_gfx950_copy_probe -> {rc}")
             return float(gbs.value)

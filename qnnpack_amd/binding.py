@@ -327,6 +327,8 @@ class Gfx950Library(QnnpackLibrary):
             L.qnnp_gfx950_operator_residual_folded.argtypes = [c_void_p]
         L.qnnp_gfx950_set_option.restype = c_int
         L.qnnp_gfx950_set_option.argtypes = [c_char_p, c_int]
+        L.qnnp_gfx950_operator_set_streaming_stores.restype = c_int
+        L.qnnp_gfx950_operator_set_streaming_stores.argtypes = [c_void_p, c_int]
         L.qnnp_gfx950_operator_kernel.restype = c_char_p
         L.qnnp_gfx950_operator_kernel.argtypes = [c_void_p]
         L.qnnp_gfx950_device_info.restype = c_int
@@ -451,6 +453,10 @@ class Gfx950Library(QnnpackLibrary):
 
     def set_option(self, key: str, value: int) -> None:
         self._check("qnnp_gfx950_set_option", self.lib.qnnp_gfx950_set_option(key.encode(), value))
+
+    def operator_set_streaming_stores(self, op, value: int) -> None:
+        """1 / 0: the streaming-store hint of this operator's launches; -1: follow the process-wide option again."""
+        self._check("qnnp_gfx950_operator_set_streaming_stores", self.lib.qnnp_gfx950_operator_set_streaming_stores(op, value))
 
     def operator_kernel(self, op) -> Optional[str]:
         name = self.lib.qnnp_gfx950_operator_kernel(op)

@@ -115,6 +115,22 @@ __global__ __launch_bounds__(256) void copy_probe_kernel(const uint4* __restrict
   for (; i < n16; i += stride) dst[i] = src[i];
 }
 
+/* the same with the streaming (nt) policy on loads and stores: what a kernel that touches every line once can reach
+ * (tools/ubench_copy.hip: +12 % over the plain form); bench.py reports BOTH and prices `frac_of_copy_kernel` against this one */
+typedef unsigned int probe_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy_probe_nt_kernel(const probe_u4* __restrict__ src, probe_u4* __restrict__ dst, size_t n16)
+{
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const probe_u4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
+                   c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+    __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
+    __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+  }
+  for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
 __global__ __launch_bounds__(256) void read_probe_kernel(const uint4* __restrict__ src, uint32_t* __restrict__ sink, size_t n16)
 {
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
@@ -130,7 +146,7 @@ __global__ __launch_bounds__(256) void read_probe_kernel(const uint4* __restrict
 
 }  // namespace
 
-/* mode 0: copy (bytes read + bytes written counted), mode 1: read only. `mbytes` per buffer (>= 512 recommended).
+/* mode 0: copy (bytes read + bytes written counted), mode 1: read only, mode 2: copy with streaming (nt) loads and stores. `mbytes` per buffer (>= 512 recommended).
  * *gbs_out = GB/s of the best of `reps` event-timed launches. */
 extern "C" int qnnp_gfx950_copy_probe(int mode, int mbytes, int reps, float* gbs_out)
 {
@@ -143,7 +159,7 @@ extern "C" int qnnp_gfx950_copy_probe(int mode, int mbytes, int reps, float* gbs
   uint4* src = nullptr;
   uint4* dst = nullptr;
   if (hipMalloc(reinterpret_cast<void**>(&src), bytes) != hipSuccess) return QNNP_HIP_ENOMEM;
-  if (hipMalloc(reinterpret_cast<void**>(&dst), mode == 0 ? bytes : 256) != hipSuccess) { (void) hipFree(src); return QNNP_HIP_ENOMEM; }
+  if (hipMalloc(reinterpret_cast<void**>(&dst), mode != 1 ? bytes : 256) != hipSuccess) { (void) hipFree(src); return QNNP_HIP_ENOMEM; }
   (void) hipMemset(src, 0x5A, bytes);
   hipEvent_t e0, e1;
   bool ok = hipEventCreate(&e0) == hipSuccess;
@@ -154,12 +170,13 @@ extern "C" int qnnp_gfx950_copy_probe(int mode, int mbytes, int reps, float* gbs
     for (int r = 0; r < reps + 1 && ok; r++) {
       (void) hipEventRecord(e0, nullptr);
       if (mode == 0) hipLaunchKernelGGL(copy_probe_kernel, grid, block, 0, nullptr, src, dst, n16);
+      else if (mode == 2) hipLaunchKernelGGL(copy_probe_nt_kernel, grid, block, 0, nullptr, reinterpret_cast<const probe_u4*>(src), reinterpret_cast<probe_u4*>(dst), n16);
       else hipLaunchKernelGGL(read_probe_kernel, grid, block, 0, nullptr, src, reinterpret_cast<uint32_t*>(dst), n16);
       float ms = 0.0f;
       ok = hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
            hipEventElapsedTime(&ms, e0, e1) == hipSuccess && hipGetLastError() == hipSuccess && ms > 0.0f;
       if (ok && r > 0) {       // the first launch is the warm-up
-        const float gbs = static_cast<float>((mode == 0 ? 2.0 : 1.0) * static_cast<double>(bytes) / (ms * 1e-3) / 1e9);
+        const float gbs = static_cast<float>((mode != 1 ? 2.0 : 1.0) * static_cast<double>(bytes) / (ms * 1e-3) / 1e9);
         if (gbs > best) best = gbs;
       }
     }

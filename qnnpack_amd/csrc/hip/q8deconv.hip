@@ -97,10 +97,13 @@ void q8_deconv_s2_stream_kernel(const DeconvParams p)
     // (lane forms of the requantization: bias + 2^31, the second half of the phase's pair table)
     const int32_t* bias_src = p.bias[ph] + (rq_is_lane<SEQ>() ? p.n_pad : 0u);
     for (uint32_t c0 = wave * 64; c0 < bias_chunks; c0 += kThreads) {
-      const uint32_t c = min(c0 + lane, bias_chunks - 1);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(bias_src) + c * 16),
-          (__attribute__((address_space(3))) void*) (lds + p.lds_bias + ph * p.n_pad * 4 + c0 * 16), 16, 0, 0);
+      // (only the lanes that have a chunk: an LDS-DMA lane writes its 16 bytes at base + lane * 16 whatever it read, and
+      //  a phase's bias line is n_pad * 4 bytes -- the surplus lanes of a clamped load spilled into the next phase's line)
+      if (c0 + lane < bias_chunks) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*) (reinterpret_cast<const uint8_t*>(bias_src) + (c0 + lane) * 16),
+            (__attribute__((address_space(3))) void*) (lds + p.lds_bias + ph * p.n_pad * 4 + c0 * 16), 16, 0, 0);
+      }
     }
   }
 

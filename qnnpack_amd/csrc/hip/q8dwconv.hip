@@ -2160,7 +2160,7 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
   p.izp = a->input_zero_point & 0xFFu;
   p.CS = p.TOH = p.IR = p.IC = p.PP = p.bands = p.slabs = 0;
   p.rq = qnnp::make_requant_dev(a->rq);
-  p.stream_out = qnnp_hip_streaming_stores() != 0 ? 1u : 0u;
+  p.stream_out = a->streaming_mode == 0 ? (qnnp_hip_streaming_stores() != 0 ? 1u : 0u) : (a->streaming_mode == 2 ? 1u : 0u);
   p.trace = nullptr;
   p.abl = 0;
 #ifdef QNNP_ENABLE_ABLATION

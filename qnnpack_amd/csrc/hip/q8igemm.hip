@@ -533,7 +533,7 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   p.lane = qnnp::make_requant_lane(a->rq);
   p.bias2u = a->bias2_pair != 0 ? a->bias2 + static_cast<size_t>(a->groups) * a->n_pad : nullptr;
   if (p.bias2u == nullptr) p.lane.kind = 0;      // no table to start from: the offset forms
-  p.stream_out = qnnp_hip_streaming_stores() != 0 ? 1u : 0u;
+  p.stream_out = a->streaming_mode == 0 ? (qnnp_hip_streaming_stores() != 0 ? 1u : 0u) : (a->streaming_mode == 2 ? 1u : 0u);
   p.a_flip = 0;
   p.fill_table = qnnp_hip_fill_table();
   p.trace = nullptr;

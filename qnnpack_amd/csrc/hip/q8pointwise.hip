@@ -27,7 +27,7 @@ constexpr int kThreads = 256;
 
 /* dense, 16-byte aligned tensors: one flat run of `vectors` uint4 */
 __global__ __launch_bounds__(kThreads)
-void q8_vadd_flat_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ sum,
+void q8_vadd_flat_kernel(const uint4* __restrict__ a, const uint4* b, uint4* sum,       // (b may BE sum: the in-place residual add, operator-run.c)
                          const uint64_t vectors, const qnnp_hip_add_params q, const uint32_t streaming)
 {
   const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kThreads;
@@ -184,7 +184,7 @@ extern "C" int qnnp_hip_vadd_run(const struct qnnp_hip_vadd_args* a, const char*
     hipLaunchKernelGGL(q8_vadd_flat_kernel, dim3(grid_for(vectors, device_cus())), dim3(kThreads), 0, stream,
                        reinterpret_cast<const uint4*>(a->a), reinterpret_cast<const uint4*>(a->b),
                        reinterpret_cast<uint4*>(a->sum), vectors, a->params,
-                       qnnp_hip_streaming_stores() != 0 ? 1u : 0u);
+                       a->streaming_mode == 0 ? (qnnp_hip_streaming_stores() != 0 ? 1u : 0u) : (a->streaming_mode == 2 ? 1u : 0u));
     if (kernel_name != nullptr) *kernel_name = "q8_vadd_flat";
   } else {
     hipLaunchKernelGGL(q8_vadd_strided_kernel, dim3(grid_for(bytes, device_cus())), dim3(kThreads), 0, stream, *a);

@@ -173,7 +173,7 @@ struct qnnp_hip_igemm_args {
   uint32_t input_height, input_width, output_height, output_width;
   uint32_t kernel_height, kernel_width, stride_height, stride_width, dilation_height, dilation_width;
   uint32_t pad_top, pad_left;
-  /* optional fused residual add (qnnpack_gfx950.h qnnp_gfx950_setup_convolution_residual_add_nhwc_q8):
+  /* optional fused residual add (qnnpack_gfx950.h qnnp_gfx950_attach_residual_add):
    * output = add(a = residual pixel, b = the requantized convolution output) with the add operator's parameters.
    * Kernels that carry the add in their epilogue set *residual_folded = 1; for the others the caller launches the
    * stand-alone add kernel in place on `output` (operator-run.c). residual == NULL: off. */
@@ -191,6 +191,9 @@ struct qnnp_hip_igemm_args {
   const int8_t* packed_w_centred;
   const int32_t* bias2_centred;
   uint32_t centre_flip;
+  /* the streaming-store hint of THIS launch (qnnp_gfx950_operator_set_streaming_stores): 0 = the process default
+   * ("streaming_stores" option), 1 = off, 2 = on */
+  uint32_t streaming_mode;
 };
 int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* args, const char** kernel_name);
 
@@ -259,6 +262,7 @@ struct qnnp_hip_dwconv_args {
   struct qnnp_hip_requant rq;
   int variant;                /* 0 auto, 1 generic direct, 2 LDS-tiled, 3 register sliding window (3x3), 4 matrix-core (gather), 5 matrix-core (LDS band), 6 column-sliding window (3x3) */
   struct qnnp_hip_dwconv_plan* plan;   /* optional plan cache owned by the caller (NULL: plan on every call) */
+  uint32_t streaming_mode;    /* as qnnp_hip_igemm_args: 0 = process default, 1 = off, 2 = on */
 };
 int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* args, const char** kernel_name);
 
@@ -288,6 +292,7 @@ struct qnnp_hip_vadd_args {
   uint32_t channels;
   uint64_t a_stride, b_stride, sum_stride;
   struct qnnp_hip_add_params params;
+  uint32_t streaming_mode;    /* as qnnp_hip_igemm_args: 0 = process default, 1 = off, 2 = on */
 };
 int qnnp_hip_vadd_run(const struct qnnp_hip_vadd_args* args, const char** kernel_name);
 

@@ -232,7 +232,7 @@ QNNP_HD struct qnnp_requant_lane qnnp_requant_lane_init(const struct qnnp_requan
   l.konst = 0;
   /* both kinds need a = n - rowterm inside int32 (u is a + 2^31 reduced mod 2^32): guaranteed when the operator's
    * accumulators are bounded at create time (|n| < 2^30 with the reduction length that bound implies, K < 2^14, so
-   * |rowterm| <= 2^14 * K < 2^28); without a bound the caller keeps the forms that only need n itself */
+   * |rowterm| <= 128 * 255 * K < 2^15 * 2^14 = 2^29, so |a| <= |n| + |rowterm| < 2^30 + 2^29 < 2^31); without a bound the caller keeps the forms that only need n itself */
   const int bounded_acc = accumulator_bits >= 1 && accumulator_bits <= 30;
   if (f.shift == 0 && zero_point_folded && bounded_acc) {
     l.kind = 1;

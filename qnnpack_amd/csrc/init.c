@@ -196,6 +196,13 @@ enum qnnp_status qnnp_gfx950_set_option(const char* key, int value)
   return qnnp_status_invalid_parameter;
 }
 
+enum qnnp_status qnnp_gfx950_operator_set_streaming_stores(qnnp_operator_t op, int value)
+{
+  if (op == NULL || value < -1 || value > 1) return qnnp_status_invalid_parameter;
+  op->streaming_mode = value < 0 ? 0u : (uint32_t) value + 1u;      /* 0 = the process default, 1 = off, 2 = on */
+  return qnnp_status_success;
+}
+
 const char* qnnp_gfx950_operator_kernel(qnnp_operator_t op)
 {
   return op == NULL ? NULL : op->kernel_name;

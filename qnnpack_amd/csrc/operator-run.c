@@ -69,6 +69,7 @@ static int launch_kernel(struct qnnp_operator* op, const void* input, const void
       const struct qnnp_hip_dwconv_args args = {
         .input = (const uint8_t*) input,
         .output = (uint8_t*) output,
+        .streaming_mode = op->streaming_mode,
         .wadj = (const int16_t*) op->d_weights,
         .bias1 = op->d_bias,
         .dwm_x = (const int8_t*) op->d_dwm_x,
@@ -266,6 +267,7 @@ static int launch_kernel(struct qnnp_operator* op, const void* input, const void
         .packed_w_centred = (const int8_t*) (op->d_weights_centred != NULL ? op->d_weights_centred : op->d_weights),
         .bias2_centred = op->d_bias_centred != NULL ? op->d_bias_centred : op->d_bias,
         .centre_flip = is_conv ? 0u : op->centre_flip,
+        .streaming_mode = op->streaming_mode,
       };
       return qnnp_hip_igemm_run(&args, &op->kernel_name);
     }
@@ -275,6 +277,7 @@ static int launch_kernel(struct qnnp_operator* op, const void* input, const void
     {
       /* reference operator-run.c, case qnnp_ukernel_type_add (q8vadd over rows of `channels` bytes) */
       const struct qnnp_hip_vadd_args args = {
+        .streaming_mode = op->streaming_mode,
         .a = (const uint8_t*) input,
         .b = (const uint8_t*) input2,
         .sum = (uint8_t*) output,
@@ -317,6 +320,7 @@ static int launch(struct qnnp_operator* op, const void* input, const void* input
   /* attached residual add (residual.c) the convolution kernel does not carry: the add kernel, in place on the output */
   const size_t out_channels = (size_t) op->groups * op->group_output_channels;
   const struct qnnp_hip_vadd_args args = {
+    .streaming_mode = op->streaming_mode,
     .a = (const uint8_t*) op->residual,
     .b = (const uint8_t*) output,
     .sum = (uint8_t*) output,

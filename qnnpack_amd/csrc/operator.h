@@ -124,6 +124,8 @@ struct qnnp_operator {
   void* d_weights;        /* igemm: int8 fragment panels; dwconv: int16 [taps][c_pad] */
   void* d_weights_rows16; /* igemm, 3-channel first layers: the [ky][16-byte row slot] fragment image (pack.h), or NULL */
   int32_t* d_bias;        /* igemm: bias2 [groups][n_pad]; dwconv: bias1 [c_pad] */
+  uint32_t streaming_mode;  /* streaming-store hint of this operator's launches: 0 = the process default, 1 = off, 2 = on
+                             * (qnnp_gfx950_operator_set_streaming_stores) */
   /* zero-point-centred image for the big GEMM kernel (pack.h qnnp_pack_igemm_w_centred, hip/q8gemm256c.hip):
    * centre_flip 0 = none; 0x80 = kernel zero point 128, the standard image IS centred (the two pointers stay NULL and
    * d_weights / d_bias serve); 0x7F = kernel zero point 127, own image + own bias pair table */

@@ -1,0 +1,22 @@
+#!/bin/bash
+# One gpurun call: GPU-tier tests, smoke, the bench line, rocprofv3 kernel stats, the GEMM's fabric traffic. gpurun_out/<tag>/.
+TAG=${1:-r04fin}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+echo "== device"; rocminfo 2>/dev/null | grep -E "gfx|Compute Unit" | head -4; nproc
+echo "== pytest -m gpu"
+timeout 1500 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider 2>&1 | tail -n 60 > $OUT/pytest_gpu.log
+tail -n 12 $OUT/pytest_gpu.log
+echo "== smoke"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 5 | tee $OUT/smoke.log
+echo "== bench"
+timeout 900 python bench.py --steps 30 --warmup 5 2>&1 | tail -n 3 | tee $OUT/bench.json | cut -c1-1500
+echo "== rocprofv3 kernel stats (headline GEMM only)"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o gemm -- python $OLDPWD/bench.py --steps 30 --warmup 5 --no-extra --no-cpu-baseline > $OLDPWD/$OUT/prof_run.log 2>&1)
+for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do cut -c1-200 $f | head -n 8; cp $f $OUT/rocprof_kernel_stats_gemm.csv; done
+echo "== rocprofv3 kernel stats (whole bench)"
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof_all -o all -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OLDPWD/$OUT/prof_all_run.log 2>&1)
+for f in $(find $OUT/prof_all -name "*kernel_stats*.csv" | head -1); do cut -c1-160 $f | head -n 14; cp $f $OUT/rocprof_kernel_stats_all.csv; done
+rm -rf $OUT/prof $OUT/prof_all
+echo "== PMC: fabric traffic and SQ counters of the GEMM"
+bash scripts/gpu_pmc_cmd.sh $TAG gemm_tcc "python tools/gemm_ab.py --only 0" TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_EA0_WRREQ_64B_sum | tee $OUT/pmc_gemm_tcc.txt
+bash scripts/gpu_pmc_cmd.sh $TAG gemm_sq "python tools/gemm_ab.py --only 0" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU | tee $OUT/pmc_gemm_sq.txt
+rm -rf $OUT/pmc_gemm_tcc $OUT/pmc_gemm_sq

@@ -73,3 +73,38 @@ def test_option_values(qnnp):
     with pytest.raises(QnnpackError):
         qnnp.set_option("streaming_stores", 2)
     qnnp.set_option("streaming_stores", 1)
+
+
+def test_the_hint_is_scoped_per_operator(qnnp):
+    """qnnp_gfx950_operator_set_streaming_stores: one operator with the hint off and one with it on in the same process,
+    launched alternately, with the process-wide option left alone; both produce the oracle's bytes, -1 restores the default."""
+    from qnnpack_amd import QnnpackError
+    case = FcCase("ss_scoped", 4100, 32, 96)
+    expected, quant = fc_expected(case)
+    inp, kernel, bias = __import__("_cases").fc_tensors(case)
+    oscale, ozp = quant
+    ops, outs = [], []
+    qnnp.set_option("gemm_kernel", 5)
+    try:
+        d_in = to_device(inp)
+        for value in (0, 1):
+            op = qnnp.create_fully_connected_nc_q8(case.input_channels, case.output_channels, case.izp, 1.0, case.kzp, 1.0,
+                                                   kernel, bias, ozp, float(oscale), case.qmin, case.qmax, 0)
+            d_out = to_device(np.zeros(expected.size, np.uint8))
+            qnnp.setup_fully_connected_nc_q8(op, case.batch, d_in, case.in_stride, d_out, case.out_stride)
+            qnnp.operator_set_streaming_stores(op, value)
+            ops.append(op); outs.append(d_out)
+        for _ in range(3):
+            for op in ops:
+                qnnp.run_operator(op)
+        for d_out in outs:
+            assert_bytes_equal(from_device(d_out), expected, "per-operator streaming hint")
+        qnnp.operator_set_streaming_stores(ops[0], -1)
+        qnnp.run_operator(ops[0])
+        assert_bytes_equal(from_device(outs[0]), expected, "per-operator streaming hint, back to the default")
+        with pytest.raises(QnnpackError):
+            qnnp.operator_set_streaming_stores(ops[0], 2)
+    finally:
+        qnnp.set_option("gemm_kernel", 0)
+        for op in ops:
+            qnnp.delete_operator(op)
