@@ -77,6 +77,7 @@ struct DwParams {
   const uint32_t* dot4;  // [4][c_pad] register image of that flavour (pack.h qnnp_pack_dwconv_dot4), or null
   uint32_t xcd_ranges;   // kernel G: 1 = contiguous ranges of the work per XCD (launch_col)
   uint32_t inv_bands, inv_slabs, inv_q4;   // kernel G: ceil(2^32 / d) of its three divisors (0 when d == 1), launch_col
+  uint32_t inv_dh;       // kernel G, dilated flavour: the same for the row dilation
   uint32_t store_mode;   // as igemm_epilogue.hip.h: 2 = 16-byte stores, 1 = dword stores, 0 = byte stores
   uint32_t abl;          // measurement builds only: bit 0 = no stores, bit 1 = no global loads (kernel F)
   unsigned long long* trace;   // measurement builds only (QNNP_ENABLE_ABLATION + env QNNP_GFX950_TRACE)
@@ -549,11 +550,17 @@ int launch_row(const DwParams& p, hipStream_t stream)
  */
 constexpr int kColThreads = 256;
 
-template <int S, bool FIX, int SEQ, bool FULL, bool DEEP, bool QUAD>
+/* DIL (the int8 walk at stride 1 only): dilated windows. Columns: the three taps sit p.dw pixels apart -- other lane
+ * offsets, nothing else. Rows: output rows of one residue class `rho` mod p.dh form an UNDILATED walk over every
+ * p.dh-th input row, so a wave takes (image, residue, segment of that residue's rows, chunk) and walks with a row
+ * stride of p.dh rows: `oy0` / `oy1` then count the residue's rows (output row rho + p.dh * t), a row index `iy` of the
+ * walk is input row rho - pad_top + p.dh * iy, valid for v_lo <= iy < v_hi. */
+template <int S, bool FIX, int SEQ, bool FULL, bool DEEP, bool QUAD, bool DIL = false>
 __device__ __forceinline__ void dwconv_col3x3_body(
     const DwParams& p, const uint32_t n, const uint32_t oy0, const uint32_t oy1, const uint32_t ox, const uint32_t cg,
-    const bool ok0, const bool ok1, const bool ok2)
+    const bool ok0, const bool ok1, const bool ok2, const uint32_t rho = 0)
 {
+  static_assert(!DIL || (S == 1 && QUAD), "the dilated walk exists for the int8 flavour at stride 1");
   // kLate: the walks of the default path (int8 dot-product walk at stride 1, pair walk at stride 2) replace padding
   // where a row is CONSUMED, not where it is requested; the int16 pair walks at stride 1 (weights outside the int8
   // classes) keep the round-2 scheme
@@ -646,8 +653,9 @@ __device__ __forceinline__ void dwconv_col3x3_body(
   const int32_t ix0 = static_cast<int32_t>(ox * S) - static_cast<int32_t>(p.pad_left);
   uint32_t coff[3];
   coff[0] = cg + (ok0 ? static_cast<uint32_t>(ix0) : 0u) * p.in_stride;
-  coff[1] = cg + (ok1 ? static_cast<uint32_t>(ix0 + 1) : 0u) * p.in_stride;
-  coff[2] = cg + (ok2 ? static_cast<uint32_t>(ix0 + 2) : 0u) * p.in_stride;
+  const int32_t dcol = DIL ? static_cast<int32_t>(p.dw) : 1;
+  coff[1] = cg + (ok1 ? static_cast<uint32_t>(ix0 + dcol) : 0u) * p.in_stride;
+  coff[2] = cg + (ok2 ? static_cast<uint32_t>(ix0 + 2 * dcol) : 0u) * p.in_stride;
   // what a padding ROW reads at this lane's columns: the input zero point -- or 0 at a padding column of a kLate walk
   uint32_t fillk[3] = {fill, fill, fill};
   if constexpr (kLate && FIX) {
@@ -657,7 +665,20 @@ __device__ __forceinline__ void dwconv_col3x3_body(
     if (!ok2) { coff[2] = 0x80000000u; fillk[2] = 0u; }
   }
   const uint32_t img_off = n * p.H * row_bytes;                     // wave-uniform
-  const int32_t iy_first = static_cast<int32_t>(oy0 * S) - static_cast<int32_t>(p.pad_top);
+  int32_t iy_first = static_cast<int32_t>(oy0 * S) - static_cast<int32_t>(p.pad_top);
+  // DIL: the walk's row index -> input row base + dh * iy (scalars)
+  int32_t v_lo = 0, v_hi = static_cast<int32_t>(p.H);
+  uint32_t row_org = img_off, row_adv_w = row_adv, out_rows = 1u;
+  if constexpr (DIL) {
+    const int32_t d = static_cast<int32_t>(p.dh);
+    const int32_t base = static_cast<int32_t>(rho) - static_cast<int32_t>(p.pad_top);
+    v_lo = base >= 0 ? 0 : (-base + d - 1) / d;
+    v_hi = static_cast<int32_t>(p.H) - 1 - base >= 0 ? (static_cast<int32_t>(p.H) - 1 - base) / d + 1 : 0;
+    row_org = img_off + static_cast<uint32_t>(base) * row_bytes;    // (wraps for base < 0: rows iy >= v_lo bring it back)
+    row_adv_w = row_adv * p.dh;
+    out_rows = p.dh;
+    iy_first = static_cast<int32_t>(oy0);
+  }
 
   struct Row { uint32_t c[3]; bool ok; };
   // One input row: three dwords. The loads are ALWAYS issued (a row outside the image is clamped to a valid one and
@@ -671,12 +692,20 @@ __device__ __forceinline__ void dwconv_col3x3_body(
     bool row_ok = true;
     // (kLate walks: always -- the clamp is scalar work, and a steady-state step may request a row below the image for the
     //  checked steps behind it; what makes a step "steady" there is that the row it CONSUMES is inside)
+    uint32_t ro;
+    if constexpr (DIL) {
+      row_ok = iy >= v_lo && iy < v_hi;
+      iy = iy >= v_hi ? v_hi - 1 : iy;
+      iy = iy < v_lo ? v_lo : iy;                 // (no valid row at all: a row below the image, or beyond the tensor -- the buffer answers 0)
+      ro = row_org + static_cast<uint32_t>(iy) * row_adv_w;
+    } else {
     if constexpr (CHECK || kLate) {
       row_ok = iy >= 0 && iy < static_cast<int32_t>(p.H);
       iy = iy < 0 ? 0 : (iy >= static_cast<int32_t>(p.H) ? static_cast<int32_t>(p.H) - 1 : iy);
     }
+    ro = img_off + static_cast<uint32_t>(iy) * row_adv;        // scalar
+    }
     r.ok = row_ok;
-    const uint32_t ro = img_off + static_cast<uint32_t>(iy) * row_adv;        // scalar
     r.c[0] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[0], ro, 0);
     r.c[1] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[1], ro, 0);
     r.c[2] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, coff[2], ro, 0);
@@ -759,11 +788,11 @@ __device__ __forceinline__ void dwconv_col3x3_body(
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       p.output, 0, static_cast<int>(p.batch * p.OH * p.OW * p.out_stride), 0x00020000);
   const uint32_t out_voff = ox * p.out_stride + cg;
-  uint32_t out_soff = (n * p.OH + oy0) * p.OW * p.out_stride;       // scalar, advances one output row per step
+  uint32_t out_soff = (n * p.OH + (DIL ? rho + out_rows * oy0 : oy0)) * p.OW * p.out_stride;   // scalar, advances one output row (DIL: p.dh rows) per step
 #ifdef QNNP_ENABLE_ABLATION
-  const uint32_t out_step = (p.abl & 8u) ? 0u : p.OW * p.out_stride;
+  const uint32_t out_step = (p.abl & 8u) ? 0u : p.OW * p.out_stride * out_rows;
 #else
-  const uint32_t out_step = p.OW * p.out_stride;
+  const uint32_t out_step = p.OW * p.out_stride * out_rows;
 #endif
 
   {
@@ -807,7 +836,7 @@ __device__ __forceinline__ void dwconv_col3x3_body(
       uint32_t t = 0;
       QNNP_DW_TRACE(p, 2);
       // steps whose newest window row (iy_first + t + 2) is inside the image: t < t_inside
-      const int32_t inside = static_cast<int32_t>(p.H) - 2 - iy_first;
+      const int32_t inside = (DIL ? v_hi : static_cast<int32_t>(p.H)) - 2 - iy_first;
       const uint32_t t_inside = inside <= 0 ? 0u : (static_cast<uint32_t>(inside) < steps ? static_cast<uint32_t>(inside) : steps);
 #define QNNP_DW_COL_STEPQ(CHECK, TA, TB, TC, RC)                                      \
       {                                                                             \
@@ -1036,7 +1065,7 @@ __device__ __forceinline__ void dwconv_col3x3_body(
 
 /* SEQ / FULL: the requantization flavour (requant.hip.h), chosen on the host -- one kernel per flavour, so that the
  * common one is not charged the registers of the rare ones (83 against 77 VGPRs: 5 instead of 6 waves per SIMD) */
-template <int S, int SEQ, bool FULL, bool DEEP, bool QUAD>
+template <int S, int SEQ, bool FULL, bool DEEP, bool QUAD, bool DIL = false>
 __global__ __launch_bounds__(kColThreads)
 void q8_dwconv_col3x3_kernel(const DwParams p)
 {
@@ -1079,16 +1108,25 @@ void q8_dwconv_col3x3_kernel(const DwParams p)
   if (j >= cols) j = cols - 1u;
   const uint32_t ox = div_by(j, p.inv_q4);
   const uint32_t cg = (j - ox * q4) * 4u;
-  const uint32_t oy0 = seg * p.TOH;
-  const uint32_t oy1 = min(p.OH, oy0 + p.TOH);
+  // DIL: segment index -> (segment of a residue class of the output rows, residue); `slabs` counts both
+  uint32_t rho = 0, rows = p.OH, sidx = seg;
+  if constexpr (DIL) {
+    sidx = div_by(seg, p.inv_dh);
+    rho = seg - sidx * p.dh;
+    rows = rho < p.OH ? div_by(p.OH - rho + p.dh - 1u, p.inv_dh) : 0u;       // output rows rho, rho + dh, ...
+  }
+  const uint32_t oy0 = sidx * p.TOH;
+  if (DIL && oy0 >= rows) return;
+  const uint32_t oy1 = min(rows, oy0 + p.TOH);
+  const int32_t dcol = DIL ? static_cast<int32_t>(p.dw) : 1;
   const int32_t ix0 = static_cast<int32_t>(ox * S) - static_cast<int32_t>(p.pad_left);
   const bool ok0 = ix0 >= 0 && ix0 < static_cast<int32_t>(p.W);
-  const bool ok1 = ix0 + 1 >= 0 && ix0 + 1 < static_cast<int32_t>(p.W);
-  const bool ok2 = ix0 + 2 >= 0 && ix0 + 2 < static_cast<int32_t>(p.W);
+  const bool ok1 = ix0 + dcol >= 0 && ix0 + dcol < static_cast<int32_t>(p.W);
+  const bool ok2 = ix0 + 2 * dcol >= 0 && ix0 + 2 * dcol < static_cast<int32_t>(p.W);
   if (__builtin_amdgcn_ballot_w64(!(ok0 && ok1 && ok2)) != 0) {
-    dwconv_col3x3_body<S, true, SEQ, FULL, DEEP, QUAD>(p, n, oy0, oy1, ox, cg, ok0, ok1, ok2);
+    dwconv_col3x3_body<S, true, SEQ, FULL, DEEP, QUAD, DIL>(p, n, oy0, oy1, ox, cg, ok0, ok1, ok2, rho);
   } else {
-    dwconv_col3x3_body<S, false, SEQ, FULL, DEEP, QUAD>(p, n, oy0, oy1, ox, cg, true, true, true);
+    dwconv_col3x3_body<S, false, SEQ, FULL, DEEP, QUAD, DIL>(p, n, oy0, oy1, ox, cg, true, true, true, rho);
   }
   QNNP_DW_TRACE(p, 5);
 #ifdef QNNP_ENABLE_ABLATION
@@ -1109,15 +1147,20 @@ uint32_t col_rows_override()
   return rows;
 }
 
+bool col_uses_dot4(const DwParams& p);
+
 // geometry of kernel G: `bands` = 64-dword chunks per flattened output row, `slabs` = row segments, `TOH` = rows each
 bool plan_col(DwParams& p)
 {
-  if (p.C % 4 != 0 || p.KH != 3 || p.KW != 3 || p.dh != 1 || p.dw != 1) return false;
+  if (p.C % 4 != 0 || p.KH != 3 || p.KW != 3) return false;
   if (p.sh != p.sw || (p.sw != 1 && p.sw != 2)) return false;
+  // dilated windows: the int8 walk at stride 1 only (its residue-class form, see the body); up to 64 rows apart
+  const bool dilated = p.dh != 1 || p.dw != 1;
+  if (dilated && !(p.sw == 1 && col_uses_dot4(p) && p.dh <= 64 && p.dw <= 64)) return false;
   // The walk's steady-state steps fetch row iy_first + t + 2 + NBUF with no lower bound (only the start-up steps
-  // check it): any API-legal padding beyond the window's own reach (top / left > 2, which no 3x3 layer of a real
-  // network has) would index rows before the image. Those shapes take the generic kernels.
-  if (p.pad_top > 2 || p.pad_left > 2) return false;
+  // check it): any API-legal padding beyond the window's own reach (top / left > 2 [x the dilation], which no 3x3 layer
+  // of a real network has) would index rows before the image. Those shapes take the generic kernels.
+  if (p.pad_top > 2 * p.dh || p.pad_left > 2 * p.dw) return false;
   // 32-bit byte offsets into both tensors
   const uint64_t in_bytes = static_cast<uint64_t>(p.batch) * p.H * p.W * p.in_stride;
   const uint64_t out_bytes = static_cast<uint64_t>(p.batch) * p.OH * p.OW * p.out_stride;
@@ -1126,7 +1169,10 @@ bool plan_col(DwParams& p)
   const uint32_t chunks = (cols + 63u) / 64u;
   // Row segments: each re-loads its halo (two rows at stride 1) and builds the first pairs again, so as few as
   // still give every SIMD several waves' worth of work (the tail of the last round is what it buys back).
-  const uint64_t waves_per_seg = static_cast<uint64_t>(p.batch) * chunks;
+  // (dilated: a "segment" here is one segment of EVERY residue class of the output rows, rows_v rows each at most)
+  const uint32_t rows_v = dilated ? (p.OH + p.dh - 1) / p.dh : p.OH;
+  const uint32_t classes = dilated ? p.dh : 1u;
+  const uint64_t waves_per_seg = static_cast<uint64_t>(p.batch) * chunks * classes;
   // (measured on the MobileNetV2 layers, batch 128: 1.3-2 rounds of waves beat 3-4 -- 35.6 against 39.6 us on
   //  layer 8 -- now that the rows in flight are really in flight; shorter segments only add start-ups and halo rows)
   // wave slots the segment count is sized for: 6 per SIMD at stride 2, 5 at stride 1 (what the 79- and 82-VGPR kernels
@@ -1144,14 +1190,14 @@ bool plan_col(DwParams& p)
     segs = one_round < 1u ? 1u : one_round;
   }
   const uint32_t min_rows = 7;
-  uint32_t max_segs = p.OH / min_rows;
+  uint32_t max_segs = rows_v / min_rows;
   if (max_segs < 1) max_segs = 1;
   if (segs > max_segs) segs = max_segs;
   if (segs < 1) segs = 1;
-  uint32_t toh = (p.OH + segs - 1) / segs;
-  if (const uint32_t forced = col_rows_override()) toh = forced < p.OH ? forced : p.OH;
+  uint32_t toh = (rows_v + segs - 1) / segs;
+  if (const uint32_t forced = col_rows_override()) toh = forced < rows_v ? forced : rows_v;
   p.TOH = toh;
-  p.slabs = (p.OH + toh - 1) / toh;
+  p.slabs = ((rows_v + toh - 1) / toh) * classes;
   p.bands = chunks;
   const uint64_t waves = static_cast<uint64_t>(p.batch) * p.slabs * chunks;
   // (the kernel divides wave and column indices through 32-bit reciprocals: exact while dividend * divisor < 2^32)
@@ -1175,6 +1221,7 @@ int launch_col(const DwParams& geometry, hipStream_t stream)
 {
   DwParams p = geometry;
   auto reciprocal = [](uint32_t d) { return d > 1u ? static_cast<uint32_t>(((UINT64_C(1) << 32) + d - 1u) / d) : 0u; };
+  p.inv_dh = reciprocal(p.dh);
   p.inv_bands = reciprocal(p.bands);
   p.inv_slabs = reciprocal(p.slabs);
   p.inv_q4 = reciprocal(p.C / 4u);
@@ -1185,7 +1232,13 @@ int launch_col(const DwParams& geometry, hipStream_t stream)
   qnnp::requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
     constexpr int kSeq = decltype(seq)::value;
     constexpr bool kFull = decltype(full)::value;
-    if (p.sw == 1) {
+    if (p.dh != 1 || p.dw != 1) {                  // (plan_col: stride 1, the int8 flavour)
+      if (p.TOH >= 12u) {
+        hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<1, kSeq, kFull, true, true, true>), dim3(blocks), dim3(kColThreads), 0, stream, p);
+      } else {
+        hipLaunchKernelGGL((q8_dwconv_col3x3_kernel<1, kSeq, kFull, false, true, true>), dim3(blocks), dim3(kColThreads), 0, stream, p);
+      }
+    } else if (p.sw == 1) {
       // four rows in flight (see the kernel) when a segment is long enough to use them: 112x112x32 30.7 -> 29.1 us,
       // 56x56x144 33.4 -> 32.3, 14-row segments level, 7x7x960 8.25 -> 8.55 with its six-row start-up
       bool deep = p.TOH >= 12u;
@@ -2178,7 +2231,7 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
   p.dwm_x = a->dwm_x; p.dwm_bias = a->dwm_bias; p.dwm_parts = a->dwm_parts; p.c_pad32 = a->c_pad32;
   p.wrange = a->w_range;
   p.dot4 = a->dot4;
-  p.inv_bands = p.inv_slabs = p.inv_q4 = 0;
+  p.inv_bands = p.inv_slabs = p.inv_q4 = p.inv_dh = 0;
   p.xcd_ranges = 0;
 
   // The plan (kernel choice + band / slab geometry) depends on the shapes fixed at setup, the variant and the
@@ -2207,7 +2260,9 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
       if (kernel_name != nullptr) *kernel_name = "q8_dwconv_row_3x3";
       return launch_row(p, stream);
     case kPlanCol:
-      if (kernel_name != nullptr) *kernel_name = col_uses_dot4(p) ? "q8_dwconv_col_3x3_dot4" : "q8_dwconv_col_3x3";
+      if (kernel_name != nullptr) {
+        *kernel_name = (p.dh != 1 || p.dw != 1) ? "q8_dwconv_col_3x3_dot4_dilated" : (col_uses_dot4(p) ? "q8_dwconv_col_3x3_dot4" : "q8_dwconv_col_3x3");
+      }
       return launch_col(p, stream);
     case kPlanCol5:
       if (kernel_name != nullptr) *kernel_name = "q8_dwconv_col_5x5_dot4";
