@@ -82,7 +82,7 @@ def conv_geometry(H, W, KH, KW, S, D):
 class ConvLayer:
     """One qnnp convolution operator with device-resident synthetic tensors (rotating buffer sets)."""
 
-    def __init__(self, lib, torch, batch, H, W, KH, KW, S, D, G, GIC, GOC, seed, min_bytes_between_reuse=0, out_scale=0.5):
+    def __init__(self, lib, torch, batch, H, W, KH, KW, S, D, G, GIC, GOC, seed, min_bytes_between_reuse=0, out_scale=0.5, kzp=127):
         self.lib = lib
         (pt, pr, pb, pl), oh, ow = conv_geometry(H, W, KH, KW, S, D)
         rng = np.random.default_rng(seed)
@@ -90,7 +90,7 @@ class ConvLayer:
         bias = rng.integers(-10000, 10001, size=G * GOC, dtype=np.int32)
         # quantization parameters of the reference bench (bench/convolution.cc:71-74)
         self.op = lib.create_convolution2d_nhwc_q8(pt, pr, pb, pl, KH, KW, S, S, D, D, G, GIC, GOC,
-                                                   127, 0.5, 127, 0.5, kernel, bias, 127, out_scale, 0, 255, 0)
+                                                   127, 0.5, kzp, 0.5, kernel, bias, 127, out_scale, 0, 255, 0)
         self.batch, self.H, self.W = batch, H, W
         self.cin, self.cout = G * GIC, G * GOC
         self.in_bytes = batch * H * W * self.cin

@@ -273,6 +273,38 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
       qnnp_log_error("failed to place %zu bytes of packed weights on the device", w_bytes + 2 * b_bytes);
       goto error;
     }
+    /* Zero-point-centred image (pack.h qnnp_pack_igemm_w_centred127; hip/q8gemm256c.hip, the weight-stationary 3x3
+     * kernel of hip/q8convwave.hip): single group, whole 32-deep K blocks, kernel zero point 128 (the standard image IS the centred
+     * one) or 127 (a second image + bias pair). The [output channel][kh][kw][input channel] kernel tensor is the GEMM
+     * layout the packer takes. */
+    if (groups == 1 && kc_slot == (uint32_t) group_input_channels && k_total % 32 == 0) {
+      if (kernel_zero_point == 128) {
+        op->centre_flip = 0x80;
+      } else if (kernel_zero_point == 127 &&
+                 /* (a second image only where a kernel takes it: the 3x3 weight-stationary kernel, the 256x256 GEMM) */
+                 ((kernel_height == 3 && kernel_width == 3 && (group_input_channels == 32 || group_input_channels == 64) &&
+                   (group_output_channels == 32 || group_output_channels == 64)) ||
+                  (kernel_size == 1 && k_total == k_pad && k_total >= 512 && n_pad % 256 == 0))) {
+        int8_t* host_wc = (int8_t*) malloc(w_bytes);
+        int32_t* host_bc = (int32_t*) malloc(b_bytes);
+        int placed = host_wc != NULL && host_bc != NULL;
+        if (placed) {
+          qnnp_pack_igemm_w_centred127((uint32_t) group_output_channels, k_total, k_pad, n_pad, input_zero_point, kernel, bias,
+              host_wc, host_bc);
+          op->d_weights_centred = qnnp_hip_alloc(w_bytes);
+          op->d_bias_centred = qnnp_upload_bias_pair(host_bc, n_pad);
+          placed = op->d_weights_centred != NULL && op->d_bias_centred != NULL &&
+              qnnp_hip_h2d(op->d_weights_centred, host_wc, w_bytes, 0) == QNNP_HIP_OK;
+        }
+        free(host_wc);
+        free(host_bc);
+        if (!placed) {
+          qnnp_log_error("failed to place %zu bytes of centred weights on the device", w_bytes + 2 * b_bytes);
+          goto error;
+        }
+        op->centre_flip = 0x7F;
+      }
+    }
     if (kc_slot == 4 && kernel_height <= 4 && kernel_width * 3 <= 16 && dilation_height == 1 && dilation_width == 1 &&
         n_pad <= 64) {
       /* first layers: the row-slot image beside the tap-slot one (hip/q8convc3.hip takes it when pixels are dense) */

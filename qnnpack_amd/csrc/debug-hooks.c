@@ -206,7 +206,7 @@ void qnnp_debug_pack_igemm_w_centred127(
     uint32_t n, uint32_t k_total, uint32_t n_pad, uint8_t izp, const uint8_t* kernel, const int32_t* bias,
     int8_t* packed, int32_t* biasc)
 {
-  qnnp_pack_igemm_w_centred127(n, k_total, n_pad, izp, kernel, bias, packed, biasc);
+  qnnp_pack_igemm_w_centred127(n, k_total, k_total, n_pad, izp, kernel, bias, packed, biasc);
 }
 
 void qnnp_debug_strip_pointwise_images(

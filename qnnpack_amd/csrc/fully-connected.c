@@ -130,7 +130,7 @@ static enum qnnp_status qnnp_create_fully_connected_nc_q8_impl(
   if (kernel_zero_point == 128) {
     op->centre_flip = 0x80;
   } else if (kernel_zero_point == 127 && k_pad == input_channels && n_pad % 256 == 0 && input_channels >= 512) {
-    qnnp_pack_igemm_w_centred127((uint32_t) output_channels, (uint32_t) input_channels, n_pad,
+    qnnp_pack_igemm_w_centred127((uint32_t) output_channels, (uint32_t) input_channels, (uint32_t) input_channels, n_pad,
         input_zero_point, kernel, bias, host_weights, host_bias);
     op->d_weights_centred = qnnp_hip_alloc(w_bytes);
     op->d_bias_centred = qnnp_upload_bias_pair(host_bias, n_pad);

@@ -213,6 +213,7 @@ static struct qnnp_hip_fused_strip_args strip_args(const struct qnnp_operator* o
   a.output_pad = op->strip_output_pad;
   if (op->fused_add != NULL) a.add = op->fused_add->add_params;
   a.rows_per_strip = op->fused_rows_per_strip;
+  a.weights_in_lds = op->fused_weights;
   return a;
 }
 
@@ -323,6 +324,7 @@ static enum qnnp_status qnnp_gfx950_setup_fused_block_impl(
   void* out_dev = op->output_on_device ? (void*) output : op->d_stage_out;
   op->fused_use_strip = 0;
   op->fused_rows_per_strip = (uint32_t) qnnp_state.opt_fused_rows;
+  op->fused_weights = (uint32_t) qnnp_state.opt_fused_weights;
   if (op->d_strip != NULL && qnnp_state.opt_fused_kernel != 1) {
     const struct qnnp_hip_fused_strip_args probe = strip_args(op, in_dev, out_dev);
     if (qnnp_hip_fused_strip_supported(&probe)) op->fused_use_strip = 1;

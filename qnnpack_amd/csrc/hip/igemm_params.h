@@ -100,7 +100,8 @@ int convlds_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipS
 
 /* q8convwave.hip */
 bool convwave_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32_t vec, uint32_t batch);
-int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipStream_t stream, const char** name, int flavour);
+int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipStream_t stream, const char** name, int flavour,
+                    const IgemmParams* centred = nullptr);
 
 /* q8pwconv.hip */
 bool pwstream_supported(const IgemmParams& p, uint32_t groups, uint32_t vec);

@@ -861,7 +861,11 @@ inline uint32_t ws_lds_bytes(const WaveArgs& a) { return a.head_bytes + kWsWaves
  *     units only (wave-uniform branch; 61 % of the units of a 56 x 56 image are interior);
  *   - unit coordinates in 32-bit scalar arithmetic (the tensor is < 2^31 bytes: launcher);
  *   - every lane writes its pixel sum (no exec-mask dance around a quarter-populated store). */
-template <int TN, int CB, int SEQ, bool FULL>
+/* CEN (round 4): the zero-point-centred image of q8gemm256c.hip / pack.h -- kernel zero point 128 (the standard image, whose
+ * row coefficient is zero) or 127 (weights w ^ 0x7F, activations ^ 0x7F): no kernel-zero-point row term, hence no pixel
+ * sums in the fix-up pass (4 v_sad_u8 + 2 DPP adds + a store per piece) and no window sum in the epilogue (9 LDS reads +
+ * 8 adds + the addend): ~55 of a unit's ~420 instructions. p.a_flip carries the mask. */
+template <int TN, int CB, int SEQ, bool FULL, bool CEN = false>
 __global__ __launch_bounds__(kWsWaves * 64, 2)
 void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArgs a)
 {
@@ -950,6 +954,10 @@ void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArg
       const uint32_t v = lane + u * 64u;
       if ((u + 1) * 64u <= pvec || v < pvec) {             // (only the last piece is partly populated)
         const v4i x = r.x[u];
+        if constexpr (CEN) {
+          const uint32_t flip = p.a_flip;
+          ds_write16_raw(patch_off + v * 16u, make_uint4(x.x ^ flip, x.y ^ flip, x.z ^ flip, x.w ^ flip));
+        } else {
         uint32_t sum = __builtin_amdgcn_sad_u8(x.x, 0u, 0u);
         sum = __builtin_amdgcn_sad_u8(x.y, 0u, sum);
         sum = __builtin_amdgcn_sad_u8(x.z, 0u, sum);
@@ -958,6 +966,7 @@ void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArg
         if (cpp > 2) sum += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(sum), 0x4E, 0xF, 0xF, false));   // lane ^ 2
         ds_write16_raw(patch_off + v * 16u, make_uint4(x.x ^ kFlip, x.y ^ kFlip, x.z ^ kFlip, x.w ^ kFlip));
         ds_write4_raw(pix_off + v * 4u, static_cast<int32_t>(sum) - 128 * static_cast<int32_t>(cin));   // (all cpp lanes of the pixel)
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1067,10 +1076,12 @@ void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArg
     // ---- fused epilogue: row term, requantization into the (now free) patch buffer, 16-byte stores ----
     {
       int32_t s = 0;
-      const int32_t* pq = pix + (ty * 10u + (i0 & 7u)) * cpp;
+      if constexpr (!CEN) {
+        const int32_t* pq = pix + (ty * 10u + (i0 & 7u)) * cpp;
 #pragma unroll
-      for (int t = 0; t < 9; t++) s += pq[((t / 3) * 10 + (t % 3)) * cpp];
-      const int32_t rowterm = with_rq_offset<SEQ>(p.row_coeff * s);
+        for (int t = 0; t < 9; t++) s += pq[((t / 3) * 10 + (t % 3)) * cpp];
+      }
+      const int32_t rowterm = with_rq_offset<SEQ>(CEN ? 0 : p.row_coeff * s);       // (CEN: a constant of the launch)
       uint64_t row_addend = 0;                       // lane forms: the row term rides in the multiply-add's addend
       if constexpr (rq_is_lane<SEQ>()) row_addend = lane_addend(rowterm, p.lane);
 #pragma unroll
@@ -1114,19 +1125,19 @@ void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArg
 #undef WS_STAMP
 }
 
-template <int TN, int CB, int SEQ, bool FULL>
+template <int TN, int CB, int SEQ, bool FULL, bool CEN>
 int launch_ws_as(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hipStream_t stream)
 {
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
   if (auto once_scope = attr_once.begin()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_ws_kernel<TN, CB, SEQ, FULL>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_ws_kernel<TN, CB, SEQ, FULL, CEN>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       (void) hipGetLastError();
     }
   }
   const uint32_t want = (a.units + kWsWaves - 1) / kWsWaves;
   const uint32_t grid = want < p.cu_count ? want : p.cu_count;
-  hipLaunchKernelGGL((q8_conv_wave_ws_kernel<TN, CB, SEQ, FULL>), dim3(grid), dim3(kWsWaves * 64), ws_lds_bytes(a), stream, p, g, a);
+  hipLaunchKernelGGL((q8_conv_wave_ws_kernel<TN, CB, SEQ, FULL, CEN>), dim3(grid), dim3(kWsWaves * 64), ws_lds_bytes(a), stream, p, g, a);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
@@ -1135,7 +1146,8 @@ int launch_ws(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hipStr
 {
   int rc = QNNP_HIP_EINVAL;
   requant_dispatch_lane(p.rq, p.lane, [&](auto seq, auto full) {
-    rc = launch_ws_as<TN, CB, decltype(seq)::value, decltype(full)::value>(p, g, a, stream);
+    if (p.a_flip != 0) rc = launch_ws_as<TN, CB, decltype(seq)::value, decltype(full)::value, true>(p, g, a, stream);
+    else rc = launch_ws_as<TN, CB, decltype(seq)::value, decltype(full)::value, false>(p, g, a, stream);
   });
   return rc;
 }
@@ -1209,7 +1221,10 @@ bool convwave_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups
   return make_args(p, g, batch, &a, &lds_bytes);
 }
 
-int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipStream_t stream, const char** name, int flavour)
+/* `centred`: the same launch with the zero-point-centred weight image, its bias pair and a_flip (q8igemm.hip), or null:
+ * the weight-stationary kernel takes it, the other flavours keep `p`. */
+int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipStream_t stream, const char** name, int flavour,
+                    const IgemmParams* centred)
 {
   WaveArgs a;
   uint32_t lds_bytes = 0;
@@ -1224,9 +1239,10 @@ int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hip
     const WaveArgs ar = reg_args<1>(a, p, g, batch, &ok);
     const uint64_t in_bytes = static_cast<uint64_t>(batch) * p.image_stride;    // (32-bit buffer offsets)
     if (ok && in_bytes < (UINT64_C(1) << 31) && ws_lds_bytes(ar) <= kLdsLimit) {
-      *name = "q8_conv_wave_ws_mfma";
-      if (p.kc == 32) return p.n == 32 ? launch_ws<1, 1>(p, g, ar, stream) : launch_ws<2, 1>(p, g, ar, stream);
-      return p.n == 32 ? launch_ws<1, 2>(p, g, ar, stream) : launch_ws<2, 2>(p, g, ar, stream);
+      const IgemmParams& pw = centred != nullptr ? *centred : p;
+      *name = centred != nullptr ? "q8_conv_wave_ws_c_mfma" : "q8_conv_wave_ws_mfma";
+      if (p.kc == 32) return p.n == 32 ? launch_ws<1, 1>(pw, g, ar, stream) : launch_ws<2, 1>(pw, g, ar, stream);
+      return p.n == 32 ? launch_ws<1, 2>(pw, g, ar, stream) : launch_ws<2, 2>(pw, g, ar, stream);
     }
   }
   if (k33 && out_bytes < (UINT64_C(1) << 31)) {

@@ -67,6 +67,7 @@ struct StripParams {
   uint32_t kb1, nb1, nb3, cb, nchunks;       // K blocks of the expand stage, hidden blocks, output blocks, blocks per chunk
   uint32_t in_pitch, hid_pitch, dw_pitch;
   uint32_t in_off, hid_off, dw_off, w2_off, b1_off, b2_off, b3_off, hid_bytes;
+  uint32_t wlds, we_off, wp_off;             // 1: a chunk's expand / project fragments are staged in LDS (below), at these offsets
   uint32_t inv_w, inv_ow;                    // magic32(W), magic32(OW): x / d == udiv(x, magic)
   uint32_t in_piece, ppp_magic;              // bytes per input staging piece (16 / 8 / 4), magic32(cin / in_piece)
   uint32_t flip1, flip2, flip3, hid_pad4;
@@ -101,6 +102,26 @@ inline uint32_t stage_mode(const RequantDev& rq, bool* offset)
   });
   *offset = seq != 2;
   return seq * 3 + clamp;
+}
+
+/* a wave-uniform pointer, in scalar registers for good (q8gemm256c.hip) */
+__device__ __forceinline__ const uint8_t* scalar_ptr(const uint8_t* ptr)
+{
+  const uint64_t v = reinterpret_cast<uint64_t>(ptr);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+  return reinterpret_cast<const uint8_t*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+/* LDS-DMA of one 1 KiB weight fragment (q8gemm256c.hip): 16 bytes per lane from base + lane * 16 to dst + lane * 16,
+ * as an instruction the compiler does not track -- behind the builtin it drains vmcnt(0) before EVERY later LDS access
+ * of the wave, and the point of these loads is to land under the stage that runs meanwhile. The waits are explicit. */
+__device__ __forceinline__ void dma_fragment(const uint8_t* base, uint32_t lane_offset, uint8_t* dst)
+{
+  const uint32_t m0v = __builtin_amdgcn_readfirstlane(
+      static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*) dst)));
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               : : "v"(lane_offset), "s"(scalar_ptr(base)), "s"(m0v) : "memory");
 }
 
 /* x / d by multiplication: magic = floor(2^32 / d) + 1 is exact for x < 2^32 / d (pixel and dword indices here are
@@ -185,7 +206,15 @@ __device__ __forceinline__ void project_blocks(v16i& acc, const v4i (&w)[8], con
  * KB1: 32-deep K blocks of the expand stage (input channels / 32, rounded up) -- compile time, so that the expand
  * loop is straight-line code; HAS_EXPAND: false = the depthwise stage reads the block input (MobileNetV2's first block).
  */
-template <int KB1, int MODE, bool HAS_EXPAND>
+/*
+ * WLDS (the 14 x 14 / 7 x 7 blocks, where a stage is one tile per wave and its weight fetch from L2 was most of it -- 2.3 k
+ * of a 7.9 k-cycle chunk in stage E, 1.9 k in stage P, plus the barrier waits behind the slowest wave): a chunk's expand
+ * and project fragments arrive by LDS-DMA while the previous stages run, and the stages read them with ds_read_b128.
+ *   after the barrier behind stage E of chunk c: every wave is done with E(c) and with P(c - 1), so the expand buffer
+ *   takes chunk c + 1 and the project buffer chunk c; each wave waits for its own pieces in front of the barrier
+ *   behind stage D, which publishes them -- a whole depthwise stage to land in.
+ */
+template <int KB1, int MODE, bool HAS_EXPAND, bool WLDS = false>
 __global__ __launch_bounds__(kThreads)
 void q8_fused_strip_kernel(const StripParams p)
 {
@@ -225,14 +254,37 @@ void q8_fused_strip_kernel(const StripParams p)
   // ---- weight fragments come straight from L2 into registers, a stage or more ahead of their first use ----
   const uint32_t cbl = wave % p.cb;              // this wave's block inside a chunk (kWaves % cb == 0: the same in every item)
   const uint32_t rt_first = wave / p.cb, rt_step = kWaves / p.cb;
+  uint8_t* we_lds = lds + p.we_off;         // WLDS: [cb][KB1] expand fragments of the chunk
+  uint8_t* wp_lds = lds + p.wp_off;         // WLDS: [nb3][cb] project fragments of the chunk
   auto load_w1 = [&](uint32_t block, v4i (&w)[KB1]) __attribute__((always_inline)) {
 #pragma unroll
     for (int kb = 0; kb < KB1; kb++) {
-      w[kb] = *reinterpret_cast<const v4i*>(p.w1 + ((static_cast<uint64_t>(block) * KB1 + kb) * 64 + lane) * 16);
+      if constexpr (WLDS) w[kb] = *reinterpret_cast<const v4i*>(we_lds + ((block % p.cb) * KB1 + kb) * 1024u + lane * 16u);
+      else w[kb] = *reinterpret_cast<const v4i*>(p.w1 + ((static_cast<uint64_t>(block) * KB1 + kb) * 64 + lane) * 16);
     }
   };
+  // WLDS: the pieces of a chunk, dealt round-robin over the waves (the fragments of a chunk's blocks are contiguous in
+  // the expand image; in the project image, per output block, the chunk's K blocks are)
+  auto dma_expand = [&](uint32_t chunk) __attribute__((always_inline)) {
+    const uint32_t first = chunk * p.cb, n = min(p.cb, p.nb1 - first) * KB1;
+    for (uint32_t i = wave; i < n; i += kWaves) {
+      dma_fragment(reinterpret_cast<const uint8_t*>(p.w1) + (static_cast<uint64_t>(first) * KB1 + i) * 1024u, lane * 16u, we_lds + i * 1024u);
+    }
+  };
+  auto dma_project = [&](uint32_t chunk) __attribute__((always_inline)) {
+    const uint32_t first = chunk * p.cb, cbn = min(p.cb, p.nb1 - first), n = p.nb3 * cbn;
+    for (uint32_t i = wave; i < n; i += kWaves) {
+      const uint32_t nbo = i / cbn, kbl = i - nbo * cbn;
+      dma_fragment(reinterpret_cast<const uint8_t*>(p.w3) + (static_cast<uint64_t>(nbo) * p.nb1 + first + kbl) * 1024u, lane * 16u,
+                   wp_lds + (nbo * p.cb + kbl) * 1024u);
+    }
+  };
+  if constexpr (WLDS) {
+    if constexpr (HAS_EXPAND) dma_expand(0);
+    dma_project(0);
+  }
   v4i w1f[KB1];
-  if constexpr (HAS_EXPAND && kPrefetch) load_w1(min(cbl, p.nb1 - 1u), w1f);     // chunk 0 (clamped: an idle wave loads something valid)
+  if constexpr (HAS_EXPAND && kPrefetch && !WLDS) load_w1(min(cbl, p.nb1 - 1u), w1f);     // chunk 0 (clamped: an idle wave loads something valid)
 
   // ---- once: biases and depthwise weights -> LDS, hidden tile = padding everywhere, input strip ----
   // ONE memory round trip: every load of the three is issued before the first store (a load-store loop is a round trip
@@ -345,6 +397,7 @@ void q8_fused_strip_kernel(const StripParams p)
     prt[j] = pc / p.nb3;
     pnb[j] = pc - prt[j] * p.nb3;
   }
+  if constexpr (WLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of chunk 0's fragments
   __syncthreads();                               // b3 resident (and the input / hidden tile complete)
   QNNP_S_STAMP(1);
 #pragma unroll
@@ -359,6 +412,7 @@ void q8_fused_strip_kernel(const StripParams p)
   // surplus registers repeat the last block and are never multiplied)
   auto load_w3 = [&](int j, uint32_t first_block, uint32_t blocks, v4i (&w)[8]) __attribute__((always_inline)) {
     const int8_t* wf = p.w3 + ((static_cast<uint64_t>(pnb[j]) * p.nb1 + first_block) * 64 + lane) * 16;
+    if constexpr (WLDS) wf = reinterpret_cast<const int8_t*>(wp_lds) + (pnb[j] * p.cb * 64u + lane) * 16u;
 #pragma unroll
     for (int kbl = 0; kbl < 8; kbl++) {
       w[kbl] = *reinterpret_cast<const v4i*>(wf + min(static_cast<uint32_t>(kbl), blocks - 1u) * 1024u);
@@ -386,26 +440,32 @@ void q8_fused_strip_kernel(const StripParams p)
     //      requantize, ^ flip2 -> hidden tile. A second tile beyond the strip recomputes the last row and stores nothing. ----
     if constexpr (HAS_EXPAND) {
       if (mine) {
-        int4 bias[4];
+        // the block's folded bias in accumulator layout, once per chunk: it is the FIRST MFMA's addend (a distinct C
+        // operand), not sixteen moves per tile
+        v16i bias;
 #pragma unroll
-        for (int rg = 0; rg < 4; rg++) bias[rg] = *reinterpret_cast<const int4*>(b1_lds + cbg * 32 + rg * 8 + khalf * 4);
-        if constexpr (!kPrefetch) load_w1(cbg, w1f);
+        for (int rg = 0; rg < 4; rg++) {
+          const int4 b = *reinterpret_cast<const int4*>(b1_lds + cbg * 32 + rg * 8 + khalf * 4);
+          bias[rg * 4 + 0] = b.x; bias[rg * 4 + 1] = b.y; bias[rg * 4 + 2] = b.z; bias[rg * 4 + 3] = b.w;
+        }
+        if constexpr (!kPrefetch || WLDS) load_w1(cbg, w1f);
         for (uint32_t rt = rt_first; rt < rtE; rt += kTilesPerRound * rt_step) {
           const uint32_t m0 = rt * 32u + col, m1 = (rt + rt_step) * 32u + col;
           const uint8_t* a0p = in_lds + min(m0, nE - 1u) * p.in_pitch + khalf * 16;
           const uint8_t* a1p = in_lds + min(m1, nE - 1u) * p.in_pitch + khalf * 16;
           v16i acc0, acc1;
 #pragma unroll
-          for (int rg = 0; rg < 4; rg++) {
-            acc0[rg * 4 + 0] = bias[rg].x; acc0[rg * 4 + 1] = bias[rg].y; acc0[rg * 4 + 2] = bias[rg].z; acc0[rg * 4 + 3] = bias[rg].w;
-          }
-          acc1 = acc0;
-#pragma unroll
           for (int kb = 0; kb < KB1; kb++) {
             const v4i a0 = *reinterpret_cast<const v4i*>(a0p + kb * 32);
             const v4i a1 = *reinterpret_cast<const v4i*>(a1p + kb * 32);
+#ifdef QNNP_STRIP_BIAS_MOVES               // (A/B at build time: the accumulators initialised by moves, as first written)
+            if (kb == 0) { acc0 = bias; acc1 = bias; }
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1f[kb], a0, acc0, 0, 0, 0);
             if constexpr (kTwoTiles) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1f[kb], a1, acc1, 0, 0, 0);
+#else
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1f[kb], a0, kb == 0 ? bias : acc0, 0, 0, 0);
+            if constexpr (kTwoTiles) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1f[kb], a1, kb == 0 ? bias : acc1, 0, 0, 0);
+#endif
           }
           uint32_t pk0[4], pk1[4];
           requant16m<MODE>(acc0, p.mode1, p.rq1, pk0);
@@ -427,15 +487,19 @@ void q8_fused_strip_kernel(const StripParams p)
         }
       }
       // the next chunk's expand fragments (clamped like the first)
-      if constexpr (kPrefetch) { if (chunk + 1 < p.nchunks) load_w1(min(cb0 + p.cb + cbl, p.nb1 - 1u), w1f); }
+      if constexpr (kPrefetch && !WLDS) { if (chunk + 1 < p.nchunks) load_w1(min(cb0 + p.cb + cbl, p.nb1 - 1u), w1f); }
     }
     v4i w3f[8];
-    if constexpr (kPrefetch) load_w3(0, cb0, cbn, w3f);      // the first owned pair's project fragments of this chunk
+    if constexpr (kPrefetch && !WLDS) load_w3(0, cb0, cbn, w3f);      // the first owned pair's project fragments of this chunk
     if (chunk == 0) QNNP_S_STAMP(2);
     if (chunk == 1) QNNP_S_STAMP(17);
     __syncthreads();
     if (chunk == 0) QNNP_S_STAMP(3);
     if (chunk == 1) QNNP_S_STAMP(18);
+    if constexpr (WLDS) {                          // (kernel comment: both buffers are free from this barrier on)
+      if constexpr (HAS_EXPAND) { if (chunk + 1 < p.nchunks) dma_expand(chunk + 1); }
+      if (chunk > 0) dma_project(chunk);
+    }
 
     // ---- stage D: depthwise as nine MFMAs per (32 pixels, 32 channels) against diagonal weight fragments ----
     if (mine) {
@@ -454,6 +518,8 @@ void q8_fused_strip_kernel(const StripParams p)
         const uint32_t oy0l = udiv(mc0, p.inv_ow), oy1l = udiv(mc1, p.inv_ow);
         const uint8_t* base0 = hid + ((oy0l * s) * PW + (mc0 - oy0l * p.OW) * s) * p.hid_pitch + cbl * 32 + khalf * 16;
         const uint8_t* base1 = hid + ((oy1l * s) * PW + (mc1 - oy1l * p.OW) * s) * p.hid_pitch + cbl * 32 + khalf * 16;
+        // (the bias is re-read per tile -- four ds_read_b128 straight into the accumulator registers: held across the
+        //  tiles as stage E holds its own it costs sixteen registers, and the kernel then spills 1-9 at its 128)
         v16i acc0, acc1;
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
@@ -483,6 +549,7 @@ void q8_fused_strip_kernel(const StripParams p)
     }
     if (chunk == 0) QNNP_S_STAMP(4);
     if (chunk == 1) QNNP_S_STAMP(19);
+    if constexpr (WLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces; the barrier publishes everybody's
     __syncthreads();
     if (chunk == 0) QNNP_S_STAMP(5);
     if (chunk == 1) QNNP_S_STAMP(20);
@@ -491,7 +558,7 @@ void q8_fused_strip_kernel(const StripParams p)
 #pragma unroll
     for (int j = 0; j < kMaxPairs; j++) {
       if (wave + static_cast<uint32_t>(j) * kWaves < npairs) {
-        if (j > 0 || !kPrefetch) load_w3(j, cb0, cbn, w3f);  // (8 waves: the first pair's fragments were fetched in front of stage D)
+        if (j > 0 || !kPrefetch || WLDS) load_w3(j, cb0, cbn, w3f);  // (8 waves: the first pair's fragments were fetched in front of stage D)
         const uint8_t* arow = dwb + (prt[j] * 32u + col) * p.dw_pitch + khalf * 16;
         switch (cbn) {                                       // wave-uniform: straight-line MFMAs per block count
           case 8: project_blocks<8>(pacc[j], w3f, arow); break;
@@ -585,24 +652,38 @@ bool plan(const qnnp_hip_fused_strip_args& a, StripParams* p, uint32_t* lds_byte
     if (rtD * p->nb3 <= static_cast<uint32_t>(kMaxPairs * kWaves) && nE <= 65535u) {
       // chunk width: the one whose stages cost least -- chunks x (two-tile rounds of stage E + of stage D), each wave
       // owning one of the chunk's blocks and every (8 / cb)-th row tile -- among those that fit; ties go to wider chunks
-      uint32_t best_cb = 0, best_cost = 0xFFFFFFFFu, best_need = 0, best_hid = 0, best_in = 0;
+      uint32_t best_cb = 0, best_cost = 0xFFFFFFFFu, best_need = 0, best_hid = 0, best_in = 0, best_wlds = 0;
       for (uint32_t cb = 8; cb >= 1; cb >>= 1) {
         if (!a.has_expand && cb < p->nb1) continue;          // the copied input must be one chunk
         const uint32_t hid_pitch = cb * 32u + 16u;
         const uint32_t in_bytes = a.has_expand ? ((rtE * 32u * p->in_pitch + 255u) & ~255u) : 0u;
         const uint32_t hid_bytes = (prows * (a.input_width + 2u) * hid_pitch + 255u) & ~255u;
         const uint32_t dw_bytes = (rtD * 32u * hid_pitch + 255u) & ~255u;
-        const uint32_t need = fixed + in_bytes + hid_bytes + dw_bytes;
+        uint32_t need = fixed + in_bytes + hid_bytes + dw_bytes;
         if (need > kLdsLimit) continue;
+        // the chunk's expand and project fragments beside the tiles, if they fit (kernel comment, WLDS)
+        const uint32_t w_bytes = ((a.has_expand ? cb * p->kb1 : 0u) + cb * p->nb3) * 1024u;
+        // (measured level to slightly behind fetching from L2 -- profiles/r04 -- hence only on request)
+        const bool wlds = a.weights_in_lds == 1u && need + w_bytes <= kLdsLimit;
+        if (a.weights_in_lds == 1u && !wlds) continue;        // (forced, for tests)
+        if (wlds) need += w_bytes;
         const uint32_t nchunks = (p->nb1 + cb - 1) / cb, per_round = static_cast<uint32_t>(kTilesPerRound) * (static_cast<uint32_t>(kWaves) / cb);
-        // (+ 3 per chunk: its two barriers, the diagonal fragments, the project stage -- measured, profiles/r04)
-        const uint32_t cost = nchunks * ((a.has_expand ? (rtE + per_round - 1) / per_round : 0u) + (rtD + per_round - 1) / per_round + 3u);
-        if (cost < best_cost) { best_cost = cost; best_cb = cb; best_need = need; best_hid = hid_bytes; best_in = in_bytes; }
+        // (+ 3 per chunk: its two barriers, the diagonal fragments, the project stage -- measured, profiles/r04; + 2 when
+        //  stages E and P fetch their fragments from L2 in front of their first MFMA)
+        // A stage's tiles are dealt one block per wave, every (waves / cb)-th row tile: rounds x (busy waves per SIMD) / 4 --
+        // the four waves of a SIMD share its issue slots, so a stage that leaves half of them idle takes half as long
+        // (7 x 7 images: one strip = 16 + 16 tiles on half the chip's CUs, two strips = 16 + 8 on all of them)
+        auto stage4 = [&](uint32_t rt) {
+          const uint32_t busy = rt * cb < static_cast<uint32_t>(kWaves) ? rt * cb : static_cast<uint32_t>(kWaves);
+          return ((rt + per_round - 1) / per_round) * ((busy + 3u) / 4u) * 4u / (static_cast<uint32_t>(kWaves) / 4u);
+        };
+        const uint32_t cost = nchunks * ((a.has_expand ? stage4(rtE) : 0u) + stage4(rtD) + 4u * 3u);
+        if (cost < best_cost) { best_cost = cost; best_cb = cb; best_need = need; best_hid = hid_bytes; best_in = in_bytes; best_wlds = wlds ? 1u : 0u; }
       }
       if (best_cb != 0) {
         const uint32_t cb = best_cb;
         const uint64_t wgs = static_cast<uint64_t>(a.batch) * strips;
-        const uint64_t total = ((wgs + cus - 1) / cus) * (best_cost + 4u);
+        const uint64_t total = ((wgs + cus - 1) / cus) * (best_cost + 4u * 4u);
         if (!found || total < best_total) {
           found = true;
           best_total = total;
@@ -613,6 +694,12 @@ bool plan(const qnnp_hip_fused_strip_args& a, StripParams* p, uint32_t* lds_byte
           p->b2_off = p->b1_off + p->hidden_pad * 4u;
           p->b3_off = p->b2_off + p->hidden_pad * 4u;
           p->in_off = fixed; p->hid_off = fixed + best_in; p->dw_off = fixed + best_in + best_hid;
+          {
+            const uint32_t dw_bytes = (rtD * 32u * p->hid_pitch + 255u) & ~255u;
+            p->wlds = best_wlds;
+            p->we_off = p->dw_off + dw_bytes;
+            p->wp_off = p->we_off + (a.has_expand ? cb * p->kb1 : 0u) * 1024u;
+          }
           *lds_bytes = best_need;
         }
       }
@@ -650,9 +737,9 @@ extern "C" int qnnp_hip_fused_strip_run(const struct qnnp_hip_fused_strip_args* 
   if (!plan(*a, &p, &lds_bytes)) return QNNP_HIP_EINVAL;
 #ifdef QNNP_ENABLE_ABLATION
   if (getenv("QNNP_GFX950_PRINT_PLAN") != nullptr) {
-    fprintf(stderr, "fused strip plan: %ux%ux%u -> %u -> %u stride %u: rows/strip %u strips %u chunk blocks %u chunks %u lds %u\n",
+    fprintf(stderr, "fused strip plan: %ux%ux%u -> %u -> %u stride %u: rows/strip %u strips %u chunk blocks %u chunks %u lds %u weights in LDS %u\n",
             a->input_height, a->input_width, a->input_channels, a->hidden_channels, a->output_channels, a->stride,
-            p.rps, p.strips, p.cb, p.nchunks, lds_bytes);
+            p.rps, p.strips, p.cb, p.nchunks, lds_bytes, p.wlds);
   }
 #endif
   p.input = a->input; p.output = a->output;
@@ -696,9 +783,13 @@ extern "C" int qnnp_hip_fused_strip_run(const struct qnnp_hip_fused_strip_args* 
   typedef void (*kernel_t)(const StripParams);
   kernel_t kernel = nullptr;
 #define QNNP_STRIP_PICK(KB)                                                                           \
-  kernel = mode == 0 ? &q8_fused_strip_kernel<KB, 0, true> : (mode == 3 ? &q8_fused_strip_kernel<KB, 3, true> : &q8_fused_strip_kernel<KB, -1, true>)
+  kernel = p.wlds != 0                                                                                  \
+      ? (mode == 0 ? &q8_fused_strip_kernel<KB, 0, true, true> : (mode == 3 ? &q8_fused_strip_kernel<KB, 3, true, true> : &q8_fused_strip_kernel<KB, -1, true, true>)) \
+      : (mode == 0 ? &q8_fused_strip_kernel<KB, 0, true> : (mode == 3 ? &q8_fused_strip_kernel<KB, 3, true> : &q8_fused_strip_kernel<KB, -1, true>))
   if (!a->has_expand) {
-    kernel = mode == 0 ? &q8_fused_strip_kernel<1, 0, false> : (mode == 3 ? &q8_fused_strip_kernel<1, 3, false> : &q8_fused_strip_kernel<1, -1, false>);
+    kernel = p.wlds != 0
+        ? (mode == 0 ? &q8_fused_strip_kernel<1, 0, false, true> : (mode == 3 ? &q8_fused_strip_kernel<1, 3, false, true> : &q8_fused_strip_kernel<1, -1, false, true>))
+        : (mode == 0 ? &q8_fused_strip_kernel<1, 0, false> : (mode == 3 ? &q8_fused_strip_kernel<1, 3, false> : &q8_fused_strip_kernel<1, -1, false>));
   } else {
     switch (p.kb1) {
       case 1: QNNP_STRIP_PICK(1); break;

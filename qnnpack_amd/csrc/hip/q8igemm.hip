@@ -207,6 +207,36 @@ void q8_igemm_mfma_kernel(const IgemmParams p_in)
         tap = kk0 / p.kc;
         ch = kk0 - tap * p.kc;
       }
+      if constexpr (VEC == 1 && !PAD3) {
+        // Byte gathers (channel counts that are not a multiple of 4), BRANCH-FREE: every load is issued -- an address
+        // that must not be read is replaced by the row's / image's base, the value by the zero point or the K padding
+        // afterwards. As sixteen `if (inside) load` per chunk this path held an exec mask per byte: 195 spilled SGPRs +
+        // 285-339 spilled VGPRs inside the K loop, and a wild address when unrelated code moved its allocation (round 3).
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          uint32_t v = 0;
+#pragma unroll
+          for (int jj = 0; jj < 4; jj++) {
+            const uint32_t kk = kk0 + d * 4 + jj;
+            const bool in_k = ctx.valid[q] && kk < p.k_total;
+            bool real = in_k;
+            uint32_t rel = kk;
+            if constexpr (IS_CONV) {
+              const uint32_t tap_c = tap < p.ks ? tap : p.ks - 1u;     // (beyond k_total: any entry of the pixel's row)
+              const int32_t off = ctx.offs[q][tap_c];
+              real = in_k && off >= 0;
+              rel = static_cast<uint32_t>(off) + ch;
+              ch += 1;
+              if (ch >= p.kc) { ch = 0; tap += 1; }
+            }
+            uint32_t b = ctx.base[q][real ? rel : 0u];
+            b = real ? b : (in_k ? (p.izp_fill & 0xFFu) : 0x80u);
+            v |= b << (8 * jj);
+          }
+          regs[q][d] = v;
+        }
+        continue;
+      }
 #pragma unroll
       for (int j = 0; j < 16 / VEC; j++) {
         const uint32_t kk = kk0 + j * VEC;
@@ -603,7 +633,20 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   const bool wave_ok = wave_shape && (wave_forced || (a->variant == 0 && wave_k33 && a->rows >= 16384u));
   if (wave_forced && !wave_ok) return QNNP_HIP_EINVAL;
   if (wave_ok) {
-    const int rc_wave = qnnp::convwave_launch(p, geom, a->rows / a->rows_per_image, stream, &name, a->variant == 12 ? 1 : 0);
+    // kernel zero points 127 / 128: the zero-point-centred image (convolution.c builds it for single-group convolutions
+    // without K padding), taken by the weight-stationary kernel
+    IgemmParams pc = p;
+    const bool centred = a->centre_flip != 0 && a->packed_w_centred != nullptr && a->bias2_centred != nullptr &&
+        a->bias2_pair != 0 && a->groups == 1;
+    if (centred) {
+      pc.packed_w = a->packed_w_centred;
+      pc.bias2 = a->bias2_centred;
+      pc.bias2u = a->bias2_centred + static_cast<size_t>(a->groups) * a->n_pad;
+      pc.a_flip = (a->centre_flip & 0xFFu) * 0x01010101u;
+      pc.row_coeff = 0;
+    }
+    const int rc_wave = qnnp::convwave_launch(p, geom, a->rows / a->rows_per_image, stream, &name, a->variant == 12 ? 1 : 0,
+                                              centred ? &pc : nullptr);
     if (kernel_name != nullptr) *kernel_name = name;
     return rc_wave;
   }

@@ -378,6 +378,8 @@ struct qnnp_hip_fused_strip_args {
   uint32_t hidden_pad, output_pad;            /* channel counts rounded up to 32 */
   struct qnnp_hip_add_params add;             /* residual: output = add(a = block input, b = project output) */
   uint32_t rows_per_strip;                    /* 0 = the kernel's own choice; else forced (A/B, tests) */
+  uint32_t weights_in_lds;                    /* 0 = the kernel's own choice (where they fit); 1 = only plans that stage the chunk's
+                                               * expand / project fragments in LDS; 2 = fragments from L2 (round-4 first form; A/B, tests) */
 };
 /* 1: the stage's folded bias must carry + 2^31 (its rounding sequence is an offset form); host-side twin of the kernel's choice */
 int qnnp_hip_fused_strip_bias_offset(const struct qnnp_hip_requant* rq);

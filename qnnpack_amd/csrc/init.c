@@ -185,6 +185,10 @@ enum qnnp_status qnnp_gfx950_set_option(const char* key, int value)
     qnnp_state.opt_fused_kernel = value;
     return qnnp_status_success;
   }
+  if (strcmp(key, "fused_weights") == 0 && value >= 0 && value <= 2) {
+    qnnp_state.opt_fused_weights = value;
+    return qnnp_status_success;
+  }
   if (strcmp(key, "fused_rows") == 0 && value >= 0 && value <= 4096) {
     qnnp_state.opt_fused_rows = value;
     return qnnp_status_success;

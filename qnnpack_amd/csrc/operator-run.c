@@ -266,7 +266,7 @@ static int launch_kernel(struct qnnp_operator* op, const void* input, const void
         /* zero-point-centred image (fully-connected.c): its own, or the standard one when that is centred already */
         .packed_w_centred = (const int8_t*) (op->d_weights_centred != NULL ? op->d_weights_centred : op->d_weights),
         .bias2_centred = op->d_bias_centred != NULL ? op->d_bias_centred : op->d_bias,
-        .centre_flip = is_conv ? 0u : op->centre_flip,
+        .centre_flip = op->centre_flip,
         .streaming_mode = op->streaming_mode,
       };
       return qnnp_hip_igemm_run(&args, &op->kernel_name);

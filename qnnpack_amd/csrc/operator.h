@@ -93,6 +93,7 @@ struct qnnp_operator {
   uint8_t strip_flip1, strip_flip2, strip_flip3, strip_dw_pad;
   int fused_use_strip;                          /* decided at setup */
   uint32_t fused_rows_per_strip;                /* "fused_rows" option at setup: 0 = the kernel's choice */
+  uint32_t fused_weights;                       /* "fused_weights" option at setup (hip/qnnp_hip.h weights_in_lds) */
 
   /* residual add attached to a convolution (residual.c, qnnp_gfx950_attach_residual_add): the operator then writes
    * add(a = residual pixel, b = convolution output) -- in the convolution kernel's epilogue where that kernel carries

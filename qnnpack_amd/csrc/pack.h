@@ -160,18 +160,18 @@ static inline void qnnp_pack_igemm_w(
  *   bias + sum (a - izp)(w - 127) = biasc + sum a'' w'',   biasc[n] = bias[n] + (127 - izp) * sum_k (w(n,k) - 127)
  * -- no per-row kernel-zero-point term (the reference folds only the INPUT zero point into its packed bias,
  * src/qnnpack/pack.h:24-43; here both zero points end up in the weights' image and the bias).
- * Single group, no K padding (k_total == k_pad); padding columns hold zero weights and a zero bias.
+ * Single group; padding columns and K padding hold zero weights (and a zero bias).
  * (Kernel zero point 128 needs nothing of its own: qnnp_pack_igemm_w's image w ^ 0x80 = w - 128 is the centred one and
  *  its bias2 has no kernel-zero-point part.)
  */
 static inline void qnnp_pack_igemm_w_centred127(
-    uint32_t n, uint32_t k_total, uint32_t n_pad,
+    uint32_t n, uint32_t k_total, uint32_t k_pad, uint32_t n_pad,
     uint8_t izp,
     const uint8_t* kernel, const int32_t* bias,
     int8_t* packed, int32_t* biasc)
 {
-  const uint32_t kblocks = k_total / 32;
-  memset(packed, 0, (size_t) n_pad * k_total);
+  const uint32_t kblocks = k_pad / 32;                     /* (K padding, if any: zero weights, as padding columns) */
+  memset(packed, 0, (size_t) n_pad * k_pad);
   const uint32_t a_off = (uint32_t) (127 - (int32_t) izp);
   for (uint32_t col = 0; col < n_pad; col++) {
     uint32_t b = 0;

@@ -19,6 +19,7 @@ struct qnnp_state {
   int opt_timing_graph;   /* 1: qnnp_gfx950_time_operator* replay a hipGraph of the launches (default) */
   int opt_fused_kernel;   /* fused blocks: 0 auto (strip kernel where it applies), 1 tile kernel only, 2 strip kernel only */
   int opt_fused_rows;     /* strip kernel: output rows per strip, 0 = its own choice */
+  int opt_fused_weights;  /* strip kernel: 0 = its own choice, 1 = chunk weights staged in LDS or refuse, 2 = weights from L2 */
 };
 
 extern struct qnnp_state qnnp_state;

@@ -1,7 +1,11 @@
 """GPU tier: the wave-per-8x8-block direct-convolution MFMA kernel (qnnpack_amd/csrc/hip/q8convwave.hip), forced
 with "gemm_kernel" = 8, against the scalar oracle: 32 / 64 input channels, 32 / 64 output channels, windows whose
 patch fits (3x3, 1x3, 3x1, 2x2, dilated 3x3 at 32 channels), asymmetric padding, image sizes that do not fill the
-8x8 blocks, many units per workgroup, zero-point and clamp variants."""
+8x8 blocks, many units per workgroup, zero-point and clamp variants; every case with kernel zero points 127 and 128
+(the zero-point-centred image of round 4: the weight-stationary kernel then runs without pixel sums and reports
+`q8_conv_wave_ws_c_mfma`) and with one that has no centred image."""
+import dataclasses
+
 import pytest
 
 from _cases import ConvCase
@@ -48,13 +52,19 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("kzp", [None, 127, 128, 77], ids=["kzp_of_case", "kzp127", "kzp128", "kzp77"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
-def test_wave_convolution_matches_oracle(waveconv, case):
+def test_wave_convolution_matches_oracle(waveconv, case, kzp):
+    if kzp is not None:
+        if case.kzp == kzp:
+            pytest.skip("the case's own zero point")
+        case = dataclasses.replace(case, kzp=kzp)
     expected, quant, out_hw = conv_expected(case)
     out, kname = conv_run(waveconv, case, quant, out_hw, to_device=to_device, from_device=from_device)
-    want = "q8_conv_wave_ws_mfma" if (waveconv._variant == 8 and _is_k33(case)) else "q8_conv_wave_mfma"
+    ws = "q8_conv_wave_ws_c_mfma" if case.kzp in (127, 128) else "q8_conv_wave_ws_mfma"
+    want = ws if (waveconv._variant == 8 and _is_k33(case)) else "q8_conv_wave_mfma"
     assert kname == want, kname
-    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}, kzp {case.kzp}]")
 
 
 @pytest.mark.parametrize("case", [

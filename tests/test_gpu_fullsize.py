@@ -58,14 +58,17 @@ def test_c2_q8gemm_4096_cubed(qnnp, variant, kernel):
         qnnp.delete_operator(op)
 
 
-@pytest.mark.parametrize("variant,kernel_name", [(0, "q8_conv_wave_ws_mfma"), (1, None), (2, "q8_gemm_mfma_256x256_conv")],
-                         ids=["auto", "offset_table_generic", "offset_table_256x256"])
-def test_c3_q8conv_3x3_56x56x64_batch128(qnnp, variant, kernel_name):
+@pytest.mark.parametrize("variant,kzp,kernel_name", [(0, 127, "q8_conv_wave_ws_c_mfma"), (0, 128, "q8_conv_wave_ws_c_mfma"),
+                                                     (0, 126, "q8_conv_wave_ws_mfma"), (1, 127, None),
+                                                     (2, 127, "q8_gemm_mfma_256x256_conv")],
+                         ids=["auto_kzp127", "auto_kzp128", "auto_kzp126", "offset_table_generic", "offset_table_256x256"])
+def test_c3_q8conv_3x3_56x56x64_batch128(qnnp, variant, kzp, kernel_name):
     """configs[2]: 3x3 s1 pad1 conv, 56x56x64 -> 64, batch 128. "auto" is the weight-stationary wave kernel, which
-    computes its patch addresses arithmetically (q8convwave.hip); "gemm_kernel" 1 and 2 force the two kernels that read the
+    computes its patch addresses arithmetically (q8convwave.hip) -- with the zero-point-centred image for kernel zero
+    points 127 (the bench's) and 128, with pixel sums for any other; "gemm_kernel" 1 and 2 force the two kernels that read the
     device-side OFFSET TABLE of csrc/indirection.c -- the path BASELINE configs[2] names literally -- at the full size."""
     import torch
-    case = ConvCase("c3_fullsize", (56, 56), (3, 3), (1, 1, 1, 1), gic=64, goc=64, batch=128)
+    case = ConvCase("c3_fullsize", (56, 56), (3, 3), (1, 1, 1, 1), gic=64, goc=64, batch=128, kzp=kzp)
     inp, kernel, bias = conv_tensors(case)
     img = 56 * 56 * 64
     sample = [0, 1, 63, 127]

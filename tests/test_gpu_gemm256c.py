@@ -145,3 +145,24 @@ def test_repeated_launches_are_stable(qnnp):
             assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
     finally:
         qnnp.set_option("gemm_kernel", 0)
+
+
+@pytest.mark.parametrize("kw,kernel", [(dict(kzp=127), "q8_gemm_mfma_256x256_c"), (dict(kzp=128), "q8_gemm_mfma_256x256_c"),
+                                       (dict(kzp=127, input_pixel_stride=1104, output_pixel_stride=528), "q8_gemm_mfma_256x256_c"),
+                                       (dict(kzp=126), "q8_gemm_mfma_256x256_lean")],
+                         ids=["kzp127", "kzp128", "kzp127_strided_pixels", "kzp126"])
+def test_pointwise_convolutions_take_it_too(qnnp, kw, kernel):
+    """a 1x1 convolution is the same GEMM over pixels (src/convolution.c:196-199 routes it to qnnp_ukernel_type_gemm):
+    convolution.c builds the centred image for single-group convolutions as fully-connected.c does"""
+    from _cases import ConvCase
+    from _runner import conv_expected, conv_run
+    # (enough rows, and a reduction beyond the long-K streaming kernel's 1024, that the automatic choice is the 256x256 tiling)
+    case = ConvCase("c_pw_1088_512", (81, 80), (1, 1), gic=1088, goc=512, batch=2, **kw)
+    o1.set_threads(16)
+    try:
+        expected, quant, out_hw = conv_expected(case)
+    finally:
+        o1.set_threads(1)
+    out, kname = conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == kernel, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}, {kw}]")

@@ -7,6 +7,8 @@ batch = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 fuse = len(sys.argv) > 2 and sys.argv[2] == "fuse"
 fold = len(sys.argv) > 2 and sys.argv[2] == "fold"      # residual adds in the project convolutions' epilogues
 lib = qnnpack_amd.load(); lib.initialize(); lib.set_stream(torch.cuda.current_stream().cuda_stream)
+if os.environ.get("QNNP_FUSED_WEIGHTS"):      # A/B: 2 = the strip kernel fetches its expand / project fragments from L2
+    lib.set_option("fused_weights", int(os.environ["QNNP_FUSED_WEIGHTS"]))
 plan = mnv2.build_plan()
 net = mnv2.DeviceNetwork(lib, torch, plan, batch, fuse=fuse, fold_adds=fold)
 net.buffers[0].copy_(torch.randint(0, 256, (net.buffers[0].numel(),), dtype=torch.uint8, device="cuda"))

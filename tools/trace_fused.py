@@ -7,6 +7,8 @@ os.environ["QNNP_GFX950_TRACE"] = "1"
 import torch, qnnpack_amd
 from examples import mobilenetv2 as mnv2
 lib = qnnpack_amd.load(); lib.initialize(); lib.set_stream(torch.cuda.current_stream().cuda_stream)
+if os.environ.get("QNNP_FUSED_WEIGHTS"):
+    lib.set_option("fused_weights", int(os.environ["QNNP_FUSED_WEIGHTS"]))
 plan = mnv2.build_plan()
 net = mnv2.DeviceNetwork(lib, torch, plan, 128, fuse=True)
 net.buffers[0].copy_(torch.randint(0, 256, (net.buffers[0].numel(),), dtype=torch.uint8, device="cuda"))
