@@ -662,6 +662,13 @@ def main():
         if graph_ms is not None:
             sweep_ms = graph_ms
         job_sweep_ms = job_time_ms(sweep_ms, world)
+        launch_floor = None
+        try:
+            dbg_lib = qnnpack_amd.load_debug()
+            launch_floor = {"blocks_256": round(dbg_lib.launch_floor_probe(31, 256, 20), 3),
+                            "blocks_4096": round(dbg_lib.launch_floor_probe(31, 4096, 20), 3)}
+        except Exception as exc:  # noqa: BLE001 -- a measurement aid, not part of the metric
+            print(f"# launch-floor probe unavailable ({exc})", file=sys.stderr)
         extra["mobilenetv2_sweep"] = {
             "images_per_s": round(total_batch / (job_sweep_ms * 1e-3), 1), "batch_per_gpu": my_batch,
             "ms_per_batch": round(job_sweep_ms, 4), "timed_as": "one hipGraph replay of the 31 operators" if graph_ms is not None else "sum of per-layer times",
@@ -678,6 +685,9 @@ def main():
             "frac_of_copy_kernel": round(act_bytes / (sweep_ms * 1e-3) / 1e9 / copy_gbs, 4) if copy_gbs else None,
             "tops": round(total_ops / (sweep_ms * 1e-3) / 1e12, 2),
             "roofline_images_per_s_per_gpu": round(PEAK_HBM_GBS * 1e9 / (act_bytes / my_batch), 1),
+            # what 31 dependent launches cost on this box with nothing in them (a hipGraph of empty kernels, one workgroup
+            # per CU / sixteen per CU, hip/mfma_probe.hip): the floor under `ms_per_batch - sum_of_layer_ms`
+            "empty_kernel_graph_us_per_launch": launch_floor,
             "layers": rows}
         extra["q8dwconv_mobilenetv2_layers"] = {
             "hbm_gbs": round(dw_bytes / (dw_ms * 1e-3) / 1e9, 1), "ms": round(dw_ms, 4),
@@ -714,6 +724,9 @@ def main():
         # the same network with every inverted-residual block as ONE fused operator (qnnp_gfx950_create_fused_block)
         extra["mobilenetv2_network_fused"] = network_bench(lib, torch, my_batch, total_batch, world, args.warmup,
                                                            max(args.steps // 2, 5), fuse=True)
+        # ... and with the one block that has no expand stage left to its two stand-alone kernels (faster there)
+        extra["mobilenetv2_network_fused_expanding_blocks"] = network_bench(lib, torch, my_batch, total_batch, world, args.warmup,
+                                                                            max(args.steps // 2, 5), fuse="expanding")
 
         # ---------------------------------------------------------- SURVEY 8f "next" rows: deconvolution, add, pooling
         extra["next_rows"] = next_rows_bench(lib, torch, my_batch, args.warmup, max(args.steps // 2, 5))

@@ -119,5 +119,16 @@ def load_debug():
                 raise RuntimeError(f"qnnp_gfx950_copy_probe -> {rc}")
             return float(gbs.value)
         dbg.copy_probe = copy_probe
+        dbg.lib.qnnp_gfx950_launch_floor_probe.restype = ctypes.c_int
+        dbg.lib.qnnp_gfx950_launch_floor_probe.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+
+        def launch_floor_probe(kernels: int = 31, blocks: int = 256, replays: int = 20) -> float:
+            """microseconds per launch of a hipGraph of `kernels` dependent EMPTY kernels (hip/mfma_probe.hip)"""
+            us = ctypes.c_float(0.0)
+            rc = dbg.lib.qnnp_gfx950_launch_floor_probe(kernels, blocks, replays, ctypes.byref(us))
+            if rc != 0:
+                raise RuntimeError(f"qnnp_gfx950_launch_floor_probe -> {rc}")
+            return float(us.value)
+        dbg.launch_floor_probe = launch_floor_probe
         _loaded_debug = dbg
     return _loaded_debug

@@ -189,3 +189,50 @@ extern "C" int qnnp_gfx950_copy_probe(int mode, int mbytes, int reps, float* gbs
   *gbs_out = best;
   return QNNP_HIP_OK;
 }
+
+/*
+ * qnnp_gfx950_launch_floor_probe(): what a dependent chain of kernel launches costs on this box with NOTHING in the
+ * kernels -- `kernels` empty launches of `blocks` x 256 threads captured as one hipGraph (stream order = a dependency
+ * edge between consecutive nodes, as in the sweep / network graphs of bench.py), replayed `replays` times; microseconds
+ * per launch of the best replay. The review of round 3 asked for this number beside the sweep's sum of layers.
+ */
+namespace {
+__global__ __launch_bounds__(256) void empty_probe_kernel(uint32_t* sink)
+{
+  if (sink != nullptr && threadIdx.x == 0xFFFFu) sink[0] = 1u;       // never
+}
+}  // namespace
+
+extern "C" int qnnp_gfx950_launch_floor_probe(int kernels, int blocks, int replays, float* us_per_launch)
+{
+  if (us_per_launch == nullptr || kernels <= 0 || kernels > 4096 || blocks <= 0 || replays <= 0) return QNNP_HIP_EINVAL;
+  hipStream_t stream = nullptr;
+  if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return QNNP_HIP_ELAUNCH;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool ok = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+  if (ok) {
+    for (int k = 0; k < kernels; k++) hipLaunchKernelGGL(empty_probe_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, nullptr);
+    ok = hipStreamEndCapture(stream, &graph) == hipSuccess && graph != nullptr;
+  }
+  ok = ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+  ok = ok && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+  float best = 0.0f;
+  for (int r = 0; ok && r < replays + 2; r++) {
+    float ms = 0.0f;
+    ok = hipEventRecord(e0, stream) == hipSuccess && hipGraphLaunch(exec, stream) == hipSuccess &&
+         hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+         hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.0f;
+    if (ok && r >= 2 && (best == 0.0f || ms < best)) best = ms;     // two warm-up replays
+  }
+  if (e0 != nullptr) (void) hipEventDestroy(e0);
+  if (e1 != nullptr) (void) hipEventDestroy(e1);
+  if (exec != nullptr) (void) hipGraphExecDestroy(exec);
+  if (graph != nullptr) (void) hipGraphDestroy(graph);
+  (void) hipStreamDestroy(stream);
+  (void) hipGetLastError();
+  if (!ok || best <= 0.0f) return QNNP_HIP_ELAUNCH;
+  *us_per_launch = best * 1e3f / static_cast<float>(kernels);
+  return QNNP_HIP_OK;
+}
