@@ -127,7 +127,8 @@ int qnnp_gfx950_operator_residual_folded(qnnp_operator_t op);
 /* Kernel-variant control for A/B measurement and tests. Keys:
  *   "gemm_kernel":   0 = auto, 1 = generic MFMA implicit-GEMM kernel, 2 = 256x256 LDS-DMA MFMA kernel,
  *                    3 = LDS-tiled direct-convolution MFMA kernel (convolutions only),
- *                    4 = the 256x256 kernel in its 4-wave flavour (one wave per SIMD, 128x128 per wave),
+ *                    4 = the 256x256 kernel in its 4-wave flavour (one wave per SIMD, 128x128 per wave) [measurement
+ *                        builds only since round 4, as 10, 11 and 16: structures that lost their A/B],
  *                    5 = barrier-free streaming kernel for short-K pointwise / fully-connected layers,
  *                    6 = its global-operand flavour (one wave per 32x32 block; small problems with long K),
  *                    7 = its 3-channel-image convolution flavour (first layers; in-register tap gather),
@@ -138,8 +139,17 @@ int qnnp_gfx950_operator_residual_folded(qnnp_operator_t op);
  *                    12 = the round-2 register-path flavour of kernel 8; 13 = stride-2 deconvolution streaming kernel
  *                    forced (1 keeps deconvolutions on the phase-table GEMMs); 14 = first-layer row-slot kernel;
  *                    15 = the lean flavour of kernel 2 (what auto picks when K % 64 == 0 and N % 256 == 0; 2 keeps the
- *                    general flavour), 16 = the lean flavour of kernel 4. A forced kernel refuses what it cannot take
- *                    (unsupported_parameter at run) instead of rerouting.
+ *                    general flavour), 16 = the lean flavour of kernel 4,
+ *                    20 = the zero-point-centred 256x256 kernel (hip/q8gemm256c.hip: what auto picks for operators with
+ *                    kernel zero point 127 or 128, K % 64 == 0, K >= 512, N % 256 == 0), 21 = its A/B structure
+ *                    (fragment reads in one burst). A forced kernel refuses what it cannot take (unsupported_parameter
+ *                    at run) instead of rerouting.
+ *   "fused_kernel":  fused inverted-residual blocks: 0 = auto (the strip kernel, hip/q8fusedstrip.hip, where it takes the
+ *                    block -- kernel zero points 127 / 128 in all three members -- else the tile kernel of rounds 1-3),
+ *                    1 = the tile kernel only, 2 = the strip kernel only (unsupported_parameter at setup otherwise)
+ *   "fused_rows":    output rows per strip of the strip kernel, 0 = its planner's choice (tests, A/B)
+ *   "fused_weights": 0 / 2 = a chunk's expand / project fragments fetched from L2 by the stage that multiplies them,
+ *                    1 = staged in LDS one stage ahead by LDS-DMA where they fit (measured level: opt-in)
  *   "dwconv_kernel": 0 = auto, 1 = generic direct kernel, 2 = LDS-tiled kernel, 3 = register sliding-window kernel (3x3),
  *                    4 = matrix-core kernel (diagonal MFMA operands; 3x3, channels % 16 == 0), tap operands gathered
  *                        from global memory, 5 = the same with the input band staged in LDS first,
@@ -150,20 +160,20 @@ int qnnp_gfx950_operator_residual_folded(qnnp_operator_t op);
  *                    connected outputs, the 4096^3-class GEMM, the element-wise add) mark those stores as streaming:
  *                    right for an operator that runs on its own (per-layer sweep +4-5 %, GEMM +2 %); 0 = plain stores,
  *                    for callers that chain operators -- a streamed tensor is not in the last-level cache when its
- *                    consumer starts (whole MobileNetV2: -1 % with the hint). Read at launch (or graph-capture) time;
- *                    process-wide like the other options (a thread that flips it affects launches of other threads --
- *                    only their speed, never their bytes).
+ *                    consumer starts (whole MobileNetV2: -1 % with the hint). Read at launch (or graph-capture) time.
+ *                    This is the DEFAULT of every operator; qnnp_gfx950_operator_set_streaming_stores below sets it per
+ *                    operator, which is what a caller with both kinds of operators in one process wants.
  * Unknown key -> invalid_parameter. Kernel choices apply to operators set up afterwards. */
 enum qnnp_status qnnp_gfx950_set_option(const char* key, int value);
 
-/* Name of the HIP kernel the operator's last setup selected (static string), or
- * NULL. Lets tests assert that the intended kernel actually ran. */
 /* The streaming-store hint ("streaming_stores" above) of ONE operator: value 1 / 0 = on / off for every later launch of
  * `op`, -1 = follow the process-wide option again (the default). An operator whose output the next operator reads at
  * once (a chained network) wants 0; an operator on its own, as the reference bench runs them, 1 -- both kinds can live
  * in one process, and no launch of another thread is affected. */
 enum qnnp_status qnnp_gfx950_operator_set_streaming_stores(qnnp_operator_t op, int value);
 
+/* Name of the HIP kernel the operator's last setup selected (static string), or
+ * NULL. Lets tests assert that the intended kernel actually ran. */
 const char* qnnp_gfx950_operator_kernel(qnnp_operator_t op);
 
 /* Device properties as seen by the library: gcnArchName copied into `arch`
