@@ -1,4 +1,5 @@
-"""GPU tier: seeded RANDOM shapes through the kernels added in round 3, against the scalar oracle, bit for bit. The
+"""GPU tier: seeded RANDOM shapes through the kernels added in rounds 3 and 4, against the scalar oracle (the fused block:
+against its stand-alone operators), bit for bit. The
 hand-picked matrices (test_gpu_dwcol5, test_gpu_dwcol, test_gpu_convc3rows, test_gpu_deconvolution, test_gpu_residual)
 aim at the edges their authors thought of; this file draws image sizes, channel counts, strides, paddings, pixel
 strides, batch, zero points and clamps at random inside each kernel's range (the seed is the case id, so a failure names
@@ -120,3 +121,114 @@ def test_random_deconvolution_stride2_stream(qnnp, seed):
     out, kname = deconv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
     assert kname.startswith("q8_deconv_s2_stream"), (kname, case)
     assert_bytes_equal(out, expected, f"{kname} [{case}]")
+
+
+# ---- round 4 ----
+@pytest.mark.parametrize("seed", range(N))
+def test_random_dilated_depthwise_walk(qnnp, seed):
+    """kernel G's residue-class form (tests/test_gpu_dwcol_dilated.py holds the hand-picked edges)"""
+    rng = np.random.default_rng(0xD100 + seed)
+    dh, dw = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+    if dh == 1 and dw == 1:
+        dh = 2
+    c = 4 * int(rng.integers(1, 60))
+    h, w = int(rng.integers(1, 45)), int(rng.integers(1, 45))
+    pad = (int(rng.integers(0, 2 * dh + 1)), int(rng.integers(0, 2 * dw + 1)), int(rng.integers(0, 2 * dh + 1)), int(rng.integers(0, 2 * dw + 1)))
+    if h + pad[0] + pad[2] < 2 * dh + 1 or w + pad[1] + pad[3] < 2 * dw + 1:      # at least one window
+        pad = (dh, dw, dh, dw)
+    case = ConvCase(f"rand_dil_{seed}", (h, w), (3, 3), pad, dilation=(dh, dw), groups=c, gic=1, goc=1,
+                    batch=int(rng.integers(1, 5)), kzp=int(rng.choice([127, 128])), **_common(rng, c, c))
+    inp, kernel, bias = conv_tensors(case)
+    expected, quant, out_hw = conv_expected(case, inp, kernel, bias)
+    out, kname = conv_run(qnnp, case, quant, out_hw, inp, kernel, bias, to_device, from_device)
+    assert kname == "q8_dwconv_col_3x3_dot4_dilated", (kname, case)
+    assert_bytes_equal(out, expected, f"{kname} [{case}]")
+
+
+@pytest.mark.parametrize("seed", range(N))
+def test_random_3x3_convolution_weight_stationary(qnnp, seed):
+    """the weight-stationary 3x3 kernel, centred (kernel zero point 127 / 128) and with pixel sums (any other)"""
+    rng = np.random.default_rng(0x3C00 + seed)
+    cin, cout = int(rng.choice([32, 64])), int(rng.choice([32, 64]))
+    h, w = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+    pad = tuple(int(x) for x in rng.integers(0, 3, size=4))
+    if h + pad[0] + pad[2] < 3 or w + pad[1] + pad[3] < 3:
+        pad = (1, 1, 1, 1)
+    kzp = int(rng.choice([127, 128, int(rng.integers(0, 256))]))
+    kw = _common(rng, cin, cout)
+    kw.pop("output_pixel_stride", None)                       # (the wave kernels want dense output pixels)
+    if "input_pixel_stride" in kw:
+        kw["input_pixel_stride"] = cin + 16 * int(rng.integers(1, 3))           # 16-byte aligned pixels
+    case = ConvCase(f"rand_ws_{seed}", (h, w), (3, 3), pad, gic=cin, goc=cout, batch=int(rng.integers(1, 6)), kzp=kzp, **kw)
+    inp, kernel, bias = conv_tensors(case)
+    expected, quant, out_hw = conv_expected(case, inp, kernel, bias)
+    qnnp.set_option("gemm_kernel", 8)
+    try:
+        out, kname = conv_run(qnnp, case, quant, out_hw, inp, kernel, bias, to_device, from_device)
+    finally:
+        qnnp.set_option("gemm_kernel", 0)
+    assert kname == ("q8_conv_wave_ws_c_mfma" if kzp in (127, 128) else "q8_conv_wave_ws_mfma"), (kname, case)
+    assert_bytes_equal(out, expected, f"{kname} [{case}]")
+
+
+@pytest.mark.parametrize("seed", range(N))
+def test_random_fused_block_strip_kernel(qnnp, seed):
+    """one inverted-residual block on the strip kernel against its three (four) stand-alone operators run in sequence:
+    random image sizes, channel counts, stride, residual, strip height, zero points 127 / 128 per member, batch"""
+    import torch
+    rng = np.random.default_rng(0xF500 + seed)
+    stride = int(rng.choice([1, 2]))
+    cin = 4 * int(rng.integers(2, 41))                          # <= 160
+    hidden = 4 * int(rng.integers(2, 120))
+    has_res = stride == 1 and rng.random() < 0.5
+    cout = cin if has_res else 4 * int(rng.integers(2, 60))
+    h, w = int(rng.integers(3, 30)), int(rng.integers(3, 30))
+    batch = int(rng.integers(1, 4))
+    oh, ow = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+    zp = lambda: int(rng.choice([127, 128]))
+    k1 = rng.integers(0, 256, size=(1, hidden, 1, 1, cin), dtype=np.uint8)
+    kd = rng.integers(0, 256, size=(hidden, 1, 3, 3, 1), dtype=np.uint8)
+    k3 = rng.integers(0, 256, size=(1, cout, 1, 1, hidden), dtype=np.uint8)
+    b1 = rng.integers(-5000, 5000, size=hidden, dtype=np.int32)
+    bd = rng.integers(-5000, 5000, size=hidden, dtype=np.int32)
+    b3 = rng.integers(-5000, 5000, size=cout, dtype=np.int32)
+    s1, sd, s3 = float(2.0 ** -int(rng.integers(8, 12))), float(2.0 ** -int(rng.integers(6, 10))), float(2.0 ** -int(rng.integers(9, 13)))
+    z = [int(rng.integers(0, 256)) for _ in range(5)]           # tensor zero points: input, hidden, dw out, project out, sum
+    ex = qnnp.create_convolution2d_nhwc_q8(0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, cin, hidden, z[0], 1.0, zp(), 1.0, k1, b1, z[1], 1.0 / s1, 0, 255, 0)
+    dw = qnnp.create_convolution2d_nhwc_q8(1, 1, 1, 1, 3, 3, stride, stride, 1, 1, hidden, 1, 1, z[1], 1.0, zp(), 1.0, kd, bd, z[2], 1.0 / sd, 0, 255, 0)
+    pr = qnnp.create_convolution2d_nhwc_q8(0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, hidden, cout, z[2], 1.0, zp(), 1.0, k3, b3, z[3], 1.0 / s3, 0, 255, 0)
+    add = qnnp.create_add_nc_q8(cout, z[0], 1.0, z[3], 0.75, z[4], 1.25, 0, 255, 0) if has_res else None
+    fused = None
+    try:
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(seed)
+        x = torch.randint(0, 256, (batch * h * w * cin,), dtype=torch.uint8, device="cuda", generator=gen)
+        t1 = torch.empty(batch * h * w * hidden, dtype=torch.uint8, device="cuda")
+        t2 = torch.empty(batch * oh * ow * hidden, dtype=torch.uint8, device="cuda")
+        t3 = torch.empty(batch * oh * ow * cout, dtype=torch.uint8, device="cuda")
+        want = torch.empty(batch * oh * ow * cout, dtype=torch.uint8, device="cuda")
+        got = torch.full((batch * oh * ow * cout,), 0xA5, dtype=torch.uint8, device="cuda")
+        qnnp.setup_convolution2d_nhwc_q8(ex, batch, h, w, x, cin, t1, hidden)
+        qnnp.setup_convolution2d_nhwc_q8(dw, batch, h, w, t1, hidden, t2, hidden)
+        qnnp.setup_convolution2d_nhwc_q8(pr, batch, oh, ow, t2, hidden, t3 if has_res else want, cout)
+        for op in (ex, dw, pr):
+            qnnp.run_operator(op)
+        if has_res:
+            qnnp.setup_add_nc_q8(add, batch * oh * ow, x, cin, t3, cout, want, cout)
+            qnnp.run_operator(add)
+        qnnp.set_option("fused_kernel", 2)                      # the strip kernel or nothing
+        qnnp.set_option("fused_rows", int(rng.choice([0, 0, 1, 2, 5])))
+        try:
+            fused = qnnp.create_fused_block(ex, dw, pr, add)
+            qnnp.setup_fused_block(fused, batch, h, w, x, cin, got, cout)
+        finally:
+            qnnp.set_option("fused_kernel", 0)
+            qnnp.set_option("fused_rows", 0)
+        qnnp.run_operator(fused)
+        torch.cuda.synchronize()
+        assert qnnp.operator_kernel(fused) == "q8_fused_strip"
+        assert torch.equal(got, want), f"strip kernel differs from the stand-alone chain: {h}x{w}x{cin} -> {hidden} -> {cout}, stride {stride}, residual {has_res}, batch {batch}"
+    finally:
+        for op in (fused, ex, dw, pr, add):
+            if op is not None:
+                qnnp.delete_operator(op)
