@@ -141,7 +141,7 @@ int qnnp_gfx950_operator_residual_folded(qnnp_operator_t op);
  *                    15 = the lean flavour of kernel 2 (what auto picks when K % 64 == 0 and N % 256 == 0; 2 keeps the
  *                    general flavour), 16 = the lean flavour of kernel 4,
  *                    20 = the zero-point-centred 256x256 kernel (hip/q8gemm256c.hip: what auto picks for operators with
- *                    kernel zero point 127 or 128, K % 64 == 0, K >= 512, N % 256 == 0), 21 = its A/B structure
+ *                    kernel zero point 127 or 128, K % 64 == 0, K >= 512, N % 256 == 0), 21 = its A/B structure in MEASUREMENT BUILDS ONLY
  *                    (fragment reads in one burst). A forced kernel refuses what it cannot take (unsupported_parameter
  *                    at run) instead of rerouting.
  *   "fused_kernel":  fused inverted-residual blocks: 0 = auto (the strip kernel, hip/q8fusedstrip.hip, where it takes the
@@ -149,7 +149,8 @@ int qnnp_gfx950_operator_residual_folded(qnnp_operator_t op);
  *                    1 = the tile kernel only, 2 = the strip kernel only (unsupported_parameter at setup otherwise)
  *   "fused_rows":    output rows per strip of the strip kernel, 0 = its planner's choice (tests, A/B)
  *   "fused_weights": 0 / 2 = a chunk's expand / project fragments fetched from L2 by the stage that multiplies them,
- *                    1 = staged in LDS one stage ahead by LDS-DMA where they fit (measured level: opt-in)
+ *                    1 = staged in LDS one stage ahead by LDS-DMA where they fit (measured level: measurement builds only,
+ *                    the product library ignores it)
  *   "dwconv_kernel": 0 = auto, 1 = generic direct kernel, 2 = LDS-tiled kernel, 3 = register sliding-window kernel (3x3),
  *                    4 = matrix-core kernel (diagonal MFMA operands; 3x3, channels % 16 == 0), tap operands gathered
  *                        from global memory, 5 = the same with the input band staged in LDS first,

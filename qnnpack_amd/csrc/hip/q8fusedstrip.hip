@@ -663,9 +663,15 @@ bool plan(const qnnp_hip_fused_strip_args& a, StripParams* p, uint32_t* lds_byte
         if (need > kLdsLimit) continue;
         // the chunk's expand and project fragments beside the tiles, if they fit (kernel comment, WLDS)
         const uint32_t w_bytes = ((a.has_expand ? cb * p->kb1 : 0u) + cb * p->nb3) * 1024u;
-        // (measured level to slightly behind fetching from L2 -- profiles/r04 -- hence only on request)
+        // (measured level to slightly behind fetching from L2 -- profiles/r04 -- hence only on request, and only in
+        //  measurement builds: the product library does not carry the flavour)
+#ifdef QNNP_ENABLE_ABLATION
         const bool wlds = a.weights_in_lds == 1u && need + w_bytes <= kLdsLimit;
         if (a.weights_in_lds == 1u && !wlds) continue;        // (forced, for tests)
+#else
+        const bool wlds = false;
+        (void) w_bytes;
+#endif
         if (wlds) need += w_bytes;
         const uint32_t nchunks = (p->nb1 + cb - 1) / cb, per_round = static_cast<uint32_t>(kTilesPerRound) * (static_cast<uint32_t>(kWaves) / cb);
         // (+ 3 per chunk: its two barriers, the diagonal fragments, the project stage -- measured, profiles/r04; + 2 when
@@ -782,14 +788,20 @@ extern "C" int qnnp_hip_fused_strip_run(const struct qnnp_hip_fused_strip_args* 
   const int mode = (p.mode2 == p.mode3 && (!a->has_expand || p.mode1 == p.mode2) && (p.mode2 == 0 || p.mode2 == 3)) ? static_cast<int>(p.mode2) : -1;
   typedef void (*kernel_t)(const StripParams);
   kernel_t kernel = nullptr;
+#ifdef QNNP_ENABLE_ABLATION
 #define QNNP_STRIP_PICK(KB)                                                                           \
   kernel = p.wlds != 0                                                                                  \
       ? (mode == 0 ? &q8_fused_strip_kernel<KB, 0, true, true> : (mode == 3 ? &q8_fused_strip_kernel<KB, 3, true, true> : &q8_fused_strip_kernel<KB, -1, true, true>)) \
       : (mode == 0 ? &q8_fused_strip_kernel<KB, 0, true> : (mode == 3 ? &q8_fused_strip_kernel<KB, 3, true> : &q8_fused_strip_kernel<KB, -1, true>))
+#else
+#define QNNP_STRIP_PICK(KB)                                                                           \
+  kernel = mode == 0 ? &q8_fused_strip_kernel<KB, 0, true> : (mode == 3 ? &q8_fused_strip_kernel<KB, 3, true> : &q8_fused_strip_kernel<KB, -1, true>)
+#endif
   if (!a->has_expand) {
-    kernel = p.wlds != 0
-        ? (mode == 0 ? &q8_fused_strip_kernel<1, 0, false, true> : (mode == 3 ? &q8_fused_strip_kernel<1, 3, false, true> : &q8_fused_strip_kernel<1, -1, false, true>))
-        : (mode == 0 ? &q8_fused_strip_kernel<1, 0, false> : (mode == 3 ? &q8_fused_strip_kernel<1, 3, false> : &q8_fused_strip_kernel<1, -1, false>));
+    kernel = mode == 0 ? &q8_fused_strip_kernel<1, 0, false> : (mode == 3 ? &q8_fused_strip_kernel<1, 3, false> : &q8_fused_strip_kernel<1, -1, false>);
+#ifdef QNNP_ENABLE_ABLATION
+    if (p.wlds != 0) kernel = mode == 0 ? &q8_fused_strip_kernel<1, 0, false, true> : (mode == 3 ? &q8_fused_strip_kernel<1, 3, false, true> : &q8_fused_strip_kernel<1, -1, false, true>);
+#endif
   } else {
     switch (p.kb1) {
       case 1: QNNP_STRIP_PICK(1); break;

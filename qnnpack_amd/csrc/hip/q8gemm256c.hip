@@ -637,7 +637,9 @@ int gemm256c_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, c
   const bool aligned = (p.k_pad / kBK) % kRing == 0;
   switch (opt) {
     case 0: *name = "q8_gemm_mfma_256x256_c"; return aligned ? launch_c<0, true>(pm, grid, stream) : launch_c<0, false>(pm, grid, stream);
+#ifdef QNNP_ENABLE_ABLATION                     // (the A/B structure that lost: measurement builds only)
     case 2: *name = "q8_gemm_mfma_256x256_c_burst"; return aligned ? launch_c<2, true>(pm, grid, stream) : launch_c<2, false>(pm, grid, stream);
+#endif
     default: return QNNP_HIP_EINVAL;
   }
 }

@@ -16,12 +16,12 @@ from test_gpu_network import oracle_forward
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("fused_kernel,rows,weights", [(0, 0, 0), (0, 1, 0), (0, 3, 0), (1, 0, 0), (0, 0, 2), (0, 2, 2)],
-                         ids=["auto", "strips_of_1", "strips_of_3", "tile_kernel", "weights_from_l2", "strips_of_2_weights_from_l2"])
+@pytest.mark.parametrize("fused_kernel,rows,weights", [(0, 0, 0), (0, 1, 0), (0, 3, 0), (1, 0, 0), (0, 2, 0)],
+                         ids=["auto", "strips_of_1", "strips_of_3", "tile_kernel", "strips_of_2"])
 @pytest.mark.parametrize("input_hw,batch", [(96, 2), (224, 1), (72, 3)])
 def test_fused_network_matches_oracle(qnnp, input_hw, batch, fused_kernel, rows, weights):
-    """"fused_weights": 0 = a chunk's expand / project fragments staged in LDS by LDS-DMA where they fit (the kernel's
-    choice), 2 = fetched from L2 by the stage that multiplies them (the first form of the kernel)"""
+    """("fused_weights" = 1, a chunk's expand / project fragments staged in LDS by LDS-DMA, exists in measurement builds only:
+    it measured level -- DESIGN 4.7b; the product library ignores the option)"""
     qnnp.set_option("fused_kernel", fused_kernel)
     qnnp.set_option("fused_rows", rows)
     qnnp.set_option("fused_weights", weights)
@@ -75,7 +75,7 @@ def _fused_network_matches_oracle(qnnp, input_hw, batch, fused_kernel):
         net.close()
 
 
-@pytest.mark.parametrize("rows,weights", [(0, 0), (2, 0), (0, 2)], ids=["auto", "strips_of_2", "weights_from_l2"])
+@pytest.mark.parametrize("rows,weights", [(0, 0), (2, 0), (4, 0)], ids=["auto", "strips_of_2", "strips_of_4"])
 def test_fused_network_equals_the_unfused_one_at_the_bench_batch(qnnp, rows, weights):
     """Batch 128, bench.py's network and quantization (extra.mobilenetv2_network_fused): strip heights, chunk widths and
     the workgroup count depend on the batch, so the fused chain is compared here, tensor by tensor, with the stand-alone
