@@ -277,12 +277,44 @@ void q8_pw_stream_mfma_kernel(const IgemmParams p)
  * is one contiguous run, 1 KiB per store instruction. Otherwise row chunks: the image has 2^log_cpr 16-byte pieces
  * per row (pitch 16 << log_cpr), of which the first cw bytes exist; consecutive lanes take consecutive pieces of a
  * row. c0 = first channel of the chunk. */
+/* dense8 (round 4): dense rows whose length is a multiple of 8 but not of 16 bytes (24-channel MobileNet layers): the
+ * block is still ONE contiguous, 16-byte aligned run in memory (32 rows x n bytes), only the image keeps its 16-byte
+ * pitch; a lane gathers its 16 output bytes as two 8-byte halves, which may sit in two image rows. Those layers took the
+ * direct-store kernel before: 4-byte stores, 3.9-4.3 TB/s where their 16-channel neighbours stream 4.9. */
 template <bool RES = false>
 __device__ __forceinline__ void stream_copy_out(
     const uint8_t* stage, bool whole_dense, uint32_t log_cpr, uint32_t unit, uint32_t c0, uint32_t cw,
-    const IgemmParams& p, uint32_t lane)
+    const IgemmParams& p, uint32_t lane, bool dense8 = false)
 {
   const uint32_t rows_here = min(32u, p.rows - unit * 32u);
+  if (dense8) {
+    const uint32_t bytes = rows_here * p.n;                  // a multiple of 8
+    const uint64_t block_ofs = static_cast<uint64_t>(unit) * 32u * p.n;
+    uint8_t* blk = p.output + block_ofs;
+    const uint32_t pitch = 16u << log_cpr;
+    for (uint32_t o = lane * 16; o < bytes; o += 1024) {
+      const uint32_t r = __umulhi(o, p.tiles_n_magic);       // o / n (launcher: magic32(n); o < 2^13)
+      const uint32_t c = o - r * p.n;                        // multiple of 8
+      const uint2 lo = *reinterpret_cast<const uint2*>(stage + r * pitch + c);
+      const bool wrap = c + 8 >= p.n;                        // the second half starts the next row
+      const uint2 hi = *reinterpret_cast<const uint2*>(stage + (wrap ? (r + 1) * pitch : r * pitch + c + 8));
+      uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      if constexpr (RES) {
+        const uint8_t* res = p.residual + block_ofs + o;
+        if (o + 16 <= bytes) {
+          const uint4 q = *reinterpret_cast<const uint4*>(res);
+          v = make_uint4(add_quantize4(q.x, v.x, p.add), add_quantize4(q.y, v.y, p.add), add_quantize4(q.z, v.z, p.add), add_quantize4(q.w, v.w, p.add));
+        } else {
+          const uint2 q = *reinterpret_cast<const uint2*>(res);
+          v.x = add_quantize4(q.x, v.x, p.add);
+          v.y = add_quantize4(q.y, v.y, p.add);
+        }
+      }
+      if (o + 16 <= bytes) store16_once(blk + o, v, p.stream_out);
+      else *reinterpret_cast<uint2*>(blk + o) = make_uint2(v.x, v.y);       // (an odd number of rows: the last 8 bytes)
+    }
+    return;
+  }
   if constexpr (RES) {
     // fused residual add: the same walk, each 16-byte piece summed with the residual's bytes of the same pixel and
     // channels (launcher: residual rows are laid out like the output rows, 16-byte aligned)
@@ -366,8 +398,10 @@ constexpr int staged_waves(int kb) { return kb <= 1 ? 7 : (kb == 2 ? 6 : (kb <= 
  * common ones are not charged the registers of the rare ones */
 template <int KB, int VEC, int SEQ, bool FULL, bool RES = false>
 __global__ __launch_bounds__(kThreads, staged_waves(KB))
-void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const uint32_t log_cpr)
+void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const uint32_t log_cpr_arg)
 {
+  const uint32_t log_cpr = log_cpr_arg & 31u;
+  const bool dense8 = (log_cpr_arg >> 31) != 0u;           // stream_copy_out's third mode
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -380,8 +414,8 @@ void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const u
   const uint32_t nb0 = blockIdx.y * nbp;                  // this workgroup column's channel blocks
   const uint32_t nbn = min(nbp, nblocks - nb0);
   const uint32_t c0 = nb0 * 32u;                          // first channel
-  const uint32_t cw = min(p.n - c0, nbn * 32u);           // valid bytes per row of the chunk (n % 16 == 0)
-  const bool whole_dense = gridDim.y == 1 && p.output_stride == p.n;
+  const uint32_t cw = min(p.n - c0, nbn * 32u);           // valid bytes per row of the chunk (n % 16 == 0, or dense8)
+  const bool whole_dense = !dense8 && gridDim.y == 1 && p.output_stride == p.n;
   const uint32_t pitch = whole_dense ? p.n : (16u << log_cpr);   // row pitch of the image
 
   // ---- once per workgroup: the column's weight fragments and bias2 into LDS (LDS-DMA) ----
@@ -518,7 +552,7 @@ void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const u
 #ifdef QNNP_ENABLE_ABLATION
       if (p.izp_fill & 1u) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); if (next >= units) break; unit = next; continue; }
 #endif
-      stream_copy_out<RES>(stage, whole_dense, log_cpr, unit, c0, cw, p, lane);
+      stream_copy_out<RES>(stage, whole_dense, log_cpr, unit, c0, cw, p, lane, dense8);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // read back before the next unit overwrites it
       if (next >= units) break;
       unit = next;
@@ -1268,6 +1302,7 @@ struct StagedPlan {
   uint32_t log_cpr;    // log2(16-byte pieces per image row) of the chunked image
   uint32_t lds_bytes;
   uint32_t per_cu;     // resident workgroups per CU the launch is sized for
+  uint32_t dense8;     // 1: dense rows of n % 16 == 8 bytes, whole rows per unit (stream_copy_out's third mode)
 };
 
 uint32_t staged_lds_bytes(uint32_t kb, uint32_t nbp, uint32_t pitch)
@@ -1277,8 +1312,27 @@ uint32_t staged_lds_bytes(uint32_t kb, uint32_t nbp, uint32_t pitch)
 
 /* How the staged kernel covers an N: whole rows per unit when that fills the chip (and fits), else columns of 2 / 4 /
  * 8 channel blocks -- the widest that still gives every wave slot about two units. */
-bool plan_staged(const IgemmParams& p, uint32_t kb, StagedPlan* plan)
+bool plan_staged(const IgemmParams& p, uint32_t kb, StagedPlan* plan, uint32_t vec = 16)
 {
+  plan->dense8 = 0;
+  // dense rows of 8 (mod 16) bytes from a 16-byte aligned base: every 32-row block starts 16-byte aligned
+  const bool dense8 = p.n % 16u == 8u && p.output_stride == p.n && reinterpret_cast<uintptr_t>(p.output) % 16u == 0 &&
+      p.d2s_sh == 0 && p.rows >= 32u &&
+      // (a residual rides in the 16-byte-load flavour only: launch_pw_staged_as)
+      (p.residual == nullptr || (vec == 16 && p.residual_stride == p.n && reinterpret_cast<uintptr_t>(p.residual) % 16u == 0));
+  if (dense8) {
+    const uint32_t nb = p.n_pad / 32u;
+    uint32_t lg = 1;
+    while ((16u << lg) < nb * 32u) lg++;
+    const uint32_t lds = staged_lds_bytes(kb, nb, 16u << lg);
+    if (lds > kMaxLds) return false;
+    plan->nbp = nb; plan->nsplit = 1; plan->log_cpr = lg; plan->lds_bytes = lds; plan->dense8 = 1;
+    uint32_t per_cu = static_cast<uint32_t>(staged_waves(static_cast<int>(kb)));
+    const uint32_t by_lds = (160u * 1024u) / lds;
+    if (by_lds < per_cu) per_cu = by_lds > 0 ? by_lds : 1u;
+    plan->per_cu = per_cu;
+    return true;
+  }
   if (p.store_mode != 2 || p.n % 16u != 0 || p.d2s_sh != 0) return false;
   const uint32_t nblocks = p.n_pad / 32u;
   const uint32_t units = (p.rows + 31u) / 32u;
@@ -1342,14 +1396,14 @@ int launch_pw_staged_as(const IgemmParams& p, const StagedPlan& plan, hipStream_
   uint32_t gx = (p.cu_count * per_cu + plan.nsplit - 1) / plan.nsplit;
   const uint32_t needed = (units + kWaves - 1) / kWaves;
   if (gx > needed) gx = needed;
-#ifdef QNNP_ENABLE_ABLATION
   IgemmParams pa = p;
+  pa.tiles_n_magic = static_cast<uint32_t>((1ull << 32) / p.n) + 1u;      // dense8: byte offset / n, exact below 2^32 / n
+  const uint32_t log_arg = plan.log_cpr | (plan.dense8 != 0 ? 0x80000000u : 0u);
+#ifdef QNNP_ENABLE_ABLATION
   pa.izp_fill = 0;
   if (const char* env = getenv("QNNP_PW_ABL")) pa.izp_fill = static_cast<uint32_t>(atoi(env));
-  hipLaunchKernelGGL(kernel, dim3(gx, plan.nsplit), dim3(kThreads), plan.lds_bytes, stream, pa, plan.nbp, plan.log_cpr);
-#else
-  hipLaunchKernelGGL(kernel, dim3(gx, plan.nsplit), dim3(kThreads), plan.lds_bytes, stream, p, plan.nbp, plan.log_cpr);
 #endif
+  hipLaunchKernelGGL(kernel, dim3(gx, plan.nsplit), dim3(kThreads), plan.lds_bytes, stream, pa, plan.nbp, log_arg);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
@@ -1488,7 +1542,7 @@ bool pwstream_supported(const IgemmParams& p, uint32_t groups, uint32_t vec)
   if (p.k_total % vec != 0) return false;
   if (pw_lds_bytes(p) <= kMaxLds) return true;
   StagedPlan plan;
-  return plan_staged(p, (p.k_total + 31u) / 32u, &plan);     // any N, in workgroup columns
+  return plan_staged(p, (p.k_total + 31u) / 32u, &plan, vec);     // any N, in workgroup columns
 }
 
 /* 3-channel-image flavour: offset-table convolution in 4-byte tap slots, at most 16 taps, one group */
@@ -1624,7 +1678,7 @@ int pwstream_launch(const IgemmParams& p0, uint32_t vec, hipStream_t stream, con
   // 16-byte aligned rows wider than one channel block: the staged flavour (whole-line stores, N in columns)
   StagedPlan plan;
   // (one 32-channel block per row: the first kernel keeps it -- 28x28x192 -> 32 measured 7.1 us there, 8.1 here)
-  if (p.n != 32 && plan_staged(p, kb, &plan)) {
+  if (p.n != 32 && plan_staged(p, kb, &plan, vec)) {
     return vec == 16 ? dispatch_kb_staged<16>(p, kb, plan, stream) : dispatch_kb_staged<8>(p, kb, plan, stream);
   }
   if (lds_bytes > kMaxLds) return QNNP_HIP_EINVAL;

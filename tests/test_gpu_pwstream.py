@@ -60,6 +60,27 @@ def test_strided_rows(pw):
     _fc(pw, FcCase("pw_strided", 130, 48, 80, input_stride=64, output_stride=96))
 
 
+@pytest.mark.parametrize("n", [8, 24, 40, 56, 72, 104, 120, 248])
+@pytest.mark.parametrize("m", [32, 33, 63, 64, 65, 97, 1000, 4097])
+def test_dense_rows_of_8_mod_16_bytes(pw, m, n):
+    """round 4: 24-channel MobileNet layers (56x56x96 -> 24, 144 -> 24) and their kin -- dense output rows whose length is a
+    multiple of 8 but not of 16 bytes leave the staged kernel as ONE contiguous 16-byte aligned run per 32-row block
+    (stream_copy_out's third mode; an odd number of rows ends in an 8-byte store)"""
+    _fc(pw, FcCase(f"pw_dense8_m{m}_n{n}", m, 96, n))
+
+
+@pytest.mark.parametrize("kw", [dict(output_stride=40), dict(input_stride=160), dict(izp=3, kzp=250), dict(qmin=100, qmax=150)],
+                         ids=lambda d: "_".join(f"{k}{v}" for k, v in d.items()))
+def test_dense8_neighbours(pw, kw):
+    """strided output rows keep the direct-store flavour; strided input rows, zero points and clamps do not matter"""
+    _fc(pw, FcCase("pw_dense8_" + "_".join(f"{k}{v}" for k, v in kw.items()), 333, 144, 24, **kw))
+
+
+@pytest.mark.parametrize("k", [16, 48, 96, 144, 200, 256])
+def test_dense8_k_blocks(pw, k):
+    _fc(pw, FcCase(f"pw_dense8_k{k}", 201, k, 24))
+
+
 def test_strided_rows_8_byte(pw):
     _fc(pw, FcCase("pw_strided8", 130, 24, 20, input_stride=40, output_stride=28))
 

@@ -108,6 +108,8 @@ def test_mobilenet_project_layers_fold_at_bench_batch(qnnp, hw, cin, cout):
     (5, 5, 28, 96, 192, "q8_pw_stream_mfma"),         # staged flavour with the channels split over workgroup columns
     (5, 3, 33, 40, 24, "q8_pw_stream_mfma"),          # direct-store flavour (24 channels), 3267 rows
     (5, 3, 33, 72, 32, "q8_pw_stream_mfma"),          # one channel block per row
+    (5, 3, 33, 48, 24, "q8_pw_stream_mfma"),          # dense 24-byte rows, 16-byte loads: the staged flavour's contiguous copy-out, odd row count
+    (5, 4, 56, 144, 24, "q8_pw_stream_mfma"),         # MobileNetV2's 56 x 56 x 144 -> 24 project layer
     (9, 7, 14, 384, 64, "q8_pw_stream_longk_mfma"),   # 1372 rows: ragged
     (9, 3, 14, 576, 96, "q8_pw_stream_longk_mfma"),
     (6, 3, 7, 960, 160, "q8_pw_stream_gwk_mfma"),     # 147 rows: ragged block, 5 channel blocks, K split over the waves
