@@ -303,9 +303,17 @@ void q8_conv_c3rows_kernel(const IgemmParams p, const C3Geom cg)
 #ifdef QNNP_ENABLE_ABLATION
       if (cg.abl & 2u) ok = ok && v.x == 0x12345678;
 #endif
-      __builtin_amdgcn_raw_buffer_store_b128(
-          __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc,
-          ok ? out_off + nb * 32u : 0xFFFFFFF0u, 0, 0);
+      // (a unit's sixteen pixels of a row x 32 channels are 512 contiguous bytes, written once: the streaming hint, under
+      //  the operator's "streaming_stores" setting -- the two builtins differ in an immediate, so hipcc cannot merge them)
+      if (p.stream_out) {
+        __builtin_amdgcn_raw_buffer_store_b128(
+            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc,
+            ok ? out_off + nb * 32u : 0xFFFFFFF0u, 0, 2);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(
+            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc,
+            ok ? out_off + nb * 32u : 0xFFFFFFF0u, 0, 0);
+      }
     }
   };
 
