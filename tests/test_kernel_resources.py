@@ -150,7 +150,8 @@ def test_streaming_store_flavours_survive_the_compiler(tmp_path):
     blob = open(LIB, "rb").read()
     want = {"q8_pw_stream_staged_kernel": 0, "q8_pw_stream_longk_kernel": 0, "q8_vadd_flat_kernel": 0,
             "q8_gemm_mfma_256x256_kernelILb0ELi4ELi256ELi0ELb0ELb1E": 0,
-            "q8_dwconv_col3x3_kernel": 0, "q8_dwconv_col5x5_kernel": 0}
+            "q8_dwconv_col3x3_kernel": 0, "q8_dwconv_col5x5_kernel": 0, "q8_conv_c3rows_kernel": 0,
+            "q8_gemm_mfma_256x256_c_kernel": 0}
     for k, elf in enumerate(_code_objects(blob)):
         path = tmp_path / f"co{k}.elf"
         path.write_bytes(elf)
@@ -159,7 +160,7 @@ def test_streaming_store_flavours_survive_the_compiler(tmp_path):
             name, body = m.group(1), m.group(2)
             for frag in want:
                 if frag in name:
-                    op = "buffer_store_dword " if "dwconv" in frag else "global_store_dwordx4"
+                    op = "buffer_store_dword " if "dwconv" in frag else ("buffer_store_dwordx4" if "c3rows" in frag else "global_store_dwordx4")
                     stores = [ln for ln in body.split("\n") if op in ln]
                     hinted = [ln for ln in stores if re.search(r"\bnt\b", ln)]
                     assert hinted and len(hinted) < len(stores), (name, len(hinted), len(stores))
