@@ -20,7 +20,13 @@ Secondary numbers travel in the same JSON line under "extra" (not separate bench
   * "mobilenetv2_network": the WHOLE network (examples/mobilenetv2.py: 52 convolutions, 10 residual adds, global
     average pooling, classifier = 64 chained operators) as one hipGraph replay, images/s; "..._adds_folded": the
     same with the residual adds carried by the project convolutions (54 launches),
-  * "next_rows": the operators SURVEY.md section 8f ranks after the hot path (deconvolution, add, pooling).
+  * "next_rows": the operators SURVEY.md section 8f ranks after the hot path (deconvolution, add, pooling),
+  * "q8gemm_4096_variants": the headline GEMM with a kernel zero point that has no centred image and with a shift >= 1
+    requantization scale; "q8fc_m1_k1024_n1000": configs[0] on the device,
+  * "conv_lists": the reference bench's ResNet-18 / ResNet-50 / ShuffleNet-v1-g2 lists (bench/convolution.cc:642-718,
+    147-184) through whatever kernel auto picks -- the general implicit-GEMM convolution path.
+Because the driver's record keeps `config`, `roofline` and `cpu_baseline` but drops `extra`, the figures of BASELINE's
+other configs are repeated as flat scalars in `roofline.secondary` (secondary_block()).
 
 The timed region is EXACTLY K steps between barriers (wall clock, max over ranks -> `value`), bracketed on the
 launch stream by HIP events as well (-> "roofline", same launches). It directly follows >= 1 s of the same GEMM
@@ -67,6 +73,34 @@ MOBILENETV2 = [(224, 224, 3, 3, 2, 1,   1,    3,   32),
                (7, 7, 1, 1, 1, 1, 1, 160, 960), (7, 7, 3, 3, 1, 1, 960, 1,   1),
                (7, 7, 1, 1, 1, 1, 1, 960, 160), (7, 7, 1, 1, 1, 1, 1, 960, 320),
                (7, 7, 1, 1, 1, 1, 1, 320, 1280), (1, 1, 1, 1, 1, 1, 1, 1280, 1000)]
+
+
+# bench/convolution.cc:642-718 -- the dense convolutions that reach the implicit-GEMM family (7x7 s2, 3x3 with 64..512
+# channels, stride-2 3x3 and 1x1). Same columns; rows the reference comments out are left out here too.
+RESNET18 = [(224, 224, 7, 7, 2, 1, 1, 3, 64), (56, 56, 3, 3, 1, 1, 1, 64, 64),
+            (56, 56, 3, 3, 2, 1, 1, 64, 128), (28, 28, 3, 3, 1, 1, 1, 128, 128), (56, 56, 1, 1, 2, 1, 1, 64, 128),
+            (28, 28, 3, 3, 2, 1, 1, 128, 256), (14, 14, 3, 3, 1, 1, 1, 256, 256), (28, 28, 1, 1, 2, 1, 1, 128, 256),
+            (14, 14, 3, 3, 2, 1, 1, 256, 512), (7, 7, 3, 3, 1, 1, 1, 512, 512), (14, 14, 1, 1, 2, 1, 1, 256, 512)]
+RESNET50 = [(224, 224, 7, 7, 2, 1, 1, 3, 64),
+            (56, 56, 1, 1, 1, 1, 1, 64, 64), (56, 56, 3, 3, 1, 1, 1, 64, 64), (56, 56, 1, 1, 1, 1, 1, 64, 256),
+            (56, 56, 1, 1, 1, 1, 1, 256, 64),
+            (56, 56, 1, 1, 1, 1, 1, 256, 128), (56, 56, 3, 3, 2, 1, 1, 128, 128), (28, 28, 1, 1, 1, 1, 1, 128, 512),
+            (56, 56, 1, 1, 2, 1, 1, 256, 512),
+            (28, 28, 1, 1, 1, 1, 1, 512, 128), (28, 28, 3, 3, 1, 1, 1, 128, 128),
+            (28, 28, 1, 1, 1, 1, 1, 512, 256), (28, 28, 3, 3, 2, 1, 1, 256, 256), (14, 14, 1, 1, 1, 1, 1, 256, 1024),
+            (28, 28, 1, 1, 2, 1, 1, 512, 1024),
+            (14, 14, 1, 1, 1, 1, 1, 1024, 256), (14, 14, 3, 3, 1, 1, 1, 256, 256),
+            (14, 14, 1, 1, 1, 1, 1, 1024, 512), (14, 14, 3, 3, 2, 1, 1, 512, 512), (7, 7, 1, 1, 1, 1, 1, 512, 2048),
+            (14, 14, 1, 1, 2, 1, 1, 1024, 2048),
+            (7, 7, 1, 1, 1, 1, 1, 2048, 512), (7, 7, 3, 3, 1, 1, 1, 512, 512)]
+# bench/convolution.cc:147-184 -- ShuffleNet v1 with 2 groups: grouped 1x1 (25 / 50 / 100 channels per group), depthwise s2
+SHUFFLENET_V1_G2 = [(224, 224, 3, 3, 2, 1, 1, 3, 24),
+                    (56, 56, 1, 1, 1, 1, 1, 24, 50), (56, 56, 3, 3, 2, 1, 50, 1, 1), (28, 28, 1, 1, 1, 1, 2, 25, 88),
+                    (28, 28, 1, 1, 1, 1, 2, 100, 25), (28, 28, 3, 3, 2, 1, 50, 1, 1), (28, 28, 1, 1, 1, 1, 2, 25, 100),
+                    (28, 28, 1, 1, 1, 1, 2, 100, 50), (28, 28, 3, 3, 2, 1, 100, 1, 1), (14, 14, 1, 1, 1, 1, 2, 50, 100),
+                    (14, 14, 1, 1, 1, 1, 2, 200, 50), (14, 14, 3, 3, 2, 1, 100, 1, 1), (14, 14, 1, 1, 1, 1, 2, 50, 200),
+                    (14, 14, 1, 1, 1, 1, 2, 200, 100), (14, 14, 3, 3, 2, 1, 200, 1, 1), (7, 7, 1, 1, 1, 1, 2, 100, 200),
+                    (7, 7, 1, 1, 1, 1, 2, 400, 100), (7, 7, 3, 3, 2, 1, 200, 1, 1), (7, 7, 1, 1, 1, 1, 2, 100, 400)]
 
 
 def conv_geometry(H, W, KH, KW, S, D):
@@ -143,6 +177,76 @@ def network_bench(lib, torch, batch, total_batch, world, warmup, iters, fuse=Fal
                 "kernels": sorted(set(net.kernels.values()))}
     finally:
         net.close()
+
+
+def layer_bound_ms(layer, weight_bytes=0):
+    """The roofline of one layer: max(ops at the dense int8 MFMA peak, activation (+ weight) bytes at the HBM peak)."""
+    return max(layer.ops / (PEAK_I8_TOPS * 1e12), (layer.in_bytes + layer.out_bytes + weight_bytes) / (PEAK_HBM_GBS * 1e9)) * 1e3
+
+
+def conv_list_bench(lib, torch, batch, shapes, seed0, warmup=2, iters=8):
+    """One reference shape list (bench/convolution.cc) at `batch` images, every row its own operator on rotating buffers
+    (> 512 MB between reuses), as the reference bench times them: per layer the kernel auto chose, time, TOP/s and the
+    fraction of max(MFMA, HBM) roofline; per list the sum of layer times as images/s."""
+    rows, total_ms, total_bound = [], 0.0, 0.0
+    for i, (H, W, KH, KW, S, D, G, GIC, GOC) in enumerate(shapes):
+        layer = ConvLayer(lib, torch, batch, H, W, KH, KW, S, D, G, GIC, GOC, seed=seed0 + i, min_bytes_between_reuse=512 << 20)
+        ms = layer.time_ms(warmup, iters)
+        wbytes = G * GOC * KH * KW * GIC
+        bound = layer_bound_ms(layer, wbytes)
+        total_ms += ms
+        total_bound += bound
+        rows.append({"shape": [H, W, KH, S, G, GIC, GOC], "kernel": layer.kernel, "us": round(ms * 1e3, 2),
+                     "tops": round(layer.ops / (ms * 1e-3) / 1e12, 1),
+                     "gbs": round((layer.in_bytes + layer.out_bytes) / (ms * 1e-3) / 1e9, 1),
+                     "bound": "mfma" if layer.ops / (PEAK_I8_TOPS * 1e12) * 1e3 >= bound else "hbm",
+                     "frac_of_bound": round(bound / ms, 3)})
+        layer.close()
+    dense3 = [r for r in rows if r["shape"][2] == 3 and r["shape"][4] == 1 and r["shape"][5] >= 64]
+    return {"batch": batch, "images_per_s_by_sum_of_layers": round(batch / (total_ms * 1e-3), 1),
+            "sum_of_layer_ms": round(total_ms, 4), "sum_of_bounds_ms": round(total_bound, 4),
+            "frac_of_bound": round(total_bound / total_ms, 3),
+            "worst_dense_3x3_frac": min((r["frac_of_bound"] for r in dense3), default=None),
+            "layers": rows}
+
+
+def gemm_variant_bench(lib, torch, kzp, in_scale, warmup, iters, seed):
+    """The 4096^3 GEMM of the headline in a less favourable class: another kernel zero point (no centred image ->
+    the lean kernel with its row term) or a requantization scale < 0.5 (shift >= 1 epilogue)."""
+    M = N = K = 4096
+    rng = np.random.default_rng(seed)
+    w = rng.integers(0, 256, size=(N, K), dtype=np.uint8)
+    bias = rng.integers(-10000, 10001, size=N, dtype=np.int32)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    a = torch.randint(0, 256, (M * K,), dtype=torch.uint8, device="cuda", generator=gen)
+    c = torch.empty(M * N, dtype=torch.uint8, device="cuda")
+    op = lib.create_fully_connected_nc_q8(K, N, 127, in_scale, kzp, 1.0, w, bias, 127, 1.0, 1, 254)
+    lib.setup_fully_connected_nc_q8(op, M, a, K, c, N)
+    lib.run_operator(op)
+    ms = lib.time_operator(op, warmup, iters)
+    tops = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    out = {"kernel": lib.operator_kernel(op), "kernel_zero_point": kzp, "requant_scale": in_scale, "us": round(ms * 1e3, 2),
+           "tops": round(tops, 1), "frac": round(tops / PEAK_I8_TOPS, 4)}
+    lib.delete_operator(op)
+    return out
+
+
+def fc_m1_bench(lib, torch, warmup, iters):
+    """BASELINE configs[0] on the device: qnnp_fully_connected_nc_q8 M=1, K=1024, N=1000 (a launch-bound GEMV)."""
+    K, N = 1024, 1000
+    rng = np.random.default_rng(5)
+    w = rng.integers(0, 256, size=(N, K), dtype=np.uint8)
+    bias = rng.integers(-10000, 10001, size=N, dtype=np.int32)
+    a = torch.randint(0, 256, (K,), dtype=torch.uint8, device="cuda")
+    c = torch.empty(N, dtype=torch.uint8, device="cuda")
+    op = lib.create_fully_connected_nc_q8(K, N, 127, 0.5, 127, 0.5, w, bias, 127, 0.5, 0, 255)
+    lib.setup_fully_connected_nc_q8(op, 1, a, K, c, N)
+    lib.run_operator(op)
+    ms = lib.time_operator(op, warmup, iters)
+    out = {"kernel": lib.operator_kernel(op), "us": round(ms * 1e3, 2), "weight_gbs": round(K * N / (ms * 1e-3) / 1e9, 1)}
+    lib.delete_operator(op)
+    return out
 
 
 def next_rows_bench(lib, torch, batch, warmup, iters):
@@ -327,6 +431,72 @@ def cpu_baseline_sweep(batch=16, seconds_budget=10.0, threads=None):
                       f"{best_threads}-thread pthreadpool (OpenMP shim; best of 8..{host} threads), {dt:.1f} s"}
 
 
+def secondary_block(extra):
+    """BASELINE's other configs as flat scalars INSIDE `roofline` (the driver's record keeps `config`, `roofline` and
+    `cpu_baseline` and drops `extra`): c0 = configs[0] ... c4 = configs[4]; every fraction is of the chip peak named
+    in the key (HBM 8 TB/s, int8 MFMA 5033 TOP/s) or of max(MFMA, HBM) time ("bound")."""
+    def get(path, default=None):
+        node = extra
+        for key in path:
+            if not isinstance(node, dict) or key not in node:
+                return default
+            node = node[key]
+        return node
+    out = {}
+    c0 = get(["q8fc_m1_k1024_n1000"])
+    if c0:
+        out["c0_fc_m1_k1024_n1000_us"] = c0["us"]
+        out["c0_kernel"] = c0["kernel"]
+    c2 = get(["q8conv_3x3_56x56x64_b128"])
+    if c2:
+        out["c2_conv3x3_56x56x64_b128_ms"] = c2["ms"]
+        out["c2_bound_ms"] = c2["roofline_ms"]
+        out["c2_frac_of_bound"] = round(c2["roofline_ms"] / c2["ms"], 4)
+        out["c2_tops"] = c2["tops"]
+        out["c2_kernel"] = c2["kernel"]
+    c3 = get(["q8dwconv_mobilenetv2_layers"])
+    if c3:
+        out["c3_dwconv_layers_hbm_gbs"] = c3["hbm_gbs"]
+        out["c3_frac_of_hbm_peak"] = c3["frac_of_hbm_peak"]
+    c4 = get(["mobilenetv2_sweep"])
+    if c4:
+        out["c4_sweep_images_per_s_graph"] = c4["images_per_s"]
+        out["c4_sweep_images_per_s_sum_of_layers"] = c4["images_per_s_by_sum_of_layers"]
+        out["c4_frac_of_hbm_peak"] = c4["frac_of_hbm_peak"]
+        out["c4_batch_per_gpu"] = c4["batch_per_gpu"]
+    for key, name in (("mobilenetv2_network", "network_images_per_s"), ("mobilenetv2_network_adds_folded", "network_adds_folded_images_per_s"),
+                      ("mobilenetv2_network_fused", "network_fused_images_per_s"),
+                      ("mobilenetv2_network_fused_expanding_blocks", "network_fused_expanding_images_per_s")):
+        v = get([key, "images_per_s"])
+        if v is not None:
+            out[name] = v
+    for key, name in (("kernel_zero_point_126", "gemm4096_kzp126"), ("requant_scale_0.3_shift1", "gemm4096_shift1"),
+                      ("kernel_zero_point_126_scale_0.3", "gemm4096_kzp126_shift1")):
+        v = get(["q8gemm_4096_variants", key])
+        if v:
+            out[name + "_frac"] = v["frac"]
+            out[name + "_us"] = v["us"]
+    more = get(["q8dwconv_5x5_dilated_and_realistic_scale"], {})
+    for key, name in (("dw5x5_56x56x72_s2", "dw5x5_s2"), ("dw5x5_28x28x240_s1", "dw5x5_28"), ("dw5x5_14x14x672_s1", "dw5x5_14"),
+                      ("dw3x3_dil2_28x28x192", "dw3x3_dil2"), ("dw3x3_56x56x144_scale0.0125", "dw3x3_realistic_scale"),
+                      ("pw_112x112x16_96_scale0.0125", "pw_layer4_realistic_scale")):
+        if key in more:
+            out[name + "_frac_of_hbm_peak"] = more[key]["frac_of_hbm_peak"]
+    nxt = get(["next_rows"], {})
+    for key, name in (("q8deconv_3x3s2_28x28x64_32", "deconv3x3s2"), ("q8deconv_2x2s2_28x28x64_32", "deconv2x2s2"),
+                      ("q8add_56x56x24", "add"), ("q8gavgpool_7x7x1280", "gavgpool")):
+        if key in nxt:
+            out[name + "_frac_of_hbm_peak"] = round(nxt[key]["gbs"] / PEAK_HBM_GBS, 4)
+    for net in ("resnet18", "resnet50", "shufflenet_v1_g2"):
+        v = get(["conv_lists", net])
+        if v:
+            out[net + "_images_per_s"] = v["images_per_s_by_sum_of_layers"]
+            out[net + "_frac_of_bound"] = v["frac_of_bound"]
+            if v["worst_dense_3x3_frac"] is not None:
+                out[net + "_worst_dense_3x3_frac_of_bound"] = v["worst_dense_3x3_frac"]
+    return out
+
+
 def stub_mode():
     """QNNP_BENCH_STUB=1: harness self-test (tests/test_bench_harness.py). The launcher, the rank / world-size checks,
     the barrier-bracketed timed region, the max-over-ranks reduction and the JSON assembly run exactly as in a real run,
@@ -398,10 +568,15 @@ def run_stub(args, world, rank):
     total_batch = args.sweep_batch * world
     start, my_batch = shard_batch(total_batch, world, rank)
     sweep_ms = job_time_ms(0.5 * (1.0 + 0.5 * rank), world)
+    act_bytes = 1.0e7 * my_batch                           # (a stand-in for the sweep's algorithmic bytes per rank)
     extra = {"mobilenetv2_sweep": {"images_per_s": round(total_batch / (sweep_ms * 1e-3), 1), "batch_per_gpu": my_batch,
-                                   "shard_start": start, "ms_per_batch": round(sweep_ms, 4), "timed_as": "stub"}}
+                                   "shard_start": start, "ms_per_batch": round(sweep_ms, 4), "timed_as": "stub",
+                                   "images_per_s_by_sum_of_layers": round(total_batch / (sweep_ms * 1e-3), 1),
+                                   "frac_of_hbm_peak": round(act_bytes / (sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                   "aggregate_hbm_gbs": round(world * act_bytes / (sweep_ms * 1e-3) / 1e9, 1),
+                                   "aggregate_frac_of_hbm_peak": round(act_bytes / (sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}}
     roofline = {"bound": "mfma", "kernel": "stub", "achieved": None, "peak": round(PEAK_I8_TOPS, 1), "unit": "TOP/s",
-                "frac": None, "traffic": None}
+                "frac": None, "traffic": None, "secondary": secondary_block(extra)}
     cpu = {"value": None, "unit": "TOPS", "cores": 0, "kind": "stub", "sample": "none (harness self-test)"} if rank == 0 else None
     if rank == 0:
         print(json.dumps(assemble_line(world=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
@@ -442,6 +617,7 @@ def main():
     ap.add_argument("--sweep-batch", type=int, default=128, help="MobileNetV2 sweep images per GPU")
     ap.add_argument("--no-extra", action="store_true", help="headline GEMM only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-conv-lists", action="store_true", help="skip the ResNet-18 / ResNet-50 / ShuffleNet shape lists")
     ap.add_argument("--gemm-kernel", type=int, default=0, help="0 auto, 1 generic MFMA kernel, 2 big-tile kernel")
     ap.add_argument("--dw-kernel", type=int, default=0,
                     help="measurement aid: 0 auto, 1 direct, 2 LDS-tiled, 3 register sliding window (depthwise layers)")
@@ -730,6 +906,22 @@ def main():
 
         # ---------------------------------------------------------- SURVEY 8f "next" rows: deconvolution, add, pooling
         extra["next_rows"] = next_rows_bench(lib, torch, my_batch, args.warmup, max(args.steps // 2, 5))
+
+        # ---------------------------------------------------------- the headline GEMM outside its most favourable class, and
+        # BASELINE configs[0] (M = 1 fully connected) on the device
+        extra["q8gemm_4096_variants"] = {
+            "kernel_zero_point_126": gemm_variant_bench(lib, torch, 126, 0.75, 3, 20, 11),     # no centred image: lean kernel
+            "requant_scale_0.3_shift1": gemm_variant_bench(lib, torch, 127, 0.3, 3, 20, 12),   # shift >= 1 epilogue
+            "kernel_zero_point_126_scale_0.3": gemm_variant_bench(lib, torch, 126, 0.3, 3, 20, 13)}
+        extra["q8fc_m1_k1024_n1000"] = fc_m1_bench(lib, torch, 5, 50)
+
+        # ---------------------------------------------------------- the reference bench's other convolution lists: the general
+        # implicit-GEMM path (7x7 s2, 3x3 with 64..512 channels, stride-2 3x3 / 1x1, grouped 1x1), bench/convolution.cc:642-718, 147-184
+        if not args.no_conv_lists:
+            extra["conv_lists"] = {"resnet18": conv_list_bench(lib, torch, my_batch, RESNET18, 1800),
+                                   "resnet50": conv_list_bench(lib, torch, my_batch, RESNET50, 5000),
+                                   "shufflenet_v1_g2": conv_list_bench(lib, torch, my_batch, SHUFFLENET_V1_G2, 1200)}
+        roofline["secondary"] = secondary_block(extra)
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:

@@ -118,8 +118,13 @@ enum qnnp_status qnnp_gfx950_setup_fused_block(
  * kernel carries it (pointwise layers: every MobileNetV2 project layer; needs residual_stride == output stride and
  * the output's alignment), otherwise the add kernel is launched in place behind the convolution.
  * qnnp_gfx950_operator_residual_folded: after a run, 1 = epilogue, 0 = separate launch, -1 = nothing attached.
- * Status: invalid_parameter (NULL / wrong operator kinds / channel mismatch / no valid setup / during capture),
- * unsupported_parameter (host-memory endpoints). */
+ * NO OVERLAP: the residual range [residual, residual + (pixels - 1) * residual_stride + channels) must not intersect
+ * the convolution's output range, not even exactly (residual == output): the kernels read the residual through
+ * non-aliasing / streaming loads while other workgroups write the output. An in-place sum is what the stand-alone add
+ * operator is for (qnnp_setup_add_nc_q8 accepts sum == a or sum == b).
+ * Status: invalid_parameter (NULL / wrong operator kinds / channel mismatch / no valid setup / during capture /
+ * residual overlapping the output), unsupported_parameter (host-memory endpoints -- answered before the overlap is
+ * looked at, the addresses of a host-staged output mean nothing on the device). */
 enum qnnp_status qnnp_gfx950_attach_residual_add(
     qnnp_operator_t convolution, qnnp_operator_t add, const uint8_t* residual, size_t residual_stride);
 int qnnp_gfx950_operator_residual_folded(qnnp_operator_t op);
@@ -170,7 +175,12 @@ enum qnnp_status qnnp_gfx950_set_option(const char* key, int value);
 /* The streaming-store hint ("streaming_stores" above) of ONE operator: value 1 / 0 = on / off for every later launch of
  * `op`, -1 = follow the process-wide option again (the default). An operator whose output the next operator reads at
  * once (a chained network) wants 0; an operator on its own, as the reference bench runs them, 1 -- both kinds can live
- * in one process, and no launch of another thread is affected. */
+ * in one process, and no launch of another thread is affected.
+ * Honoured by every kernel that has a streaming form: convolution / fully connected / depthwise operators, the
+ * element-wise add, and deconvolutions that run as GEMMs (kernel == stride, and the per-phase GEMMs). Kernels WITHOUT a
+ * streaming form write plain stores whatever the setting, and the call still answers success for them: the stride-2
+ * 3x3 / 4x4 deconvolution stream kernel, global average pooling (its output is a few KB) and fused blocks (their output
+ * feeds the next block). */
 enum qnnp_status qnnp_gfx950_operator_set_streaming_stores(qnnp_operator_t op, int value);
 
 /* Name of the HIP kernel the operator's last setup selected (static string), or

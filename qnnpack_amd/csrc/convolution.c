@@ -298,11 +298,17 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
         }
         free(host_wc);
         free(host_bc);
-        if (!placed) {
-          qnnp_log_error("failed to place %zu bytes of centred weights on the device", w_bytes + 2 * b_bytes);
-          goto error;
+        if (placed) {
+          op->centre_flip = 0x7F;
+        } else {
+          /* the centred image is an optimisation, not a requirement: without it the operator runs on the standard
+           * image (row term in the kernel) -- drop what was placed and carry on */
+          qnnp_log_error("no room for %zu bytes of centred weights on the device: the operator keeps the standard image", w_bytes + 2 * b_bytes);
+          qnnp_hip_free(op->d_weights_centred);
+          qnnp_hip_free(op->d_bias_centred);
+          op->d_weights_centred = NULL;
+          op->d_bias_centred = NULL;
         }
-        op->centre_flip = 0x7F;
       }
     }
     if (kc_slot == 4 && kernel_height <= 4 && kernel_width * 3 <= 16 && dilation_height == 1 && dilation_width == 1 &&

@@ -136,10 +136,16 @@ static enum qnnp_status qnnp_create_fully_connected_nc_q8_impl(
     op->d_bias_centred = qnnp_upload_bias_pair(host_bias, n_pad);
     if (op->d_weights_centred == NULL || op->d_bias_centred == NULL ||
         qnnp_hip_h2d(op->d_weights_centred, host_weights, w_bytes, 0) != QNNP_HIP_OK) {
-      qnnp_log_error("failed to place %zu bytes of centred weights on the device", w_bytes + 2 * b_bytes);
-      goto error;
+      /* the centred image is an optimisation, not a requirement: without it the operator runs on the standard image
+       * (the lean kernel with its row term) -- drop what was placed and carry on */
+      qnnp_log_error("no room for %zu bytes of centred weights on the device: the operator keeps the standard image", w_bytes + 2 * b_bytes);
+      qnnp_hip_free(op->d_weights_centred);
+      qnnp_hip_free(op->d_bias_centred);
+      op->d_weights_centred = NULL;
+      op->d_bias_centred = NULL;
+    } else {
+      op->centre_flip = 0x7F;
     }
-    op->centre_flip = 0x7F;
   }
   free(host_weights);
   free(host_bias);

@@ -352,8 +352,8 @@ int qnnp_fused_block_launch(struct qnnp_operator* op, const void* input, void* o
 }
 
 /* ---- public entry points: run the implementation inside the right device context ------------------
- * create: the calling thread's selected device (qnnp_gfx950_set_device, default = the primary one) becomes the
- * operator's device; setup: the operator's device. The previous HIP device of the thread is restored on return. */
+ * create: the device of the member operators (the block's own device images live beside theirs, whatever device the
+ * calling thread has selected); setup: the operator's device. The previous HIP device of the thread is restored on return. */
 
 enum qnnp_status qnnp_gfx950_create_fused_block(
     qnnp_operator_t expand, qnnp_operator_t depthwise, qnnp_operator_t project, qnnp_operator_t residual_add,
@@ -362,9 +362,12 @@ enum qnnp_status qnnp_gfx950_create_fused_block(
   if (!qnnp_state.initialized) {
     return qnnp_gfx950_create_fused_block_impl(expand, depthwise, project, residual_add, fused_out);   /* logs and answers qnnp_status_uninitialized */
   }
-  const int token = qnnp_hip_enter(qnnp_hip_device());
+  /* The block borrows its members' device images and adds its own (build_strip_images: alloc + upload), so everything
+   * device-side must happen on THEIR device -- not on whichever one the calling thread has selected. Members on
+   * different devices are refused by the implementation; a NULL depthwise as well. */
+  const int token = qnnp_hip_enter(depthwise != NULL ? depthwise->device : qnnp_hip_device());
   if (token < 0) {
-    return qnnp_status_unsupported_hardware;
+    return depthwise != NULL ? qnnp_status_invalid_parameter : qnnp_status_unsupported_hardware;
   }
   if (qnnp_hip_graph_capturing()) {
     /* inside qnnp_gfx950_graph_begin ... graph_end on this device only operator launches are recordable: an upload

@@ -28,6 +28,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -715,6 +717,72 @@ bool plan(const qnnp_hip_fused_strip_args& a, StripParams* p, uint32_t* lds_byte
   return found;
 }
 
+typedef void (*strip_kernel_t)(const StripParams);
+
+// The kernel of a plan: one per (expand K blocks, common rounding mode); -1 = per-stage switch inside. Fills the
+// requantization parameters and stage modes of `p` on the way (they select the instantiation).
+strip_kernel_t pick_kernel(const qnnp_hip_fused_strip_args& a, StripParams* pp)
+{
+  StripParams& p = *pp;
+  bool unused = false;
+  if (a.has_expand) { p.rq1 = make_requant_dev(a.expand_rq); p.mode1 = stage_mode(p.rq1, &unused); }
+  p.rq2 = make_requant_dev(a.dw_rq); p.mode2 = stage_mode(p.rq2, &unused);
+  p.rq3 = make_requant_dev(a.project_rq); p.mode3 = stage_mode(p.rq3, &unused);
+  const int mode = (p.mode2 == p.mode3 && (!a.has_expand || p.mode1 == p.mode2) && (p.mode2 == 0 || p.mode2 == 3)) ? static_cast<int>(p.mode2) : -1;
+  strip_kernel_t kernel = nullptr;
+#ifdef QNNP_ENABLE_ABLATION
+#define QNNP_STRIP_PICK(KB)                                                                           \
+  kernel = p.wlds != 0                                                                                  \
+      ? (mode == 0 ? &q8_fused_strip_kernel<KB, 0, true, true> : (mode == 3 ? &q8_fused_strip_kernel<KB, 3, true, true> : &q8_fused_strip_kernel<KB, -1, true, true>)) \
+      : (mode == 0 ? &q8_fused_strip_kernel<KB, 0, true> : (mode == 3 ? &q8_fused_strip_kernel<KB, 3, true> : &q8_fused_strip_kernel<KB, -1, true>))
+#else
+#define QNNP_STRIP_PICK(KB)                                                                           \
+  kernel = mode == 0 ? &q8_fused_strip_kernel<KB, 0, true> : (mode == 3 ? &q8_fused_strip_kernel<KB, 3, true> : &q8_fused_strip_kernel<KB, -1, true>)
+#endif
+  if (!a.has_expand) {
+    kernel = mode == 0 ? &q8_fused_strip_kernel<1, 0, false> : (mode == 3 ? &q8_fused_strip_kernel<1, 3, false> : &q8_fused_strip_kernel<1, -1, false>);
+#ifdef QNNP_ENABLE_ABLATION
+    if (p.wlds != 0) kernel = mode == 0 ? &q8_fused_strip_kernel<1, 0, false, true> : (mode == 3 ? &q8_fused_strip_kernel<1, 3, false, true> : &q8_fused_strip_kernel<1, -1, false, true>);
+#endif
+  } else {
+    switch (p.kb1) {
+      case 1: QNNP_STRIP_PICK(1); break;
+      case 2: QNNP_STRIP_PICK(2); break;
+      case 3: QNNP_STRIP_PICK(3); break;
+      case 4: QNNP_STRIP_PICK(4); break;
+      default: QNNP_STRIP_PICK(5); break;
+    }
+  }
+#undef QNNP_STRIP_PICK
+  return kernel;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of ONE kernel: made once per (kernel, device),
+// and the outcome is remembered -- a device or runtime that refuses the opt-in makes the plan unsupported at SETUP
+// (qnnp_hip_fused_strip_supported), where the block can still take the tile kernel or stay with its stand-alone
+// operators, instead of failing every run with a launch error.
+bool lds_optin(strip_kernel_t kernel)
+{
+  struct Entry { strip_kernel_t kernel; uint32_t ok, refused; };
+  static std::mutex mu;
+  static Entry table[64];
+  static int used = 0;
+  const int device = qnnp_hip_device();
+  const uint32_t bit = 1u << (static_cast<uint32_t>(device < 0 ? 0 : device) & 31u);
+  std::lock_guard<std::mutex> lock(mu);
+  Entry* e = nullptr;
+  for (int i = 0; i < used; i++) if (table[i].kernel == kernel) { e = &table[i]; break; }
+  if (e == nullptr && used < 64) { e = &table[used++]; e->kernel = kernel; e->ok = e->refused = 0; }
+  if (e != nullptr) {
+    if ((e->ok & bit) != 0) return true;
+    if ((e->refused & bit) != 0) return false;
+  }
+  const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit) == hipSuccess;
+  if (!ok) (void) hipGetLastError();
+  if (e != nullptr) (ok ? e->ok : e->refused) |= bit;
+  return ok;
+}
+
 }  // namespace
 
 }  // namespace qnnp
@@ -730,7 +798,9 @@ extern "C" int qnnp_hip_fused_strip_supported(const struct qnnp_hip_fused_strip_
 {
   qnnp::StripParams p{};
   uint32_t lds_bytes = 0;
-  return a != nullptr && qnnp::plan(*a, &p, &lds_bytes) ? 1 : 0;
+  if (a == nullptr || !qnnp::plan(*a, &p, &lds_bytes)) return 0;
+  // a plan above 64 KiB of LDS is only as good as the device's answer to the opt-in of ITS kernel
+  return lds_bytes <= 64u * 1024u || qnnp::lds_optin(qnnp::pick_kernel(*a, &p)) ? 1 : 0;
 }
 
 extern "C" int qnnp_hip_fused_strip_run(const struct qnnp_hip_fused_strip_args* a, const char** kernel_name)
@@ -773,48 +843,16 @@ extern "C" int qnnp_hip_fused_strip_run(const struct qnnp_hip_fused_strip_args* 
   p.w1 = a->expand_w; p.b1 = a->expand_bias;
   p.w2 = a->dw_w; p.b2 = a->dw_bias;
   p.w3 = a->project_w; p.b3 = a->project_bias;
-  bool unused = false;
-  if (a->has_expand) { p.rq1 = make_requant_dev(a->expand_rq); p.mode1 = stage_mode(p.rq1, &unused); }
-  p.rq2 = make_requant_dev(a->dw_rq); p.mode2 = stage_mode(p.rq2, &unused);
-  p.rq3 = make_requant_dev(a->project_rq); p.mode3 = stage_mode(p.rq3, &unused);
   p.add = a->add;
   p.trace = nullptr;
 #ifdef QNNP_ENABLE_ABLATION
   p.trace = static_cast<unsigned long long*>(qnnp_hip_trace_buffer());
 #endif
   if (p.hidden_pad != a->hidden_pad || p.output_pad != a->output_pad) return QNNP_HIP_EINVAL;
-
-  // one kernel per (expand K blocks, common rounding mode); -1 = per-stage switch inside
-  const int mode = (p.mode2 == p.mode3 && (!a->has_expand || p.mode1 == p.mode2) && (p.mode2 == 0 || p.mode2 == 3)) ? static_cast<int>(p.mode2) : -1;
-  typedef void (*kernel_t)(const StripParams);
-  kernel_t kernel = nullptr;
-#ifdef QNNP_ENABLE_ABLATION
-#define QNNP_STRIP_PICK(KB)                                                                           \
-  kernel = p.wlds != 0                                                                                  \
-      ? (mode == 0 ? &q8_fused_strip_kernel<KB, 0, true, true> : (mode == 3 ? &q8_fused_strip_kernel<KB, 3, true, true> : &q8_fused_strip_kernel<KB, -1, true, true>)) \
-      : (mode == 0 ? &q8_fused_strip_kernel<KB, 0, true> : (mode == 3 ? &q8_fused_strip_kernel<KB, 3, true> : &q8_fused_strip_kernel<KB, -1, true>))
-#else
-#define QNNP_STRIP_PICK(KB)                                                                           \
-  kernel = mode == 0 ? &q8_fused_strip_kernel<KB, 0, true> : (mode == 3 ? &q8_fused_strip_kernel<KB, 3, true> : &q8_fused_strip_kernel<KB, -1, true>)
-#endif
-  if (!a->has_expand) {
-    kernel = mode == 0 ? &q8_fused_strip_kernel<1, 0, false> : (mode == 3 ? &q8_fused_strip_kernel<1, 3, false> : &q8_fused_strip_kernel<1, -1, false>);
-#ifdef QNNP_ENABLE_ABLATION
-    if (p.wlds != 0) kernel = mode == 0 ? &q8_fused_strip_kernel<1, 0, false, true> : (mode == 3 ? &q8_fused_strip_kernel<1, 3, false, true> : &q8_fused_strip_kernel<1, -1, false, true>);
-#endif
-  } else {
-    switch (p.kb1) {
-      case 1: QNNP_STRIP_PICK(1); break;
-      case 2: QNNP_STRIP_PICK(2); break;
-      case 3: QNNP_STRIP_PICK(3); break;
-      case 4: QNNP_STRIP_PICK(4); break;
-      default: QNNP_STRIP_PICK(5); break;
-    }
-  }
-#undef QNNP_STRIP_PICK
-  // (dynamic LDS above 64 KiB needs the attribute, per device and per kernel: cheap enough to repeat)
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
-  (void) hipGetLastError();
+  const strip_kernel_t kernel = pick_kernel(*a, &p);
+  // (dynamic LDS above 64 KiB needs the opt-in, per device and per kernel: made once, its outcome remembered -- the
+  //  `supported` probe setup calls has already made it, so a refusal was answered there and setup chose another kernel)
+  if (lds_bytes > 64u * 1024u && !lds_optin(kernel)) return QNNP_HIP_EINVAL;
   const uint64_t blocks = static_cast<uint64_t>(a->batch) * p.strips;
   if (blocks > 0x7FFFFFFFull) return QNNP_HIP_EINVAL;
   hipStream_t stream = reinterpret_cast<hipStream_t>(qnnp_hip_get_stream());

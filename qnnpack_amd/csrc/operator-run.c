@@ -141,6 +141,7 @@ static int launch_kernel(struct qnnp_operator* op, const void* input, const void
           .d2s_stride_w = op->stride_width,
           .d2s_input_h = (uint32_t) op->input_height,
           .d2s_input_w = (uint32_t) op->input_width,
+          .streaming_mode = op->streaming_mode,
         };
         const int rc_d2s = qnnp_hip_igemm_run(&dargs, &op->kernel_name);
         if (rc_d2s != QNNP_HIP_EINVAL) {
@@ -218,6 +219,7 @@ static int launch_kernel(struct qnnp_operator* op, const void* input, const void
           .out_image_rows = output_size,
           .phases = (const struct qnnp_hip_igemm_phase*) op->d_phase_table,
           .nphases = op->phase_table_entries,
+          .streaming_mode = op->streaming_mode,
         };
         return qnnp_hip_igemm_run(&pargs, &op->kernel_name);
       }

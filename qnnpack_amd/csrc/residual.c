@@ -62,19 +62,6 @@ enum qnnp_status qnnp_gfx950_attach_residual_add(
   if (residual_stride > UINT32_MAX) {
     return qnnp_status_unsupported_parameter;
   }
-  {
-    /* the kernels read the residual through __restrict__ / streaming loads while they write the output: the two
-     * ranges must not overlap (the in-place form is the add kernel's own business, operator-run.c) */
-    const size_t pixels = convolution->batch_size * convolution->output_height * convolution->output_width;
-    const uintptr_t r0 = (uintptr_t) residual;
-    const uintptr_t r1 = r0 + (pixels - 1) * residual_stride + channels;
-    const uintptr_t o0 = (uintptr_t) convolution->output;
-    const uintptr_t o1 = o0 + (pixels - 1) * convolution->output_pixel_stride + channels;
-    if (pixels != 0 && r0 < o1 && o0 < r1) {
-      qnnp_log_error("failed to attach residual add: the residual tensor overlaps the convolution's output");
-      return qnnp_status_invalid_parameter;
-    }
-  }
   const int token = qnnp_hip_enter(convolution->device);
   if (token < 0) {
     return qnnp_status_invalid_parameter;
@@ -87,6 +74,21 @@ enum qnnp_status qnnp_gfx950_attach_residual_add(
     /* the fused form exists for device-resident pipelines; host endpoints keep the two-operator form */
     qnnp_log_error("failed to attach residual add: input, output and residual must be memory of the operator's device");
     status = qnnp_status_unsupported_parameter;
+  }
+  if (status == qnnp_status_success) {
+    /* The kernels read the residual through __restrict__ / streaming loads while they write the output: the two ranges
+     * must not overlap -- not even exactly (the in-place form is the stand-alone add operator's business,
+     * operator-run.c). Checked only here, where both are known to be memory of this device: `convolution->output` is
+     * then the address the kernels write (a host-staged output was refused above with its own status). */
+    const size_t pixels = convolution->batch_size * convolution->output_height * convolution->output_width;
+    const uintptr_t r0 = (uintptr_t) residual;
+    const uintptr_t r1 = r0 + (pixels - 1) * residual_stride + channels;
+    const uintptr_t o0 = (uintptr_t) convolution->output;
+    const uintptr_t o1 = o0 + (pixels - 1) * convolution->output_pixel_stride + channels;
+    if (pixels != 0 && r0 < o1 && o0 < r1) {
+      qnnp_log_error("failed to attach residual add: the residual tensor overlaps the convolution's output");
+      status = qnnp_status_invalid_parameter;
+    }
   }
   if (status == qnnp_status_success) {
     convolution->residual_params = add->add_params;

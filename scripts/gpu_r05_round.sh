@@ -1,0 +1,28 @@
+#!/bin/bash
+# One gpurun call: GPU-tier tests, smoke, the bench line, rocprofv3 kernel stats (GEMM only + whole bench). gpurun_out/<tag>/.
+TAG=${1:-r05a}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+echo "== device"; rocminfo 2>/dev/null | grep -E "gfx|Compute Unit" | head -4; nproc
+echo "== pytest -m gpu"
+timeout 1500 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider 2>&1 | tail -n 60 > $OUT/pytest_gpu.log
+tail -n 12 $OUT/pytest_gpu.log
+echo "== smoke"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 5 | tee $OUT/smoke.log
+echo "== bench"
+timeout 900 python bench.py --steps 20 --warmup 5 2> $OUT/bench.err | tail -n 1 > $OUT/bench.json
+python - <<PY
+import json
+d = json.load(open("$OUT/bench.json"))
+print(json.dumps({k: d[k] for k in ("value", "ms_per_step")}), json.dumps(d["roofline"]["secondary"], indent=0).replace("\n", " "))
+for net, v in d["extra"].get("conv_lists", {}).items():
+    print(net, v["images_per_s_by_sum_of_layers"], v["frac_of_bound"])
+    for r in v["layers"]:
+        print("  ", r)
+PY
+tail -n 5 $OUT/bench.err
+echo "== rocprofv3 kernel stats (headline GEMM only)"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o gemm -- python $OLDPWD/bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline > $OLDPWD/$OUT/prof_run.log 2>&1)
+for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do cut -c1-200 $f | head -n 6; cp $f $OUT/rocprof_kernel_stats_gemm.csv; done
+echo "== rocprofv3 kernel stats (whole bench)"
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof_all -o all -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OLDPWD/$OUT/prof_all_run.log 2>&1)
+for f in $(find $OUT/prof_all -name "*kernel_stats*.csv" | head -1); do cut -c1-160 $f | head -n 14; cp $f $OUT/rocprof_kernel_stats_all.csv; done
+rm -rf $OUT/prof $OUT/prof_all

@@ -30,7 +30,7 @@ def _line(stdout):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("gpus", [1, 2, 3])
+@pytest.mark.parametrize("gpus", [1, 2, 3, 8])
 def test_bench_spawns_its_ranks_and_prints_one_line(gpus):
     res = subprocess.run([sys.executable, BENCH, "--gpus", str(gpus), "--steps", "6", "--warmup", "1", "--sweep-batch", "10"],
                          env=_env(), capture_output=True, text=True, timeout=300)
@@ -48,6 +48,13 @@ def test_bench_spawns_its_ranks_and_prints_one_line(gpus):
     assert line["cpu_baseline"] is not None                     # N > 1 lines carry the baseline object too
     sweep = line["extra"]["mobilenetv2_sweep"]
     assert sweep["batch_per_gpu"] == 10 and sweep["shard_start"] == 0       # rank 0's shard of 10 x N images
+    # the whole job's sweep figures: N shards in the slowest rank's time
+    assert abs(sweep["images_per_s"] - 10 * gpus / (sweep["ms_per_batch"] * 1e-3)) <= 0.01 * sweep["images_per_s"]
+    assert abs(sweep["aggregate_hbm_gbs"] - gpus * sweep["aggregate_frac_of_hbm_peak"] * 8000.0) <= 0.02 * sweep["aggregate_hbm_gbs"] + 0.1
+    # BASELINE's other configs travel inside `roofline` (the driver's record drops `extra`)
+    secondary = line["roofline"]["secondary"]
+    assert secondary["c4_sweep_images_per_s_graph"] == sweep["images_per_s"] and secondary["c4_batch_per_gpu"] == 10
+    assert all(not isinstance(v, (dict, list)) for v in secondary.values())
     if gpus > 1:
         per_rank = line["roofline"]["per_rank_launch_ms"]
         assert len(per_rank) == gpus and per_rank == sorted(per_rank)       # rank r sleeps longer than rank r-1
@@ -96,3 +103,52 @@ def test_assemble_line_contract_fields():
     assert abs(line["value"] - 8 * 2 * 4096 ** 3 / 0.07e-3 / 1e12) < 1.0
     assert len(line["roofline"]["per_rank_launch_ms"]) == 8 and len(line["roofline"]["per_rank_frac"]) == 8
     assert "model" not in line["config"]
+
+
+def test_more_ranks_than_gpus_is_refused_by_the_launcher_itself():
+    """`--gpus 8` on a node that shows fewer devices: the launcher refuses before any rank starts (exit code 2, no line)"""
+    env = _env()
+    env.pop("QNNP_BENCH_STUB")
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        pytest.skip("this box has eight GPUs: the refusal cannot be provoked")
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 2, (res.returncode, res.stderr[-500:])
+    assert "--gpus 8 requested" in res.stderr and "refusing" in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_secondary_block_is_flat_and_carries_every_config():
+    """roofline.secondary: flat scalars only (the driver's record truncates nothing it does not have to walk), one group
+    of keys per BASELINE config, absent sources simply absent"""
+    sys.path.insert(0, ROOT)
+    import bench
+    extra = {
+        "q8fc_m1_k1024_n1000": {"kernel": "q8_pw_stream_mfma", "us": 4.2, "weight_gbs": 243.0},
+        "q8conv_3x3_56x56x64_b128": {"kernel": "q8_conv_wave_ws_c_mfma", "ms": 0.02, "tops": 1480.0, "gbs": 2569.0,
+                                     "frac_of_copy_kernel": 0.5, "roofline_ms": 0.0064},
+        "q8dwconv_mobilenetv2_layers": {"hbm_gbs": 3824.0, "ms": 0.16, "frac_of_hbm_peak": 0.478, "frac_of_copy_kernel": 0.8},
+        "mobilenetv2_sweep": {"images_per_s": 320000.0, "images_per_s_by_sum_of_layers": 336000.0, "frac_of_hbm_peak": 0.409,
+                              "batch_per_gpu": 128},
+        "mobilenetv2_network_fused": {"images_per_s": 299000.0},
+        "q8gemm_4096_variants": {"kernel_zero_point_126": {"frac": 0.46, "us": 59.0}},
+        "q8dwconv_5x5_dilated_and_realistic_scale": {"dw5x5_56x56x72_s2": {"frac_of_hbm_peak": 0.3}},
+        "next_rows": {"q8deconv_3x3s2_28x28x64_32": {"gbs": 1700.0}},
+        "conv_lists": {"resnet18": {"images_per_s_by_sum_of_layers": 50000.0, "frac_of_bound": 0.2, "worst_dense_3x3_frac": 0.1}},
+    }
+    sec = bench.secondary_block(extra)
+    assert all(not isinstance(v, (dict, list)) for v in sec.values())
+    assert sec["c0_fc_m1_k1024_n1000_us"] == 4.2
+    assert sec["c2_conv3x3_56x56x64_b128_ms"] == 0.02 and sec["c2_frac_of_bound"] == 0.32
+    assert sec["c3_frac_of_hbm_peak"] == 0.478
+    assert sec["c4_sweep_images_per_s_graph"] == 320000.0 and sec["c4_sweep_images_per_s_sum_of_layers"] == 336000.0
+    assert sec["network_fused_images_per_s"] == 299000.0 and "network_images_per_s" not in sec
+    assert sec["gemm4096_kzp126_frac"] == 0.46 and sec["dw5x5_s2_frac_of_hbm_peak"] == 0.3
+    assert sec["deconv3x3s2_frac_of_hbm_peak"] == round(1700.0 / 8000.0, 4)
+    assert sec["resnet18_worst_dense_3x3_frac_of_bound"] == 0.1
+    assert bench.secondary_block({}) == {}
+    # the shape lists are the reference's (bench/convolution.cc:642-718, 147-184): row counts and the rows the review named
+    assert len(bench.RESNET18) == 11 and len(bench.RESNET50) == 23 and len(bench.SHUFFLENET_V1_G2) == 19
+    assert (28, 28, 3, 3, 1, 1, 1, 128, 128) in bench.RESNET18 and (7, 7, 3, 3, 1, 1, 1, 512, 512) in bench.RESNET50
+    assert (224, 224, 7, 7, 2, 1, 1, 3, 64) == bench.RESNET18[0] == bench.RESNET50[0]

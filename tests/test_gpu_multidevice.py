@@ -215,6 +215,61 @@ def test_one_process_drives_two_gpus(qnnp):
     qnnp.delete_operator(op)
 
 
+def test_fused_block_lives_on_its_members_device_not_the_callers(qnnp):
+    """A fused block borrows its members' device images and uploads its own (strip images) at create: those must land on
+    the MEMBERS' device whatever device the creating thread has selected. On one GPU the same sequence runs with device 0
+    on both sides (create from a worker thread that never selected a device); with two GPUs the members live on GPU 1
+    while the creator has GPU 0 selected, and the block is then set up and run on GPU 1 and compared with its parts."""
+    import torch
+    two = qnnp.device_count() >= 2
+    member_dev = 1 if two else 0
+    rng = np.random.default_rng(77)
+    k1 = rng.integers(0, 256, (1, 96, 1, 1, 16), dtype=np.uint8)
+    kd = rng.integers(0, 256, (96, 1, 3, 3, 1), dtype=np.uint8)
+    k3 = rng.integers(0, 256, (1, 24, 1, 1, 96), dtype=np.uint8)
+    b96, b24 = rng.integers(-5000, 5000, 96).astype(np.int32), rng.integers(-5000, 5000, 24).astype(np.int32)
+    made = {}
+
+    def make_members():
+        qnnp.set_device(member_dev)
+        made["ex"] = qnnp.create_convolution2d_nhwc_q8(0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 16, 96, 120, 0.02, 127, 0.01, k1, b96, 110, 0.05, 0, 255, 0)
+        made["dw"] = qnnp.create_convolution2d_nhwc_q8(1, 1, 1, 1, 3, 3, 1, 1, 1, 1, 96, 1, 1, 110, 0.05, 127, 0.01, kd, b96, 100, 0.06, 0, 255, 0)
+        made["pr"] = qnnp.create_convolution2d_nhwc_q8(0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 96, 24, 100, 0.06, 127, 0.01, k3, b24, 128, 0.07, 0, 255, 0)
+    t = threading.Thread(target=make_members)
+    t.start(); t.join(timeout=120)
+    assert set(made) == {"ex", "dw", "pr"}
+    assert qnnp.get_device() == 0                          # this thread still has device 0 selected
+    fused = qnnp.create_fused_block(made["ex"], made["dw"], made["pr"])
+    dev = f"cuda:{member_dev}"
+    batch, hw = 2, 20
+    x = torch.randint(0, 256, (batch * hw * hw * 16,), dtype=torch.uint8, device=dev)
+    h1 = torch.empty(batch * hw * hw * 96, dtype=torch.uint8, device=dev)
+    h2 = torch.empty_like(h1)
+    want = torch.empty(batch * hw * hw * 24, dtype=torch.uint8, device=dev)
+    got = torch.full_like(want, FILL)
+    qnnp.set_stream(None)
+    try:
+        qnnp.setup_convolution2d_nhwc_q8(made["ex"], batch, hw, hw, x, 16, h1, 96)
+        qnnp.setup_convolution2d_nhwc_q8(made["dw"], batch, hw, hw, h1, 96, h2, 96)
+        qnnp.setup_convolution2d_nhwc_q8(made["pr"], batch, hw, hw, h2, 96, want, 24)
+        for name in ("ex", "dw", "pr"):
+            qnnp.run_operator(made[name])
+        qnnp.setup_fused_block(fused, batch, hw, hw, x, 16, got, 24)
+        qnnp.run_operator(fused)
+        torch.cuda.synchronize(member_dev)
+        assert torch.equal(got, want), "fused block differs from its stand-alone chain"
+        if two:
+            # members of two devices in one block are refused
+            other = qnnp.create_convolution2d_nhwc_q8(0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 96, 24, 100, 0.06, 127, 0.01, k3, b24, 128, 0.07, 0, 255, 0)
+            assert qnnp.create_fused_block_status(made["ex"], made["dw"], other)[0] == Status.invalid_parameter
+            qnnp.delete_operator(other)
+    finally:
+        qnnp.set_stream(torch.cuda.current_stream().cuda_stream)
+        qnnp.delete_operator(fused)
+        for h in made.values():
+            qnnp.delete_operator(h)
+
+
 def test_thread_per_gpu_example_runs(qnnp):
     """examples/multi_gpu_threads.py: the one-process / one-thread-per-GPU form on however many GPUs the box has (a second
     caller of the path the two-GPU test above covers; with one GPU it still selects and binds the device from a worker
