@@ -127,22 +127,6 @@ __device__ __forceinline__ void dma16(const uint8_t* src, uint8_t* lds_wave_base
                : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
 
-/* The same through a buffer descriptor: per-lane 32-bit offset, an offset beyond the tensor writes zeros. M0 is NOT
- * restored here (four pieces per unit in the pipelined 3x3 loop: the save / restore pair would be half of its scalar
- * instructions); nothing else in that kernel reads M0 -- tests/test_kernel_resources.py disassembles it and checks. */
-__device__ __forceinline__ void dma16_buf(uint32_t lane_offset, __amdgpu_buffer_rsrc_t rsrc, uint32_t lds_dst_uniform)
-{
-  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_dst_uniform);
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
-               : : "v"(lane_offset), "s"(rsrc), "s"(dst) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void ws_wait_vmcnt()
-{
-  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
-  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
-}
-
 // 16-byte / 4-byte LDS stores the compiler does not see as LDS accesses (see the header: no vmcnt(0) in front)
 __device__ __forceinline__ void ds_write16_raw(uint32_t off, uint4 v)
 {
@@ -861,12 +845,7 @@ void q8_conv_wave_reg_kernel(const IgemmParams p, const ConvGeom g, const WaveAr
 constexpr int kWsWaves = 8;
 constexpr uint32_t kWsPixBytes = 1024;             // per wave: one dword per 16-byte patch chunk (the pixel's sum, replicated)
 
-/* pipelined loop: per wave a landing buffer of whole 1 KiB LDS-DMA pieces and TWO patch buffers (each with its pixel sums) */
-inline uint32_t ws_landing_bytes(uint32_t kc) { return ((6u * 10u * (kc >> 4) + 63u) / 64u) * 1024u; }
-inline uint32_t ws_lds_bytes(const WaveArgs& a, bool pipe = false, uint32_t kc = 64)
-{
-  return a.head_bytes + kWsWaves * (pipe ? ws_landing_bytes(kc) + 2u * (a.patch_bytes + kWsPixBytes) : a.patch_bytes + kWsPixBytes);
-}
+inline uint32_t ws_lds_bytes(const WaveArgs& a) { return a.head_bytes + kWsWaves * (a.patch_bytes + kWsPixBytes); }
 
 /* What the first two versions of this kernel taught (stamps + PMC, profiles/r03): with weights in registers, with two
  * patches in flight, with the epilogue software-pipelined into the next K loop -- always 4.1-4.3 k cycles per unit and
@@ -886,31 +865,13 @@ inline uint32_t ws_lds_bytes(const WaveArgs& a, bool pipe = false, uint32_t kc =
  * row coefficient is zero) or 127 (weights w ^ 0x7F, activations ^ 0x7F): no kernel-zero-point row term, hence no pixel
  * sums in the fix-up pass (4 v_sad_u8 + 2 DPP adds + a store per piece) and no window sum in the epilogue (9 LDS reads +
  * 8 adds + the addend): ~55 of a unit's ~420 instructions. p.a_flip carries the mask. */
-/* PIPE (round 5): the unit loop as a software pipeline -- LDS-DMA into a landing buffer, two patch buffers per wave.
- * What the cycle stamps of the loop above say (profiles/r05/conv33_prologue_and_unit_stamps_r05trace.txt): a unit is
- * acc init 0.2 k + K loop 1.6 k + epilogue 0.75 k + fix-up 0.5 k = 3.15 k cycles per wave for 1.15 k cycles of matrix
- * pipe: with two waves per SIMD the pipe is 73 % busy, and what keeps the two K loops apart is the fix-up pass behind
- * the epilogue -- it waits for the patch requested late in the K loop (the compiler sinks the four buffer loads behind
- * the seventh tap) and its registers are live across the whole epilogue. Here:
- *   - the patch of unit u+2 is requested by LDS-DMA (buffer form: no registers, out-of-range = zeros) into a per-wave
- *     landing buffer while unit u is multiplied: a whole unit to land instead of a third of one;
- *   - between taps 1 .. 4 of unit u the landed patch of unit u+1 goes landing buffer -> registers -> (border fix,
- *     re-centring, pixel sums) -> the OTHER patch buffer, piece by piece, each piece's landing space re-requested for
- *     unit u+2 at once: the pass sits in the shadow of the multiplies, and behind the epilogue the next K loop starts at
- *     once;
- *   - waits are COUNTED by hand (the DMA is inline asm the compiler does not see): before piece k the queue holds, behind
- *     it, NP-1-k older-unit pieces, the TN stores of the previous epilogue and k new requests -- always NP-1+TN younger
- *     operations (the prologue issues TN discarded stores so that this also holds for a wave's first unit).
- * The prologue requests the WEIGHTS first (their address needs nothing but the argument block: ~1.7 k cycles earlier than
- * behind the patch geometry), then the first patch; the second patch is in flight across the barrier.
- * Costs 13.5 KiB of LDS per wave instead of 4.75; 16 registers fewer. Instruction order in the K loop is pinned per tap. */
-template <int TN, int CB, int SEQ, bool FULL, bool CEN = false, bool PIPE = false>
+template <int TN, int CB, int SEQ, bool FULL, bool CEN = false>
 __global__ __launch_bounds__(kWsWaves * 64, 2)
 void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [weights][bias][counter][waves x (patch | pixel sums)]
   // (measurement builds: the prologue's stamps go to "workgroup" blockIdx.x + 256 of the trace buffer -- item 0: cycles at
-  //  entry / first patch requested / weights requested / patch in LDS / barrier passed / weights in registers / loop done,
+  //  entry / weights requested / first patch requested / patch in LDS / barrier passed / weights in registers / loop done,
   //  item 1: the 100 MHz wall clock at entry and exit. tools/trace_conv33.py prints them.)
 #define WS_PRO(slot) QNNP_TRACE(p, blockIdx.x + 256u, 0, slot)
   WS_PRO(0);
@@ -923,23 +884,23 @@ void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArg
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t buf_bytes = a.patch_bytes + kWsPixBytes;      // one patch buffer with its pixel sums
-  constexpr uint32_t kLand = PIPE ? static_cast<uint32_t>(NP) * 1024u : 0u;   // (PIPE: landing buffer in front of the two patch buffers)
-  uint8_t* land = lds + a.head_bytes + wave * (PIPE ? kLand + 2u * buf_bytes : buf_bytes);
-  uint8_t* patch = land + kLand;
+  uint8_t* patch = lds + a.head_bytes + wave * (a.patch_bytes + kWsPixBytes);
   int32_t* pix = reinterpret_cast<int32_t*>(patch + a.patch_bytes);
 
-  if constexpr (PIPE) {
-    // ---- weights + bias by LDS-DMA FIRST: nothing but the argument block stands in front of these requests
+  // ---- prologue, first half: weights + bias by LDS-DMA, once per workgroup. FIRST (round 5): nothing but the argument
+  //      block stands in front of these requests, while the first patch's addresses take ~1.8 k cycles of cold-start
+  //      arithmetic (profiles/r05/conv3x3_prologue_and_unit_stamps_r05trace.txt) -- and the barrier waits for the weights
+  {
     const uint32_t pieces = a.w_bytes >> 10;
     const uint8_t* src = reinterpret_cast<const uint8_t*>(p.packed_w) + lane * 16u;
     for (uint32_t i = wave; i < pieces; i += kWsWaves) dma16(src + i * 1024u, w_lds + i * 1024u);
     if (wave == kWsWaves - 1 && lane < p.n / 4u) {
+      // (lane forms of the requantization: bias + 2^31, the second half of the pair table)
       dma16(reinterpret_cast<const uint8_t*>(rq_is_lane<SEQ>() ? p.bias2u : p.bias2) + lane * 16u, reinterpret_cast<uint8_t*>(bias_lds));
     }
-    __builtin_amdgcn_sched_barrier(0);
-    WS_PRO(1);
   }
+  __builtin_amdgcn_sched_barrier(0);
+  WS_PRO(1);
 
   const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * a.units / gridDim.x);
   const uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * a.units / gridDim.x);
@@ -994,34 +955,6 @@ void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArg
   };
   // the fetched patch: (border units: pixels outside the image become the zero point,) re-centred into LDS, per-pixel
   // channel sums (of a') beside it
-  // one 1 KiB piece of a fetched patch into the buffer at LDS offsets (patch_off, pix_off)
-  auto fix_piece = [&](v4i x, const Where& w, int u, uint32_t patch_off, uint32_t pix_off) __attribute__((always_inline)) {
-    if (w.border) {
-      const int32_t iy = w.iy0 + static_cast<int32_t>(pyx[u] >> 16);
-      const int32_t ix = w.ix0 + static_cast<int32_t>(pyx[u] & 0xFFFFu);
-      const bool inb = static_cast<uint32_t>(iy) < g.H && static_cast<uint32_t>(ix) < g.W;
-      x.x = inb ? x.x : static_cast<int>(fill4);
-      x.y = inb ? x.y : static_cast<int>(fill4);
-      x.z = inb ? x.z : static_cast<int>(fill4);
-      x.w = inb ? x.w : static_cast<int>(fill4);
-    }
-    const uint32_t v = lane + u * 64u;
-    if ((u + 1) * 64u <= pvec || v < pvec) {               // (only the last piece is partly populated)
-      if constexpr (CEN) {
-        const uint32_t flip = p.a_flip;
-        ds_write16_raw(patch_off + v * 16u, make_uint4(x.x ^ flip, x.y ^ flip, x.z ^ flip, x.w ^ flip));
-      } else {
-        uint32_t sum = __builtin_amdgcn_sad_u8(x.x, 0u, 0u);
-        sum = __builtin_amdgcn_sad_u8(x.y, 0u, sum);
-        sum = __builtin_amdgcn_sad_u8(x.z, 0u, sum);
-        sum = __builtin_amdgcn_sad_u8(x.w, 0u, sum);
-        sum += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(sum), 0xB1, 0xF, 0xF, false));        // lane ^ 1
-        if (cpp > 2) sum += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(sum), 0x4E, 0xF, 0xF, false));   // lane ^ 2
-        ds_write16_raw(patch_off + v * 16u, make_uint4(x.x ^ kFlip, x.y ^ kFlip, x.z ^ kFlip, x.w ^ kFlip));
-        ds_write4_raw(pix_off + v * 4u, static_cast<int32_t>(sum) - 128 * static_cast<int32_t>(cin));   // (all cpp lanes of the pixel)
-      }
-    }
-  };
   auto fix_up = [&](Raw& r, const Where& w) __attribute__((always_inline)) {
     const uint32_t patch_off = lds_off(patch);
     const uint32_t pix_off = lds_off(pix);
@@ -1060,60 +993,20 @@ void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArg
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   };
 
+  // ---- prologue, second half: the first patch (an HBM round trip) behind the weights
   uint32_t cur = lo + wave;                        // round-robin walk: every unit costs the same, a counter buys no balance
   Raw raw;
   Where here = locate(min(cur, a.units - 1u));
+#pragma unroll
+  for (int u = 0; u < NP; u++) fetch_piece(here, u, raw);
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       p.output, 0, static_cast<int>(a.units / tiles * g.OH * g.OW * p.n), 0x00020000);   // (launcher: < 2^31)
-  const uint32_t land_off = lds_off(land);
-  Where next_p = here;                             // (PIPE: unit 1 of this wave)
-  // landing buffer -> (border fix, re-centring, pixel sums) -> a patch buffer, one piece
-  auto land_to_patch = [&](const Where& w, int u, uint32_t patch_off) __attribute__((always_inline)) {
-    const v4i x = *reinterpret_cast<const v4i*>(land + (lane + u * 64u) * 16u);
-    fix_piece(x, w, u, patch_off, patch_off + a.patch_bytes);
-  };
-  if constexpr (PIPE) {
-    // ---- prologue (weights are on their way): first patch -> landing buffer -> patch buffer 0; second patch requested;
-    //      TN discarded stores so that the unit loop's counted waits hold from its first unit on
-#pragma unroll
-    for (int u = 0; u < NP; u++) dma16_buf(rel[u] + here.origin, in_rsrc, land_off + u * 1024u);
-    WS_PRO(2);
-    ws_wait_vmcnt<0>();
-#pragma unroll
-    for (int u = 0; u < NP; u++) land_to_patch(here, u, lds_off(patch));
-    WS_PRO(3);
-    next_p = locate(min(cur + kWsWaves, a.units - 1u));
-#pragma unroll
-    for (int u = 0; u < NP; u++) dma16_buf(rel[u] + next_p.origin, in_rsrc, land_off + u * 1024u);
-#pragma unroll
-    for (int tn = 0; tn < TN; tn++) {
-      const v4i zero = {0, 0, 0, 0};
-      __builtin_amdgcn_raw_buffer_store_b128(
-          __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, zero), out_rsrc, 0xFFFFFFF0u, 0, 0);
-    }
-    // (every wave has waited for its own share of the weights above; the second patch stays in flight across the barrier)
-    asm volatile("s_barrier" ::: "memory");
-  } else {
-    // ---- prologue: first patch requested first (an HBM round trip), then weights + bias by LDS-DMA, once per workgroup
-#pragma unroll
-    for (int u = 0; u < NP; u++) fetch_piece(here, u, raw);
-    __builtin_amdgcn_sched_barrier(0);
-    WS_PRO(1);
-    {
-      const uint32_t pieces = a.w_bytes >> 10;
-      const uint8_t* src = reinterpret_cast<const uint8_t*>(p.packed_w) + lane * 16u;
-      for (uint32_t i = wave; i < pieces; i += kWsWaves) dma16(src + i * 1024u, w_lds + i * 1024u);
-      if (wave == kWsWaves - 1 && lane < p.n / 4u) {
-        // (lane forms of the requantization: bias + 2^31, the second half of the pair table)
-        dma16(reinterpret_cast<const uint8_t*>(rq_is_lane<SEQ>() ? p.bias2u : p.bias2) + lane * 16u, reinterpret_cast<uint8_t*>(bias_lds));
-      }
-    }
-    WS_PRO(2);
-    fix_up(raw, here);                                // needs the patch only
-    WS_PRO(3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
+  __builtin_amdgcn_sched_barrier(0);
+  WS_PRO(2);
+  fix_up(raw, here);                                // needs the patch only
+  WS_PRO(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   WS_PRO(4);
 
   // ---- every weight fragment into registers, for good ----
@@ -1141,9 +1034,12 @@ void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArg
   uint32_t unit_no = 0;
   (void) unit_no;
 #define WS_STAMP(slot) do { if (wave == 0) { QNNP_TRACE(p, blockIdx.x, unit_no, slot); } } while (0)
-#define QNNP_T(n) std::integral_constant<int, n>{}
-  // accumulators start at the folded bias
-  auto init_acc = [&](v16i (&acc)[TN]) __attribute__((always_inline)) {
+  while (cur < hi) {
+    WS_STAMP(0);
+    const Where next = locate(min(cur + kWsWaves, a.units - 1u));
+
+    // accumulators start at the folded bias
+    v16i acc[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; tn++)
 #pragma unroll
@@ -1154,155 +1050,89 @@ void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArg
         acc[tn][rg * 4 + 2] = b.z;
         acc[tn][rg * 4 + 3] = b.w;
       }
-  };
-  // fragment addresses of a patch buffer: 3 kernel rows x CB channel blocks, the kernel column is an immediate
-  struct ABase { const uint8_t* at[3][CB]; };
-  auto a_bases = [&](const uint8_t* buf) __attribute__((always_inline)) -> ABase {
-    ABase b;
-#pragma unroll
-    for (int ky = 0; ky < 3; ky++) {
-      const uint32_t swz = (ty + ky) & (cpp - 1u);
-#pragma unroll
-      for (int cb = 0; cb < CB; cb++) b.at[ky][cb] = buf + rowbase + ky * 10 * cin + ((((cb << 1) | khalf) ^ swz) << 4);
-    }
-    return b;
-  };
-  auto read_a = [&](const ABase& b, auto t_c, AF& f) __attribute__((always_inline)) {
-    constexpr int t = decltype(t_c)::value;
-    constexpr int ky = t / 3, kx = t % 3;
-#pragma unroll
-    for (int cb = 0; cb < CB; cb++) f.a[cb] = *reinterpret_cast<const v4i*>(b.at[ky][cb] + kx * cin);
-  };
-  auto mma = [&](v16i (&acc)[TN], auto t_c, const AF& f) __attribute__((always_inline)) {
-    constexpr int t = decltype(t_c)::value;
-#pragma unroll
-    for (int cb = 0; cb < CB; cb++)
-#pragma unroll
-      for (int tn = 0; tn < TN; tn++)
-        acc[tn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wreg[t][cb][tn], f.a[cb], acc[tn], 0, 0, 0);
-  };
-  // ---- fused epilogue: row term, requantization in registers, 16-byte stores ----
-  auto epilogue = [&](v16i (&acc)[TN], const Where& at, const int32_t* pix_of_unit) __attribute__((always_inline)) {
-    int32_t s = 0;
-    if constexpr (!CEN) {
-      const int32_t* pq = pix_of_unit + (ty * 10u + (i0 & 7u)) * cpp;
-#pragma unroll
-      for (int t = 0; t < 9; t++) s += pq[((t / 3) * 10 + (t % 3)) * cpp];
-    }
-    const int32_t rowterm = with_rq_offset<SEQ>(CEN ? 0 : p.row_coeff * s);       // (CEN: a constant of the launch)
-    uint64_t row_addend = 0;                       // lane forms: the row term rides in the multiply-add's addend
-    if constexpr (rq_is_lane<SEQ>()) row_addend = lane_addend(rowterm, p.lane);
-#pragma unroll
-    for (int tn = 0; tn < TN; tn++) {
-      uint32_t pk[4];
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        if constexpr (rq_is_lane<SEQ>()) {
-          pk[rg] = q31_requantize_pack4_lane<SEQ, FULL>(
-              static_cast<uint32_t>(acc[tn][rg * 4 + 0]), static_cast<uint32_t>(acc[tn][rg * 4 + 1]),
-              static_cast<uint32_t>(acc[tn][rg * 4 + 2]), static_cast<uint32_t>(acc[tn][rg * 4 + 3]), row_addend, p.lane, p.rq);
-        } else {
-          pk[rg] = q31_requantize_pack4<SEQ, FULL, false>(
-              add_wrap(acc[tn][rg * 4 + 0], rowterm), add_wrap(acc[tn][rg * 4 + 1], rowterm),
-              add_wrap(acc[tn][rg * 4 + 2], rowterm), add_wrap(acc[tn][rg * 4 + 3], rowterm), p.rq);
-        }
-      }
-      const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
-      const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
-      // this lane now holds 16 consecutive channels of ITS position: tn * 32 + khalf * 16 .. + 15. Stored directly --
-      // no staging image, no read-back: the round trip through LDS cost ~370 cycles per unit of pure latency (two
-      // dependent ds_read -> store pairs) for the sake of whole-line stores, and with two waves per SIMD nothing hides it
-      const v4i v = {static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
-      const uint32_t oy = at.oy0 + ty;
-      const uint32_t ox = at.ox0 + (i0 & 7u);
-      const bool ok = oy < g.OH && ox < g.OW;
-      __builtin_amdgcn_raw_buffer_store_b128(
-          __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc,
-          ok ? at.out_img + (oy * g.OW + ox) * p.n + tn * 32 + khalf * 16 : 0xFFFFFFF0u, 0, 0);
-    }
-  };
-
-  if constexpr (PIPE) {
-    // ---- the pipelined unit loop: buffer (u & 1) is multiplied while unit u+1's patch goes into the other one and unit
-    //      u+2's is requested. Two bodies with the buffers swapped, so every LDS address is a register plus an immediate.
-    const ABase base0 = a_bases(patch), base1 = a_bases(patch + buf_bytes);
-    const uint32_t off0 = lds_off(patch), off1 = off0 + buf_bytes;
-    Where next = next_p;                             // (its patch is on its way into the landing buffer since the prologue)
-    auto body = [&](const ABase& mine, const int32_t* my_pix, uint32_t other_off) __attribute__((always_inline)) {
-      WS_STAMP(0);
-      const Where next2 = locate(min(cur + 2 * kWsWaves, a.units - 1u));
-      v16i acc[TN];
-      init_acc(acc);
-      // step t: the MFMAs of tap t, the fragment reads of tap t+1, and for t = 1 .. NP: piece t-1 of unit u+1's patch into
-      // the other buffer, its registers re-used for the same piece of unit u+2
-      auto side = [&](int u) __attribute__((always_inline)) {
-        if (u < NP) {
-          ws_wait_vmcnt<NP - 1 + TN>();                 // piece u of unit u+1 has landed (see the header for the count)
-          land_to_patch(next, u, other_off);
-          dma16_buf(rel[u] + next2.origin, in_rsrc, land_off + u * 1024u);
-        }
-      };
-      AF f0, f1;
-      WS_STAMP(1);
-      read_a(mine, QNNP_T(0), f0);
-      read_a(mine, QNNP_T(1), f1); mma(acc, QNNP_T(0), f0);                 __builtin_amdgcn_sched_barrier(0);
-      read_a(mine, QNNP_T(2), f0); mma(acc, QNNP_T(1), f1); side(0);        __builtin_amdgcn_sched_barrier(0);
-      read_a(mine, QNNP_T(3), f1); mma(acc, QNNP_T(2), f0); side(1);        __builtin_amdgcn_sched_barrier(0);
-      read_a(mine, QNNP_T(4), f0); mma(acc, QNNP_T(3), f1); side(2);        __builtin_amdgcn_sched_barrier(0);
-      read_a(mine, QNNP_T(5), f1); mma(acc, QNNP_T(4), f0); side(3);        __builtin_amdgcn_sched_barrier(0);
-      read_a(mine, QNNP_T(6), f0); mma(acc, QNNP_T(5), f1);                 __builtin_amdgcn_sched_barrier(0);
-      read_a(mine, QNNP_T(7), f1); mma(acc, QNNP_T(6), f0);                 __builtin_amdgcn_sched_barrier(0);
-      read_a(mine, QNNP_T(8), f0); mma(acc, QNNP_T(7), f1);                 __builtin_amdgcn_sched_barrier(0);
-      mma(acc, QNNP_T(8), f0);
-      WS_STAMP(2);
-      __builtin_amdgcn_sched_barrier(0);
-      epilogue(acc, here, my_pix);
-      WS_STAMP(3);
-      // (no fence here: the ds_writes into the other buffer are asm volatile with a memory clobber -- a compiler barrier --
-      //  and a wave's LDS operations execute in issue order; a release fence would also drain the requests of unit u+2)
-      WS_STAMP(5);
-      unit_no++;
-      here = next;
-      next = next2;
-      cur += kWsWaves;
-    };
-    static_assert(NP <= 4, "one patch piece per tap 1 .. 4");
-    while (cur < hi) {
-      body(base0, pix, off1);
-      if (cur >= hi) break;
-      body(base1, reinterpret_cast<const int32_t*>(reinterpret_cast<const uint8_t*>(pix) + buf_bytes), off0);
-    }
-    WS_PRO(6);
-    QNNP_TRACE_WALL(p, blockIdx.x + 256u, 1, 1);
-    return;
-  }
-
-  while (cur < hi) {
-    WS_STAMP(0);
-    const Where next = locate(min(cur + kWsWaves, a.units - 1u));
-    v16i acc[TN];
-    init_acc(acc);
     {
-      const ABase mine = a_bases(patch);
+      const uint8_t* abase[3][CB];
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++) {
+        const uint32_t swz = (ty + ky) & (cpp - 1u);
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) abase[ky][cb] = patch + rowbase + ky * 10 * cin + ((((cb << 1) | khalf) ^ swz) << 4);
+      }
+      auto read_a = [&](auto t_c, AF& f) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_c)::value;
+        constexpr int ky = t / 3, kx = t % 3;
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) f.a[cb] = *reinterpret_cast<const v4i*>(abase[ky][cb] + kx * cin);
+      };
+      auto mma = [&](auto t_c, const AF& f) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_c)::value;
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+          for (int tn = 0; tn < TN; tn++)
+            acc[tn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wreg[t][cb][tn], f.a[cb], acc[tn], 0, 0, 0);
+      };
       // the next unit's patch is requested piece by piece between the taps
       auto piece = [&](int u) __attribute__((always_inline)) { if (u < NP) fetch_piece(next, u, raw); };
+#define QNNP_T(n) std::integral_constant<int, n>{}
       AF f0, f1;
       WS_STAMP(1);
-      read_a(mine, QNNP_T(0), f0);
-      read_a(mine, QNNP_T(1), f1); mma(acc, QNNP_T(0), f0);
-      read_a(mine, QNNP_T(2), f0); mma(acc, QNNP_T(1), f1); piece(0);
-      read_a(mine, QNNP_T(3), f1); mma(acc, QNNP_T(2), f0); piece(1);
-      read_a(mine, QNNP_T(4), f0); mma(acc, QNNP_T(3), f1); piece(2);
-      read_a(mine, QNNP_T(5), f1); mma(acc, QNNP_T(4), f0); piece(3);
-      read_a(mine, QNNP_T(6), f0); mma(acc, QNNP_T(5), f1); piece(4);
-      read_a(mine, QNNP_T(7), f1); mma(acc, QNNP_T(6), f0); piece(5);
-      read_a(mine, QNNP_T(8), f0); mma(acc, QNNP_T(7), f1); piece(6);
-      mma(acc, QNNP_T(8), f0);
+      read_a(QNNP_T(0), f0);
+      read_a(QNNP_T(1), f1); mma(QNNP_T(0), f0);
+      read_a(QNNP_T(2), f0); mma(QNNP_T(1), f1); piece(0);
+      read_a(QNNP_T(3), f1); mma(QNNP_T(2), f0); piece(1);
+      read_a(QNNP_T(4), f0); mma(QNNP_T(3), f1); piece(2);
+      read_a(QNNP_T(5), f1); mma(QNNP_T(4), f0); piece(3);
+      read_a(QNNP_T(6), f0); mma(QNNP_T(5), f1); piece(4);
+      read_a(QNNP_T(7), f1); mma(QNNP_T(6), f0); piece(5);
+      read_a(QNNP_T(8), f0); mma(QNNP_T(7), f1); piece(6);
+      mma(QNNP_T(8), f0);
+#undef QNNP_T
     }
     WS_STAMP(2);
     __builtin_amdgcn_sched_barrier(0);
-    epilogue(acc, here, pix);
-    WS_STAMP(3);
+
+    // ---- fused epilogue: row term, requantization into the (now free) patch buffer, 16-byte stores ----
+    {
+      int32_t s = 0;
+      if constexpr (!CEN) {
+        const int32_t* pq = pix + (ty * 10u + (i0 & 7u)) * cpp;
+#pragma unroll
+        for (int t = 0; t < 9; t++) s += pq[((t / 3) * 10 + (t % 3)) * cpp];
+      }
+      const int32_t rowterm = with_rq_offset<SEQ>(CEN ? 0 : p.row_coeff * s);       // (CEN: a constant of the launch)
+      uint64_t row_addend = 0;                       // lane forms: the row term rides in the multiply-add's addend
+      if constexpr (rq_is_lane<SEQ>()) row_addend = lane_addend(rowterm, p.lane);
+#pragma unroll
+      for (int tn = 0; tn < TN; tn++) {
+        uint32_t pk[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          if constexpr (rq_is_lane<SEQ>()) {
+            pk[rg] = q31_requantize_pack4_lane<SEQ, FULL>(
+                static_cast<uint32_t>(acc[tn][rg * 4 + 0]), static_cast<uint32_t>(acc[tn][rg * 4 + 1]),
+                static_cast<uint32_t>(acc[tn][rg * 4 + 2]), static_cast<uint32_t>(acc[tn][rg * 4 + 3]), row_addend, p.lane, p.rq);
+          } else {
+            pk[rg] = q31_requantize_pack4<SEQ, FULL, false>(
+                add_wrap(acc[tn][rg * 4 + 0], rowterm), add_wrap(acc[tn][rg * 4 + 1], rowterm),
+                add_wrap(acc[tn][rg * 4 + 2], rowterm), add_wrap(acc[tn][rg * 4 + 3], rowterm), p.rq);
+          }
+        }
+        const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+        // this lane now holds 16 consecutive channels of ITS position: tn * 32 + khalf * 16 .. + 15. Stored directly --
+        // no staging image, no read-back: the round trip through LDS cost ~370 cycles per unit of pure latency (two
+        // dependent ds_read -> store pairs) for the sake of whole-line stores, and with two waves per SIMD nothing hides it
+        const v4i v = {static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
+        const uint32_t oy = here.oy0 + ty;
+        const uint32_t ox = here.ox0 + (i0 & 7u);
+        const bool ok = oy < g.OH && ox < g.OW;
+        __builtin_amdgcn_raw_buffer_store_b128(
+            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc,
+            ok ? here.out_img + (oy * g.OW + ox) * p.n + tn * 32 + khalf * 16 : 0xFFFFFFF0u, 0, 0);
+      }
+      WS_STAMP(3);
+    }
     WS_STAMP(4);
     // ---- the next unit's patch (fetched between the taps) into the patch buffer ----
     fix_up(raw, next);
@@ -1314,48 +1144,33 @@ void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArg
   WS_PRO(6);
   QNNP_TRACE_WALL(p, blockIdx.x + 256u, 1, 1);
 #undef WS_PRO
-#undef QNNP_T
 #undef WS_STAMP
 }
 
-template <int TN, int CB, int SEQ, bool FULL, bool CEN, bool PIPE>
+template <int TN, int CB, int SEQ, bool FULL, bool CEN>
 int launch_ws_as(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hipStream_t stream)
 {
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
   if (auto once_scope = attr_once.begin()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_ws_kernel<TN, CB, SEQ, FULL, CEN, PIPE>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_ws_kernel<TN, CB, SEQ, FULL, CEN>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       (void) hipGetLastError();
     }
   }
   const uint32_t want = (a.units + kWsWaves - 1) / kWsWaves;
   const uint32_t grid = want < p.cu_count ? want : p.cu_count;
-  hipLaunchKernelGGL((q8_conv_wave_ws_kernel<TN, CB, SEQ, FULL, CEN, PIPE>), dim3(grid), dim3(kWsWaves * 64), ws_lds_bytes(a, PIPE, p.kc), stream, p, g, a);
+  hipLaunchKernelGGL((q8_conv_wave_ws_kernel<TN, CB, SEQ, FULL, CEN>), dim3(grid), dim3(kWsWaves * 64), ws_lds_bytes(a), stream, p, g, a);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
-/* The pipelined unit loop (two patch buffers per wave) is the product's; the one-buffer loop it replaces exists in
- * measurement builds only, for the A/B (QNNP_CONV_WS_PIPE=0). */
 template <int TN, int CB>
 int launch_ws(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hipStream_t stream)
 {
   int rc = QNNP_HIP_EINVAL;
-  bool pipe = false;             // (measured level-to-slower and its counted waits do not hold at full size: never the product's)
-#ifdef QNNP_ENABLE_ABLATION
-  if (const char* env = getenv("QNNP_CONV_WS_PIPE")) pipe = atoi(env) != 0;
-#endif
   requant_dispatch_lane(p.rq, p.lane, [&](auto seq, auto full) {
-#ifdef QNNP_ENABLE_ABLATION
-    if (pipe) {
-      if (p.a_flip != 0) rc = launch_ws_as<TN, CB, decltype(seq)::value, decltype(full)::value, true, true>(p, g, a, stream);
-      else rc = launch_ws_as<TN, CB, decltype(seq)::value, decltype(full)::value, false, true>(p, g, a, stream);
-      return;
-    }
-#endif
-    if (p.a_flip != 0) rc = launch_ws_as<TN, CB, decltype(seq)::value, decltype(full)::value, true, false>(p, g, a, stream);
-    else rc = launch_ws_as<TN, CB, decltype(seq)::value, decltype(full)::value, false, false>(p, g, a, stream);
+    if (p.a_flip != 0) rc = launch_ws_as<TN, CB, decltype(seq)::value, decltype(full)::value, true>(p, g, a, stream);
+    else rc = launch_ws_as<TN, CB, decltype(seq)::value, decltype(full)::value, false>(p, g, a, stream);
   });
-  (void) pipe;
   return rc;
 }
 
@@ -1445,7 +1260,7 @@ int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hip
     bool ok = false;
     const WaveArgs ar = reg_args<1>(a, p, g, batch, &ok);
     const uint64_t in_bytes = static_cast<uint64_t>(batch) * p.image_stride;    // (32-bit buffer offsets)
-    if (ok && in_bytes < (UINT64_C(1) << 31) && ws_lds_bytes(ar, true, p.kc) <= kLdsLimit) {
+    if (ok && in_bytes < (UINT64_C(1) << 31) && ws_lds_bytes(ar) <= kLdsLimit) {
       const IgemmParams& pw = centred != nullptr ? *centred : p;
       *name = centred != nullptr ? "q8_conv_wave_ws_c_mfma" : "q8_conv_wave_ws_mfma";
       if (p.kc == 32) return p.n == 32 ? launch_ws<1, 1>(pw, g, ar, stream) : launch_ws<2, 1>(pw, g, ar, stream);

@@ -22,7 +22,7 @@ pro = t[256:512, 0, :7]
 ok = pro[:, 0] > 0
 pro = pro[ok]
 d = np.diff(pro, axis=1)
-names = ["entry->patch requested", "->weights requested", "->patch in LDS", "->barrier passed", "->weights in registers", "->loop done"]
+names = ["entry->weights requested", "->patch requested", "->patch in LDS", "->barrier passed", "->weights in registers", "->loop done"]
 print(f"{ok.sum()} workgroups, wave 0, mean / median / max cycles:")
 for i, nm in enumerate(names):
     print(f"  {nm:26s} {d[:, i].mean():9.0f} {np.median(d[:, i]):9.0f} {d[:, i].max():9.0f}")
