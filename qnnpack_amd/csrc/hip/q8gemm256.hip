@@ -906,14 +906,32 @@ bool gemm256_lean_supported(const IgemmParams& p)
 
 int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, bool waves4, bool rows128, bool pingpong, int lean)
 {
-  const uint32_t bm = rows128 ? 128u : 256u;
-  const uint32_t tiles_m = (p.rows + bm - 1) / bm;
   const uint32_t tiles_n = (p.n_pad + kBN - 1) / kBN;
-  const dim3 grid(tiles_m * tiles_n, groups, 1);
   const bool conv = p.offsets != nullptr;
+  // 128 x 256 tiles (four waves, two workgroups per CU): lost the A/B on the 4096^3 GEMM, but a problem whose 256-row
+  // tiling does not even give every CU one workgroup (ResNet's 14x14 / 7x7 layers at batch 128: 98 or 50 tiles on 256 CUs)
+  // is bounded by that, not by the loop -- round 5, profiles/r05: 3x3 256 -> 256 at 14x14 43 -> 2x us
+  bool underfilled = false;
+#ifdef QNNP_ENABLE_ABLATION
+  const char* env_fill = getenv("QNNP_GEMM_ROWS128_AUTO");
+  const bool fill_auto = env_fill == nullptr || atoi(env_fill) != 0;
+#else
+  const bool fill_auto = true;
+#endif
+  if (fill_auto && !waves4 && !pingpong && !rows128 && lean <= 1) {
+    const uint64_t tiles256 = static_cast<uint64_t>((p.rows + 255u) / 256u) * tiles_n * groups;
+    underfilled = tiles256 < p.cu_count && p.rows > 128u;
+  }
+  const uint32_t bm = (rows128 || underfilled) ? 128u : 256u;
+  const uint32_t tiles_m = (p.rows + bm - 1) / bm;
+  const dim3 grid(tiles_m * tiles_n, groups, 1);
+  if (underfilled) {
+    *name = conv ? "q8_gemm_mfma_128x256_conv" : "q8_gemm_mfma_128x256";
+    return conv ? launch256<true, 2, 128>(p, grid, stream) : launch256<false, 2, 128>(p, grid, stream);
+  }
 #ifndef QNNP_ENABLE_ABLATION
-  // The structures that LOST their A/B (profiles/r03/gemm_structures_ab_r03a.txt: 4 waves of 128 x 128, 128 x 256 tiles with
-  // two workgroups per CU, the ping-pong schedule) are evidence, not product: measurement builds only.
+  // The structures that LOST their A/B (profiles/r03/gemm_structures_ab_r03a.txt: 4 waves of 128 x 128, forced 128 x 256
+  // tiles, the ping-pong schedule) are evidence, not product: measurement builds only.
   if (waves4 || rows128 || pingpong) return QNNP_HIP_EINVAL;
 #else
   if (rows128) {
