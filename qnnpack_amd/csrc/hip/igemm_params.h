@@ -103,6 +103,10 @@ bool convwave_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups
 int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipStream_t stream, const char** name, int flavour,
                     const IgemmParams* centred = nullptr);
 
+/* q8convpatch.hip: dense 3x3 with 64 .. 512 input channels and output channels in multiples of 128 */
+bool convpatch_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32_t vec, uint32_t batch);
+int convpatch_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipStream_t stream, const char** name);
+
 /* q8pwconv.hip */
 bool pwstream_supported(const IgemmParams& p, uint32_t groups, uint32_t vec);
 int pwstream_launch(const IgemmParams& p, uint32_t vec, hipStream_t stream, const char** name);

@@ -650,6 +650,16 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
     if (kernel_name != nullptr) *kernel_name = name;
     return rc_wave;
   }
+  // Dense 3x3 with many channels (ResNet's 128 / 256 / 512-channel layers): patch in LDS, weights streamed (q8convpatch.hip);
+  // "gemm_kernel" = 22 forces it, 1 / 2 / 3 keep the kernels it replaces.
+  const bool patch_ok = a->offsets != nullptr && !pad3 && a->rows_per_image > 0 &&
+      qnnp::convpatch_supported(p, geom, a->groups, vec, a->rows / a->rows_per_image);
+  if (a->variant == 22 && !patch_ok) return QNNP_HIP_EINVAL;
+  if (patch_ok && (a->variant == 22 || (a->variant == 0 && a->rows >= 4096u))) {
+    const int rc_patch = qnnp::convpatch_launch(p, geom, a->rows / a->rows_per_image, stream, &name);
+    if (kernel_name != nullptr) *kernel_name = name;
+    return rc_patch;
+  }
   if (a->variant == 3 && !lds_ok) return QNNP_HIP_EINVAL;
   if (lds_ok && (a->variant == 3 || (a->variant == 0 && a->kernel_height * a->kernel_width > 1))) {
     const int rc_lds = qnnp::convlds_launch(p, geom, a->rows / a->rows_per_image, stream, &name);
