@@ -51,8 +51,6 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int kPtWaves = 8;
-constexpr int kPtThreads = kPtWaves * 64;
 constexpr uint32_t pt_stages(int kstep) { return kstep == 128 ? 2u : 4u; }   // ring slots by bytes of K per step
 constexpr uint32_t kPtFlip = 0x80808080u;
 constexpr uint32_t kPtLdsLimit = 160 * 1024;
@@ -139,10 +137,16 @@ __device__ __forceinline__ void pt_ds_write4(uint32_t off, int32_t v)
  *       4 (4 x 2, <= 256 positions). */
 /* KSTEP = bytes of K per ring step and barrier: 128 (two ring slots, one step ahead: 16 MFMAs per wave between barriers) or
  *         64 (four slots, three steps ahead; the only choice for 64 input channels). */
-template <int NTB, int KSTEP, int SEQ, bool FULL>
-__global__ __launch_bounds__(kPtThreads, 2)
+/* MB = 32-position blocks of the tile (4 or 8). The workgroup has MB * NTB / 4 waves, each 2 x 2 blocks: 8 waves for
+ *      (4, 8) and (8, 4); FOUR waves for (4, 4) -- half the ring, so that two workgroups share a CU where one 8-wave
+ *      workgroup with a 64 KiB ring would be alone: one's prologue, barriers and epilogue run under the other's multiplies. */
+template <int MB, int NTB, int KSTEP, int SEQ, bool FULL>
+__global__ __launch_bounds__(MB * NTB * 16, 2)
 void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs a)
 {
+  constexpr int kPtWaves = MB * NTB / 4;
+  constexpr int kPtThreads = kPtWaves * 64;
+  static_assert((MB == 4 || MB == 8) && (NTB == 4 || NTB == 8) && kPtWaves <= 8, "tile flavours");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [patch][pixel sums][bias][ring of weight steps]
   constexpr uint32_t kWNG = NTB / 2;                  // waves along channels
   constexpr int kSub = KSTEP / 32;                    // 32-deep sub-steps (MFMA K) per step: 4 or 2
@@ -240,30 +244,31 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
   asm volatile("s_barrier" ::: "memory");
   PT_STAMP(2);
 
-  // ---- one pass over the landed patch, a thread per pixel: re-centre in place (a ^ 0x80), the pixel's channel sum (of a') beside it
+  // ---- one pass over the landed patch, four threads per pixel (a quarter of its chunks each): re-centre in place (a ^ 0x80),
+  //      the pixel's channel sum (of a') beside it
   if (!(abl & 32u)) {
     const bool sums = p.row_coeff != 0;
-    for (uint32_t q = tid; q < a.ppix; q += kPtThreads) {
-      const uint32_t base = lds0 + q * ps;
+    const uint32_t per = cpp >> 2;                    // chunks per thread: 1 .. 8
+    for (uint32_t t = tid; t < a.ppix * 4u; t += kPtThreads) {
+      const uint32_t q = t >> 2;
+      const uint32_t mine = q * ps + (t & 3u) * per * 16u;
       uint32_t s = 0;
-      for (uint32_t c = 0; c < cpp; c += 4u) {
-        v4i x[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) x[j] = *reinterpret_cast<const v4i*>(lds + q * ps + (c + j) * 16u);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          if (sums) {
-            s = __builtin_amdgcn_sad_u8(x[j].x, 0u, s);
-            s = __builtin_amdgcn_sad_u8(x[j].y, 0u, s);
-            s = __builtin_amdgcn_sad_u8(x[j].z, 0u, s);
-            s = __builtin_amdgcn_sad_u8(x[j].w, 0u, s);
-          }
-          x[j].x ^= static_cast<int>(kPtFlip); x[j].y ^= static_cast<int>(kPtFlip);
-          x[j].z ^= static_cast<int>(kPtFlip); x[j].w ^= static_cast<int>(kPtFlip);
-          pt_ds_write16(base + (c + j) * 16u, x[j]);
+      for (uint32_t c = 0; c < per; c++) {
+        v4i x = *reinterpret_cast<const v4i*>(lds + mine + c * 16u);
+        if (sums) {
+          s = __builtin_amdgcn_sad_u8(x.x, 0u, s);
+          s = __builtin_amdgcn_sad_u8(x.y, 0u, s);
+          s = __builtin_amdgcn_sad_u8(x.z, 0u, s);
+          s = __builtin_amdgcn_sad_u8(x.w, 0u, s);
         }
+        x.x ^= static_cast<int>(kPtFlip); x.y ^= static_cast<int>(kPtFlip); x.z ^= static_cast<int>(kPtFlip); x.w ^= static_cast<int>(kPtFlip);
+        pt_ds_write16(lds0 + mine + c * 16u, x);
       }
-      if (sums) pt_ds_write4(lds0 + a.pix_off + q * 4u, static_cast<int32_t>(s) - 128 * static_cast<int32_t>(C));
+      if (sums) {
+        s += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(s), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+        s += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(s), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+        if ((t & 3u) == 0u) pt_ds_write4(lds0 + a.pix_off + q * 4u, static_cast<int32_t>(s) - 128 * static_cast<int32_t>(C));
+      }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -429,48 +434,38 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
 #undef PT_STAMP
 }
 
-template <int NTB, int KSTEP, int SEQ, bool FULL>
+template <int MB, int NTB, int KSTEP, int SEQ, bool FULL>
 int launch_patch_as(const IgemmParams& p, const ConvGeom& g, const PatchArgs& a, uint32_t lds_bytes, hipStream_t stream)
 {
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
   if (auto once_scope = attr_once.begin()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_patch_kernel<NTB, KSTEP, SEQ, FULL>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_patch_kernel<MB, NTB, KSTEP, SEQ, FULL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kPtLdsLimit)) != hipSuccess) {
       (void) hipGetLastError();
     }
   }
-  hipLaunchKernelGGL((q8_conv_patch_kernel<NTB, KSTEP, SEQ, FULL>), dim3(a.tiles_m * a.tiles_n), dim3(kPtThreads), lds_bytes, stream, p, g, a);
+  hipLaunchKernelGGL((q8_conv_patch_kernel<MB, NTB, KSTEP, SEQ, FULL>), dim3(a.tiles_m * a.tiles_n), dim3(MB * NTB * 16), lds_bytes, stream, p, g, a);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
-/* Tile geometry and LDS plan, or false when the shape is outside the kernel's range. */
-bool plan_patch(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32_t vec, uint32_t batch, PatchArgs* a, uint32_t* ntb,
-                uint32_t* lds_bytes)
+/* Tile geometry and LDS plan of one flavour (mb position blocks x ntb channel blocks), or false when it does not fit. */
+bool plan_flavour(const IgemmParams& p, const ConvGeom& g, uint32_t batch, uint32_t mb, uint32_t ntb, PatchArgs* a, uint32_t* lds_bytes)
 {
-  if (groups != 1 || vec != 16 || p.fill_table == nullptr || p.offsets == nullptr || batch == 0) return false;
-  if (g.KH != 3 || g.KW != 3 || g.dh != 1 || g.dw != 1 || g.sh != g.sw || g.sh == 0 || g.sh > 2) return false;
   const uint32_t C = p.kc;
-  if (!(C == 64 || C == 128 || C == 256 || C == 512)) return false;
-  if (p.k_total != 9u * C || p.k_pad != p.k_total) return false;
-  if (p.n != p.n_pad || p.n % 128u != 0 || p.store_mode != 2) return false;
-  if (g.OW == 0 || g.OH == 0 || g.OW > 128u || p.rows != batch * g.OH * g.OW) return false;
-  const uint64_t out_bytes = static_cast<uint64_t>(p.rows - 1u) * p.output_stride + p.n;
-  if (out_bytes >= (UINT64_C(1) << 31) - 512u) return false;
-  *ntb = p.n % 256u == 0 ? 8u : 4u;
-  const uint32_t pmax = *ntb == 8u ? 128u : 256u;
+  const uint32_t pmax = mb * 32u;
   const uint32_t cpp = C >> 4;
+  if (p.n % (ntb * 32u) != 0 || g.OW > pmax) return false;
   uint32_t imgs = 1, rows = g.OH;
   if (g.OH * g.OW <= pmax) {
     imgs = pmax / (g.OH * g.OW);
     if (imgs > batch) imgs = batch;
   } else {
     rows = pmax / g.OW;
-    if (rows == 0) return false;
     const uint32_t tiles_r = (g.OH + rows - 1) / rows;
     rows = (g.OH + tiles_r - 1) / tiles_r;            // even rows per tile
   }
   const uint32_t kstep = C % 128u == 0 ? 128u : 64u;
-  const uint32_t ring = pt_stages(static_cast<int>(kstep)) * *ntb * (kstep / 32u) * 1024u;
+  const uint32_t ring = pt_stages(static_cast<int>(kstep)) * ntb * (kstep / 32u) * 1024u;
   for (;;) {
     a->imgs = imgs; a->rows = rows;
     a->pr = (rows - 1u) * g.sh + 3u;
@@ -481,7 +476,7 @@ bool plan_patch(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32
     const uint32_t patch_bytes = ((a->chunks + 63u) / 64u) * 1024u;
     a->pix_off = patch_bytes;
     a->bias_off = a->pix_off + ((a->ppix * 4u + 15u) & ~15u);
-    a->ring_off = (a->bias_off + *ntb * 128u + 1023u) & ~1023u;
+    a->ring_off = (a->bias_off + ntb * 128u + 1023u) & ~1023u;
     *lds_bytes = a->ring_off + ring;
     if (*lds_bytes <= kPtLdsLimit) break;
     if (imgs > 1) imgs--;                              // fewer images, then fewer rows, per tile
@@ -492,12 +487,13 @@ bool plan_patch(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32
   a->pos = a->imgs * a->rows * g.OW;
   a->tiles_r = a->imgs > 1 ? 1u : (g.OH + a->rows - 1u) / a->rows;
   a->tiles_m = a->imgs > 1 ? (batch + a->imgs - 1u) / a->imgs : batch * a->tiles_r;
-  a->tiles_n = p.n / (*ntb * 32u);
+  a->tiles_n = p.n / (ntb * 32u);
   if (static_cast<uint64_t>(a->tiles_m) * a->tiles_n >= (UINT64_C(1) << 31)) return false;
-  // the reciprocal divisions are exact while dividend * divisor < 2^32: the operands are tile ids (< 2^31 / tiles_n ...),
-  // positions (< 256) and patch pixels (< 2^16)
+  // the reciprocal divisions are exact while dividend * divisor < 2^32: the operands are tile ids, positions (< 256) and
+  // patch chunks (< 2^16)
   if (static_cast<uint64_t>(a->tiles_m) * a->tiles_n * a->tiles_n >= (UINT64_C(1) << 32)) return false;
   if (static_cast<uint64_t>(a->tiles_m) * a->tiles_r >= (UINT64_C(1) << 32)) return false;
+  if (a->chunks >= 65536u) return false;
   a->inv_ow = pt_magic(g.OW);
   a->inv_rw = pt_magic(a->rows * g.OW);
   a->inv_pw = pt_magic(a->pw);
@@ -505,7 +501,7 @@ bool plan_patch(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32
   a->inv_tiles_r = pt_magic(a->tiles_r);
   a->inv_tiles_n = pt_magic(a->tiles_n);
   a->ps = C + 16u;
-  a->inv_cpp1 = pt_magic(cpp + 1u);                   // (chunk indices stay below 2^16: exact)
+  a->inv_cpp1 = pt_magic(cpp + 1u);
   a->csteps = C / kstep;
   a->ksteps = 9u * a->csteps;
   a->abl = 0;
@@ -515,6 +511,41 @@ bool plan_patch(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32
   return true;
 }
 
+/* The flavour of a shape: (8, 4) for output channels in odd multiples of 128; otherwise (4, 8), or the four-wave (4, 4) when
+ * (4, 8) would launch fewer workgroups than the chip has CUs. */
+bool plan_patch(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32_t vec, uint32_t batch, PatchArgs* a, uint32_t* mb,
+                uint32_t* ntb, uint32_t* lds_bytes)
+{
+  if (groups != 1 || vec != 16 || p.fill_table == nullptr || p.offsets == nullptr || batch == 0) return false;
+  if (g.KH != 3 || g.KW != 3 || g.dh != 1 || g.dw != 1 || g.sh != g.sw || g.sh == 0 || g.sh > 2) return false;
+  const uint32_t C = p.kc;
+  if (!(C == 64 || C == 128 || C == 256 || C == 512)) return false;
+  if (p.k_total != 9u * C || p.k_pad != p.k_total) return false;
+  if (p.n != p.n_pad || p.n % 128u != 0 || p.store_mode != 2) return false;
+  if (g.OW == 0 || g.OH == 0 || p.rows != batch * g.OH * g.OW) return false;
+  const uint64_t out_bytes = static_cast<uint64_t>(p.rows - 1u) * p.output_stride + p.n;
+  if (out_bytes >= (UINT64_C(1) << 31) - 512u) return false;
+  uint32_t forced = 0;
+#ifdef QNNP_ENABLE_ABLATION
+  if (const char* env = getenv("QNNP_PATCH_TILE")) forced = static_cast<uint32_t>(atoi(env));   // 84, 44 or 48 = (mb, ntb)
+#endif
+  if (forced != 0) {
+    *mb = forced / 10u; *ntb = forced % 10u;
+    return ((*mb == 8 && *ntb == 4) || (*mb == 4 && (*ntb == 4 || *ntb == 8))) && plan_flavour(p, g, batch, *mb, *ntb, a, lds_bytes);
+  }
+  if (p.n % 256u != 0) { *mb = 8; *ntb = 4; return plan_flavour(p, g, batch, 8, 4, a, lds_bytes); }
+  // (same box, interleaved -- profiles/r05/conv_patch_tile_flavours_ab_r05piter4.txt: two four-wave workgroups per CU LOSE to one
+  //  eight-wave workgroup on 14x14 256 -> 256, 22.4 against 24.3 us, and on the stride-2 rows; they win where the eight-wave
+  //  tiling leaves CUs without a workgroup: 7x7 512 -> 512, 128 workgroups on 256 CUs, 32.8 -> 28.8 us)
+  *mb = 4; *ntb = 8;
+  const bool wide = plan_flavour(p, g, batch, 4, 8, a, lds_bytes);
+  if (wide && static_cast<uint64_t>(a->tiles_m) * a->tiles_n >= p.cu_count) return true;
+  PatchArgs narrow;
+  uint32_t narrow_lds = 0;
+  if (plan_flavour(p, g, batch, 4, 4, &narrow, &narrow_lds)) { *a = narrow; *lds_bytes = narrow_lds; *ntb = 4; return true; }
+  return wide;
+}
+
 }  // namespace
 
 /* dense 3x3 (stride 1 or 2, dilation 1), one group, 64 / 128 / 256 / 512 input channels, output channels a multiple of
@@ -522,24 +553,28 @@ bool plan_patch(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32
 bool convpatch_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32_t vec, uint32_t batch)
 {
   PatchArgs a;
-  uint32_t ntb = 0, lds_bytes = 0;
-  return plan_patch(p, g, groups, vec, batch, &a, &ntb, &lds_bytes);
+  uint32_t mb = 0, ntb = 0, lds_bytes = 0;
+  return plan_patch(p, g, groups, vec, batch, &a, &mb, &ntb, &lds_bytes);
 }
 
 int convpatch_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipStream_t stream, const char** name)
 {
   PatchArgs a;
-  uint32_t ntb = 0, lds_bytes = 0;
-  if (!plan_patch(p, g, 1, 16, batch, &a, &ntb, &lds_bytes)) return QNNP_HIP_EINVAL;
+  uint32_t mb = 0, ntb = 0, lds_bytes = 0;
+  if (!plan_patch(p, g, 1, 16, batch, &a, &mb, &ntb, &lds_bytes)) return QNNP_HIP_EINVAL;
   *name = "q8_conv_patch_mfma";
   int rc = QNNP_HIP_EINVAL;
   requant_dispatch_lane(p.rq, p.lane, [&](auto seq, auto full) {
     constexpr int kSeq = decltype(seq)::value;
     constexpr bool kFull = decltype(full)::value;
     if (p.kc % 128u == 0) {
-      rc = ntb == 8u ? launch_patch_as<8, 128, kSeq, kFull>(p, g, a, lds_bytes, stream) : launch_patch_as<4, 128, kSeq, kFull>(p, g, a, lds_bytes, stream);
+      if (mb == 8u) rc = launch_patch_as<8, 4, 128, kSeq, kFull>(p, g, a, lds_bytes, stream);
+      else if (ntb == 8u) rc = launch_patch_as<4, 8, 128, kSeq, kFull>(p, g, a, lds_bytes, stream);
+      else rc = launch_patch_as<4, 4, 128, kSeq, kFull>(p, g, a, lds_bytes, stream);
     } else {
-      rc = ntb == 8u ? launch_patch_as<8, 64, kSeq, kFull>(p, g, a, lds_bytes, stream) : launch_patch_as<4, 64, kSeq, kFull>(p, g, a, lds_bytes, stream);
+      if (mb == 8u) rc = launch_patch_as<8, 4, 64, kSeq, kFull>(p, g, a, lds_bytes, stream);
+      else if (ntb == 8u) rc = launch_patch_as<4, 8, 64, kSeq, kFull>(p, g, a, lds_bytes, stream);
+      else rc = launch_patch_as<4, 4, 64, kSeq, kFull>(p, g, a, lds_bytes, stream);
     }
   });
   return rc;
