@@ -328,6 +328,24 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
         qnnp_log_error("failed to place %zu bytes of packed weights on the device", r_bytes);
         goto error;
       }
+    } else if (kc_slot == 4 && (kernel_height == 5 || kernel_height == 7) && kernel_width * 3 <= 32 &&
+               dilation_height == 1 && dilation_width == 1 && n_pad <= 64) {
+      /* ... and with 32-byte row slots for the larger windows (5x5, ResNet's 7x7 entry layer): same pointer, the window
+       * decides which image it is (hip/q8convc3.hip) */
+      const size_t r_bytes = qnnp_conv_rows32_size(n_pad, kernel_height);
+      int8_t* host_rows = (int8_t*) malloc(r_bytes);
+      if (host_rows == NULL) {
+        qnnp_log_error("failed to allocate %zu bytes for packed weights", r_bytes);
+        goto error;
+      }
+      qnnp_pack_conv_rows32((uint32_t) group_output_channels, kernel_height, kernel_width, 3, n_pad, kernel, host_rows);
+      op->d_weights_rows16 = qnnp_hip_alloc(r_bytes);
+      const int placed = op->d_weights_rows16 != NULL && qnnp_hip_h2d(op->d_weights_rows16, host_rows, r_bytes, 0) == QNNP_HIP_OK;
+      free(host_rows);
+      if (!placed) {
+        qnnp_log_error("failed to place %zu bytes of packed weights on the device", r_bytes);
+        goto error;
+      }
     }
   }
   free(host_weights);

@@ -353,6 +353,218 @@ int launch_c3rows(const IgemmParams& p, const C3Geom& cg, hipStream_t stream)
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
+/*
+ * The same idea for LARGER windows (round 5): K = [ky][32-byte row slot] -- K block ky is kernel row ky, a lane's operand half
+ * h is bytes 16 h .. 16 h + 15 of that row's slot: KR = kernel_height fetches of 16 bytes per lane and unit instead of two.
+ * ResNet's entry layer (bench/convolution.cc:646, 224x224x3 -> 112x112x64, 7x7 stride 2: 21 bytes per window row) ran 307 us
+ * on the offset-table tile kernel (profiles/r05/bench_r05a.json: 0.05 of its HBM bound); this is one tenth of that.
+ * Differences from q8_conv_c3rows_kernel above, all of them simplifications:
+ *   - every fetch is dword-aligned (address & ~3) and moved into place with v_alignbyte; the launcher requires the tensor's
+ *     size to be a multiple of four bytes, so no dword straddles its end and the first / last image need no special path:
+ *     what lies outside the tensor is padding, fetched as zeros and replaced like every out-of-image tap;
+ *   - the kernel-zero-point row term is VALU work (v_dot4_u32_u8 of the raw bytes against a 0 / 1 mask of the slot's real
+ *     bytes, the two halves joined by v_permlane32_swap): KR more MFMAs per channel block would double the matrix time here;
+ *   - one set of slot registers: the next unit's fetches are issued as soon as the MFMAs have consumed the current ones and
+ *     fly under the epilogue.
+ */
+template <int NB, int KR, int SEQ, bool FULL>
+__global__ __launch_bounds__(kC3Threads, 2)
+void q8_conv_c3rows32_kernel(const IgemmParams p, const C3Geom cg)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t px = lane & 31u;
+  const uint32_t h = lane >> 5;
+  const uint32_t prow = px >> 4, pcol = px & 15u;
+  const uint32_t kbytes = cg.KW * 3u;                       // real bytes of a row slot (<= 32; launcher)
+  const int32_t nreal = static_cast<int32_t>(kbytes) - 16 * static_cast<int32_t>(h);   // ... of this lane's half (may be <= 0)
+
+  v4i w[NB][KR];
+  v16i bias[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++) {
+#pragma unroll
+    for (int kb = 0; kb < KR; kb++) w[nb][kb] = *reinterpret_cast<const v4i*>(cg.w_rows16 + ((nb * KR + kb) * 64u + lane) * 16u);
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const v4i b = *reinterpret_cast<const v4i*>(p.bias2 + nb * 32 + rg * 8 + h * 4);
+      bias[nb][rg * 4 + 0] = with_rq_offset<SEQ>(b.x); bias[nb][rg * 4 + 1] = with_rq_offset<SEQ>(b.y);
+      bias[nb][rg * 4 + 2] = with_rq_offset<SEQ>(b.z); bias[nb][rg * 4 + 3] = with_rq_offset<SEQ>(b.w);
+    }
+  }
+  uint32_t ones[4];                                         // 0x01 in every REAL byte of this lane's half: the row sum's weights
+#pragma unroll
+  for (int d = 0; d < 4; d++) ones[d] = byte_range_mask(0 - 4 * d, nreal - 4 * d) & 0x01010101u;
+
+  const uint32_t in_bytes = static_cast<uint32_t>(p.input_end - p.input);          // (launcher: < 2^31, a multiple of 4)
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.input), 0, static_cast<int>(in_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.output, 0, static_cast<int>((p.rows - 1u) * p.output_stride + p.n), 0x00020000);   // (launcher: < 2^31)
+
+  const uint32_t row_bytes = cg.W * 3u;
+  const uint32_t lane_in = prow * cg.sh * row_bytes + pcol * cg.sw * 3u + h * 16u;   // this lane's half of row slot 0, relative to the unit's first window
+  const uint32_t lane_out = (prow * cg.OW + pcol) * p.output_stride + h * 16u;
+  const uint32_t fill4 = (p.izp_fill & 0xFFu) * 0x01010101u;
+  const int32_t total_real = static_cast<int32_t>(kbytes * cg.KH);
+
+  struct Where { uint32_t origin, out0; int32_t iy0, ix0; uint32_t rows_left, cols_left; bool border, slow; };   // (wave-uniform)
+  auto locate = [&](uint32_t unit) __attribute__((always_inline)) -> Where {
+    const uint32_t t = div_magic(unit, cg.inv_segs);
+    const uint32_t seg = unit - t * cg.segs;
+    const uint32_t img = div_magic(t, cg.inv_pairs);
+    const uint32_t pair = t - img * cg.pairs;
+    const uint32_t oy = pair * 2u, ox = seg * 16u;
+    Where u;
+    u.iy0 = static_cast<int32_t>(oy * cg.sh) - static_cast<int32_t>(cg.pad_top);
+    u.ix0 = static_cast<int32_t>(ox * cg.sw) - static_cast<int32_t>(cg.pad_left);
+    u.rows_left = cg.OH - oy;
+    u.cols_left = cg.OW - ox;
+    u.out0 = ((img * cg.OH + oy) * cg.OW + ox) * p.output_stride;
+    // byte offset of the unit's first window inside the tensor, modulo 2^32 ("negative" = beyond the descriptor's range: zeros)
+    u.origin = img * static_cast<uint32_t>(p.image_stride) + static_cast<uint32_t>(u.iy0 * static_cast<int32_t>(cg.W) + u.ix0) * 3u;
+    const int32_t iy_last = u.iy0 + static_cast<int32_t>(cg.sh + cg.KH) - 1;
+    const int32_t ix_last = u.ix0 + static_cast<int32_t>(15u * cg.sw + cg.KW) - 1;
+    u.border = u.iy0 < 0 || u.ix0 < 0 || iy_last >= static_cast<int32_t>(cg.H) || ix_last >= static_cast<int32_t>(cg.W);
+    // the first windows of the first image start BEFORE the tensor: a fetch from a "negative" offset returns zeros for all
+    // sixteen bytes, the real pixels behind the tensor's first byte included -- those few units fetch from offset >= 0 and
+    // shift (below)
+    u.slow = static_cast<int32_t>(u.origin) < 0;
+    return u;
+  };
+  struct Slots { v4i x[KR]; uint32_t tail[KR]; uint32_t shifts; };     // shifts: 2 bits per row, bytes by which the fetch address was rounded down
+  auto fetch = [&](const Where& u, Slots& s) __attribute__((always_inline)) {
+    uint32_t shifts = 0;
+#pragma unroll
+    for (int kb = 0; kb < KR; kb++) {
+      uint32_t addr = u.origin + lane_in + kb * row_bytes;
+      if (u.slow) addr = static_cast<uint32_t>(max(static_cast<int32_t>(addr), 0));       // (scalar branch; byte-aligned fetch, no tail needed)
+      else { shifts |= (addr & 3u) << (2 * kb); addr &= ~3u; }
+      s.x[kb] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, addr, 0, 0));
+      s.tail[kb] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, addr + 16u, 0, 0);
+    }
+    s.shifts = shifts;
+  };
+
+  const uint32_t units = (p.rows / (cg.OH * cg.OW)) * cg.pairs * cg.segs;
+  const uint32_t unit_stride = gridDim.x * kC3Waves;
+  uint32_t unit = blockIdx.x * kC3Waves + wave;
+  if (unit >= units) return;
+
+  Where here = locate(unit);
+  Slots s;
+  fetch(here, s);
+  for (;;) {
+    // ---- the slots into place; out-of-image taps -> the zero point; row sum of the raw bytes; re-centre
+    uint32_t sum = 0;
+    const int32_t ixl = here.ix0 + static_cast<int32_t>(pcol * cg.sw);
+    const int32_t iyl = here.iy0 + static_cast<int32_t>(prow * cg.sh);
+    const int32_t left = ixl < 0 ? -ixl : 0;                                                  // pixels
+    const int32_t right = ixl + static_cast<int32_t>(cg.KW) - static_cast<int32_t>(cg.W);     // > 0: pixels past the row
+    const int32_t lo = 3 * left - 16 * static_cast<int32_t>(h);
+    const int32_t hi = static_cast<int32_t>(kbytes) - 3 * (right > 0 ? right : 0) - 16 * static_cast<int32_t>(h);
+    uint32_t keep_cols[4] = {~0u, ~0u, ~0u, ~0u};          // bytes of this half that are pixels of the image row (the same for every kernel row)
+    if (here.border) {
+#pragma unroll
+      for (int d = 0; d < 4; d++) keep_cols[d] = byte_range_mask(lo - 4 * d, hi - 4 * d);
+    }
+#pragma unroll
+    for (int kb = 0; kb < KR; kb++) {
+      const uint32_t shb = __builtin_amdgcn_ubfe(s.shifts, 2 * kb, 2);
+      const uint32_t d0 = static_cast<uint32_t>(s.x[kb].x), d1 = static_cast<uint32_t>(s.x[kb].y);
+      const uint32_t d2 = static_cast<uint32_t>(s.x[kb].z), d3 = static_cast<uint32_t>(s.x[kb].w);
+      uint32_t x[4] = {__builtin_amdgcn_alignbyte(d1, d0, shb), __builtin_amdgcn_alignbyte(d2, d1, shb),
+                       __builtin_amdgcn_alignbyte(d3, d2, shb), __builtin_amdgcn_alignbyte(s.tail[kb], d3, shb)};
+      if (here.slow) {                                     // (scalar; a handful of units per launch) loaded byte i is slot byte i + delta
+        const int32_t want = static_cast<int32_t>(here.origin + lane_in + kb * row_bytes);
+        const uint32_t delta = want < 0 ? static_cast<uint32_t>(min(-want, 16)) : 0u;
+        uint64_t l64 = d0 | (static_cast<uint64_t>(d1) << 32), h64 = d2 | (static_cast<uint64_t>(d3) << 32);
+        const uint32_t sh = 8u * delta;
+        if (sh >= 128u) { l64 = 0; h64 = 0; }
+        else if (sh >= 64u) { h64 = l64 << (sh - 64u); l64 = 0; }
+        else if (sh != 0u) { h64 = (h64 << sh) | (l64 >> (64u - sh)); l64 <<= sh; }
+        x[0] = static_cast<uint32_t>(l64); x[1] = static_cast<uint32_t>(l64 >> 32);
+        x[2] = static_cast<uint32_t>(h64); x[3] = static_cast<uint32_t>(h64 >> 32);
+      }
+      if (here.border) {                                   // (scalar)
+        const bool row_out = static_cast<uint32_t>(iyl + kb) >= cg.H;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          const uint32_t keep = row_out ? 0u : keep_cols[d];
+          x[d] = (x[d] & keep) | (fill4 & ~keep);
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        sum = __builtin_amdgcn_udot4(x[d], ones[d], sum, false);
+        x[d] ^= kFlip;
+      }
+      s.x[kb] = v4i{static_cast<int>(x[0]), static_cast<int>(x[1]), static_cast<int>(x[2]), static_cast<int>(x[3])};
+    }
+    // ---- the multiplies; then the next unit's fetches, into the registers they have just left
+    v16i acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      acc[nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[nb][0], s.x[0], bias[nb], 0, 0, 0);
+#pragma unroll
+      for (int kb = 1; kb < KR; kb++) acc[nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[nb][kb], s.x[kb], acc[nb], 0, 0, 0);
+    }
+    const Where done = here;
+    const bool more = unit + unit_stride < units;
+    if (more) {
+      unit += unit_stride;
+      here = locate(unit);
+      fetch(here, s);
+    }
+    // ---- epilogue of the unit just multiplied: row term, Q31 requantization, 16-byte stores
+    int32_t rowterm = 0;
+    if (p.row_coeff != 0) {
+      const auto both = __builtin_amdgcn_permlane32_swap(sum, sum, false, false);          // (the other half's sum)
+      const int32_t total = static_cast<int32_t>(both[0] + both[1]) - 128 * total_real;    // sum of a' over the real K positions
+      rowterm = p.row_coeff * total;
+    }
+    const bool pixel_ok = prow < done.rows_left && pcol < done.cols_left;
+    const uint32_t out_off = done.out0 + lane_out;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      uint32_t pk[4];
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        pk[rg] = q31_requantize_pack4<SEQ, FULL>(add_wrap(acc[nb][rg * 4 + 0], rowterm), add_wrap(acc[nb][rg * 4 + 1], rowterm),
+                                                add_wrap(acc[nb][rg * 4 + 2], rowterm), add_wrap(acc[nb][rg * 4 + 3], rowterm), p.rq);
+      }
+      const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+      const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+      const v4i v = {static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
+      const bool ok = pixel_ok && nb * 32u + h * 16u < p.n;          // (n % 16 == 0: launcher)
+      if (p.stream_out) {
+        __builtin_amdgcn_raw_buffer_store_b128(
+            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc,
+            ok ? out_off + nb * 32u : 0xFFFFFFF0u, 0, 2);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(
+            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc,
+            ok ? out_off + nb * 32u : 0xFFFFFFF0u, 0, 0);
+      }
+    }
+    if (!more) break;
+  }
+}
+
+template <int NB, int KR>
+int launch_c3rows32(const IgemmParams& p, const C3Geom& cg, hipStream_t stream)
+{
+  const uint32_t units = (p.rows / (cg.OH * cg.OW)) * cg.pairs * cg.segs;
+  uint32_t grid = p.cu_count * 2u;                          // two 4-wave workgroups per CU (two waves per SIMD: ~200 registers)
+  const uint32_t needed = (units + kC3Waves - 1) / kC3Waves;
+  if (grid > needed) grid = needed;
+  requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+    hipLaunchKernelGGL((q8_conv_c3rows32_kernel<NB, KR, decltype(seq)::value, decltype(full)::value>), dim3(grid),
+                       dim3(kC3Threads), 0, stream, p, cg);
+  });
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
 }  // namespace
 
 /* dense 3-byte pixels, one group, window rows of <= 16 bytes and <= 4 rows, 32 or 64 output channels in whole 16-byte
@@ -398,6 +610,42 @@ int conv_c3rows_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_
   }
   if (wide) return two ? launch_c3rows<2, 4, 1>(p, cg, stream) : launch_c3rows<1, 4, 1>(p, cg, stream);
   return two ? launch_c3rows<2, 3, 1>(p, cg, stream) : launch_c3rows<1, 3, 1>(p, cg, stream);
+}
+
+/* the 32-byte-slot flavour: dense 3-byte pixels, one group, 5 or 7 window rows of <= 32 bytes, a tensor of whole dwords */
+bool conv_c3rows32_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, const int8_t* w_rows32, uint32_t real_kc)
+{
+  if (w_rows32 == nullptr || groups != 1 || real_kc != 3 || p.input_stride != 3) return false;
+  if (g.KW * 3u > 32u || !(g.KH == 5 || g.KH == 7) || g.dh != 1 || g.dw != 1) return false;
+  if (p.n_pad > 64 || p.n % 16u != 0 || p.output_stride % 16u != 0 || (reinterpret_cast<uintptr_t>(p.output) & 15u) != 0) return false;
+  if (p.rows == 0 || p.rows_per_image == 0 || g.OW == 0 || g.OH == 0 || p.rows_per_image != g.OH * g.OW) return false;
+  if (p.rows % p.rows_per_image != 0) return false;
+  const uint64_t in_bytes = static_cast<uint64_t>(p.input_end - p.input);
+  const uint64_t out_bytes = static_cast<uint64_t>(p.rows) * p.output_stride;
+  if (in_bytes < 16 || in_bytes % 4u != 0 || (reinterpret_cast<uintptr_t>(p.input) & 3u) != 0) return false;
+  if (in_bytes >= (UINT64_C(1) << 31) || out_bytes >= (UINT64_C(1) << 31)) return false;
+  if (p.image_stride != static_cast<uint64_t>(g.H) * g.W * 3u) return false;
+  const uint64_t segs = (g.OW + 15u) / 16u, pairs = (g.OH + 1u) / 2u;
+  const uint64_t units = static_cast<uint64_t>(p.rows / p.rows_per_image) * pairs * segs;
+  if (units * segs >= (UINT64_C(1) << 32) || units * pairs >= (UINT64_C(1) << 32)) return false;
+  return true;
+}
+
+int conv_c3rows32_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_rows32, hipStream_t stream, const char** name)
+{
+  C3Geom cg;
+  cg.H = g.H; cg.W = g.W; cg.OH = g.OH; cg.OW = g.OW; cg.KH = g.KH; cg.KW = g.KW; cg.sh = g.sh; cg.sw = g.sw;
+  cg.pad_top = g.pad_top; cg.pad_left = g.pad_left;
+  cg.segs = (g.OW + 15u) / 16u;
+  cg.pairs = (g.OH + 1u) / 2u;
+  cg.inv_segs = cg.segs > 1 ? static_cast<uint32_t>(((UINT64_C(1) << 32) + cg.segs - 1) / cg.segs) : 0u;
+  cg.inv_pairs = cg.pairs > 1 ? static_cast<uint32_t>(((UINT64_C(1) << 32) + cg.pairs - 1) / cg.pairs) : 0u;
+  cg.w_rows16 = w_rows32;
+  cg.abl = 0;
+  *name = "q8_conv_c3rows32_mfma";
+  const bool two = p.n_pad > 32;
+  if (g.KH == 7) return two ? launch_c3rows32<2, 7>(p, cg, stream) : launch_c3rows32<1, 7>(p, cg, stream);
+  return two ? launch_c3rows32<2, 5>(p, cg, stream) : launch_c3rows32<1, 5>(p, cg, stream);
 }
 
 }  // namespace qnnp

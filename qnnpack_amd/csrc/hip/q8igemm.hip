@@ -669,11 +669,18 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   // 3-channel images (first layers) with dense pixels: one 16-byte fetch per kernel row (q8convc3.hip);
   // "gemm_kernel" = 14 forces it, 7 keeps the tap-gather kernel below
   const bool rows16_ok = pad3 && p.store_mode == 2 && qnnp::conv_c3rows_supported(p, geom, a->groups, a->packed_w_rows16, a->kc);
-  if (a->variant == 14 && !rows16_ok) return QNNP_HIP_EINVAL;
+  if (a->variant == 14 && !rows16_ok && !(pad3 && p.store_mode == 2 && qnnp::conv_c3rows32_supported(p, geom, a->groups, a->packed_w_rows16, a->kc))) return QNNP_HIP_EINVAL;
   if (rows16_ok && (a->variant == 14 || (a->variant == 0 && a->rows >= 2048))) {
     const int rc_r16 = qnnp::conv_c3rows_launch(p, geom, a->packed_w_rows16, stream, &name);
     if (kernel_name != nullptr) *kernel_name = name;
     return rc_r16;
+  }
+  // ... and its 32-byte-slot flavour for 5- and 7-row windows (ResNet's 7x7 entry layer); "gemm_kernel" = 14 forces it too
+  const bool rows32_ok = pad3 && p.store_mode == 2 && qnnp::conv_c3rows32_supported(p, geom, a->groups, a->packed_w_rows16, a->kc);
+  if (rows32_ok && (a->variant == 14 || (a->variant == 0 && a->rows >= 2048))) {
+    const int rc_r32 = qnnp::conv_c3rows32_launch(p, geom, a->packed_w_rows16, stream, &name);
+    if (kernel_name != nullptr) *kernel_name = name;
+    return rc_r32;
   }
   // 3-channel images (first layers): barrier-free streaming kernel with an in-register tap gather.
   const bool c3_ok = pad3 && qnnp::convstream_c3_supported(p, a->groups);

@@ -118,6 +118,34 @@ static inline void qnnp_pack_conv_rows16(
   }
 }
 
+/*
+ * The same with 32-byte row slots (hip/q8convc3.hip, q8_conv_c3rows32_kernel): windows whose rows are 17 .. 32 bytes of a dense
+ * 3-channel image -- ResNet's 7x7 entry layer, bench/convolution.cc:646: 21 bytes -- or have more than four rows. Packed K index
+ * = ky * 32 + kx * 3 + c: K block ky is kernel row ky, its two 16-byte halves are the two fetches of that row; the slot's
+ * unused bytes are zero weights. kernel_height K blocks per 32 channels.
+ */
+static inline size_t qnnp_conv_rows32_size(uint32_t n_pad, uint32_t kh) { return (size_t) (n_pad / 32) * kh * 1024; }
+static inline void qnnp_pack_conv_rows32(
+    uint32_t n, uint32_t kh, uint32_t kw, uint32_t kc, uint32_t n_pad,
+    const uint8_t* kernel, int8_t* packed /* [n_pad / 32][kh][64][16] */)
+{
+  memset(packed, 0, qnnp_conv_rows32_size(n_pad, kh));
+  for (uint32_t col = 0; col < n; col++) {
+    const uint32_t nb = col / 32;
+    const uint32_t lane_lo = col % 32;
+    for (uint32_t ky = 0; ky < kh; ky++) {
+      for (uint32_t kx = 0; kx < kw; kx++) {
+        for (uint32_t c = 0; c < kc; c++) {
+          const int32_t ws = (int32_t) kernel[(((size_t) col * kh + ky) * kw + kx) * kc + c] - 128;
+          const uint32_t kp = kx * kc + c;             /* byte of the row slot: < 32 */
+          const uint32_t lane = lane_lo + 32 * (kp / 16);
+          packed[((((size_t) nb * kh + ky) * 64) + lane) * 16 + (kp % 16)] = (int8_t) ws;
+        }
+      }
+    }
+  }
+}
+
 static inline void qnnp_pack_igemm_w(
     uint32_t groups, uint32_t n, uint32_t k_total,
     uint32_t n_pad, uint32_t k_pad,

@@ -65,7 +65,9 @@ def test_row_slot_kernel_matches_oracle(rows16, case):
 @pytest.mark.parametrize("case", [
     ConvCase("r_bad_pixel_stride", (9, 10), (3, 3), _pad(1, 1), gic=3, goc=32, input_pixel_stride=5),
     ConvCase("r_bad_1x7", (6, 20), (1, 7), (0, 3, 0, 3), gic=3, goc=32),
-    ConvCase("r_bad_5x3", (12, 12), (5, 3), (2, 1, 2, 1), gic=3, goc=32),
+    ConvCase("r_bad_6x3", (12, 12), (6, 3), (2, 1, 3, 1), gic=3, goc=32),
+    ConvCase("r_bad_7x7_tensor_not_whole_dwords", (9, 9), (7, 7), _pad(3, 3), gic=3, goc=64),        # 243 bytes
+    ConvCase("r_bad_7x11", (16, 16), (7, 11), _pad(3, 5), gic=3, goc=32),                              # 33-byte window rows
     ConvCase("r_bad_dilated", (12, 12), (3, 3), _pad(2, 2), dilation=(2, 2), gic=3, goc=32),
     ConvCase("r_bad_n24", (9, 9), (3, 3), _pad(1, 1), gic=3, goc=24),
     ConvCase("r_bad_n96", (9, 9), (3, 3), _pad(1, 1), gic=3, goc=96),
@@ -83,4 +85,49 @@ def test_automatic_dispatch_takes_the_row_slot_kernel_for_the_first_layer(qnnp):
     expected, quant, out_hw = conv_expected(case)
     out, kname = conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
     assert kname == KERNEL, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} (automatic) vs oracle")
+
+
+# ---- the 32-byte-slot flavour (q8_conv_c3rows32_kernel, round 5): 5- and 7-row windows of up to 32 bytes per row ----
+KERNEL32 = "q8_conv_c3rows32_mfma"
+CASES32 = [
+    ConvCase("w_7x7_s2_resnet_entry", (224, 224), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=64),
+    ConvCase("w_7x7_s2_small", (32, 32), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=64, batch=2),
+    ConvCase("w_7x7_s1", (12, 16), (7, 7), _pad(3, 3), gic=3, goc=64, batch=3),
+    ConvCase("w_7x7_nopad", (12, 12), (7, 7), gic=3, goc=32),
+    ConvCase("w_7x7_pad_right_bottom_only", (10, 12), (7, 7), (0, 6, 6, 0), gic=3, goc=64, batch=2),
+    ConvCase("w_7x7_pad_left_top_only", (10, 12), (7, 7), (6, 0, 0, 6), gic=3, goc=64, batch=2),
+    ConvCase("w_7x7_images_meet_in_a_unit", (6, 6), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=64, batch=8),
+    ConvCase("w_7x7_window_wider_than_image", (4, 2), (7, 7), _pad(3, 3), gic=3, goc=32, batch=4),
+    ConvCase("w_7x7_one_pixel_images", (1, 1), (7, 7), _pad(3, 3), gic=3, goc=64, batch=72),
+    ConvCase("w_7x7_s3", (20, 20), (7, 7), _pad(3, 3), subsampling=(3, 3), gic=3, goc=48),
+    ConvCase("w_7x10_widest_row", (16, 16), (7, 10), (3, 5, 3, 4), gic=3, goc=32),                     # 30-byte window rows
+    ConvCase("w_7x6_row_of_18", (16, 16), (7, 6), (3, 3, 3, 2), gic=3, goc=16, batch=2),
+    ConvCase("w_5x5_s1", (14, 14), (5, 5), _pad(2, 2), gic=3, goc=32, batch=2),
+    ConvCase("w_5x5_s2_n64", (28, 28), (5, 5), _pad(2, 2), subsampling=(2, 2), gic=3, goc=64),
+    ConvCase("w_5x3", (12, 12), (5, 3), (2, 1, 2, 1), gic=3, goc=32),
+    ConvCase("w_5x9", (12, 16), (5, 9), (2, 4, 2, 4), gic=3, goc=32),
+    ConvCase("w_7x7_out_stride", (8, 8), (7, 7), _pad(3, 3), gic=3, goc=32, output_pixel_stride=48),
+    ConvCase("w_7x7_zp", (10, 10), (7, 7), _pad(3, 3), gic=3, goc=64, izp=9, kzp=200, batch=2),
+    ConvCase("w_7x7_zp_extremes", (10, 10), (7, 7), _pad(3, 3), gic=3, goc=64, izp=255, kzp=0, batch=2),
+    ConvCase("w_7x7_zp_extremes2", (10, 10), (7, 7), _pad(3, 3), gic=3, goc=64, izp=0, kzp=255, batch=2),
+    ConvCase("w_7x7_kzp128_no_row_term", (10, 10), (7, 7), _pad(3, 3), gic=3, goc=64, kzp=128, batch=2),
+    ConvCase("w_7x7_clamp", (10, 10), (7, 7), _pad(3, 3), gic=3, goc=64, qmin=90, qmax=160, batch=2),
+    ConvCase("w_7x7_many_units", (64, 48), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=64, batch=40),
+]
+
+
+@pytest.mark.parametrize("case", CASES32, ids=lambda c: c.name)
+def test_wide_row_slot_kernel_matches_oracle(rows16, case):
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(rows16, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == KERNEL32, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+def test_automatic_dispatch_takes_the_wide_row_slot_kernel_for_a_7x7_entry_layer(qnnp):
+    case = ConvCase("w_auto_7x7", (64, 64), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=64, batch=2)
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == KERNEL32, kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} (automatic) vs oracle")
