@@ -364,8 +364,7 @@ int launch_c3rows(const IgemmParams& p, const C3Geom& cg, hipStream_t stream)
  *     what lies outside the tensor is padding, fetched as zeros and replaced like every out-of-image tap;
  *   - the kernel-zero-point row term is VALU work (v_dot4_u32_u8 of the raw bytes against a 0 / 1 mask of the slot's real
  *     bytes, the two halves joined by v_permlane32_swap): KR more MFMAs per channel block would double the matrix time here;
- *   - one set of slot registers: the next unit's fetches are issued as soon as the MFMAs have consumed the current ones and
- *     fly under the epilogue.
+ *   - two sets of slot registers with swapping roles, as above: the next unit's fetches fly under the whole current unit.
  */
 template <int NB, int KR, int SEQ, bool FULL>
 __global__ __launch_bounds__(kC3Threads, 2)
@@ -381,20 +380,24 @@ void q8_conv_c3rows32_kernel(const IgemmParams p, const C3Geom cg)
 
   v4i w[NB][KR];
   v16i bias[NB];
+  {
+    const int32_t* bias_tab = rq_is_lane<SEQ>() ? p.bias2u : p.bias2;      // (lane forms: bias + 2^31, the second half of the pair table)
 #pragma unroll
-  for (int nb = 0; nb < NB; nb++) {
+    for (int nb = 0; nb < NB; nb++) {
 #pragma unroll
-    for (int kb = 0; kb < KR; kb++) w[nb][kb] = *reinterpret_cast<const v4i*>(cg.w_rows16 + ((nb * KR + kb) * 64u + lane) * 16u);
+      for (int kb = 0; kb < KR; kb++) w[nb][kb] = *reinterpret_cast<const v4i*>(cg.w_rows16 + ((nb * KR + kb) * 64u + lane) * 16u);
 #pragma unroll
-    for (int rg = 0; rg < 4; rg++) {
-      const v4i b = *reinterpret_cast<const v4i*>(p.bias2 + nb * 32 + rg * 8 + h * 4);
-      bias[nb][rg * 4 + 0] = with_rq_offset<SEQ>(b.x); bias[nb][rg * 4 + 1] = with_rq_offset<SEQ>(b.y);
-      bias[nb][rg * 4 + 2] = with_rq_offset<SEQ>(b.z); bias[nb][rg * 4 + 3] = with_rq_offset<SEQ>(b.w);
+      for (int rg = 0; rg < 4; rg++) {
+        const v4i b = *reinterpret_cast<const v4i*>(bias_tab + nb * 32 + rg * 8 + h * 4);
+        bias[nb][rg * 4 + 0] = b.x; bias[nb][rg * 4 + 1] = b.y; bias[nb][rg * 4 + 2] = b.z; bias[nb][rg * 4 + 3] = b.w;
+      }
     }
   }
-  uint32_t ones[4];                                         // 0x01 in every REAL byte of this lane's half: the row sum's weights
-#pragma unroll
-  for (int d = 0; d < 4; d++) ones[d] = byte_range_mask(0 - 4 * d, nreal - 4 * d) & 0x01010101u;
+  // 0x01 in every REAL byte of this lane's half: as a weight fragment, the same for all 32 "channels", its product with the
+  // activation operand is the row sum of a' over the real K positions -- in EVERY element of the accumulator, so each lane finds
+  // its position's sum in its own registers: KR more MFMAs on a pipe that is a third busy instead of 4 KR v_dot4 and an exchange
+  const v4i ones = {static_cast<int>(byte_range_mask(0, nreal) & 0x01010101u), static_cast<int>(byte_range_mask(-4, nreal - 4) & 0x01010101u),
+                    static_cast<int>(byte_range_mask(-8, nreal - 8) & 0x01010101u), static_cast<int>(byte_range_mask(-12, nreal - 12) & 0x01010101u)};
 
   const uint32_t in_bytes = static_cast<uint32_t>(p.input_end - p.input);          // (launcher: < 2^31, a multiple of 4)
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -406,7 +409,6 @@ void q8_conv_c3rows32_kernel(const IgemmParams p, const C3Geom cg)
   const uint32_t lane_in = prow * cg.sh * row_bytes + pcol * cg.sw * 3u + h * 16u;   // this lane's half of row slot 0, relative to the unit's first window
   const uint32_t lane_out = (prow * cg.OW + pcol) * p.output_stride + h * 16u;
   const uint32_t fill4 = (p.izp_fill & 0xFFu) * 0x01010101u;
-  const int32_t total_real = static_cast<int32_t>(kbytes * cg.KH);
 
   struct Where { uint32_t origin, out0; int32_t iy0, ix0; uint32_t rows_left, cols_left; bool border, slow; };   // (wave-uniform)
   auto locate = [&](uint32_t unit) __attribute__((always_inline)) -> Where {
@@ -434,6 +436,9 @@ void q8_conv_c3rows32_kernel(const IgemmParams p, const C3Geom cg)
   };
   struct Slots { v4i x[KR]; uint32_t tail[KR]; uint32_t shifts; };     // shifts: 2 bits per row, bytes by which the fetch address was rounded down
   auto fetch = [&](const Where& u, Slots& s) __attribute__((always_inline)) {
+    // (W % 4 == 0 gives every kernel row of a lane the same alignment; a flavour that fetched all rows from ONE rounded-down vector
+    //  offset, the row advancing as the instruction's scalar offset, measured 15-25 % SLOWER -- 73-86 against 60-68 us, same box:
+    //  this kernel is bound by the vector-memory path, not by its address arithmetic)
     uint32_t shifts = 0;
 #pragma unroll
     for (int kb = 0; kb < KR; kb++) {
@@ -455,8 +460,7 @@ void q8_conv_c3rows32_kernel(const IgemmParams p, const C3Geom cg)
   Slots s;
   fetch(here, s);
   for (;;) {
-    // ---- the slots into place; out-of-image taps -> the zero point; row sum of the raw bytes; re-centre
-    uint32_t sum = 0;
+    // ---- the slots into place; out-of-image taps -> the zero point; re-centre
     const int32_t ixl = here.ix0 + static_cast<int32_t>(pcol * cg.sw);
     const int32_t iyl = here.iy0 + static_cast<int32_t>(prow * cg.sh);
     const int32_t left = ixl < 0 ? -ixl : 0;                                                  // pixels
@@ -494,20 +498,23 @@ void q8_conv_c3rows32_kernel(const IgemmParams p, const C3Geom cg)
           x[d] = (x[d] & keep) | (fill4 & ~keep);
         }
       }
-#pragma unroll
-      for (int d = 0; d < 4; d++) {
-        sum = __builtin_amdgcn_udot4(x[d], ones[d], sum, false);
-        x[d] ^= kFlip;
-      }
-      s.x[kb] = v4i{static_cast<int>(x[0]), static_cast<int>(x[1]), static_cast<int>(x[2]), static_cast<int>(x[3])};
+      s.x[kb] = v4i{static_cast<int>(x[0] ^ kFlip), static_cast<int>(x[1] ^ kFlip), static_cast<int>(x[2] ^ kFlip), static_cast<int>(x[3] ^ kFlip)};
     }
-    // ---- the multiplies; then the next unit's fetches, into the registers they have just left
+    // ---- the multiplies (and the row sums, where the kernel zero point asks for them); then the next unit's fetches, into the
+    //      registers they have just left
     v16i acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
       acc[nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[nb][0], s.x[0], bias[nb], 0, 0, 0);
 #pragma unroll
       for (int kb = 1; kb < KR; kb++) acc[nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[nb][kb], s.x[kb], acc[nb], 0, 0, 0);
+    }
+    int32_t rowterm = with_rq_offset<SEQ>(0);
+    if (p.row_coeff != 0) {                                // (scalar)
+      v16i racc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int kb = 0; kb < KR; kb++) racc = __builtin_amdgcn_mfma_i32_32x32x32_i8(ones, s.x[kb], racc, 0, 0, 0);
+      rowterm = with_rq_offset<SEQ>(p.row_coeff * racc[0]);
     }
     const Where done = here;
     const bool more = unit + unit_stride < units;
@@ -516,13 +523,10 @@ void q8_conv_c3rows32_kernel(const IgemmParams p, const C3Geom cg)
       here = locate(unit);
       fetch(here, s);
     }
-    // ---- epilogue of the unit just multiplied: row term, Q31 requantization, 16-byte stores
-    int32_t rowterm = 0;
-    if (p.row_coeff != 0) {
-      const auto both = __builtin_amdgcn_permlane32_swap(sum, sum, false, false);          // (the other half's sum)
-      const int32_t total = static_cast<int32_t>(both[0] + both[1]) - 128 * total_real;    // sum of a' over the real K positions
-      rowterm = p.row_coeff * total;
-    }
+    // ---- epilogue of the unit just multiplied: row term (in the multiply-add's addend where the lane forms apply), Q31
+    //      requantization, 16-byte stores
+    uint64_t row_addend = 0;
+    if constexpr (rq_is_lane<SEQ>()) row_addend = lane_addend(rowterm, p.lane);
     const bool pixel_ok = prow < done.rows_left && pcol < done.cols_left;
     const uint32_t out_off = done.out0 + lane_out;
 #pragma unroll
@@ -530,8 +534,14 @@ void q8_conv_c3rows32_kernel(const IgemmParams p, const C3Geom cg)
       uint32_t pk[4];
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
-        pk[rg] = q31_requantize_pack4<SEQ, FULL>(add_wrap(acc[nb][rg * 4 + 0], rowterm), add_wrap(acc[nb][rg * 4 + 1], rowterm),
-                                                add_wrap(acc[nb][rg * 4 + 2], rowterm), add_wrap(acc[nb][rg * 4 + 3], rowterm), p.rq);
+        if constexpr (rq_is_lane<SEQ>()) {
+          pk[rg] = q31_requantize_pack4_lane<SEQ, FULL>(
+              static_cast<uint32_t>(acc[nb][rg * 4 + 0]), static_cast<uint32_t>(acc[nb][rg * 4 + 1]),
+              static_cast<uint32_t>(acc[nb][rg * 4 + 2]), static_cast<uint32_t>(acc[nb][rg * 4 + 3]), row_addend, p.lane, p.rq);
+        } else {
+          pk[rg] = q31_requantize_pack4<SEQ, FULL, false>(add_wrap(acc[nb][rg * 4 + 0], rowterm), add_wrap(acc[nb][rg * 4 + 1], rowterm),
+                                                         add_wrap(acc[nb][rg * 4 + 2], rowterm), add_wrap(acc[nb][rg * 4 + 3], rowterm), p.rq);
+        }
       }
       const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
       const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
@@ -555,10 +565,10 @@ template <int NB, int KR>
 int launch_c3rows32(const IgemmParams& p, const C3Geom& cg, hipStream_t stream)
 {
   const uint32_t units = (p.rows / (cg.OH * cg.OW)) * cg.pairs * cg.segs;
-  uint32_t grid = p.cu_count * 2u;                          // two 4-wave workgroups per CU (two waves per SIMD: ~200 registers)
+  uint32_t grid = p.cu_count * 2u;                          // two 4-wave workgroups per CU (two waves per SIMD: ~220 registers)
   const uint32_t needed = (units + kC3Waves - 1) / kC3Waves;
   if (grid > needed) grid = needed;
-  requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+  requant_dispatch_lane(p.rq, p.lane, [&](auto seq, auto full) {
     hipLaunchKernelGGL((q8_conv_c3rows32_kernel<NB, KR, decltype(seq)::value, decltype(full)::value>), dim3(grid),
                        dim3(kC3Threads), 0, stream, p, cg);
   });
