@@ -918,7 +918,8 @@ int gemm256_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, co
 #else
   const bool fill_auto = true;
 #endif
-  if (fill_auto && !waves4 && !pingpong && !rows128 && lean <= 1) {
+  // (lean == 1: the automatic choice -- a forced "gemm_kernel" keeps its tile; plain GEMMs the lean flavour takes keep it)
+  if (fill_auto && !waves4 && !pingpong && !rows128 && lean == 1 && !(gemm256_lean_supported(p))) {
     const uint64_t tiles256 = static_cast<uint64_t>((p.rows + 255u) / 256u) * tiles_n * groups;
     underfilled = tiles256 < p.cu_count && p.rows > 128u;
   }

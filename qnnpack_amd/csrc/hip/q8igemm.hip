@@ -709,7 +709,14 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   //  the tiled kernel; with ~200 row blocks and few channel blocks the one-wave-per-block kernel below keeps the lead:
   //  7x7x960 -> 160 11.1 against 6.6 us)
   const uint32_t lk_units = (a->rows + 31u) / 32u;
-  const bool lk_auto = a->rows <= 65536u && (lk_units >= 512u || a->n_pad >= 512u);
+  // (round 5: problems the 256-wide LDS-DMA GEMM takes -- N >= 256, K >= 512, rows >= 2048 -- go THERE, not to the long-K / one-wave
+  //  kernels: ResNet-50's 14x14 1024 -> 256 25.4 -> 14.6 us, 7x7 512 -> 2048 28.8 -> 12.0, 7x7 2048 -> 512 41.4 -> 22.4, same box,
+  //  profiles/r05/pointwise_rows_by_forced_kernel_r05var.txt)
+  //  -- when the channels fill whole 256-wide tiles: MobileNetV2's 7x7 960 -> 320 (a quarter of its second tile is padding) stays
+  //  on the one-wave kernel, 11.2 against 13.0 us)
+  const bool big_first = a->variant == 0 && !pad3 && a->n >= 256 && a->n % 256u == 0 && a->k_total >= 512 && a->rows >= 2048 &&
+      qnnp::gemm256_supported(p, vec);
+  const bool lk_auto = !big_first && a->rows <= 65536u && (lk_units >= 512u || a->n_pad >= 512u);
   if (lk_ok && (a->variant == 9 || (a->variant == 0 && lk_auto))) {
     const int rc_lk = qnnp::pwstream_longk_launch(p, stream, &name);
     if (kernel_name != nullptr) *kernel_name = name;
@@ -723,7 +730,7 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   // (selected when the 128-row x 128-channel tiling of the generic kernel would not even give ~1.5 workgroups
   //  per CU; MobileNetV2 layer 30 -- 490 tiles -- measured faster on the tiled kernel, layers 19-29 on this one)
   const uint64_t generic_tiles = static_cast<uint64_t>((a->rows + 127u) / 128u) * ((a->n_pad + 127u) / 128u);
-  if (gw_ok && (a->variant == 6 || (a->variant == 0 && generic_tiles <= 400u))) {
+  if (gw_ok && (a->variant == 6 || (a->variant == 0 && generic_tiles <= 400u && !big_first))) {
     const int rc_gw = qnnp::pwstream_gw_launch(p, stream, &name);
     if (kernel_name != nullptr) *kernel_name = name;
     if (rc_gw == QNNP_HIP_OK) folded();
@@ -731,7 +738,10 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   }
   // Large MFMA-bound problems take the 256x256 LDS-DMA kernel; everything else the generic one.
   const bool big_ok = !pad3 && qnnp::gemm256_supported(p, vec);
-  const bool big_auto = a->n >= 256 && a->k_total >= 512 && a->rows >= 2048;
+  // (strided 1x1 convolutions -- a table row per output pixel, one tap -- from K = 256: ResNet-50's 56x56 stride-2 256 -> 512
+  //  70.8 -> 51.3 us on the offset-table flavour of the 256-wide kernel)
+  const bool strided_pw = a->offsets != nullptr && a->ks == 1 && a->n % 256u == 0 && a->k_total >= 256;
+  const bool big_auto = a->n >= 256 && (a->k_total >= 512 || strided_pw) && a->rows >= 2048;
   const bool big_forced = a->variant == 2 || a->variant == 4 || a->variant == 10 || a->variant == 11 || a->variant == 15 || a->variant == 16;   // 10: 128 x 256 tiles, two workgroups per CU; 11: ping-pong schedule; 15: lean flavour
   if (big_forced && !big_ok) return QNNP_HIP_EINVAL;
   int rc;
