@@ -224,10 +224,21 @@ def gemm_variant_bench(lib, torch, kzp, in_scale, warmup, iters, seed):
     op = lib.create_fully_connected_nc_q8(K, N, 127, in_scale, kzp, 1.0, w, bias, 127, 1.0, 1, 254)
     lib.setup_fully_connected_nc_q8(op, M, a, K, c, N)
     lib.run_operator(op)
-    ms = lib.time_operator(op, warmup, iters)
+    # timed as the headline's `sustained_launch_ms`: a hipGraph of 64 launches, median of five batches of `iters` replays
+    # (a short back-to-back loop right after another kernel family measures the clock ramp, not the kernel: 66 us for the
+    #  headline configuration itself against 57 in the sustained state)
+    lib.set_async(True)
+    lib.graph_begin()
+    for _ in range(64):
+        lib.run_operator(op)
+    graph = lib.graph_end()
+    ms = lib.graph_time(graph, warmup, iters) / 64.0
+    lib.graph_destroy(graph)
+    lib.set_async(False)
     tops = 2.0 * M * N * K / (ms * 1e-3) / 1e12
     out = {"kernel": lib.operator_kernel(op), "kernel_zero_point": kzp, "requant_scale": in_scale, "us": round(ms * 1e3, 2),
-           "tops": round(tops, 1), "frac": round(tops / PEAK_I8_TOPS, 4)}
+           "tops": round(tops, 1), "frac": round(tops / PEAK_I8_TOPS, 4),
+           "timed_as": "median of 5 batches of replays of a 64-launch hipGraph"}
     lib.delete_operator(op)
     return out
 
@@ -910,9 +921,9 @@ def main():
         # ---------------------------------------------------------- the headline GEMM outside its most favourable class, and
         # BASELINE configs[0] (M = 1 fully connected) on the device
         extra["q8gemm_4096_variants"] = {
-            "kernel_zero_point_126": gemm_variant_bench(lib, torch, 126, 0.75, 3, 20, 11),     # no centred image: lean kernel
-            "requant_scale_0.3_shift1": gemm_variant_bench(lib, torch, 127, 0.3, 3, 20, 12),   # shift >= 1 epilogue
-            "kernel_zero_point_126_scale_0.3": gemm_variant_bench(lib, torch, 126, 0.3, 3, 20, 13)}
+            "kernel_zero_point_126": gemm_variant_bench(lib, torch, 126, 0.75, 1, 12, 11),     # no centred image: lean kernel
+            "requant_scale_0.3_shift1": gemm_variant_bench(lib, torch, 127, 0.3, 1, 12, 12),   # shift >= 1 epilogue
+            "kernel_zero_point_126_scale_0.3": gemm_variant_bench(lib, torch, 126, 0.3, 1, 12, 13)}
         extra["q8fc_m1_k1024_n1000"] = fc_m1_bench(lib, torch, 5, 50)
 
         # ---------------------------------------------------------- the reference bench's other convolution lists: the general

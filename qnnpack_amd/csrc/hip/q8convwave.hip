@@ -1103,6 +1103,7 @@ void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArg
       const int32_t rowterm = with_rq_offset<SEQ>(CEN ? 0 : p.row_coeff * s);       // (CEN: a constant of the launch)
       uint64_t row_addend = 0;                       // lane forms: the row term rides in the multiply-add's addend
       if constexpr (rq_is_lane<SEQ>()) row_addend = lane_addend(rowterm, p.lane);
+      v4i outv[TN];
 #pragma unroll
       for (int tn = 0; tn < TN; tn++) {
         uint32_t pk[4];
@@ -1120,16 +1121,47 @@ void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArg
         }
         const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
         const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
-        // this lane now holds 16 consecutive channels of ITS position: tn * 32 + khalf * 16 .. + 15. Stored directly --
-        // no staging image, no read-back: the round trip through LDS cost ~370 cycles per unit of pure latency (two
-        // dependent ds_read -> store pairs) for the sake of whole-line stores, and with two waves per SIMD nothing hides it
-        const v4i v = {static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
-        const uint32_t oy = here.oy0 + ty;
-        const uint32_t ox = here.ox0 + (i0 & 7u);
-        const bool ok = oy < g.OH && ox < g.OW;
-        __builtin_amdgcn_raw_buffer_store_b128(
-            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc,
-            ok ? here.out_img + (oy * g.OW + ox) * p.n + tn * 32 + khalf * 16 : 0xFFFFFFF0u, 0, 0);
+        // this lane now holds 16 consecutive channels of ITS position: tn * 32 + khalf * 16 .. + 15
+        outv[tn] = v4i{static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
+      }
+      if (TN == 2 && p.stream_out != 0) {
+        // WHOLE-LINE stores (round 5): stored as they are, the two pieces are halves of 64-byte pixels -- every store instruction
+        // writes 32-byte runs, and the streaming hint on such pieces measured 4 % slower (profiles/r04/streaming_stores_*).
+        // Four v_permlane16_swap move positions 16-31's first piece into the second register and positions 0-15's second piece
+        // into the first: register S then holds ALL FOUR 16-byte chunks of positions 16 S .. 16 S + 15 (lane L: position
+        // 16 S + (L & 15), chunk 2 * ((L >> 4) & 1) + (L >> 5)), i.e. two output rows of eight 64-byte pixels = 4 + 4 whole
+        // 128-byte lines per instruction, written exactly once: streaming stores, no read-back, no LDS.
+        int* a0 = reinterpret_cast<int*>(&outv[0]);
+        int* a1 = reinterpret_cast<int*>(&outv[TN - 1]);
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(static_cast<uint32_t>(a0[d]), static_cast<uint32_t>(a1[d]), false, false);
+          a0[d] = static_cast<int>(sw[0]);
+          a1[d] = static_cast<int>(sw[1]);
+        }
+        const uint32_t lx = lane & 7u, lr = (lane >> 3) & 1u;
+        const uint32_t chunk = ((lane >> 4) & 1u) * 2u + khalf;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+          const uint32_t oy = here.oy0 + lr + 2u * half;
+          const uint32_t ox = here.ox0 + lx;
+          const bool ok = oy < g.OH && ox < g.OW;
+          __builtin_amdgcn_raw_buffer_store_b128(
+              __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, outv[half == 0 ? 0 : TN - 1]), out_rsrc,
+              ok ? here.out_img + (oy * g.OW + ox) * p.n + chunk * 16u : 0xFFFFFFF0u, 0, 2);
+        }
+      } else {
+        // stored directly -- no staging image, no read-back: the round trip through LDS cost ~370 cycles per unit of pure
+        // latency (two dependent ds_read -> store pairs), and with two waves per SIMD nothing hides it
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++) {
+          const uint32_t oy = here.oy0 + ty;
+          const uint32_t ox = here.ox0 + (i0 & 7u);
+          const bool ok = oy < g.OH && ox < g.OW;
+          __builtin_amdgcn_raw_buffer_store_b128(
+              __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, outv[tn]), out_rsrc,
+              ok ? here.out_img + (oy * g.OW + ox) * p.n + tn * 32 + khalf * 16 : 0xFFFFFFF0u, 0, 0);
+        }
       }
       WS_STAMP(3);
     }

@@ -599,6 +599,13 @@ int launch_c(const IgemmParams& p, const dim3& grid, hipStream_t stream)
 #undef QNNP_ABL_CASE
   }
 #endif
+  if (p.rq.f.shift != 0 && p.rq.f.bounded && p.rq.f.ofs_kind == 2 && !p.rq.full_range) {
+    // bounded accumulators, shift >= 1, a clamp other than [0, 255] (requant_dispatch_ofs knows the bounded form for the common
+    // clamp only): the bounded sequence with the clamp class picked here
+    if (p.rq.zp_late == 0) hipLaunchKernelGGL((q8_gemm_mfma_256x256_c_kernel<kRqBoundedOfs, 1, ALIGNED, OPT>), grid, dim3(kThreads), 0, stream, p);
+    else hipLaunchKernelGGL((q8_gemm_mfma_256x256_c_kernel<kRqBoundedOfs, 2, ALIGNED, OPT>), grid, dim3(kThreads), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+  }
   requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
     constexpr int kSeq = decltype(seq)::value;
     if constexpr (decltype(full)::value) {

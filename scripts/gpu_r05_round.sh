@@ -26,3 +26,9 @@ echo "== rocprofv3 kernel stats (whole bench)"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof_all -o all -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OLDPWD/$OUT/prof_all_run.log 2>&1)
 for f in $(find $OUT/prof_all -name "*kernel_stats*.csv" | head -1); do cut -c1-160 $f | head -n 14; cp $f $OUT/rocprof_kernel_stats_all.csv; done
 rm -rf $OUT/prof $OUT/prof_all
+echo "== PMC: fabric traffic and SQ counters of the GEMM"
+bash scripts/gpu_pmc_cmd.sh $TAG gemm_tcc "python tools/gemm_ab.py --only 0" TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_EA0_WRREQ_64B_sum | tee $OUT/pmc_gemm_tcc.txt
+bash scripts/gpu_pmc_cmd.sh $TAG gemm_sq "python tools/gemm_ab.py --only 0" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU | tee $OUT/pmc_gemm_sq.txt
+rm -rf $OUT/pmc_gemm_tcc $OUT/pmc_gemm_sq
+echo "== pointwise / strided rows of the ResNet lists by forced kernel"
+timeout 600 python tools/conv_variants_time.py 2>&1 | grep -v amdgpu.ids | tee $OUT/pointwise_rows_by_forced_kernel.txt | cut -c1-120
