@@ -8,7 +8,7 @@ rounds = int(sys.argv[8]) if len(sys.argv) > 8 else 3
 variant = int(sys.argv[9]) if len(sys.argv) > 9 else 0
 lib = qnnpack_amd.load(); lib.initialize(); lib.set_stream(torch.cuda.current_stream().cuda_stream)
 lib.set_option("gemm_kernel", variant)
-layer = bench.ConvLayer(lib, torch, 128, H, W, K, K, S, 1, G, GIC, GOC, seed=5, min_bytes_between_reuse=512 << 20)
+layer = bench.ConvLayer(lib, torch, 128, H, W, K, K, S, 1, G, GIC, GOC, seed=5, min_bytes_between_reuse=512 << 20, kzp=int(os.environ.get("KZP", "127")))
 bound = bench.layer_bound_ms(layer, G * GOC * K * K * GIC)
 for _ in range(rounds):
     ms = layer.time_ms(2, 10)
