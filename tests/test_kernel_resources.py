@@ -65,7 +65,8 @@ def kernels(tmp_path_factory):
 # spill in its 1-byte flavours and is reported by test_report_of_spilling_kernels below, not asserted
 DEFAULT_PATH = ["q8_gemm_mfma_256x256_c_kernel", "q8_gemm_mfma_256x256_kernelILb0ELi4E", "q8_gemm_mfma_256x256_kernelILb1ELi4E", "q8_pw_stream_staged_kernel", "q8_pw_stream_longk_kernel",
                 "q8_pw_stream_gw_kernel", "q8_pw_stream_gwk_kernel", "q8_conv_stream_c3s_kernel",
-                "q8_dwconv_col3x3_kernel", "q8_conv_wave_reg_kernel", "q8_conv_wave_ws_kernel", "q8_conv_lds_mfma", "q8_vadd", "q8_gavgpool"]
+                "q8_dwconv_col3x3_kernel", "q8_conv_wave_reg_kernel", "q8_conv_wave_ws_kernel", "q8_conv_lds_mfma", "q8_vadd", "q8_gavgpool",
+                "q8_conv_patch_kernel", "q8_conv_c3rows32_kernel"]
 
 
 def test_default_path_kernels_do_not_spill(kernels):
@@ -88,6 +89,9 @@ def test_default_path_kernels_do_not_spill(kernels):
     ("25q8_conv_stream_c3s_kernelILi3ELb1E", 96, "first-layer kernel: 5 per CU"),
     ("27q8_gemm_mfma_256x256_kernelILb0ELi4ELi256ELi0ELb0E", 256, "256x256 GEMM: 2 waves per SIMD"),
     ("29q8_gemm_mfma_256x256_c_kernel", 256, "256x256 GEMM, zero-point-centred flavour: 2 waves per SIMD"),
+    ("20q8_conv_patch_kernelILi8ELi4E", 128, "patch kernel, 256 positions x 128 channels: TWO 8-wave workgroups per CU (4 waves per SIMD)"),
+    ("20q8_conv_patch_kernelILi4ELi8E", 256, "patch kernel, 128 positions x 256 channels: 2 waves per SIMD"),
+    ("23q8_conv_c3rows32_kernel", 256, "7x7 / 5x5 first-layer kernel: 2 waves per SIMD"),
 ])
 def test_register_budgets_of_the_occupancy_critical_kernels(kernels, fragment, max_vgpr, why):
     hits = {n: k for n, k in kernels.items() if fragment in n}
@@ -135,7 +139,7 @@ def test_lean_gemm_is_the_only_writer_of_m0_in_its_kernels(tmp_path):
                 assert re.match(r"s_mov_b32 m0, s\d+\b", ln), (name, ln)
             dma = [ln.strip() for ln in body.split("\n") if "global_load_lds" in ln]
             assert dma and all(re.match(r"global_load_lds_dwordx4 v\d+, s\[\d+:\d+\]", ln) for ln in dma), (name, dma[:3])
-    assert seen == 1 + 14, seen     # the lean flavour + the centred flavour's 7 requantization / clamp classes x aligned or not (its burst-read A/B structure is in measurement builds only)
+    assert seen == 1 + 18, seen     # the lean flavour + the centred flavour's 9 requantization / clamp classes (round 5: + the bounded sequence under an explicit clamp) x aligned or not (its burst-read A/B structure is in measurement builds only)
 
 
 def test_streaming_store_flavours_survive_the_compiler(tmp_path):
@@ -150,7 +154,8 @@ def test_streaming_store_flavours_survive_the_compiler(tmp_path):
     blob = open(LIB, "rb").read()
     want = {"q8_pw_stream_staged_kernel": 0, "q8_pw_stream_longk_kernel": 0, "q8_vadd_flat_kernel": 0,
             "q8_gemm_mfma_256x256_kernelILb0ELi4ELi256ELi0ELb0ELb1E": 0,
-            "q8_dwconv_col3x3_kernel": 0, "q8_dwconv_col5x5_kernel": 0, "q8_conv_c3rows_kernel": 0,
+            "q8_dwconv_col3x3_kernel": 0, "q8_dwconv_col5x5_kernel": 0, "q8_conv_c3rows_kernel": 0, "q8_conv_c3rows32_kernel": 0,
+            "q8_conv_wave_ws_kernelILi2ELi2E": 0,        # (round 5: whole-line stores of the 64 -> 64 weight-stationary 3x3 kernel)
             "q8_gemm_mfma_256x256_c_kernel": 0}
     for k, elf in enumerate(_code_objects(blob)):
         path = tmp_path / f"co{k}.elf"
@@ -160,9 +165,36 @@ def test_streaming_store_flavours_survive_the_compiler(tmp_path):
             name, body = m.group(1), m.group(2)
             for frag in want:
                 if frag in name:
-                    op = "buffer_store_dword " if "dwconv" in frag else ("buffer_store_dwordx4" if "c3rows" in frag else "global_store_dwordx4")
+                    op = "buffer_store_dword " if "dwconv" in frag else ("buffer_store_dwordx4" if ("c3rows" in frag or "conv_wave_ws" in frag) else "global_store_dwordx4")
                     stores = [ln for ln in body.split("\n") if op in ln]
                     hinted = [ln for ln in stores if re.search(r"\bnt\b", ln)]
                     assert hinted and len(hinted) < len(stores), (name, len(hinted), len(stores))
                     want[frag] += 1
     assert all(v > 0 for v in want.values()), want
+
+
+def test_patch_kernel_is_the_only_writer_of_m0_in_its_code(tmp_path):
+    """q8_conv_patch_kernel (hip/q8convpatch.hip) issues every LDS-DMA as inline assembly and leaves m0 as it set it (a save /
+    restore pair per piece would be half of the ring's scalar instructions). Sound only while nothing the compiler emits in
+    that kernel reads or writes m0: every m0 reference in its disassembly must be one of its own `s_mov_b32 m0, sN`, and every
+    LDS-DMA one of the two forms the assembly spells out (flat per-lane address: the patch; scalar base + lane offset: the ring)."""
+    if not os.path.exists(LIB):
+        pytest.skip("library not built")
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    blob = open(LIB, "rb").read()
+    seen = 0
+    for k, elf in enumerate(_code_objects(blob)):
+        path = tmp_path / f"co{k}.elf"
+        path.write_bytes(elf)
+        dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", str(path)], capture_output=True, text=True, check=True).stdout
+        for m in re.finditer(r"^[0-9a-f]+ <(\S*q8_conv_patch_kernel\S*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", dis, re.S | re.M):
+            name, body = m.group(1), m.group(2)
+            seen += 1
+            m0_lines = [ln.strip() for ln in body.split("\n") if re.search(r"\bm0\b", ln)]
+            assert m0_lines, name
+            for ln in m0_lines:
+                assert re.match(r"s_mov_b32 m0, s\d+\b", ln), (name, ln)
+            dma = [ln.strip() for ln in body.split("\n") if "global_load_lds" in ln]
+            assert dma and all(re.match(r"global_load_lds_dwordx4 v(\d+|\[\d+:\d+\]), (s\[\d+:\d+\]|off)", ln) for ln in dma), (name, dma[:3])
+    assert seen == 3 * 2 * 7, seen      # three tile flavours x two step widths x seven requantization classes
