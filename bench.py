@@ -184,13 +184,14 @@ def layer_bound_ms(layer, weight_bytes=0):
     return max(layer.ops / (PEAK_I8_TOPS * 1e12), (layer.in_bytes + layer.out_bytes + weight_bytes) / (PEAK_HBM_GBS * 1e9)) * 1e3
 
 
-def conv_list_bench(lib, torch, batch, shapes, seed0, warmup=2, iters=8):
+def conv_list_bench(lib, torch, batch, shapes, seed0, warmup=2, iters=8, out_scale=0.5):
     """One reference shape list (bench/convolution.cc) at `batch` images, every row its own operator on rotating buffers
     (> 512 MB between reuses), as the reference bench times them: per layer the kernel auto chose, time, TOP/s and the
     fraction of max(MFMA, HBM) roofline; per list the sum of layer times as images/s."""
     rows, total_ms, total_bound = [], 0.0, 0.0
     for i, (H, W, KH, KW, S, D, G, GIC, GOC) in enumerate(shapes):
-        layer = ConvLayer(lib, torch, batch, H, W, KH, KW, S, D, G, GIC, GOC, seed=seed0 + i, min_bytes_between_reuse=512 << 20)
+        layer = ConvLayer(lib, torch, batch, H, W, KH, KW, S, D, G, GIC, GOC, seed=seed0 + i, min_bytes_between_reuse=512 << 20,
+                          out_scale=out_scale)
         ms = layer.time_ms(warmup, iters)
         wbytes = G * GOC * KH * KW * GIC
         bound = layer_bound_ms(layer, wbytes)
@@ -487,6 +488,9 @@ def secondary_block(extra):
         if v:
             out[name + "_frac"] = v["frac"]
             out[name + "_us"] = v["us"]
+    v = get(["mobilenetv2_sweep_realistic_scale", "images_per_s_by_sum_of_layers"])
+    if v is not None:
+        out["c4_sweep_realistic_scale_images_per_s_sum_of_layers"] = v
     more = get(["q8dwconv_5x5_dilated_and_realistic_scale"], {})
     for key, name in (("dw5x5_56x56x72_s2", "dw5x5_s2"), ("dw5x5_28x28x240_s1", "dw5x5_28"), ("dw5x5_14x14x672_s1", "dw5x5_14"),
                       ("dw3x3_dil2_28x28x192", "dw3x3_dil2"), ("dw3x3_56x56x144_scale0.0125", "dw3x3_realistic_scale"),
@@ -900,6 +904,15 @@ def main():
                           "requant_scale": round(0.25 / oscale, 6)}
             layer.close()
         extra["q8dwconv_5x5_dilated_and_realistic_scale"] = more
+        # the whole sweep at that scale (0.0125, shift 6: the packed shift >= 1 tail of requant.hip.h where the lane forms
+        # apply), per layer on rotating buffers -- to be read beside `mobilenetv2_sweep.images_per_s_by_sum_of_layers`
+        if not args.no_conv_lists:
+            rs = conv_list_bench(lib, torch, my_batch, MOBILENETV2, 2100, out_scale=20.0)
+            extra["mobilenetv2_sweep_realistic_scale"] = {
+                "requant_scale": 0.0125, "batch_per_gpu": my_batch,
+                "images_per_s_by_sum_of_layers": rs["images_per_s_by_sum_of_layers"], "sum_of_layer_ms": rs["sum_of_layer_ms"],
+                "vs_scale_0.5_sum_of_layers": round(sum(r["ms"] for r in rows) / rs["sum_of_layer_ms"], 4),
+                "layers": [{"layer": i + 1, "kernel": r["kernel"], "us": r["us"]} for i, r in enumerate(rs["layers"])]}
 
         # ---------------------------------------------------------- the whole network (64 chained operators, one hipGraph)
         extra["mobilenetv2_network"] = network_bench(lib, torch, my_batch, total_batch, world, args.warmup,

@@ -186,6 +186,10 @@ void qnnp_debug_requant_lane(
     } else {
       const uint32_t u = (uint32_t) acc[i] - (uint32_t) rowterm[i] + UINT32_C(0x80000000);   /* a + 2^31 */
       const uint64_t addend = qnnp_requant_lane_addend(rowterm[i], l);
+      if (l.kind == 2 && l.shift <= QNNP_REQUANT_LANE_PK_MAX_SHIFT && folded && lo == 0 && hi == 255) {
+        out[i] = qnnp_requant_lane_sn_pk(u, addend, l);   /* the sequence requant_dispatch_lane picks for this operator */
+        continue;
+      }
       y = l.kind == 1 ? qnnp_requant_lane_s0(u, addend, l) : qnnp_requant_lane_sn(u, addend, l);
     }
     if (y < lo) y = lo;

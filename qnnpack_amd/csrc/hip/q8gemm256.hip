@@ -792,6 +792,8 @@ void q8_gemm_mfma_256x256_kernel(const IgemmParams p)
       if (p.lane.kind == 1) {
         if (p.rq.full_range) epilogue_lane(std::integral_constant<int, kRqShift0Lane>{}, std::true_type{});
         else epilogue_lane(std::integral_constant<int, kRqShift0Lane>{}, std::false_type{});
+      } else if (p.lane.shift <= QNNP_REQUANT_LANE_PK_MAX_SHIFT) {
+        epilogue_lane(std::integral_constant<int, kRqBoundedLanePk>{}, std::true_type{});     // (round 5: the packed tail)
       } else {
         epilogue_lane(std::integral_constant<int, kRqBoundedLane>{}, std::true_type{});
       }

@@ -94,7 +94,11 @@ constexpr int kRqBoundedOfs = 4;
  * requant_dispatch_lane see them. */
 constexpr int kRqShift0Lane = 5;
 constexpr int kRqBoundedLane = 6;
-template <int SEQ> constexpr bool rq_is_lane() { return SEQ == kRqShift0Lane || SEQ == kRqBoundedLane; }
+/* kRqBoundedLane with shift <= 7 (requant_math.h, qnnp_requant_lane_sn_pk): the sign of the rounding correction is the
+ * multiply-add's carry out, and the shift works on int16 pairs -- 3.75 instead of 5.25 instructions per value after
+ * the multiply-add. Full [0, 255] clamp only (the saturating packs are the clamp). */
+constexpr int kRqBoundedLanePk = 7;
+template <int SEQ> constexpr bool rq_is_lane() { return SEQ == kRqShift0Lane || SEQ == kRqBoundedLane || SEQ == kRqBoundedLanePk; }
 
 inline qnnp_requant_lane make_requant_lane(const qnnp_hip_requant& rq)
 {
@@ -256,6 +260,32 @@ __device__ __forceinline__ uint64_t lane_addend(int32_t rowterm, const qnnp_requ
   return static_cast<uint64_t>(static_cast<uint32_t>(rowterm) + 0x80000000u) * l.mult2 + l.konst;
 }
 
+/* v = q + (k1 - 1) + (q >= 0) of qnnp_requant_lane_sn_pk for four values: the multiply-adds with their carries out, then
+ * the adds that consume them (the carry takes the instruction's one scalar read, so k1 - 1 comes in a VGPR). Two asm
+ * blocks of four, not eight of one: the compiler neither interleaves inline asm nor knows its latencies, and it pads
+ * every block with an s_nop. */
+__device__ __forceinline__ void lane_mad_round4(
+    uint32_t u0, uint32_t u1, uint32_t u2, uint32_t u3, uint32_t m2, uint64_t addend, uint32_t k1m1_v,
+    int32_t& v0, int32_t& v1, int32_t& v2, int32_t& v3)
+{
+  uint64_t t0, t1, t2, t3, c0, c1, c2, c3;
+  asm("v_mad_u64_u32 %0, %4, %8, %12, %13\n\t"
+      "v_mad_u64_u32 %1, %5, %9, %12, %13\n\t"
+      "v_mad_u64_u32 %2, %6, %10, %12, %13\n\t"
+      "v_mad_u64_u32 %3, %7, %11, %12, %13"
+      : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3)
+      : "v"(u0), "v"(u1), "v"(u2), "v"(u3), "s"(m2), "v"(addend));
+  uint32_t r0, r1, r2, r3;
+  asm("v_addc_co_u32_e64 %0, %4, %8, %12, %4\n\t"
+      "v_addc_co_u32_e64 %1, %5, %9, %12, %5\n\t"
+      "v_addc_co_u32_e64 %2, %6, %10, %12, %6\n\t"
+      "v_addc_co_u32_e64 %3, %7, %11, %12, %7"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "+s"(c0), "+s"(c1), "+s"(c2), "+s"(c3)
+      : "v"(static_cast<uint32_t>(t0 >> 32)), "v"(static_cast<uint32_t>(t1 >> 32)), "v"(static_cast<uint32_t>(t2 >> 32)),
+        "v"(static_cast<uint32_t>(t3 >> 32)), "v"(k1m1_v));
+  v0 = static_cast<int32_t>(r0); v1 = static_cast<int32_t>(r1); v2 = static_cast<int32_t>(r2); v3 = static_cast<int32_t>(r3);
+}
+
 /* u = a + 2^31 for four channels of one row; `addend` = lane_addend of that row. The multiplier stays the scalar
  * operand of the multiply-add (one per VOP3 instruction on gfx9), the addend is the lane's register pair. */
 template <int SEQ, bool FULL_RANGE>
@@ -264,6 +294,31 @@ __device__ __forceinline__ uint32_t q31_requantize_pack4_lane(
 {
   static_assert(rq_is_lane<SEQ>(), "lane forms only");
   const uint32_t m2 = l.mult2;
+  if constexpr (SEQ == kRqBoundedLanePk) {
+    static_assert(FULL_RANGE, "the packed tail is the [0, 255] clamp");
+    uint32_t k1m1 = l.k1 - 1u;
+    asm("" : "+v"(k1m1));
+    const uint32_t sh2 = l.shift * 0x10001u;          // the shift for both halves of a pair
+    // The matrix-core hazard: gfx950 has no interlock between an MFMA's write of its accumulators and a VALU read of them
+    // (8 passes + 3 wait states here); hipcc pads in front of the first reader it KNOWS, and it does not look inside
+    // inline asm -- the first version of this tail read accumulators three instructions after the MFMA and returned
+    // garbage. So one instruction the compiler does know reads the accumulator block first (u3 | 0, the zero opaque), and
+    // the asm takes its result. CONTRACT: u0..u3 come from one MFMA result (every caller passes acc[4 rg .. 4 rg + 3]).
+    uint32_t zero = 0;
+    asm("" : "+s"(zero));
+    const uint32_t u3f = u3 | zero;
+    int32_t v0, v1, v2, v3;
+    lane_mad_round4(u0, u1, u2, u3f, m2, addend, k1m1, v0, v1, v2, v3);
+    const auto p01 = __builtin_amdgcn_cvt_pk_i16(v0, v1);   // saturating: qnnp_requant_lane_sn_pk says why that is exact
+    const auto p23 = __builtin_amdgcn_cvt_pk_i16(v2, v3);
+    uint32_t lo, hi;
+    asm("v_pk_ashrrev_i16 %0, %2, %3\n\t"
+        "v_pk_ashrrev_i16 %1, %2, %4\n\t"
+        "v_sat_pk_u8_i16 %0, %0\n\t"
+        "v_sat_pk_u8_i16 %1, %1"
+        : "=&v"(lo), "=&v"(hi) : "s"(sh2), "v"(p01), "v"(p23));
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+  }
   int32_t y0 = static_cast<int32_t>(static_cast<uint32_t>((static_cast<uint64_t>(u0) * m2 + addend) >> 32));
   int32_t y1 = static_cast<int32_t>(static_cast<uint32_t>((static_cast<uint64_t>(u1) * m2 + addend) >> 32));
   int32_t y2 = static_cast<int32_t>(static_cast<uint32_t>((static_cast<uint64_t>(u2) * m2 + addend) >> 32));
@@ -317,12 +372,13 @@ __host__ __device__ __forceinline__ void requant_dispatch_lane(const RequantDev&
 {
   using Shift0Lane = std::integral_constant<int, kRqShift0Lane>;
   using BoundedLane = std::integral_constant<int, kRqBoundedLane>;
+  using BoundedLanePk = std::integral_constant<int, kRqBoundedLanePk>;
   using Shift0Ofs = std::integral_constant<int, kRqShift0Ofs>;
   using General = std::integral_constant<int, kRqGeneral>;
   if (lane.kind == 1) {
     if (rq.full_range) f(Shift0Lane{}, std::true_type{}); else f(Shift0Lane{}, std::false_type{});
   } else if (lane.kind == 2 && rq.full_range) {
-    f(BoundedLane{}, std::true_type{});
+    if (lane.shift <= QNNP_REQUANT_LANE_PK_MAX_SHIFT) f(BoundedLanePk{}, std::true_type{}); else f(BoundedLane{}, std::true_type{});
   } else if (rq.f.shift == 0) {
     if (rq.full_range) f(Shift0Ofs{}, std::true_type{}); else f(Shift0Ofs{}, std::false_type{});
   } else {

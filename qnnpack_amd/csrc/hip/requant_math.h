@@ -264,6 +264,29 @@ QNNP_HD int32_t qnnp_requant_lane_sn(uint32_t u, uint64_t addend, const struct q
   return qnnp_asr32((int32_t) v, l.shift);
 }
 
+/*
+ * Kind 2 with shift <= 7 under the full [0, 255] clamp: the packed tail (round 5). Returns the output BYTE.
+ *   - the sign of q comes out of the multiply-add itself: L (as a 64-bit pattern) is 2^64 + 2M (rowterm - 2^31) + 2^31,
+ *     inside (0, 2^64) for every |rowterm| <= 2^30, so u * 2M + L == 2^64 + (2M n + 2^31) exactly and the addition's
+ *     carry out is (2M n + 2^31 >= 0) == (q >= 0): v = q + (k1 - 1) + carry is one add-with-carry instead of a shift and
+ *     a three-operand add;
+ *   - two v's are then saturated to int16 in one instruction, shifted as a pair, and saturated to bytes as a pair: an
+ *     in-range result needs 0 <= v < 256 * 2^s <= 2^15, so the first saturation only ever touches values the clamp
+ *     sends to 0 or 255 anyway (-32768 >> s < 0, 32767 >> s >= 255 for s <= 7).
+ * 3.75 instructions per value after the multiply-add against 5.25.
+ */
+QNNP_HD uint8_t qnnp_requant_lane_sn_pk(uint32_t u, uint64_t addend, const struct qnnp_requant_lane l)
+{
+  const uint64_t prod = (uint64_t) u * (uint64_t) l.mult2;
+  const uint64_t t = prod + addend;
+  const uint32_t carry = t < prod ? 1u : 0u;
+  const int32_t v = (int32_t) ((uint32_t) (t >> 32) + (l.k1 - 1u) + carry);
+  int32_t h = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+  h = qnnp_asr32(h, l.shift);
+  return (uint8_t) (h < 0 ? 0 : (h > 255 ? 255 : h));
+}
+#define QNNP_REQUANT_LANE_PK_MAX_SHIFT 7u
+
 QNNP_HD int32_t qnnp_requant_scale(int32_t n, const struct qnnp_requant_fast f)
 {
   if (f.shift == 0) return qnnp_requant_scale_s0(n, f);

@@ -164,7 +164,8 @@ def test_bounded_requantization_sequence_matches_oracle(debug_hooks):
             for k in range(-12, 13):
                 ties += [v for v in ((k << s) + (1 << (s - 1)) + d for d in (-1, 0, 1)) if -lim < v < lim]
         acc[6:6 + len(ties)] = np.array(ties, dtype=np.int64).astype(np.int32)
-        for scale in [0.49999997, 0.25, 0.3, 1 / 255.0, 0.0031, 2.0 ** -12, 1.7e-5, 2.0 ** -20, 1.9e-6]:
+        # (shift 1..7 under the [0, 255] clamp answer through the packed tail, qnnp_requant_lane_sn_pk: carry-out sign, int16 pairs)
+        for scale in [0.49999997, 0.25, 0.3, 0.12, 0.05, 0.02, 0.0125, 2.0 ** -7, 1 / 255.0, 0.0031, 2.0 ** -12, 1.7e-5, 2.0 ** -20, 1.9e-6]:
             for zp, qmin, qmax in [(0, 0, 255), (127, 0, 255), (255, 0, 255), (100, 128, 255), (7, 5, 9)]:
                 out = np.empty(acc.size, np.uint8)
                 bounded = ctypes.c_int(-1)

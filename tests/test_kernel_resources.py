@@ -197,4 +197,4 @@ def test_patch_kernel_is_the_only_writer_of_m0_in_its_code(tmp_path):
                 assert re.match(r"s_mov_b32 m0, s\d+\b", ln), (name, ln)
             dma = [ln.strip() for ln in body.split("\n") if "global_load_lds" in ln]
             assert dma and all(re.match(r"global_load_lds_dwordx4 v(\d+|\[\d+:\d+\]), (s\[\d+:\d+\]|off)", ln) for ln in dma), (name, dma[:3])
-    assert seen == 3 * 2 * 7, seen      # three tile flavours x two step widths x seven requantization classes
+    assert seen == 3 * 2 * 8, seen      # three tile flavours x two step widths x eight requantization classes
