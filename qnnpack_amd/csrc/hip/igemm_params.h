@@ -85,6 +85,12 @@ struct IgemmParams {
                              // 0x7F7F7F7F (on 127); 0 = the operator has no centred image
   uint32_t tiles_n_magic;    // q8gemm256c.hip only: floor(2^32 / tiles_n) + 1, so that x / tiles_n == hi32(x * magic) for the
                              // tile ids of a launch (x * tiles_n < 2^32); set by gemm256c_launch
+  // strided 1x1 convolutions on the staged pointwise streaming kernel (round 5): `offsets` holds one VALID entry per
+  // output pixel of an image (ks == 1, no tap on padding); row m reads input + (m / rows_per_image) * image_stride +
+  // offsets[m % rows_per_image]. rpi_magic = floor(2^32 / rows_per_image) + 1 when rows * rows_per_image < 2^32 (then
+  // m / rows_per_image == hi32(m * magic)), else 0 = divide. offsets_dense == 0: the kernel never looks at `offsets`.
+  uint32_t offsets_dense;
+  uint32_t rpi_magic;
 };
 
 /* convolution geometry for the LDS-tiled direct-convolution kernel */

@@ -565,6 +565,14 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   if (p.bias2u == nullptr) p.lane.kind = 0;      // no table to start from: the offset forms
   p.stream_out = a->streaming_mode == 0 ? (qnnp_hip_streaming_stores() != 0 ? 1u : 0u) : (a->streaming_mode == 2 ? 1u : 0u);
   p.a_flip = 0;
+  // a table row per output pixel with its one tap inside the image: a strided 1x1 convolution without padding taps
+  p.offsets_dense = (a->offsets != nullptr && a->ks == 1 && a->kernel_height == 1 && a->kernel_width == 1 && a->groups == 1 &&
+                     a->pad_top == 0 && a->pad_left == 0 && a->rows_per_image > 0 && a->output_height > 0 && a->output_width > 0 &&
+                     static_cast<uint64_t>(a->output_height - 1) * a->stride_height < a->input_height &&
+                     static_cast<uint64_t>(a->output_width - 1) * a->stride_width < a->input_width &&
+                     a->rows_per_image == a->output_height * a->output_width) ? 1u : 0u;
+  p.rpi_magic = (p.offsets_dense != 0 && static_cast<uint64_t>(a->rows) * a->rows_per_image < (UINT64_C(1) << 32))
+                    ? static_cast<uint32_t>((UINT64_C(1) << 32) / a->rows_per_image) + 1u : 0u;
   p.fill_table = qnnp_hip_fill_table();
   p.trace = nullptr;
 #ifdef QNNP_ENABLE_ABLATION

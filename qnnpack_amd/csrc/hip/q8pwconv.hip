@@ -456,6 +456,11 @@ void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const u
     uint32_t m = unit * 32u + row_in_block;
     if (m >= p.rows) m = p.rows - 1;                      // clamped rows are never stored
     const uint8_t* row = p.input + static_cast<uint64_t>(m) * p.input_stride + khalf * 16;
+    if (p.offsets_dense != 0) {                           // strided 1x1 convolution (wave-uniform): the row's table entry
+      const uint32_t img = p.rpi_magic != 0 ? __umulhi(m, p.rpi_magic) : m / p.rows_per_image;
+      const uint32_t pix = m - img * p.rows_per_image;
+      row = p.input + static_cast<uint64_t>(img) * p.image_stride + static_cast<uint32_t>(p.offsets[pix]) + khalf * 16;
+    }
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) {
       const uint8_t* src = row + kb * 32;
@@ -1537,11 +1542,14 @@ uint32_t pw_lds_bytes(const IgemmParams& p)
 /* pointwise / fully-connected form only (no offset table), one group, K <= 256, weights + bias <= 64 KiB */
 bool pwstream_supported(const IgemmParams& p, uint32_t groups, uint32_t vec)
 {
-  if (p.offsets != nullptr || groups != 1 || (vec != 16 && vec != 8)) return false;
+  if ((p.offsets != nullptr && p.offsets_dense == 0) || groups != 1 || (vec != 16 && vec != 8)) return false;
   if (p.fill_table == nullptr || p.rows == 0 || p.k_total == 0 || p.k_total > 256u) return false;
   if (p.k_total % vec != 0) return false;
-  if (pw_lds_bytes(p) <= kMaxLds) return true;
   StagedPlan plan;
+  if (p.offsets != nullptr) {       // strided 1x1 convolution: the staged flavour only (the one that reads the table)
+    return p.d2s_sh == 0 && p.n != 32 && plan_staged(p, (p.k_total + 31u) / 32u, &plan, vec);
+  }
+  if (pw_lds_bytes(p) <= kMaxLds) return true;
   return plan_staged(p, (p.k_total + 31u) / 32u, &plan, vec);     // any N, in workgroup columns
 }
 
@@ -1681,6 +1689,7 @@ int pwstream_launch(const IgemmParams& p0, uint32_t vec, hipStream_t stream, con
   if (p.n != 32 && plan_staged(p, kb, &plan, vec)) {
     return vec == 16 ? dispatch_kb_staged<16>(p, kb, plan, stream) : dispatch_kb_staged<8>(p, kb, plan, stream);
   }
+  if (p.offsets != nullptr) return QNNP_HIP_EINVAL;        // (pwstream_supported said so)
   if (lds_bytes > kMaxLds) return QNNP_HIP_EINVAL;
   return vec == 16 ? dispatch_kb<16>(p, kb, lds_bytes, stream) : dispatch_kb<8>(p, kb, lds_bytes, stream);
 }

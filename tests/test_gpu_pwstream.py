@@ -102,6 +102,44 @@ def test_pointwise_convolution(pw, case):
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 
 
+# ---- strided 1x1 convolutions (round 5): the staged flavour reads a table row per output pixel (ResNet's downsampling
+#      shortcuts; reference: the same indirection + q8conv path as any convolution, src/convolution.c:414-421) ----
+@pytest.mark.parametrize("case", [
+    ConvCase("pw_1x1_s2_64_128", (28, 28), subsampling=(2, 2), gic=64, goc=128, batch=3),
+    ConvCase("pw_1x1_s2_odd_sizes", (27, 29), subsampling=(2, 2), gic=32, goc=48, batch=2),
+    ConvCase("pw_1x1_s3x2_rect", (20, 31), subsampling=(3, 2), gic=16, goc=64, batch=5),
+    ConvCase("pw_1x1_s2_strided_pixels", (15, 15), subsampling=(2, 2), gic=64, goc=96, batch=2, input_pixel_stride=80, output_pixel_stride=112),
+    ConvCase("pw_1x1_s2_8_byte_rows", (16, 18), subsampling=(2, 2), gic=24, goc=64, batch=2),
+    ConvCase("pw_1x1_s2_256_512", (14, 14), subsampling=(2, 2), gic=256, goc=512, batch=4),
+    ConvCase("pw_1x1_s2_kzp126", (12, 12), subsampling=(2, 2), gic=128, goc=256, batch=2, kzp=126, izp=3),
+    ConvCase("pw_1x1_s4_one_column", (13, 3), subsampling=(4, 4), gic=48, goc=80, batch=7),
+], ids=lambda c: c.name)
+def test_strided_pointwise_convolution(pw, case):
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(pw, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == KERNEL, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("case", [
+    ConvCase("pw_1x1_s2_padded", (14, 14), padding=(1, 1, 1, 1), subsampling=(2, 2), gic=64, goc=128),   # taps on padding
+    ConvCase("pw_1x1_s2_n32", (14, 14), subsampling=(2, 2), gic=64, goc=32),          # one channel block: the first flavour, no table
+    ConvCase("pw_1x1_s2_grouped", (14, 14), subsampling=(2, 2), groups=2, gic=32, goc=64),
+], ids=lambda c: c.name)
+def test_strided_pointwise_shapes_it_does_not_take(qnnp, case):
+    from qnnpack_amd import QnnpackError
+    expected, quant, out_hw = conv_expected(case)
+    qnnp.set_option("gemm_kernel", 5)
+    try:
+        with pytest.raises(QnnpackError):
+            conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    finally:
+        qnnp.set_option("gemm_kernel", 0)
+    out, kname = conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)   # auto: another kernel, same bytes
+    assert kname != KERNEL
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
 @pytest.mark.parametrize("case", [FcCase("pw_bad_k", 64, 260, 16),       # K > 256
                                   FcCase("pw_bad_align", 64, 20, 16),    # rows only 4-byte aligned
                                   FcCase("pw_bad_lds", 64, 256, 500)],   # weights exceed the LDS budget and the rows are
