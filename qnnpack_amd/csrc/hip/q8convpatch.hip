@@ -70,6 +70,7 @@ struct PatchArgs {
   uint32_t inv_cpp1;          // ceil(2^32 / (C / 16 + 1))
   uint32_t pix_off, bias_off, ring_off;   // LDS byte offsets (the patch is at 0)
   uint32_t ksteps, csteps;    // K steps of the flavour (64 or 128 bytes): 9 * C / KSTEP; steps per tap
+  uint32_t nch;               // CHUNK flavour: the patch holds 128 of the C channels at a time, C / 128 chunks (1: the whole patch)
   uint32_t abl;               // measurement builds only (QNNP_PATCH_ABL): 1 = no ring requests in the loop, 2 = no per-step barrier,
                               // 4 = no fragment reads in the loop, 8 = no MFMA, 16 = both waves of a SIMD request in the same half,
                               // 32 = no patch pass (no re-centring, no sums), 64 = no epilogue stores
@@ -140,10 +141,16 @@ __device__ __forceinline__ void pt_ds_write4(uint32_t off, int32_t v)
 /* MB = 32-position blocks of the tile (4 or 8). The workgroup has MB * NTB / 4 waves, each 2 x 2 blocks: 8 waves for
  *      (4, 8) and (8, 4); FOUR waves for (4, 4) -- half the ring, so that two workgroups share a CU where one 8-wave
  *      workgroup with a 64 KiB ring would be alone: one's prologue, barriers and epilogue run under the other's multiplies. */
-template <int MB, int NTB, int KSTEP, int SEQ, bool FULL>
+/* CHUNK (KSTEP 128 only; round 5): the patch of all C channels does not fit beside the ring for a full tile of positions
+ *       (stride 2 with 256 / 512 channels: four patch pixels per position) -- the non-chunked plan then shrinks the tile to
+ *       28-56 positions and the MFMAs run 22-44 % full. Here the patch holds 128 channels at a time: K runs chunk-major
+ *       (chunk, tap), the patch is re-staged and re-centred between chunks (three barriers, the pipeline restarts), the pixel
+ *       sums accumulate over the chunks, and the weight stream jumps through the packed image (tap-major there). */
+template <int MB, int NTB, int KSTEP, int SEQ, bool FULL, bool CHUNK = false>
 __global__ __launch_bounds__(MB * NTB * 16, 2)
 void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs a)
 {
+  static_assert(!CHUNK || KSTEP == 128, "channel chunks are one 128-byte step per tap");
   constexpr int kPtWaves = MB * NTB / 4;
   constexpr int kPtThreads = kPtWaves * 64;
   static_assert((MB == 4 || MB == 8) && (NTB == 4 || NTB == 8) && kPtWaves <= 8, "tile flavours");
@@ -178,7 +185,7 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
   if (a.imgs > 1) { img0 = tile_m * a.imgs; row0 = 0; }
   else { img0 = pt_div(tile_m, a.inv_tiles_r); row0 = (tile_m - img0 * a.tiles_r) * a.rows; }
 
-  const uint32_t C = p.kc;
+  const uint32_t C = CHUNK ? 128u : p.kc;             // channels the patch holds
   const uint32_t cpp = C >> 4;
   const uint32_t ps = a.ps;                           // bytes between patch pixels in LDS: C + 16
   const uint32_t kblocks = p.k_pad >> 5;
@@ -200,23 +207,35 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
   }
   const uint32_t lane16 = lane * 16u;
   uint32_t wr_off = 0;                               // ring offset of the next step to request
-  auto stage = [&]() __attribute__((always_inline)) {
+  uint32_t st_tap = 0, st_ch = 0;                    // CHUNK: (tap, chunk) of the next step to request; its K offset in the
+  auto stage = [&]() __attribute__((always_inline)) { //        packed image is (tap * nch + chunk) * 128 bytes
 #pragma unroll
     for (int i = 0; i < kPpw; i++) {
-      pt_dma16_saddr(w_src[i], lane16, w_dst[i] + wr_off);
-      w_src[i] += kSub * 1024u;
+      if constexpr (CHUNK) {
+        pt_dma16_saddr(w_src[i] + (st_tap * a.nch + st_ch) * (kSub * 1024u), lane16, w_dst[i] + wr_off);
+      } else {
+        pt_dma16_saddr(w_src[i], lane16, w_dst[i] + wr_off);
+        w_src[i] += kSub * 1024u;
+      }
     }
+    if constexpr (CHUNK) { if (++st_tap == 9u) { st_tap = 0; st_ch++; } }
     wr_off = (wr_off + kStepBytes) & kRingMask;
   };
 #pragma unroll
   for (int i = 0; i < kAhead; i++) stage();           // (ksteps >= 9 > kAhead)
 
   // ---- the patch: LDS chunk v = pixel q * (cpp + 1) + c <- chunk c of input pixel (img0 + il, iy, ix), or the zero-point line
-  //      of the fill table (pixels outside the image; c == cpp is the pixel's padding chunk)
-  {
+  //      of the fill table (pixels outside the image; c == cpp is the pixel's padding chunk). `ch`: the channel chunk (CHUNK).
+  // CHUNK: the source of a lane's first kCache pieces is worked out once (chunk 0) and kept -- the later chunks are the same
+  // pixels 128 bytes further (stamps of the first build, 14x14 512 -> 512: 6.1 k cycles of address arithmetic per chunk for
+  // four waves, a third of a chunk's nine multiply steps)
+  constexpr int kCache = CHUNK ? 16 : 1;
+  const uint8_t* src_cache[kCache];
+  uint32_t src_inside = 0;                           // bit i: piece i of this lane reads the image (not the zero-point line)
+  auto load_patch = [&](uint32_t ch) __attribute__((always_inline)) {
     const uint8_t* zp_line = p.fill_table + (p.izp_fill & 0xFFu) * 16u;
     const uint32_t pieces = (a.chunks + 63u) >> 6;
-    for (uint32_t piece = wave; piece < pieces; piece += kPtWaves) {
+    auto source = [&](uint32_t piece, bool* inside_out) __attribute__((always_inline)) -> const uint8_t* {
       const uint32_t v = min(piece * 64u + lane, a.chunks - 1u);
       const uint32_t q = pt_div(v, a.inv_cpp1);
       const uint32_t c = v - q * (cpp + 1u);
@@ -228,17 +247,39 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
       const int32_t ix = static_cast<int32_t>(pc) - static_cast<int32_t>(g.pad_left);
       const uint32_t img = img0 + il;
       const bool inside = c < cpp && img < a.batch && static_cast<uint32_t>(iy) < g.H && static_cast<uint32_t>(ix) < g.W;
-      const uint8_t* src = inside
+      *inside_out = inside;
+      return inside
           ? p.input + static_cast<uint64_t>(img) * p.image_stride +
                 static_cast<uint64_t>(static_cast<uint32_t>(iy) * g.W + static_cast<uint32_t>(ix)) * p.input_stride + (c << 4)
           : zp_line;
-      pt_dma16(src, lds0 + piece * 1024u);
+    };
+    uint32_t first = wave;
+    if constexpr (CHUNK) {
+#pragma unroll
+      for (int i = 0; i < kCache; i++) {
+        const uint32_t piece = wave + static_cast<uint32_t>(i) * kPtWaves;
+        if (piece < pieces) {                          // (wave-uniform)
+          if (ch == 0) {
+            bool inside;
+            src_cache[i] = source(piece, &inside);
+            src_inside |= inside ? (1u << i) : 0u;
+          }
+          pt_dma16(src_cache[i] + (((src_inside >> i) & 1u) != 0u ? ch * 128u : 0u), lds0 + piece * 1024u);
+        }
+      }
+      first = wave + static_cast<uint32_t>(kCache) * kPtWaves;
     }
-    if (wave == kPtWaves - 1 && lane < NTB * 8u) {
+    for (uint32_t piece = first; piece < pieces; piece += kPtWaves) {
+      bool inside;
+      const uint8_t* src = source(piece, &inside);
+      pt_dma16(src + (inside ? ch * 128u : 0u), lds0 + piece * 1024u);
+    }
+    if (ch == 0 && wave == kPtWaves - 1 && lane < NTB * 8u) {
       const int32_t* b = (rq_is_lane<SEQ>() ? p.bias2u : p.bias2) + nb_tile * 32u;
       pt_dma16(reinterpret_cast<const uint8_t*>(b) + lane * 16u, lds0 + a.bias_off);
     }
-  }
+  };
+  load_patch(0);
   PT_STAMP(1);
   pt_wait_vmcnt<0>();
   asm volatile("s_barrier" ::: "memory");
@@ -246,8 +287,54 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
 
   // ---- one pass over the landed patch, four threads per pixel (a quarter of its chunks each): re-centre in place (a ^ 0x80),
   //      the pixel's channel sum (of a') beside it
-  if (!(abl & 32u)) {
+  auto patch_pass = [&](uint32_t ch) __attribute__((always_inline)) {
+    if (abl & 32u) return;
     const bool sums = p.row_coeff != 0;
+    if constexpr (CHUNK) {
+      // two chunks per thread; four tasks per trip with all eight reads in front (the plain loop below is one LDS round trip per
+      // task: 3.8 k cycles per chunk for the four-wave flavour by the stamps)
+      const uint32_t total = a.ppix * 4u;
+      for (uint32_t t0 = tid; t0 < total; t0 += kPtThreads * 4u) {
+        v4i x[4][2];
+        uint32_t mine[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t t = min(t0 + static_cast<uint32_t>(u) * kPtThreads, total - 1u);
+          mine[u] = (t >> 2) * ps + (t & 3u) * 32u;
+          x[u][0] = *reinterpret_cast<const v4i*>(lds + mine[u]);
+          x[u][1] = *reinterpret_cast<const v4i*>(lds + mine[u] + 16u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t t = t0 + static_cast<uint32_t>(u) * kPtThreads;
+          if (t < total) {                            // (whole quads: total is a multiple of four)
+            uint32_t s = 0;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+              v4i y = x[u][c];
+              if (sums) {
+                s = __builtin_amdgcn_sad_u8(y.x, 0u, s);
+                s = __builtin_amdgcn_sad_u8(y.y, 0u, s);
+                s = __builtin_amdgcn_sad_u8(y.z, 0u, s);
+                s = __builtin_amdgcn_sad_u8(y.w, 0u, s);
+              }
+              y.x ^= static_cast<int>(kPtFlip); y.y ^= static_cast<int>(kPtFlip); y.z ^= static_cast<int>(kPtFlip); y.w ^= static_cast<int>(kPtFlip);
+              pt_ds_write16(lds0 + mine[u] + c * 16u, y);
+            }
+            if (sums) {
+              s += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(s), 0xB1, 0xF, 0xF, false));
+              s += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(s), 0x4E, 0xF, 0xF, false));
+              if ((t & 3u) == 0u) {
+                int32_t sum = static_cast<int32_t>(s) - 128 * 128;
+                if (ch != 0) sum += pix[t >> 2];      // (the same thread wrote it a chunk ago)
+                pt_ds_write4(lds0 + a.pix_off + (t >> 2) * 4u, sum);
+              }
+            }
+          }
+        }
+      }
+      return;
+    }
     const uint32_t per = cpp >> 2;                    // chunks per thread: 1 .. 8
     for (uint32_t t = tid; t < a.ppix * 4u; t += kPtThreads) {
       const uint32_t q = t >> 2;
@@ -267,10 +354,13 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
       if (sums) {
         s += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(s), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
         s += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(s), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
-        if ((t & 3u) == 0u) pt_ds_write4(lds0 + a.pix_off + q * 4u, static_cast<int32_t>(s) - 128 * static_cast<int32_t>(C));
+        if ((t & 3u) == 0u) {
+          pt_ds_write4(lds0 + a.pix_off + q * 4u, static_cast<int32_t>(s) - 128 * static_cast<int32_t>(C));
+        }
       }
     }
-  }
+  };
+  patch_pass(0);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   PT_STAMP(3);
 
@@ -318,10 +408,19 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
     f.b[0] = pt_ds_read16<sub * 1024>(bcur);
     f.b[1] = pt_ds_read16<sub * 1024 + kSub * 1024>(bcur);
   };
+  // The same four reads WITH their wait, as one asm block: for the places where the registers cross an irregular edge of the
+  // control flow (the chunk loop's header) -- hipcc is free to copy an asm output the moment the asm ends, and a copy of a
+  // register whose ds_read is still in flight copies the OLD value (the first chunked build re-started every chunk with the
+  // previous step's fragments that way). Inside the regular step loop the deferred waits are checked by the parity tests.
+  auto load_now = [&](Frags& f) __attribute__((always_inline)) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %6 offset:%7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.b[0]), "=&v"(f.b[1])
+                 : "v"(acur[0]), "v"(acur[1]), "v"(bcur), "n"(kSub * 1024) : "memory");
+  };
   auto advance = [&]() __attribute__((always_inline)) {       // to the next step: KSTEP bytes further, or the next tap's pixel
     rd_off = (rd_off + kStepBytes) & kRingMask;
     bcur = bbase + rd_off;
-    if (++kc == a.csteps) {
+    if (CHUNK || ++kc == a.csteps) {
       kc = 0;
       tap = min(tap + 1u, 8u);
       const uint32_t ky = (tap * 11u) >> 5;          // tap / 3 for tap < 9
@@ -340,7 +439,7 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
   Frags fa, fb;
   fa.a[0] = fa.a[1] = fa.b[0] = fa.b[1] = fb.a[0] = fb.a[1] = fb.b[0] = fb.b[1] = v4i{0, 0, 0, 0};
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the bias reads above are the compiler's: none may be pending beside the counted ones)
-  load(fa, std::integral_constant<uint32_t, 0>{});
+  if constexpr (CHUNK) load_now(fa); else load(fa, std::integral_constant<uint32_t, 0>{});
   // One sub-step: the MFMAs of `cur`, whose fragments were requested a sub-step ago, while `nxt` receives the next sub-step's.
   // Before the LAST sub-step of a step: counted wait + barrier (the next step's fragments are in their slot, everyone has left
   // the previous one's), then the next step's first fragments. STAGE (first sub-step): request the step kAhead ahead into the
@@ -383,6 +482,29 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
   };
   using T = std::true_type;
   using F = std::false_type;
+  if constexpr (CHUNK) {
+    // chunk-major: nine steps (taps) per chunk; a chunk's last step reads nothing ahead (the patch is about to change) but
+    // still requests the next chunk's first weights, which land under the re-staging
+    using V0 = std::integral_constant<int, 0>;
+    for (uint32_t ch = 0; ch < a.nch; ch++) {
+      if (ch != 0) {
+        asm volatile("s_barrier" ::: "memory");       // every wave has its last fragments of the previous chunk
+        load_patch(ch);
+        pt_wait_vmcnt<0>();
+        asm volatile("s_barrier" ::: "memory");
+        patch_pass(ch);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        rd_off = (rd_off + kStepBytes) & kRingMask;   // (the last step did not advance)
+        bcur = bbase + rd_off;
+        tap = 0;
+        acur[0] = abase0[0];
+        acur[1] = abase0[1];
+        load_now(fa);
+      }
+      for (uint32_t t = 0; t < 8u; t++) step_body(T{}, V0{}, F{});
+      if (ch + 1u < a.nch) step_body(T{}, V0{}, T{}); else step_body(F{}, V0{}, T{});
+    }
+  } else {
   // at the barrier of step s the requests of steps s + 2 .. s + kAhead may stay in flight; the last kAhead steps request nothing
   for (uint32_t step = 0; step + kAhead < a.ksteps; step++) step_body(T{}, std::integral_constant<int, (kAhead - 1) * kPpw>{}, F{});
   if constexpr (kAhead == 3) {
@@ -390,6 +512,7 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
     step_body(F{}, std::integral_constant<int, 0>{}, F{});
   }
   step_body(F{}, std::integral_constant<int, 0>{}, T{});
+  }
   PT_STAMP(4);
 
   // ---- fused epilogue: row term (sum of the window's pixel sums), requantization in registers, 16-byte stores
@@ -434,24 +557,26 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
 #undef PT_STAMP
 }
 
-template <int MB, int NTB, int KSTEP, int SEQ, bool FULL>
+template <int MB, int NTB, int KSTEP, int SEQ, bool FULL, bool CHUNK = false>
 int launch_patch_as(const IgemmParams& p, const ConvGeom& g, const PatchArgs& a, uint32_t lds_bytes, hipStream_t stream)
 {
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
   if (auto once_scope = attr_once.begin()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_patch_kernel<MB, NTB, KSTEP, SEQ, FULL>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_patch_kernel<MB, NTB, KSTEP, SEQ, FULL, CHUNK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kPtLdsLimit)) != hipSuccess) {
       (void) hipGetLastError();
     }
   }
-  hipLaunchKernelGGL((q8_conv_patch_kernel<MB, NTB, KSTEP, SEQ, FULL>), dim3(a.tiles_m * a.tiles_n), dim3(MB * NTB * 16), lds_bytes, stream, p, g, a);
+  hipLaunchKernelGGL((q8_conv_patch_kernel<MB, NTB, KSTEP, SEQ, FULL, CHUNK>), dim3(a.tiles_m * a.tiles_n), dim3(MB * NTB * 16), lds_bytes, stream, p, g, a);
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
 /* Tile geometry and LDS plan of one flavour (mb position blocks x ntb channel blocks), or false when it does not fit. */
-bool plan_flavour(const IgemmParams& p, const ConvGeom& g, uint32_t batch, uint32_t mb, uint32_t ntb, PatchArgs* a, uint32_t* lds_bytes)
+bool plan_flavour(const IgemmParams& p, const ConvGeom& g, uint32_t batch, uint32_t mb, uint32_t ntb, PatchArgs* a, uint32_t* lds_bytes,
+                  bool chunked = false)
 {
-  const uint32_t C = p.kc;
+  if (chunked && (p.kc % 128u != 0 || p.kc < 256u)) return false;
+  const uint32_t C = chunked ? 128u : p.kc;            // channels the patch holds at a time
   const uint32_t pmax = mb * 32u;
   const uint32_t cpp = C >> 4;
   if (p.n % (ntb * 32u) != 0 || g.OW > pmax) return false;
@@ -464,7 +589,7 @@ bool plan_flavour(const IgemmParams& p, const ConvGeom& g, uint32_t batch, uint3
     const uint32_t tiles_r = (g.OH + rows - 1) / rows;
     rows = (g.OH + tiles_r - 1) / tiles_r;            // even rows per tile
   }
-  const uint32_t kstep = C % 128u == 0 ? 128u : 64u;
+  const uint32_t kstep = p.kc % 128u == 0 ? 128u : 64u;
   const uint32_t ring = pt_stages(static_cast<int>(kstep)) * ntb * (kstep / 32u) * 1024u;
   for (;;) {
     a->imgs = imgs; a->rows = rows;
@@ -503,7 +628,8 @@ bool plan_flavour(const IgemmParams& p, const ConvGeom& g, uint32_t batch, uint3
   a->ps = C + 16u;
   a->inv_cpp1 = pt_magic(cpp + 1u);
   a->csteps = C / kstep;
-  a->ksteps = 9u * a->csteps;
+  a->ksteps = 9u * (p.kc / kstep);
+  a->nch = chunked ? p.kc / 128u : 1u;
   a->abl = 0;
 #ifdef QNNP_ENABLE_ABLATION
   if (const char* env = getenv("QNNP_PATCH_ABL")) a->abl = static_cast<uint32_t>(atoi(env));
@@ -529,6 +655,21 @@ bool plan_patch(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32
 #ifdef QNNP_ENABLE_ABLATION
   if (const char* env = getenv("QNNP_PATCH_TILE")) forced = static_cast<uint32_t>(atoi(env));   // 84, 44 or 48 = (mb, ntb)
 #endif
+  // the whole patch, or 128 channels of it at a time where that buys a fuller tile of positions (the LDS limit shrank the
+  // whole-patch tile: stride 2 with 256 / 512 channels)
+  int chunk_mode = -1;                                 // -1 automatic, 0 never, 1 wherever it plans
+#ifdef QNNP_ENABLE_ABLATION
+  if (const char* env = getenv("QNNP_PATCH_CHUNK")) chunk_mode = atoi(env);
+#endif
+  auto plan_flavour = [&](const IgemmParams& pp, const ConvGeom& gg, uint32_t b, uint32_t m, uint32_t n, PatchArgs* out, uint32_t* lds) {
+    PatchArgs whole, part;
+    uint32_t lds_whole = 0, lds_part = 0;
+    const bool ok_whole = qnnp::plan_flavour(pp, gg, b, m, n, &whole, &lds_whole, false);
+    const bool ok_part = chunk_mode != 0 && qnnp::plan_flavour(pp, gg, b, m, n, &part, &lds_part, true);
+    if (ok_part && (!ok_whole || chunk_mode == 1 || part.pos > whole.pos)) { *out = part; *lds = lds_part; return true; }
+    if (ok_whole) { *out = whole; *lds = lds_whole; return true; }
+    return false;
+  };
   if (forced != 0) {
     *mb = forced / 10u; *ntb = forced % 10u;
     return ((*mb == 8 && *ntb == 4) || (*mb == 4 && (*ntb == 4 || *ntb == 8))) && plan_flavour(p, g, batch, *mb, *ntb, a, lds_bytes);
@@ -567,7 +708,11 @@ int convpatch_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hi
   requant_dispatch_lane(p.rq, p.lane, [&](auto seq, auto full) {
     constexpr int kSeq = decltype(seq)::value;
     constexpr bool kFull = decltype(full)::value;
-    if (p.kc % 128u == 0) {
+    if (a.nch > 1u) {
+      if (mb == 8u) rc = launch_patch_as<8, 4, 128, kSeq, kFull, true>(p, g, a, lds_bytes, stream);
+      else if (ntb == 8u) rc = launch_patch_as<4, 8, 128, kSeq, kFull, true>(p, g, a, lds_bytes, stream);
+      else rc = launch_patch_as<4, 4, 128, kSeq, kFull, true>(p, g, a, lds_bytes, stream);
+    } else if (p.kc % 128u == 0) {
       if (mb == 8u) rc = launch_patch_as<8, 4, 128, kSeq, kFull>(p, g, a, lds_bytes, stream);
       else if (ntb == 8u) rc = launch_patch_as<4, 8, 128, kSeq, kFull>(p, g, a, lds_bytes, stream);
       else rc = launch_patch_as<4, 4, 128, kSeq, kFull>(p, g, a, lds_bytes, stream);

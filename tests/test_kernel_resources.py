@@ -95,6 +95,9 @@ def test_default_path_kernels_do_not_spill(kernels):
 ])
 def test_register_budgets_of_the_occupancy_critical_kernels(kernels, fragment, max_vgpr, why):
     hits = {n: k for n, k in kernels.items() if fragment in n}
+    if "q8_conv_patch_kernelILi8ELi4E" in fragment:
+        # (the channel-chunked flavour -- last template argument true -- is alone on its CU by its LDS plan: 256 registers)
+        hits = {n: k for n, k in hits.items() if "Lb0EEEvNS_11IgemmParams" in n}
     assert hits, f"kernel {fragment} not found"
     for name, k in hits.items():
         assert k["vgpr"] <= max_vgpr, (name, k, why)
@@ -197,4 +200,4 @@ def test_patch_kernel_is_the_only_writer_of_m0_in_its_code(tmp_path):
                 assert re.match(r"s_mov_b32 m0, s\d+\b", ln), (name, ln)
             dma = [ln.strip() for ln in body.split("\n") if "global_load_lds" in ln]
             assert dma and all(re.match(r"global_load_lds_dwordx4 v(\d+|\[\d+:\d+\]), (s\[\d+:\d+\]|off)", ln) for ln in dma), (name, dma[:3])
-    assert seen == 3 * 2 * 8, seen      # three tile flavours x two step widths x eight requantization classes
+    assert seen == 3 * 3 * 8, seen      # three tile flavours x (two step widths + the channel-chunked 128-byte one) x eight requantization classes
