@@ -57,6 +57,22 @@ def test_chunked_shapes_at_a_fine_scale(qnnp, shape, kzp):
     assert_bytes_equal(out, expected, f"{shape} kzp {kzp} ({kname}) vs oracle at requantization scale 1e-4")
 
 
+@pytest.mark.parametrize("shape", [(28, 28, 1, 128, 128, 8), (14, 14, 1, 256, 256, 24), (7, 7, 1, 512, 512, 96), (56, 56, 2, 64, 128, 8),
+                                   (56, 56, 2, 128, 128, 8), (28, 28, 2, 128, 256, 24), (28, 28, 1, 64, 128, 8)],
+                         ids=lambda s: "x".join(str(v) for v in s))
+def test_whole_patch_shapes_at_a_fine_scale(qnnp, shape):
+    """the same bar for the flavours that keep the whole patch (their fragment reads use the same deferred waits)"""
+    H, W, S, GIC, GOC, batch = shape
+    rng = np.random.default_rng(GIC * 5 + GOC + S)
+    kernel = rng.integers(0, 256, size=(1, GOC, 3, 3, GIC)).astype(np.uint8)
+    inp = rng.integers(0, 256, size=batch * H * W * GIC).astype(np.uint8)
+    bias = rng.integers(-3000, 3001, size=GOC, dtype=np.int32)
+    out, expected, kname = _run(qnnp, H, W, S, GIC, GOC, batch, kernel, bias, inp, 1e-4)
+    assert kname == KERNEL, kname
+    assert float(np.mean((expected > 0) & (expected < 255))) > 0.95
+    assert_bytes_equal(out, expected, f"{shape} ({kname}) vs oracle at requantization scale 1e-4")
+
+
 def test_one_tap_and_chunk_of_the_weights_at_a_time(qnnp):
     H, W, S, GIC, GOC, batch = 14, 14, 2, 256, 512, 96
     rng = np.random.default_rng(11)
