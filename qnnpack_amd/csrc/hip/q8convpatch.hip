@@ -589,6 +589,12 @@ bool plan_flavour(const IgemmParams& p, const ConvGeom& g, uint32_t batch, uint3
     const uint32_t tiles_r = (g.OH + rows - 1) / rows;
     rows = (g.OH + tiles_r - 1) / tiles_r;            // even rows per tile
   }
+#ifdef QNNP_ENABLE_ABLATION
+  if (const char* env = getenv("QNNP_PATCH_ROWS")) {   // measurement builds: at most this many output rows per tile
+    const uint32_t cap = static_cast<uint32_t>(atoi(env));
+    if (cap != 0 && imgs == 1 && rows > cap) rows = cap;
+  }
+#endif
   const uint32_t kstep = p.kc % 128u == 0 ? 128u : 64u;
   const uint32_t ring = pt_stages(static_cast<int>(kstep)) * ntb * (kstep / 32u) * 1024u;
   for (;;) {
