@@ -194,7 +194,11 @@ void q8_gemm_mfma_256x256_c_kernel(const IgemmParams p)
 
   // ---- LDS-DMA sources: wave-uniform bases + loop-invariant 32-bit lane offsets ----
   // activation tile image: [256 rows][4 chunks of 16 B], chunk slot s of row r holds logical chunk s ^ ((r >> 2) & 3)
-  const uint8_t* a_base = scalar_ptr(p.input + static_cast<uint64_t>(m_tile * kBM) * p.input_stride + static_cast<uint64_t>(g) * p.kc);
+  // (round 5: strided 1x1 convolutions -- igemm_params.h `offsets_dense`: a row's address comes from the operator's table, one
+  //  valid entry per output pixel; the lane offsets are then absolute, the launcher checks that the tensor ends below 2^32)
+  const bool table_rows = p.offsets_dense != 0;
+  const uint8_t* a_base = scalar_ptr(table_rows ? p.input + static_cast<uint64_t>(g) * p.kc
+      : p.input + static_cast<uint64_t>(m_tile * kBM) * p.input_stride + static_cast<uint64_t>(g) * p.kc);
   uint32_t a_voff[2];
 #pragma unroll
   for (int i = 0; i < 2; i++) {
@@ -204,6 +208,11 @@ void q8_gemm_mfma_256x256_c_kernel(const IgemmParams p)
     uint32_t m = m_tile * kBM + r;
     if (m >= p.rows) m = p.rows - 1;             // clamp: results of those rows are never stored
     a_voff[i] = (m - m_tile * kBM) * p.input_stride + chunk * 16;
+    if (table_rows) {
+      const uint32_t img = p.rpi_magic != 0 ? __umulhi(m, p.rpi_magic) : m / p.rows_per_image;
+      const uint32_t pix = m - img * p.rows_per_image;
+      a_voff[i] = img * static_cast<uint32_t>(p.image_stride) + static_cast<uint32_t>(p.offsets[pix]) + chunk * 16;
+    }
   }
   // weight fragment F = i * 8 + wave: channel block nb0 + i * 4 + (wave >> 1), K block (wave & 1) of the tile's two
   const uint8_t* w_base = scalar_ptr(reinterpret_cast<const uint8_t*>(p.packed_w) + static_cast<uint64_t>(g) * nblocks * kblocks * 1024 +
@@ -625,7 +634,12 @@ int launch_c(const IgemmParams& p, const dim3& grid, hipStream_t stream)
 /* p as the general kernels get it, with the centred image */
 bool gemm256c_supported(const IgemmParams& p, uint32_t vec)
 {
-  return vec == 16 && p.offsets == nullptr && p.a_flip != 0 && p.bias2u != nullptr && p.store_mode == 2 &&
+  if (p.offsets != nullptr) {                   // strided 1x1 convolution through the table: absolute 32-bit lane offsets
+    if (p.offsets_dense == 0 || p.rows_per_image == 0) return false;
+    const uint64_t images = (static_cast<uint64_t>(p.rows) + p.rows_per_image - 1) / p.rows_per_image;
+    if (images * p.image_stride + p.k_pad >= (1ull << 32)) return false;
+  }
+  return vec == 16 && p.a_flip != 0 && p.bias2u != nullptr && p.store_mode == 2 &&
          p.k_total == p.k_pad && p.k_pad % kBK == 0 && p.k_pad / kBK >= 2 * kRing && p.n_pad % kBN == 0 &&
          p.k_pad <= (1u << 22) && static_cast<uint64_t>(p.input_stride) * 256u < (1ull << 32) &&
          p.residual == nullptr && p.rows >= 1;

@@ -6,11 +6,11 @@ folded zero point), strided rows, and what it must refuse."""
 import numpy as np
 import pytest
 
-from _cases import FcCase
+from _cases import ConvCase, FcCase
 from _gpu import from_device, to_device
 from oracle import o1
 from qnnpack_amd.binding import QnnpackError
-from _runner import assert_bytes_equal, fc_expected, fc_run
+from _runner import assert_bytes_equal, conv_expected, conv_run, fc_expected, fc_run
 
 pytestmark = pytest.mark.gpu
 
@@ -54,6 +54,28 @@ def test_n_and_quantization(centred, n, kw):
 
 def test_strided_rows(centred):
     _fc(centred, FcCase("c_strided", 300, 640, 256, input_stride=656, output_stride=272))
+
+
+# ---- strided 1x1 convolutions (round 5): the rows' addresses come from the operator's offset table (ResNet-50's K = 512 / 1024
+#      downsampling shortcuts; reference: indirection + q8conv, src/indirection.c:18-79) ----
+@pytest.mark.parametrize("case", [
+    ConvCase("c_1x1_s2_512_256", (9, 11), subsampling=(2, 2), gic=512, goc=256, batch=3),
+    ConvCase("c_1x1_s2_odd_1024_512", (13, 7), subsampling=(2, 2), gic=1024, goc=512, batch=5),
+    ConvCase("c_1x1_s3x2_640_256_kzp128", (20, 17), subsampling=(3, 2), gic=640, goc=256, batch=4, kzp=128, izp=9),
+    ConvCase("c_1x1_s2_strided_pixels", (8, 8), subsampling=(2, 2), gic=512, goc=256, batch=40, input_pixel_stride=528, output_pixel_stride=272),
+], ids=lambda c: c.name)
+def test_strided_pointwise_convolution(centred, case):
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(centred, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == centred._kname, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+def test_strided_pointwise_with_padding_taps_is_refused(centred):
+    case = ConvCase("c_1x1_s2_padded", (14, 14), padding=(1, 1, 1, 1), subsampling=(2, 2), gic=512, goc=256)
+    _, quant, out_hw = conv_expected(case)
+    with pytest.raises(QnnpackError):
+        conv_run(centred, case, quant, out_hw, to_device=to_device, from_device=from_device)
 
 
 @pytest.mark.parametrize("kw", [dict(kzp=126), dict(kzp=0), dict(kzp=129)], ids=lambda d: f"kzp{d['kzp']}")
