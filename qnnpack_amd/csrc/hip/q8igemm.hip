@@ -724,7 +724,10 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   //  on the one-wave kernel, 11.2 against 13.0 us)
   const bool big_first = a->variant == 0 && !pad3 && a->n >= 256 && a->n % 256u == 0 && a->k_total >= 512 && a->rows >= 2048 &&
       qnnp::gemm256_supported(p, vec);
-  const bool lk_auto = !big_first && a->rows <= 65536u && (lk_units >= 512u || a->n_pad >= 512u);
+  // (round 5: many rows with FEW channels -- ResNet-50's 28x28 512 -> 128: the weights of the whole row fit LDS and the flavour with
+  //  the next unit's rows in flight streams them; 35 us on the generic tile kernel before)
+  const bool lk_many_rows = a->rows > 65536u && a->n_pad <= 128u && a->k_total <= 640u;
+  const bool lk_auto = !big_first && (a->rows <= 65536u || lk_many_rows) && (lk_units >= 512u || a->n_pad >= 512u);
   if (lk_ok && (a->variant == 9 || (a->variant == 0 && lk_auto))) {
     const int rc_lk = qnnp::pwstream_longk_launch(p, stream, &name);
     if (kernel_name != nullptr) *kernel_name = name;

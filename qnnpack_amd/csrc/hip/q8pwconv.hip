@@ -576,10 +576,14 @@ void q8_pw_stream_staged_kernel(const IgemmParams p, const uint32_t nbp, const u
 constexpr uint32_t kMaxLdsLongK = 96 * 1024;
 constexpr int longk_waves(int kbmax) { return kbmax <= 12 ? 4 : (kbmax <= 20 ? 3 : 2); }
 
-template <int KBMAX, int SEQ, bool FULL, bool RES = false>
-__global__ __launch_bounds__(kThreads, longk_waves(KBMAX))
+/* PF (round 5; KBMAX <= 20): many rows after all -- ResNet-50's 28x28 512 -> 128 is 3136 units, two or more per wave. The rows of
+ * a wave's NEXT unit are requested before the current one is multiplied (a second register set, the loop unrolled twice so
+ * that the sets swap roles without copies); without it every unit is a full memory round trip in front of its first MFMA. */
+template <int KBMAX, int SEQ, bool FULL, bool RES = false, bool PF = false>
+__global__ __launch_bounds__(kThreads, PF ? 2 : longk_waves(KBMAX))
 void q8_pw_stream_longk_kernel(const IgemmParams p, const uint32_t nbp, const uint32_t log_cpr)
 {
+  static_assert(!PF || KBMAX <= 20, "two row sets of 32 K blocks do not fit the register file");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -666,8 +670,8 @@ void q8_pw_stream_longk_kernel(const IgemmParams p, const uint32_t nbp, const ui
   const std::integral_constant<int, SEQ> shift0{};
   const std::integral_constant<bool, FULL> full{};
   (void) shift0; (void) full;
-  for (;;) {
-    const uint32_t rs = recentre(a);
+  auto process = [&](uint32_t unit_now, v4i (&x)[KBMAX]) __attribute__((always_inline)) {
+    const uint32_t rs = recentre(x);
     const int32_t rowterm = with_rq_offset<SEQ>(p.row_coeff * static_cast<int32_t>(rs - raw_to_centred));
     uint64_t row_addend = 0;
     if constexpr (rq_is_lane<SEQ>()) row_addend = lane_addend(rowterm, p.lane);
@@ -688,7 +692,7 @@ void q8_pw_stream_longk_kernel(const IgemmParams p, const uint32_t nbp, const ui
       for (int kb = 0; kb < KBMAX; kb++) {
         if (static_cast<uint32_t>(kb) < kbn) {
           const v4i w = *reinterpret_cast<const v4i*>(wf + kb * 1024);
-          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, a[kb], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, x[kb], acc, 0, 0, 0);
         }
       }
       if constexpr (rq_is_lane<SEQ>()) {
@@ -698,12 +702,31 @@ void q8_pw_stream_longk_kernel(const IgemmParams p, const uint32_t nbp, const ui
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // image complete before it is read back
-    stream_copy_out<RES>(stage, whole_dense, log_cpr, unit, c0, cw, p, lane);
+    stream_copy_out<RES>(stage, whole_dense, log_cpr, unit_now, c0, cw, p, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // read back before the next unit overwrites it
-    const uint32_t next = unit + unit_stride;
-    if (next >= units) break;
-    unit = next;
-    load_rows(unit, a);
+  };
+  if constexpr (PF) {
+    v4i b[KBMAX];
+    for (;;) {
+      uint32_t next = unit + unit_stride;
+      if (next < units) load_rows(next, b);
+      process(unit, a);
+      if (next >= units) break;
+      unit = next;
+      next = unit + unit_stride;
+      if (next < units) load_rows(next, a);
+      process(unit, b);
+      if (next >= units) break;
+      unit = next;
+    }
+  } else {
+    for (;;) {
+      process(unit, a);
+      const uint32_t next = unit + unit_stride;
+      if (next >= units) break;
+      unit = next;
+      load_rows(unit, a);
+    }
   }
 }
 
@@ -1487,19 +1510,29 @@ bool plan_longk(const IgemmParams& p, StagedPlan* plan, int* kbmax)
   return true;
 }
 
-template <int KBMAX, int SEQ, bool FULL, bool RES = false>
+template <int KBMAX, int SEQ, bool FULL, bool RES = false, bool PF = false>
 int launch_longk_as(const IgemmParams& p, const StagedPlan& plan, hipStream_t stream)
 {
   if constexpr (!RES) {
     if (p.residual != nullptr) return launch_longk_as<KBMAX, SEQ, FULL, true>(p, plan, stream);
   }
-  auto kernel = q8_pw_stream_longk_kernel<KBMAX, SEQ, FULL, RES>;
+  if constexpr (!RES && !PF && KBMAX <= 20) {
+    // more units than waves: the flavour that requests the next unit's rows before it multiplies the current one
+    const uint32_t units_all = (p.rows + 31u) / 32u;
+    uint32_t per_cu = plan.per_cu < 2u ? plan.per_cu : 2u;
+    const uint32_t gx_pf = (p.cu_count * per_cu + plan.nsplit - 1) / plan.nsplit;
+    if (static_cast<uint64_t>(gx_pf) * kWaves * 5u <= static_cast<uint64_t>(units_all) * 4u) {      // >= 1.25 units per wave
+      return launch_longk_as<KBMAX, SEQ, FULL, false, true>(p, plan, stream);
+    }
+  }
+  auto kernel = q8_pw_stream_longk_kernel<KBMAX, SEQ, FULL, RES, PF>;
   static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
   if (auto once_scope = attr_once.begin()) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsLongK);
   }
   const uint32_t units = (p.rows + 31u) / 32u;
-  uint32_t gx = (p.cu_count * plan.per_cu + plan.nsplit - 1) / plan.nsplit;
+  const uint32_t per_cu_now = PF && plan.per_cu > 2u ? 2u : plan.per_cu;       // (PF: 2 waves per SIMD by its registers)
+  uint32_t gx = (p.cu_count * per_cu_now + plan.nsplit - 1) / plan.nsplit;
   const uint32_t needed = (units + kWaves - 1) / kWaves;
   if (gx > needed) gx = needed;
   hipLaunchKernelGGL(kernel, dim3(gx, plan.nsplit), dim3(kThreads), plan.lds_bytes, stream, p, plan.nbp, plan.log_cpr);

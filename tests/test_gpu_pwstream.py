@@ -304,6 +304,25 @@ def test_longk_channel_layouts_and_quantization(longk, case):
     _fc_longk(longk, case)
 
 
+@pytest.mark.parametrize("case", [
+    FcCase("lk_pf_k512_n128", 90000, 512, 128),                       # more units than waves: the next unit's rows in flight (K budget 20)
+    FcCase("lk_pf_k384_n96_odd_rows", 100001, 384, 96),               # K budget 12, a ragged last unit
+    FcCase("lk_pf_k640_n64_zp", 81000, 640, 64, izp=3, kzp=126),
+    FcCase("lk_pf_strided", 85000, 512, 48, input_stride=528, output_stride=64),
+], ids=lambda c: c.name)
+def test_longk_many_rows_prefetching_flavour(longk, case):
+    _fc_longk(longk, case)
+
+
+def test_longk_takes_resnet50_512_to_128_automatically(qnnp):
+    """28x28x512 -> 128 at batch 128 (100352 rows, four channel blocks): the long-K flavour with the next unit in flight."""
+    case = ConvCase("lk_1x1_512_128", (28, 28), gic=512, goc=128, batch=128)
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == LONGK_KERNEL, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
 def test_longk_pointwise_convolution_and_auto_selection(qnnp):
     """14x14x384 -> 96 at a batch that gives 784 row blocks: chosen automatically (MobileNetV2 layer 20)."""
     case = ConvCase("lk_1x1_384_96", (14, 14), gic=384, goc=96, batch=128)
