@@ -1386,6 +1386,14 @@ bool plan_staged(const IgemmParams& p, uint32_t kb, StagedPlan* plan, uint32_t v
       nbp = nblocks;
     }
   }
+#ifdef QNNP_ENABLE_ABLATION
+  if (const char* env = getenv("QNNP_PW_NBP")) {            // measurement builds: channel blocks per workgroup column
+    const uint32_t forced = static_cast<uint32_t>(atoi(env));
+    if (forced >= 1 && forced <= nblocks && staged_lds_bytes(kb, forced, forced >= nblocks ? whole_pitch : forced * 32u) <= kMaxLds) {
+      nbp = forced >= nblocks ? nblocks : forced;
+    }
+  }
+#endif
   plan->nbp = nbp;
   plan->nsplit = (nblocks + nbp - 1) / nbp;
   if (plan->nsplit == 1) {
