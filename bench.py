@@ -374,9 +374,8 @@ def cpu_baseline_gemm(seconds_budget=12.0):
         lib.delete_operator(op)
         tops = 2.0 * M * N * K * iters / dt / 1e12
         return {"value": round(tops, 5), "unit": "TOPS", "cores": best_threads, "kind": "reference",
-                "sample": f"reference SSE2 4x4c2 q8gemm via qnnp_fully_connected_nc_q8, M={M} rows of the "
-                          f"N=K=4096 problem x {iters} runs, {best_threads}-thread pthreadpool (OpenMP shim; best of "
-                          f"8..{cores} threads on a host reporting {cores}), {dt:.1f} s"}
+                "sample": f"reference SSE2 q8gemm, M={M} rows of N=K=4096 x {iters} runs, {best_threads} of {cores} "
+                          f"threads (best), {dt:.1f} s"}
     M = 32
     a = rng.integers(0, 256, size=(M, K), dtype=np.uint8)
     o1.set_threads(cores)
@@ -440,8 +439,8 @@ def cpu_baseline_sweep(batch=16, seconds_budget=10.0, threads=None):
     for op in ops:
         lib.delete_operator(op)
     return {"images_per_s": round(batch * passes / dt, 1), "cores": best_threads, "kind": "reference",
-            "sample": f"reference SSE2 microkernels via qnnp_run_operator, all 31 layers, batch {batch} x {passes} passes, "
-                      f"{best_threads}-thread pthreadpool (OpenMP shim; best of 8..{host} threads), {dt:.1f} s"}
+            "sample": f"reference SSE2 microkernels, all 31 layers, batch {batch} x {passes} passes, {best_threads} of {host} "
+                      f"threads (best), {dt:.1f} s"}
 
 
 def secondary_block(extra):
@@ -545,6 +544,35 @@ def assemble_line(*, world, steps, warmup, ms_per_step, ev_ms_per_rank, gemm_ker
     }
 
 
+CONTRACT_LINE_MAX = 6000      # bytes: the driver keeps the last 8 KB of stdout (round 5's 23 KB line was cut and never parsed)
+
+
+def emit(line, full_out):
+    """Print the contract line (LAST line of stdout) without `extra`; the whole object, `extra` included, goes to
+    `full_out` (default gpurun_out/bench_full.json). Per-layer tables belong in the file, never on the line."""
+    contract = {k: v for k, v in line.items() if k != "extra"}
+    text = json.dumps(contract)
+    if full_out:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(full_out)), exist_ok=True)
+            with open(full_out, "w") as f:
+                json.dump(line, f)
+                f.write("\n")
+            print(f"# full record (per-layer tables) written to {full_out}", file=sys.stderr)
+        except OSError as exc:
+            print(f"# could not write {full_out}: {exc}", file=sys.stderr)
+    if len(text) > CONTRACT_LINE_MAX:
+        # never let the line outgrow the capture again: drop the optional blocks, largest first, and say so
+        for key in ("secondary", "per_rank_frac"):
+            if isinstance(contract.get("roofline"), dict) and key in contract["roofline"] and len(text) > CONTRACT_LINE_MAX:
+                contract["roofline"] = {k: v for k, v in contract["roofline"].items() if k != key}
+                contract["roofline"]["dropped_for_length"] = contract["roofline"].get("dropped_for_length", []) + [key]
+                text = json.dumps(contract)
+    sys.stderr.flush()
+    print(text, flush=True)
+    return text
+
+
 def gather_floats(value, world):
     """[value of rank 0, ..., value of rank world-1] on every rank (all_gather over the harness process group)."""
     if world <= 1:
@@ -595,10 +623,10 @@ def run_stub(args, world, rank):
                 "frac": None, "traffic": None, "secondary": secondary_block(extra)}
     cpu = {"value": None, "unit": "TOPS", "cores": 0, "kind": "stub", "sample": "none (harness self-test)"} if rank == 0 else None
     if rank == 0:
-        print(json.dumps(assemble_line(world=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
-                                       ev_ms_per_rank=per_rank, gemm_kernel="stub",
-                                       info={"arch": "stub", "compute_units": 0}, roofline=roofline, cpu=cpu,
-                                       extra=extra, data="stub (no device work: harness self-test)")), flush=True)
+        emit(assemble_line(world=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
+                           ev_ms_per_rank=per_rank, gemm_kernel="stub",
+                           info={"arch": "stub", "compute_units": 0}, roofline=roofline, cpu=cpu,
+                           extra=extra, data="stub (no device work: harness self-test)"), args.full_out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -632,6 +660,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--sweep-batch", type=int, default=128, help="MobileNetV2 sweep images per GPU")
     ap.add_argument("--no-extra", action="store_true", help="headline GEMM only")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
+                    help="file that receives the whole record (the contract line plus `extra`: per-layer tables); '' = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-lists", action="store_true", help="skip the ResNet-18 / ResNet-50 / ShuffleNet shape lists")
     ap.add_argument("--gemm-kernel", type=int, default=0, help="0 auto, 1 generic MFMA kernel, 2 big-tile kernel")
@@ -732,15 +762,39 @@ def main():
     # run back to back, where K separate asynchronous calls from Python leave ~1 us between kernels (r05e: 58.66 us per
     # step by HIP events against 57.72 by rocprofv3 per kernel). One untimed replay first (the graph's upload).
     timed_graph = None
+    capturing = False
     try:
         lib.graph_begin()
+        capturing = True
         for _ in range(args.steps):
             lib.run_operator(op)
         timed_graph = lib.graph_end()
+        capturing = False
         lib.graph_launch(timed_graph)
     except Exception as exc:                                  # capture unavailable: K separate launches
         print(f"# graph capture of the timed steps unavailable ({exc}); timing {args.steps} separate launches", file=sys.stderr)
+        if capturing:                                         # never launch into a stream that is still capturing
+            try:
+                lib.graph_destroy(lib.graph_end())
+            except Exception:  # noqa: BLE001
+                pass
+        elif timed_graph is not None:
+            try:
+                lib.graph_destroy(timed_graph)
+            except Exception:  # noqa: BLE001
+                pass
         timed_graph = None
+        torch.cuda.synchronize()
+    # the same K steps as K separate asynchronous launches (rounds 1-4's method; ~1 us of launch gap per step): reported beside
+    # the graph figure so the two methods can be compared round to round
+    sep0, sep1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    sep0.record(head_stream)
+    for _ in range(args.steps):
+        lib.run_operator(op)
+    sep1.record(head_stream)
+    torch.cuda.synchronize()
+    separate_ms = sep0.elapsed_time(sep1) / args.steps
     stream = head_stream
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # (the launch stream: set_stream above)
     torch.cuda.synchronize()
@@ -777,11 +831,12 @@ def main():
     roofline = {"bound": "mfma", "kernel": gemm_kernel, "achieved": round(achieved, 2), "peak": round(PEAK_I8_TOPS, 1),
                 "unit": "TOP/s", "frac": round(achieved / PEAK_I8_TOPS, 4), "traffic": traffic,
                 "launch_ms": round(ev_ms, 5), "algorithmic_bytes_per_launch": 3 * M * N + 4 * N,
-                "timed_as": ("HIP events around the K timed steps, submitted as one replay of a hipGraph of K launches captured before the timed region"
-                             if timed_graph is not None else "HIP events around the K timed steps (K separate launches)") + " (the launches `value` is computed from)",
+                "timed_as": ("HIP events around the K timed steps (one replay of a hipGraph of K launches)"
+                             if timed_graph is not None else "HIP events around the K timed steps (K separate launches)"),
+                "separate_launches_ms": round(separate_ms, 5),
                 "sustained_launch_ms": round(sustained_ms, 5),
                 "sustained_tops": round(gemm_ops / (sustained_ms * 1e-3) / 1e12, 2),
-                "sustained_as": "median of 5 batches of 48 replays of a 64-launch hipGraph (>= 200 ms per batch, 1 s in all), run right before the timed steps"}
+                "sustained_as": "median of 5 x 48 replays of a 64-launch hipGraph, right before the timed steps"}
     copy_gbs = None
     try:
         # this chip's own streaming ceiling: a plain 16-byte-per-lane copy / read kernel over 1 GiB buffers
@@ -980,12 +1035,16 @@ def main():
         # other ranks wait at the closing barrier meanwhile) -- a SCALE line carries its baseline too
         cpu = cpu_baseline_gemm(12.0 if world == 1 else 5.0)
         if "mobilenetv2_sweep" in extra:
-            extra["mobilenetv2_sweep"]["cpu_baseline"] = cpu_baseline_sweep(seconds_budget=10.0 if world == 1 else 4.0)
+            sweep_cpu = cpu_baseline_sweep(seconds_budget=10.0 if world == 1 else 4.0)
+            extra["mobilenetv2_sweep"]["cpu_baseline"] = sweep_cpu
+            if sweep_cpu and isinstance(roofline.get("secondary"), dict):
+                roofline["secondary"]["c4_cpu_reference_images_per_s"] = sweep_cpu["images_per_s"]
+                roofline["secondary"]["c4_cpu_reference_threads"] = sweep_cpu["cores"]
 
     if rank == 0:
-        print(json.dumps(assemble_line(world=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
-                                       ev_ms_per_rank=ev_ms_per_rank, gemm_kernel=gemm_kernel, info=info,
-                                       roofline=roofline, cpu=cpu, extra=extra, data="synthetic")), flush=True)
+        emit(assemble_line(world=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
+                           ev_ms_per_rank=ev_ms_per_rank, gemm_kernel=gemm_kernel, info=info,
+                           roofline=roofline, cpu=cpu, extra=extra, data="synthetic"), args.full_out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

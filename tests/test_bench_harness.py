@@ -31,11 +31,20 @@ def _line(stdout):
 
 
 @pytest.mark.parametrize("gpus", [1, 2, 3, 8])
-def test_bench_spawns_its_ranks_and_prints_one_line(gpus):
-    res = subprocess.run([sys.executable, BENCH, "--gpus", str(gpus), "--steps", "6", "--warmup", "1", "--sweep-batch", "10"],
+def test_bench_spawns_its_ranks_and_prints_one_line(gpus, tmp_path):
+    full_out = str(tmp_path / "bench_full.json")
+    res = subprocess.run([sys.executable, BENCH, "--gpus", str(gpus), "--steps", "6", "--warmup", "1", "--sweep-batch", "10",
+                          "--full-out", full_out],
                          env=_env(), capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     line = _line(res.stdout)
+    # the contract line is the LAST line of stdout, short enough for the driver's capture, and carries no `extra`;
+    # the per-layer tables are in the --full-out file, which repeats the line's fields
+    assert res.stdout.rstrip().splitlines()[-1].startswith("{")
+    assert len(res.stdout.rstrip().splitlines()[-1]) < 6000 and "extra" not in line
+    full = json.load(open(full_out))
+    assert {k: v for k, v in full.items() if k != "extra"} == line
+    line["extra"] = full["extra"]
     assert line["n_gpus"] == gpus and line["steps"] == 6 and line["warmup"] == 1
     assert line["metric"] == "q8gemm_int8_tops" and line["unit"] == "TOPS" and line["scaling"] == "weak"
     assert line["data"].startswith("stub")
@@ -103,6 +112,40 @@ def test_assemble_line_contract_fields():
     assert abs(line["value"] - 8 * 2 * 4096 ** 3 / 0.07e-3 / 1e12) < 1.0
     assert len(line["roofline"]["per_rank_launch_ms"]) == 8 and len(line["roofline"]["per_rank_frac"]) == 8
     assert "model" not in line["config"]
+
+
+def test_contract_line_stays_short_with_a_realistic_extra(capsys, tmp_path):
+    """Round 5's line was 23 KB (per-layer arrays under `extra`) and the driver, which keeps the last 8 KB of stdout, could
+    not parse it. The fixture is that very record: emitted through bench.emit it must come out under 6000 bytes, as the
+    last stdout line, with roofline / secondary / cpu_baseline intact and every per-layer table in the side file."""
+    sys.path.insert(0, ROOT)
+    import bench
+    record = json.load(open(os.path.join(ROOT, "profiles", "r05", "bench_r05f.json")))
+    assert len(json.dumps(record)) > 20000 and "layers" in record["extra"]["mobilenetv2_sweep"]
+    full_out = str(tmp_path / "sub" / "bench_full.json")
+    text = bench.emit(record, full_out)
+    out = capsys.readouterr().out
+    assert out.rstrip().splitlines()[-1] == text
+    assert len(text) < 6000, len(text)
+    line = json.loads(text)
+    assert "extra" not in line
+    assert line["roofline"]["frac"] == record["roofline"]["frac"]
+    assert line["roofline"]["secondary"]["c4_sweep_images_per_s_graph"] == record["roofline"]["secondary"]["c4_sweep_images_per_s_graph"]
+    assert line["cpu_baseline"]["kind"] == "reference"
+    assert json.load(open(full_out)) == record
+    # a line that still outgrows the budget sheds its optional blocks instead of being cut by the capture
+    fat = json.loads(json.dumps(record))
+    fat["roofline"]["secondary"] = {f"k{i}": "x" * 40 for i in range(200)}
+    slim = json.loads(bench.emit(fat, ""))
+    assert "secondary" not in slim["roofline"] and slim["roofline"]["dropped_for_length"] == ["secondary"]
+    assert slim["roofline"]["frac"] == record["roofline"]["frac"] and slim["cpu_baseline"] is not None
+
+
+def test_cpu_baseline_sample_strings_are_short():
+    """`cpu_baseline.sample` says what was timed in < 120 characters (round-5 review): the templates at their widest fill"""
+    src = open(BENCH).read()
+    assert 'f"reference SSE2 q8gemm, M={M} rows of N=K=4096 x {iters} runs, {best_threads} of {cores} "' in src
+    assert len(f"reference SSE2 q8gemm, M={512} rows of N=K=4096 x {400} runs, {128} of {256} threads (best), {12.0:.1f} s") < 120
 
 
 def test_more_ranks_than_gpus_is_refused_by_the_launcher_itself():
