@@ -87,7 +87,7 @@ struct IgemmParams {
                              // tile ids of a launch (x * tiles_n < 2^32); set by gemm256c_launch
   // strided 1x1 convolutions on the staged pointwise streaming kernel (round 5): `offsets` holds one VALID entry per
   // output pixel of an image (ks == 1, no tap on padding); row m reads input + (m / rows_per_image) * image_stride +
-  // offsets[m % rows_per_image]. rpi_magic = floor(2^32 / rows_per_image) + 1 when rows * rows_per_image < 2^32 (then
+  // offsets[m % rows_per_image]. rpi_magic = floor(2^32 / rows_per_image) + 1 when rows_per_image > 1 and rows * rows_per_image < 2^32 (then
   // m / rows_per_image == hi32(m * magic)), else 0 = divide. offsets_dense == 0: the kernel never looks at `offsets`.
   uint32_t offsets_dense;
   uint32_t rpi_magic;
@@ -132,6 +132,8 @@ int conv_c3rows32_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* 
 /* q8gemm256c.hip: the zero-point-centred flavour (p carries the centred image, its bias pair table and a_flip) */
 bool gemm256c_supported(const IgemmParams& p, uint32_t vec);
 int gemm256c_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, uint32_t opt);
+/* q8gemm256x.hip: the same GEMM on v_mfma_i32_16x16x64_i8 (round 6); takes what gemm256c_supported accepts */
+int gemm256x_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name);
 
 /* q8gemm256.hip */
 bool gemm256_supported(const IgemmParams& p, uint32_t vec);

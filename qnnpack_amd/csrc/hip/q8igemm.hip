@@ -571,7 +571,10 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
                      static_cast<uint64_t>(a->output_height - 1) * a->stride_height < a->input_height &&
                      static_cast<uint64_t>(a->output_width - 1) * a->stride_width < a->input_width &&
                      a->rows_per_image == a->output_height * a->output_width) ? 1u : 0u;
-  p.rpi_magic = (p.offsets_dense != 0 && static_cast<uint64_t>(a->rows) * a->rows_per_image < (UINT64_C(1) << 32))
+  // (rows_per_image == 1 -- one output pixel per image, e.g. a 2x2 input at stride 2 -- has no 32-bit magic: 2^32 / 1 + 1
+  //  wraps to 1 and hi32(m * 1) is 0 for every row. It takes the divide, which is m / 1.)
+  p.rpi_magic = (p.offsets_dense != 0 && a->rows_per_image > 1 &&
+                 static_cast<uint64_t>(a->rows) * a->rows_per_image < (UINT64_C(1) << 32))
                     ? static_cast<uint32_t>((UINT64_C(1) << 32) / a->rows_per_image) + 1u : 0u;
   p.fill_table = qnnp_hip_fill_table();
   p.trace = nullptr;
@@ -757,8 +760,9 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   if (big_forced && !big_ok) return QNNP_HIP_EINVAL;
   int rc;
   // Operators with a zero-point-centred weight image (kernel zero point 127 or 128, q8gemm256c.hip): no row term at all.
-  // "gemm_kernel" 20 forces it; 21 = its A/B structure (fragment reads in one burst).
-  const bool c_forced = a->variant == 20 || a->variant == 21;
+  // "gemm_kernel" 20 forces it; 21 = its A/B structure (fragment reads in one burst); 23 = the v_mfma_i32_16x16x64_i8 flavour
+  // (q8gemm256x.hip, round 6).
+  const bool c_forced = a->variant == 20 || a->variant == 21 || a->variant == 23;
   if (c_forced || (a->variant == 0 && big_auto && a->centre_flip != 0)) {
     qnnp::IgemmParams pc = p;
     const uint32_t opt = a->variant == 21 ? 2u : 0u;
@@ -772,7 +776,8 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
       c_ok = big_ok && qnnp::gemm256c_supported(pc, vec);
     }
     if (c_ok) {
-      rc = qnnp::gemm256c_launch(pc, a->groups, stream, &name, opt);
+      rc = a->variant == 23 ? qnnp::gemm256x_launch(pc, a->groups, stream, &name)
+                            : qnnp::gemm256c_launch(pc, a->groups, stream, &name, opt);
       if (kernel_name != nullptr) *kernel_name = name;
       return rc;
     }

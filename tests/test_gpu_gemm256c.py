@@ -15,8 +15,9 @@ from _runner import assert_bytes_equal, conv_expected, conv_run, fc_expected, fc
 pytestmark = pytest.mark.gpu
 
 # ("gemm_kernel" 21, the A/B structure with the fragment reads in one burst, lost its A/B and exists in measurement builds only)
-_NAME = {20: "q8_gemm_mfma_256x256_c"}
-_MIN_K = {20: 512}
+# ("gemm_kernel" 23, round 6: the same GEMM on v_mfma_i32_16x16x64_i8, q8gemm256x.hip)
+_NAME = {20: "q8_gemm_mfma_256x256_c", 23: "q8_gemm_mfma_256x256_c16"}
+_MIN_K = {20: 512, 23: 512}
 
 
 @pytest.fixture(params=sorted(_NAME), ids=lambda v: _NAME[v].replace("q8_gemm_mfma_256x256_", "").replace("c_", "") or "c")
@@ -61,6 +62,8 @@ def test_strided_rows(centred):
 @pytest.mark.parametrize("case", [
     ConvCase("c_1x1_s2_512_256", (9, 11), subsampling=(2, 2), gic=512, goc=256, batch=3),
     ConvCase("c_1x1_s2_odd_1024_512", (13, 7), subsampling=(2, 2), gic=1024, goc=512, batch=5),
+    # ONE output pixel per image (rows_per_image == 1: no 32-bit division magic for a divisor of 1), several row tiles
+    ConvCase("c_1x1_s2_one_pixel_per_image", (2, 2), subsampling=(2, 2), gic=512, goc=256, batch=600),
     ConvCase("c_1x1_s3x2_640_256_kzp128", (20, 17), subsampling=(3, 2), gic=640, goc=256, batch=4, kzp=128, izp=9),
     ConvCase("c_1x1_s2_strided_pixels", (8, 8), subsampling=(2, 2), gic=512, goc=256, batch=40, input_pixel_stride=528, output_pixel_stride=272),
 ], ids=lambda c: c.name)
@@ -114,16 +117,17 @@ def _accumulators(n):
     return np.clip(acc, -2**31, 2**31 - 1).astype(np.int32)
 
 
+@pytest.mark.parametrize("code", sorted(_NAME))
 @pytest.mark.parametrize("kzp", [127, 128])
 @pytest.mark.parametrize("scale", SCALES, ids=lambda s: f"{s:.3e}")
-def test_epilogue_corners(qnnp, scale, kzp):
+def test_epilogue_corners(qnnp, scale, kzp, code):
     """Accumulators driven by the bias alone (activations on their zero point): +-2^31, ties of both roundings, the
     unfolded zero-point corners -- through the offset / general sequences of the centred kernel."""
     N, K, M = 1024, 640, 260
     acc = _accumulators(N)
     kernel = np.random.default_rng(9).integers(0, 256, size=(N, K), dtype=np.uint8)
     inp = np.full(M * K, 77, np.uint8)
-    qnnp.set_option("gemm_kernel", 20)
+    qnnp.set_option("gemm_kernel", code)
     try:
         for zp, qmin, qmax in QUANT:
             op = qnnp.create_fully_connected_nc_q8(K, N, 77, 1.0, kzp, float(scale), kernel, acc, zp, 1.0, qmin, qmax, 0)
@@ -131,7 +135,7 @@ def test_epilogue_corners(qnnp, scale, kzp):
                 d_in, d_out = to_device(inp), to_device(np.zeros(M * N, np.uint8))
                 qnnp.setup_fully_connected_nc_q8(op, M, d_in, K, d_out, N)
                 qnnp.run_operator(op)
-                assert qnnp.operator_kernel(op) == "q8_gemm_mfma_256x256_c"
+                assert qnnp.operator_kernel(op) == _NAME[code]
                 out = from_device(d_out).reshape(M, N)
             finally:
                 qnnp.delete_operator(op)
@@ -155,15 +159,16 @@ def test_auto_takes_the_centred_flavour_where_it_applies(qnnp, kzp, k, n, kernel
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 
 
-def test_repeated_launches_are_stable(qnnp):
+@pytest.mark.parametrize("code", sorted(_NAME))
+def test_repeated_launches_are_stable(qnnp, code):
     """The barrier-free tail and the image slots race with nothing: 20 launches of one operator, identical bytes."""
     case = FcCase("c_repeat", 2048, 1280, 1024)
     expected, quant = fc_expected(case)
-    qnnp.set_option("gemm_kernel", 20)
+    qnnp.set_option("gemm_kernel", code)
     try:
         for _ in range(20):
             out, kname = fc_run(qnnp, case, quant, to_device=to_device, from_device=from_device)
-            assert kname == "q8_gemm_mfma_256x256_c", kname
+            assert kname == _NAME[code], kname
             assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
     finally:
         qnnp.set_option("gemm_kernel", 0)

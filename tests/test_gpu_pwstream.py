@@ -113,6 +113,9 @@ def test_pointwise_convolution(pw, case):
     ConvCase("pw_1x1_s2_256_512", (14, 14), subsampling=(2, 2), gic=256, goc=512, batch=4),
     ConvCase("pw_1x1_s2_kzp126", (12, 12), subsampling=(2, 2), gic=128, goc=256, batch=2, kzp=126, izp=3),
     ConvCase("pw_1x1_s4_one_column", (13, 3), subsampling=(4, 4), gic=48, goc=80, batch=7),
+    # ONE output pixel per image (rows_per_image == 1: the 32-bit division magic does not exist for a divisor of 1)
+    ConvCase("pw_1x1_s2_one_pixel_per_image", (2, 2), subsampling=(2, 2), gic=64, goc=96, batch=70),
+    ConvCase("pw_1x1_s2_one_pixel_image", (1, 1), subsampling=(2, 2), gic=32, goc=64, batch=2100),
 ], ids=lambda c: c.name)
 def test_strided_pointwise_convolution(pw, case):
     expected, quant, out_hw = conv_expected(case)

@@ -11,7 +11,8 @@ sys.path.insert(0, ROOT)
 NAMES = {0: "shipped 256x256 (8 waves, interleaved)", 2: "256x256 forced", 4: "256x256 4 waves 128x128/wave",
          10: "128x256 x 2 workgroups per CU", 11: "256x256 ping-pong + setprio",
          16: "256x256 4 waves, lean", 15: "256x256 lean (saddr DMA, ring unrolled)",
-         20: "centred (product)", 21: "centred, fragment reads in one burst"}
+         20: "centred, 32x32x32 MFMA", 21: "centred, fragment reads in one burst",
+         23: "centred, 16x16x64 MFMA (round 6)"}
 
 
 def main():
