@@ -760,8 +760,8 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   if (big_forced && !big_ok) return QNNP_HIP_EINVAL;
   int rc;
   // Operators with a zero-point-centred weight image (kernel zero point 127 or 128, q8gemm256c.hip): no row term at all.
-  // "gemm_kernel" 20 forces it; 21 = its A/B structure (fragment reads in one burst); 23 = the v_mfma_i32_16x16x64_i8 flavour
-  // (q8gemm256x.hip, round 6).
+  // Round 6: auto takes the v_mfma_i32_16x16x64_i8 flavour (q8gemm256x.hip: 59.1 -> 52.6 us on 4096^3, same box, interleaved;
+  // "gemm_kernel" 23 forces it); 20 keeps the 32x32x32 one (q8gemm256c.hip), 21 = that one's A/B structure (fragment reads in one burst).
   const bool c_forced = a->variant == 20 || a->variant == 21 || a->variant == 23;
   if (c_forced || (a->variant == 0 && big_auto && a->centre_flip != 0)) {
     qnnp::IgemmParams pc = p;
@@ -776,7 +776,7 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
       c_ok = big_ok && qnnp::gemm256c_supported(pc, vec);
     }
     if (c_ok) {
-      rc = a->variant == 23 ? qnnp::gemm256x_launch(pc, a->groups, stream, &name)
+      rc = (a->variant == 23 || a->variant == 0) ? qnnp::gemm256x_launch(pc, a->groups, stream, &name)
                             : qnnp::gemm256c_launch(pc, a->groups, stream, &name, opt);
       if (kernel_name != nullptr) *kernel_name = name;
       return rc;

@@ -13,13 +13,14 @@ from oracle import o1
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant,kernel", [(0, "q8_gemm_mfma_256x256_c"),
+@pytest.mark.parametrize("variant,kernel", [(0, "q8_gemm_mfma_256x256_c16"), (20, "q8_gemm_mfma_256x256_c"),
                                             (15, "q8_gemm_mfma_256x256_lean"), (2, "q8_gemm_mfma_256x256")],
-                         ids=["auto", "lean", "general"])
+                         ids=["auto", "centred_32x32x32", "lean", "general"])
 def test_c2_q8gemm_4096_cubed(qnnp, variant, kernel):
-    """configs[1]: q8gemm M=N=K=4096 through qnnp_fully_connected_nc_q8 -- the shipped kernel (round 4: the
-    zero-point-centred flavour, q8gemm256c.hip, is what "auto" picks for this shape and these zero points), its
-    A/B sibling, and the lean and general flavours of the kernel it came from (what other zero points run on)."""
+    """configs[1]: q8gemm M=N=K=4096 through qnnp_fully_connected_nc_q8 -- the shipped kernel (round 6: the
+    zero-point-centred flavour on v_mfma_i32_16x16x64_i8, q8gemm256x.hip, is what "auto" picks for this shape and these
+    zero points), the 32x32x32 flavour it replaced, and the lean and general flavours of the kernel both came from (what
+    other zero points run on)."""
     import torch
     qnnp.set_option("gemm_kernel", variant)
     M = N = K = 4096
@@ -201,7 +202,7 @@ def test_c5_mobilenetv2_first_layer(qnnp):
         qnnp.delete_operator(op)
 
 
-@pytest.mark.parametrize("kzp,kernel", [(127, "q8_gemm_mfma_256x256_c"), (128, "q8_gemm_mfma_256x256_c"),
+@pytest.mark.parametrize("kzp,kernel", [(127, "q8_gemm_mfma_256x256_c16"), (128, "q8_gemm_mfma_256x256_c16"),
                                         (126, "q8_gemm_mfma_256x256_lean")], ids=["kzp127", "kzp128", "kzp126"])
 def test_c2_q8gemm_4096_cubed_full_output_vs_compiled_reference(qnnp, kzp, kernel):
     """(both centring classes of the shipped kernel, and a zero point that keeps the lean flavour)

@@ -147,8 +147,8 @@ def test_epilogue_corners(qnnp, scale, kzp, code):
         qnnp.set_option("gemm_kernel", 0)
 
 
-@pytest.mark.parametrize("kzp,k,n,kernel", [(127, 1088, 2048, "q8_gemm_mfma_256x256_c"),
-                                            (128, 1088, 2048, "q8_gemm_mfma_256x256_c"),
+@pytest.mark.parametrize("kzp,k,n,kernel", [(127, 1088, 2048, "q8_gemm_mfma_256x256_c16"),
+                                            (128, 1088, 2048, "q8_gemm_mfma_256x256_c16"),
                                             (126, 1088, 2048, "q8_gemm_mfma_256x256_lean"),
                                             (127, 1088, 2080, "q8_gemm_mfma_128x256")])     # (N % 256 != 0: no centred flavour; underfilled: 128-row tiles)
 def test_auto_takes_the_centred_flavour_where_it_applies(qnnp, kzp, k, n, kernel):
@@ -174,8 +174,8 @@ def test_repeated_launches_are_stable(qnnp, code):
         qnnp.set_option("gemm_kernel", 0)
 
 
-@pytest.mark.parametrize("kw,kernel", [(dict(kzp=127), "q8_gemm_mfma_256x256_c"), (dict(kzp=128), "q8_gemm_mfma_256x256_c"),
-                                       (dict(kzp=127, input_pixel_stride=1104, output_pixel_stride=528), "q8_gemm_mfma_256x256_c"),
+@pytest.mark.parametrize("kw,kernel", [(dict(kzp=127), "q8_gemm_mfma_256x256_c16"), (dict(kzp=128), "q8_gemm_mfma_256x256_c16"),
+                                       (dict(kzp=127, input_pixel_stride=1104, output_pixel_stride=528), "q8_gemm_mfma_256x256_c16"),
                                        (dict(kzp=126), "q8_gemm_mfma_256x256_lean")],
                          ids=["kzp127", "kzp128", "kzp127_strided_pixels", "kzp126"])
 def test_pointwise_convolutions_take_it_too(qnnp, kw, kernel):
