@@ -148,7 +148,8 @@ int qnnp_gfx950_operator_residual_folded(qnnp_operator_t op);
  *                    20 = the zero-point-centred 256x256 kernel (hip/q8gemm256c.hip: what auto picks for operators with
  *                    kernel zero point 127 or 128, K % 64 == 0, K >= 512, N % 256 == 0), 21 = its A/B structure in MEASUREMENT BUILDS ONLY
  *                    (fragment reads in one burst), 23 = the centred kernel on v_mfma_i32_16x16x64_i8 (hip/q8gemm256x.hip,
- *                    round 6). A forced kernel refuses what it cannot take (unsupported_parameter
+ *                    round 6), 24 = its 128x128-tile sibling for mid-size problems (hip/q8gemm128x.hip: any K % 64 == 0, two
+ *                    workgroups per CU). A forced kernel refuses what it cannot take (unsupported_parameter
  *                    at run) instead of rerouting.
  *   "fused_kernel":  fused inverted-residual blocks: 0 = auto (the strip kernel, hip/q8fusedstrip.hip, where it takes the
  *                    block -- kernel zero points 127 / 128 in all three members -- else the tile kernel of rounds 1-3),

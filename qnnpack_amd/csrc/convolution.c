@@ -284,7 +284,9 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
                  /* (a second image only where a kernel takes it: the 3x3 weight-stationary kernel, the 256x256 GEMM) */
                  ((kernel_height == 3 && kernel_width == 3 && (group_input_channels == 32 || group_input_channels == 64) &&
                    (group_output_channels == 32 || group_output_channels == 64)) ||
-                  (kernel_size == 1 && k_total == k_pad && k_total >= 512 && n_pad % 256 == 0))) {
+                  (kernel_size == 1 && k_total == k_pad && k_total >= 512 && n_pad % 256 == 0) ||
+                  /* ... and the 128-wide tiling of hip/q8gemm128x.hip: any K % 64 == 0 */
+                  (kernel_size == 1 && k_total == k_pad && k_total % 64 == 0 && group_output_channels % 16 == 0))) {
         int8_t* host_wc = (int8_t*) malloc(w_bytes);
         int32_t* host_bc = (int32_t*) malloc(b_bytes);
         int placed = host_wc != NULL && host_bc != NULL;
@@ -303,7 +305,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
         } else {
           /* the centred image is an optimisation, not a requirement: without it the operator runs on the standard
            * image (row term in the kernel) -- drop what was placed and carry on */
-          qnnp_log_error("no room for %zu bytes of centred weights on the device: the operator keeps the standard image", w_bytes + 2 * b_bytes);
+          qnnp_log_warning("no room for %zu bytes of centred weights on the device: the operator keeps the standard image", w_bytes + 2 * b_bytes);
           qnnp_hip_free(op->d_weights_centred);
           qnnp_hip_free(op->d_bias_centred);
           op->d_weights_centred = NULL;

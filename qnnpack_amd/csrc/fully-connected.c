@@ -129,7 +129,9 @@ static enum qnnp_status qnnp_create_fully_connected_nc_q8_impl(
    * kernel takes (no K padding, channel blocks of 256, MFMA-bound sizes). */
   if (kernel_zero_point == 128) {
     op->centre_flip = 0x80;
-  } else if (kernel_zero_point == 127 && k_pad == input_channels && n_pad % 256 == 0 && input_channels >= 512) {
+  } else if (kernel_zero_point == 127 && k_pad == input_channels &&
+             /* (the 256-wide tiling's shapes, or the 128-wide one's: hip/q8gemm128x.hip takes any K % 64 == 0) */
+             ((n_pad % 256 == 0 && input_channels >= 512) || (input_channels % 64 == 0 && output_channels % 16 == 0))) {
     qnnp_pack_igemm_w_centred127((uint32_t) output_channels, (uint32_t) input_channels, (uint32_t) input_channels, n_pad,
         input_zero_point, kernel, bias, host_weights, host_bias);
     op->d_weights_centred = qnnp_hip_alloc(w_bytes);
@@ -138,7 +140,7 @@ static enum qnnp_status qnnp_create_fully_connected_nc_q8_impl(
         qnnp_hip_h2d(op->d_weights_centred, host_weights, w_bytes, 0) != QNNP_HIP_OK) {
       /* the centred image is an optimisation, not a requirement: without it the operator runs on the standard image
        * (the lean kernel with its row term) -- drop what was placed and carry on */
-      qnnp_log_error("no room for %zu bytes of centred weights on the device: the operator keeps the standard image", w_bytes + 2 * b_bytes);
+      qnnp_log_warning("no room for %zu bytes of centred weights on the device: the operator keeps the standard image", w_bytes + 2 * b_bytes);
       qnnp_hip_free(op->d_weights_centred);
       qnnp_hip_free(op->d_bias_centred);
       op->d_weights_centred = NULL;

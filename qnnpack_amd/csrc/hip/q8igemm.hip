@@ -701,6 +701,31 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
     if (kernel_name != nullptr) *kernel_name = name;
     return rc_c3;
   }
+  // Mid-size GEMMs on the zero-point-centred image: 128-row tiles of four waves, two or three workgroups per CU (q8gemm128x.hip,
+  // round 6); "gemm_kernel" = 24 forces it (25 / 26: with 64- / 128-channel tiles). Where auto takes it (measured at batch 128,
+  // profiles/r06/mid_gemm_by_forced_kernel_r06d.txt) is decided below, next to the kernel it replaces.
+  qnnp::IgemmParams pmid = p;
+  bool mid_ok = !pad3 && a->centre_flip != 0 && a->packed_w_centred != nullptr && a->bias2_centred != nullptr && a->bias2_pair != 0 &&
+      a->groups == 1 && p.d2s_sh == 0;
+  if (mid_ok) {
+    pmid.packed_w = a->packed_w_centred;
+    pmid.bias2 = a->bias2_centred;
+    pmid.bias2u = a->bias2_centred + static_cast<size_t>(a->groups) * a->n_pad;
+    pmid.a_flip = (a->centre_flip & 0xFFu) * 0x01010101u;
+    pmid.row_coeff = 0;
+    mid_ok = qnnp::gemm128x_supported(pmid, vec);
+  }
+  const bool mid_forced = a->variant == 24 || a->variant == 25 || a->variant == 26;     // 25 / 26: 64- / 128-wide tiles (A/B)
+  if (mid_forced && !mid_ok) return QNNP_HIP_EINVAL;
+  auto launch_mid = [&]() {
+    const int rc_mid = qnnp::gemm128x_launch(pmid, a->groups, stream, &name, a->variant == 25 ? 64u : (a->variant == 26 ? 128u : 0u));
+    if (kernel_name != nullptr) *kernel_name = name;
+    return rc_mid;
+  };
+  if (mid_forced) return launch_mid();
+  // (strided 1x1 convolutions over few rows -- ResNet-18's 28x28 128 -> 256 and 14x14 256 -> 512 shortcuts, 25 k / 6 k output pixels:
+  //  7.9 -> 6.1 us and 8.2 -> 5.4 against the streaming kernel's table rows; with 100 k rows the streaming kernel keeps them)
+  if (a->variant == 0 && mid_ok && a->offsets != nullptr && a->rows <= 32768u && a->k_total >= 128u && a->k_total <= 256u && a->rows >= 2048u) return launch_mid();
   // Short-K pointwise / fully-connected layers over many rows: barrier-free streaming kernel.
   const bool pw_ok = !pad3 && qnnp::pwstream_supported(p, a->groups, vec) && (p.d2s_sh == 0 || vec == 16);
   if ((a->variant == 5 || p.d2s_sh != 0) && !pw_ok) return QNNP_HIP_EINVAL;   /* depth-to-space exists in this kernel only */
@@ -731,6 +756,9 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   //  the next unit's rows in flight streams them; 35 us on the generic tile kernel before)
   const bool lk_many_rows = a->rows > 65536u && a->n_pad <= 128u && a->k_total <= 640u;
   const bool lk_auto = !big_first && (a->rows <= 65536u || lk_many_rows) && (lk_units >= 512u || a->n_pad >= 512u);
+  // (round 6: what the long-K kernel took automatically goes to the 128-row centred GEMM where that exists -- MobileNetV2's 14x14 project
+  //  layers 7.2 -> 5.6, 8.1 -> 6.2, 9.7 -> 7.3 us, 7x7x320 -> 1280 12.4 -> 7.9, ResNet-50's 28x28 512 -> 128 32.6 -> 21.2)
+  if (a->variant == 0 && lk_ok && lk_auto && mid_ok && a->rows >= 2048u) return launch_mid();
   if (lk_ok && (a->variant == 9 || (a->variant == 0 && lk_auto))) {
     const int rc_lk = qnnp::pwstream_longk_launch(p, stream, &name);
     if (kernel_name != nullptr) *kernel_name = name;
@@ -744,6 +772,9 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   // (selected when the 128-row x 128-channel tiling of the generic kernel would not even give ~1.5 workgroups
   //  per CU; MobileNetV2 layer 30 -- 490 tiles -- measured faster on the tiled kernel, layers 19-29 on this one)
   const uint64_t generic_tiles = static_cast<uint64_t>((a->rows + 127u) / 128u) * ((a->n_pad + 127u) / 128u);
+  // (round 6: with >= 256 channels the 128-row centred GEMM is ahead -- 7x7x960 -> 320 10.5 -> 8.0 us; 160 channels stay here, 5.9 / 7.0
+  //  against 6.0 / 7.8)
+  if (a->variant == 0 && gw_ok && generic_tiles <= 400u && !big_first && mid_ok && a->n >= 256u && a->rows >= 2048u) return launch_mid();
   if (gw_ok && (a->variant == 6 || (a->variant == 0 && generic_tiles <= 400u && !big_first))) {
     const int rc_gw = qnnp::pwstream_gw_launch(p, stream, &name);
     if (kernel_name != nullptr) *kernel_name = name;
@@ -763,6 +794,10 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   // Round 6: auto takes the v_mfma_i32_16x16x64_i8 flavour (q8gemm256x.hip: 59.1 -> 52.6 us on 4096^3, same box, interleaved;
   // "gemm_kernel" 23 forces it); 20 keeps the 32x32x32 one (q8gemm256c.hip), 21 = that one's A/B structure (fragment reads in one burst).
   const bool c_forced = a->variant == 20 || a->variant == 21 || a->variant == 23;
+  // (round 6: launches of at most ~100 tiles of 256 x 256 leave most CUs idle for the length of a long K loop -- ResNet-50's 7x7 2048 -> 512,
+  //  50 tiles: 22.1 -> 15.0 us on 128-row tiles, 14x14 1024 -> 256, 98 tiles: 17.1 -> 16.0; from ~200 tiles on the wide kernel leads)
+  if (a->variant == 0 && big_auto && mid_ok &&
+      static_cast<uint64_t>((a->rows + 255u) / 256u) * ((a->n_pad + 255u) / 256u) <= 100u) return launch_mid();
   if (c_forced || (a->variant == 0 && big_auto && a->centre_flip != 0)) {
     qnnp::IgemmParams pc = p;
     const uint32_t opt = a->variant == 21 ? 2u : 0u;

@@ -317,21 +317,25 @@ def test_longk_many_rows_prefetching_flavour(longk, case):
     _fc_longk(longk, case)
 
 
-def test_longk_takes_resnet50_512_to_128_automatically(qnnp):
-    """28x28x512 -> 128 at batch 128 (100352 rows, four channel blocks): the long-K flavour with the next unit in flight."""
-    case = ConvCase("lk_1x1_512_128", (28, 28), gic=512, goc=128, batch=128)
+@pytest.mark.parametrize("kzp,kernel", [(126, LONGK_KERNEL), (127, "q8_gemm_mfma_128x128_c16")], ids=["kzp126", "kzp127"])
+def test_longk_takes_resnet50_512_to_128_automatically(qnnp, kzp, kernel):
+    """28x28x512 -> 128 at batch 128 (100352 rows, four channel blocks): the long-K flavour with the next unit in flight -- round 6:
+    where the operator has a zero-point-centred image (kernel zero point 127 / 128) the 128-row centred GEMM takes it (32.6 -> 21.2 us)."""
+    case = ConvCase("lk_1x1_512_128", (28, 28), gic=512, goc=128, batch=128, kzp=kzp)
     expected, quant, out_hw = conv_expected(case)
     out, kname = conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
-    assert kname == LONGK_KERNEL, kname
+    assert kname == kernel, kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 
 
-def test_longk_pointwise_convolution_and_auto_selection(qnnp):
-    """14x14x384 -> 96 at a batch that gives 784 row blocks: chosen automatically (MobileNetV2 layer 20)."""
-    case = ConvCase("lk_1x1_384_96", (14, 14), gic=384, goc=96, batch=128)
+@pytest.mark.parametrize("kzp,kernel", [(126, LONGK_KERNEL), (127, "q8_gemm_mfma_128x128_c16")], ids=["kzp126", "kzp127"])
+def test_longk_pointwise_convolution_and_auto_selection(qnnp, kzp, kernel):
+    """14x14x384 -> 96 at a batch that gives 784 row blocks: chosen automatically (MobileNetV2 layer 20) -- round 6: with a centred
+    image the 128-row centred GEMM is (8.1 -> 6.2 us); other kernel zero points keep the long-K flavour."""
+    case = ConvCase("lk_1x1_384_96", (14, 14), gic=384, goc=96, batch=128, kzp=kzp)
     expected, quant, out_hw = conv_expected(case)
     out, kname = conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
-    assert kname == LONGK_KERNEL, kname
+    assert kname == kernel, kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 
 

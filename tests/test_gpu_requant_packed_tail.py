@@ -70,7 +70,7 @@ def test_packed_tail_matches_oracle(qnnp, case):
     assert all(k.startswith(kname_want) for k in seen), (name, seen)
 
 
-@pytest.mark.parametrize("kzp,kname_want", [(126, "q8_gemm_mfma_256x256_lean"), (127, "q8_gemm_mfma_256x256_c16")])
+@pytest.mark.parametrize("kzp,kname_want", [(126, "q8_gemm_mfma_256x256_lean"), (127, "q8_gemm_mfma_128x128_c16")])
 def test_packed_tail_in_the_gemm_epilogues(qnnp, kzp, kname_want):
     """the lean 256 x 256 GEMM (kernel zero point without a centred image) takes the packed tail in its lane-form epilogue; the
     centred one keeps the bounded offset form -- both against the oracle at the same scales and zero points"""
