@@ -212,6 +212,43 @@ def conv_list_bench(lib, torch, batch, shapes, seed0, warmup=2, iters=8, out_sca
             "layers": rows}
 
 
+def reference_lists_bench(lib, torch, batch, skip=("MobileNetV2", "ResNet18", "ResNet50", "ShuffleNetV1G2"), seconds_budget=240.0):
+    """Every OTHER shape list of the reference's convolution benchmark (bench/convolution.cc:108-942: ShuffleNet v1 g1/g3/g4/g8 and
+    v2, MobileNet v1, SqueezeNet 1.0 / 1.1, VGG, the three depthwise lists; the table is the committed fixture
+    tests/golden/reference_bench_shapes.json) at `batch` images: each DISTINCT shape timed once on rotating buffers as
+    conv_list_bench does, each list summed over its rows as the reference bench runs them (a repeated row counts every time).
+    Rows are compact: [H, W, KH, S, D, G, GCin, GCout, kernel, us, fraction of max(MFMA, HBM) bound]."""
+    path = os.path.join(ROOT, "tests", "golden", "reference_bench_shapes.json")
+    table = json.load(open(path))["lists"]
+    cache, out, t0 = {}, {}, time.perf_counter()
+    for name, shapes in table.items():
+        if name in skip:
+            continue
+        rows, total_ms, total_bound, partial = [], 0.0, 0.0, False
+        for shape in shapes:
+            key = tuple(shape)
+            if key not in cache:
+                if time.perf_counter() - t0 > seconds_budget:
+                    partial = True
+                    continue
+                H, W, KH, KW, S, D, G, GIC, GOC = key
+                layer = ConvLayer(lib, torch, batch, H, W, KH, KW, S, D, G, GIC, GOC, seed=9000 + len(cache),
+                                  min_bytes_between_reuse=512 << 20)
+                ms = layer.time_ms(2, 6)
+                cache[key] = (layer.kernel, ms, layer_bound_ms(layer, G * GOC * KH * KW * GIC))
+                layer.close()
+            kernel, ms, bound = cache[key]
+            H, W, KH, KW, S, D, G, GIC, GOC = key
+            total_ms += ms
+            total_bound += bound
+            rows.append([H, W, KH, S, D, G, GIC, GOC, kernel.replace("q8_", ""), round(ms * 1e3, 2), round(bound / ms, 3)])
+        out[name] = {"rows": len(shapes), "timed_rows": len(rows), "partial": partial,
+                     "images_per_s_by_sum_of_layers": round(batch / (total_ms * 1e-3), 1) if total_ms and not partial else None,
+                     "sum_of_layer_ms": round(total_ms, 4), "frac_of_bound": round(total_bound / total_ms, 3) if total_ms else None,
+                     "worst_row": min(rows, key=lambda r: r[-1]) if rows else None, "layers": rows}
+    return out
+
+
 def gemm_variant_bench(lib, torch, kzp, in_scale, warmup, iters, seed):
     """The 4096^3 GEMM of the headline in a less favourable class: another kernel zero point (no centred image ->
     the lean kernel with its row term) or a requantization scale < 0.5 (shift >= 1 epilogue)."""
@@ -509,6 +546,10 @@ def secondary_block(extra):
             out[net + "_frac_of_bound"] = v["frac_of_bound"]
             if v["worst_dense_3x3_frac"] is not None:
                 out[net + "_worst_dense_3x3_frac_of_bound"] = v["worst_dense_3x3_frac"]
+    for name, v in (get(["reference_bench_lists"], {}) or {}).items():
+        if v.get("images_per_s_by_sum_of_layers") is not None:
+            out["list_" + name + "_images_per_s"] = v["images_per_s_by_sum_of_layers"]
+            out["list_" + name + "_frac_of_bound"] = v["frac_of_bound"]
     return out
 
 
@@ -563,6 +604,11 @@ def emit(line, full_out):
             print(f"# could not write {full_out}: {exc}", file=sys.stderr)
     if len(text) > CONTRACT_LINE_MAX:
         # never let the line outgrow the capture again: drop the optional blocks, largest first, and say so
+        sec = contract["roofline"].get("secondary") if isinstance(contract.get("roofline"), dict) else None
+        if isinstance(sec, dict) and any(k.startswith("list_") for k in sec):     # the per-list scalars of the other bench lists first
+            contract["roofline"] = dict(contract["roofline"], secondary={k: v for k, v in sec.items() if not k.startswith("list_")},
+                                        dropped_for_length=["secondary.list_*"])
+            text = json.dumps(contract)
         for key in ("secondary", "per_rank_frac"):
             if isinstance(contract.get("roofline"), dict) and key in contract["roofline"] and len(text) > CONTRACT_LINE_MAX:
                 contract["roofline"] = {k: v for k, v in contract["roofline"].items() if k != key}
@@ -1027,6 +1073,8 @@ def main():
             extra["conv_lists"] = {"resnet18": conv_list_bench(lib, torch, my_batch, RESNET18, 1800),
                                    "resnet50": conv_list_bench(lib, torch, my_batch, RESNET50, 5000),
                                    "shufflenet_v1_g2": conv_list_bench(lib, torch, my_batch, SHUFFLENET_V1_G2, 1200)}
+            # ... and every other list of that file (kernel, us and fraction of bound per row: the full record only)
+            extra["reference_bench_lists"] = reference_lists_bench(lib, torch, my_batch)
         roofline["secondary"] = secondary_block(extra)
 
     cpu = None
