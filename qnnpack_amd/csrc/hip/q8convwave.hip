@@ -1179,6 +1179,272 @@ void q8_conv_wave_ws_kernel(const IgemmParams p, const ConvGeom g, const WaveArg
 #undef WS_STAMP
 }
 
+/*
+ * The weight-stationary kernel on v_mfma_i32_16x16x64_i8 (round 6; 64 input channels, the zero-point-centred image): same unit
+ * (4 rows x 8 positions x all channels), same patch path (buffer loads between the taps, re-centred on their way into the wave's
+ * patch buffer), same weights-in-registers idea -- with the matrix shape that costs the least energy per MAC on this chip
+ * (tools/ubench_mfma2.hip: 4.08 against 3.45 PetaOP/s sustained on random operands; this kernel's loop holds the matrix pipe
+ * ~73 % busy at a power-limited clock, profiles/r05/conv3x3_prologue_and_unit_stamps_r05trace.txt). One instruction covers a tap's
+ * 64 channels: a unit is 9 taps x 2 position tiles x TN16 channel tiles of 16 x 16. Operand lane l = (position or channel l & 15,
+ * 16-byte K chunk g = l >> 4); result lane l, register r: position l & 15, channel 4 g + r.
+ *   - weight fragments from pack.h's 32 x 32 image with other lane addresses (q8gemm256x.hip): tile tn, tap t -> fragment
+ *     (tn >> 1, 2 t + (g >> 1)), position (16 (tn & 1) + (l & 15) + 32 (g & 1)) * 16; 9 x TN16 x 4 registers for the wave's life;
+ *   - activation fragment of (position tile tm, tap): lane -> patch pixel (2 tm + ((l & 15) >> 3) + ky, (l & 7) + kx), chunk
+ *     g ^ f(patch row), f(py) = 2 (py & 1): the four 4-lane runs a ds_read_b128 lane group touches land on four different bank
+ *     quads (the swizzle py & 3 of the 32 x 32 kernel would pair them two by two);
+ *   - epilogue: requantize 4 -> 1 dword, one 4 x 4 lane transpose per position tile: lane (position, g) holds channels
+ *     16 g .. 16 g + 15 of its position, and a store instruction writes two output rows of eight whole 64-byte pixels.
+ */
+template <int TN16, int SEQ, bool FULL>
+__global__ __launch_bounds__(kWsWaves * 64, 2)
+void q8_conv_wave_ws16_kernel(const IgemmParams p, const ConvGeom g, const WaveArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [weights][bias][counter][waves x (patch | unused pixel sums)]
+  constexpr uint32_t kPR = 6u;                     // patch rows (10 columns) of a 4 x 8 unit
+  constexpr uint32_t cin = 64u, cpp = 4u;
+  constexpr uint32_t pvec = kPR * 10u * cpp;       // 16-byte chunks of the patch
+  constexpr int NP = (pvec + 63u) / 64u;           // 1 KiB pieces of the patch
+  uint8_t* w_lds = lds;
+  int32_t* bias_lds = reinterpret_cast<int32_t*>(lds + a.w_bytes);
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint8_t* patch = lds + a.head_bytes + wave * (a.patch_bytes + kWsPixBytes);
+
+  // ---- prologue, first half: weights + bias by LDS-DMA, once per workgroup, in front of everything else ----
+  {
+    const uint32_t pieces = a.w_bytes >> 10;
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(p.packed_w) + lane * 16u;
+    for (uint32_t i = wave; i < pieces; i += kWsWaves) dma16(src + i * 1024u, w_lds + i * 1024u);
+    if (wave == kWsWaves - 1 && lane < p.n / 4u) {
+      dma16(reinterpret_cast<const uint8_t*>(rq_is_lane<SEQ>() ? p.bias2u : p.bias2) + lane * 16u, reinterpret_cast<uint8_t*>(bias_lds));
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * a.units / gridDim.x);
+  const uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * a.units / gridDim.x);
+  const uint32_t tiles = a.tiles_x * a.tiles_y;
+  const uint32_t fill4 = p.izp_fill;               // the raw zero point in every byte
+  const uint32_t fpos = lane & 15u;                // position inside a 16-position tile: row fpos >> 3, column fpos & 7
+  const uint32_t fg = lane >> 4;                   // K chunk of an operand; channel quad of a result
+
+  // ---- the gather pattern of a patch: per piece u this lane's chunk v = lane + 64 u is pixel (py, px) of the patch, source
+  //      chunk (v & 3) ^ 2 (py & 1); only the patch origin moves ----
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.input), 0, static_cast<int>(a.units / tiles * p.image_stride), 0x00020000);   // (launcher: < 2^31)
+  uint32_t rel[NP], pyx[NP];
+#pragma unroll
+  for (int u = 0; u < NP; u++) {
+    const uint32_t v = min(lane + u * 64u, pvec - 1u);
+    const uint32_t sl = v & (cpp - 1u);
+    const uint32_t q = v >> 2;
+    const uint32_t py = (q * 6554u) >> 16;                 // q / 10 for q < 100
+    const uint32_t px = q - py * 10u;
+    rel[u] = (py * g.W + px) * p.input_stride + ((sl ^ ((py & 1u) << 1)) << 4);
+    pyx[u] = (py << 16) | px;
+  }
+  struct Raw { v4i x[NP]; };
+  struct Where { uint32_t origin; int32_t iy0, ix0; uint32_t out_img, oy0, ox0; bool border; };   // (wave-uniform)
+  auto locate = [&](uint32_t unit) __attribute__((always_inline)) -> Where {
+    const uint32_t img = div_magic(unit, a.inv_tiles);
+    const uint32_t rr = unit - img * tiles;
+    const uint32_t tyi = div_magic(rr, a.inv_tiles_x);
+    const uint32_t txi = rr - tyi * a.tiles_x;
+    Where w;
+    w.oy0 = tyi * 4u;
+    w.ox0 = txi * 8u;
+    w.iy0 = static_cast<int32_t>(w.oy0) - static_cast<int32_t>(g.pad_top);
+    w.ix0 = static_cast<int32_t>(w.ox0) - static_cast<int32_t>(g.pad_left);
+    w.origin = img * static_cast<uint32_t>(p.image_stride) +
+        static_cast<uint32_t>(w.iy0 * static_cast<int32_t>(g.W) + w.ix0) * p.input_stride;
+    w.out_img = img * g.OH * g.OW * p.n;
+    w.border = w.iy0 < 0 || w.ix0 < 0 || w.iy0 + static_cast<int32_t>(kPR) > static_cast<int32_t>(g.H) ||
+               w.ix0 + 10 > static_cast<int32_t>(g.W);
+    return w;
+  };
+  auto fetch_piece = [&](const Where& w, int u, Raw& r) __attribute__((always_inline)) {
+    r.x[u] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, rel[u] + w.origin, 0, 0));
+  };
+  // the fetched patch: (border units: pixels outside the image become the zero point,) re-centred into LDS
+  auto fix_up = [&](Raw& r, const Where& w) __attribute__((always_inline)) {
+    const uint32_t patch_off = lds_off(patch);
+    if (w.border) {
+#pragma unroll
+      for (int u = 0; u < NP; u++) {
+        const int32_t iy = w.iy0 + static_cast<int32_t>(pyx[u] >> 16);
+        const int32_t ix = w.ix0 + static_cast<int32_t>(pyx[u] & 0xFFFFu);
+        const bool inb = static_cast<uint32_t>(iy) < g.H && static_cast<uint32_t>(ix) < g.W;
+        r.x[u].x = inb ? r.x[u].x : static_cast<int>(fill4);
+        r.x[u].y = inb ? r.x[u].y : static_cast<int>(fill4);
+        r.x[u].z = inb ? r.x[u].z : static_cast<int>(fill4);
+        r.x[u].w = inb ? r.x[u].w : static_cast<int>(fill4);
+      }
+    }
+    const uint32_t flip = p.a_flip;
+#pragma unroll
+    for (int u = 0; u < NP; u++) {
+      const uint32_t v = lane + u * 64u;
+      if ((u + 1) * 64u <= pvec || v < pvec) {             // (only the last piece is partly populated)
+        const v4i x = r.x[u];
+        ds_write16_raw(patch_off + v * 16u, make_uint4(x.x ^ flip, x.y ^ flip, x.z ^ flip, x.w ^ flip));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  };
+
+  // ---- prologue, second half: the first patch (an HBM round trip) behind the weights
+  uint32_t cur = lo + wave;
+  Raw raw;
+  Where here = locate(min(cur, a.units - 1u));
+#pragma unroll
+  for (int u = 0; u < NP; u++) fetch_piece(here, u, raw);
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.output, 0, static_cast<int>(a.units / tiles * g.OH * g.OW * p.n), 0x00020000);   // (launcher: < 2^31)
+  __builtin_amdgcn_sched_barrier(0);
+  fix_up(raw, here);                                // needs the patch only
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- every weight fragment into registers, for good ----
+  const uint32_t kblocks = p.k_pad / 32;
+  v4i wreg[9][TN16];
+  {
+    const uint8_t* w_lane = w_lds + (fpos + 32u * (fg & 1u)) * 16u;
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+      for (int tn = 0; tn < TN16; tn++)
+        wreg[t][tn] = *reinterpret_cast<const v4i*>(w_lane + ((tn >> 1) * kblocks + 2 * t + (fg >> 1)) * 1024u + (tn & 1) * 256u);
+  }
+
+  // fragment bases: position tile tm, kernel row ky (the swizzle depends on the parity of the patch row)
+  const uint32_t tyl = fpos >> 3;
+  struct AF { v4i a[2]; };
+  while (cur < hi) {
+    const Where next = locate(min(cur + kWsWaves, a.units - 1u));
+
+    // accumulators start at the folded bias: register r of tile tn = channel 16 tn + 4 g + r
+    v4i acc[2][TN16];
+#pragma unroll
+    for (int tn = 0; tn < TN16; tn++) {
+      const v4i b = *reinterpret_cast<const v4i*>(bias_lds + tn * 16 + fg * 4);
+      acc[0][tn] = b;
+      acc[1][tn] = b;
+    }
+    {
+      const uint8_t* abase[3][2];
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++) {
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) {
+          const uint32_t py = tm * 2u + tyl + ky;
+          abase[ky][tm] = patch + ((py * 10u + (fpos & 7u)) << 6) + ((fg ^ ((py & 1u) << 1)) << 4);
+        }
+      }
+      auto read_a = [&](auto t_c, AF& f) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_c)::value;
+        constexpr int ky = t / 3, kx = t % 3;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) f.a[tm] = *reinterpret_cast<const v4i*>(abase[ky][tm] + kx * cin);
+      };
+      auto mma = [&](auto t_c, const AF& f) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_c)::value;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+          for (int tn = 0; tn < TN16; tn++)
+            acc[tm][tn] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wreg[t][tn], f.a[tm], acc[tm][tn], 0, 0, 0);
+      };
+      // the next unit's patch is requested piece by piece between the taps
+      auto piece = [&](int u) __attribute__((always_inline)) { if (u < NP) fetch_piece(next, u, raw); };
+#define QNNP_T(n) std::integral_constant<int, n>{}
+      AF f0, f1;
+      read_a(QNNP_T(0), f0);
+      read_a(QNNP_T(1), f1); mma(QNNP_T(0), f0);
+      read_a(QNNP_T(2), f0); mma(QNNP_T(1), f1); piece(0);
+      read_a(QNNP_T(3), f1); mma(QNNP_T(2), f0); piece(1);
+      read_a(QNNP_T(4), f0); mma(QNNP_T(3), f1); piece(2);
+      read_a(QNNP_T(5), f1); mma(QNNP_T(4), f0); piece(3);
+      read_a(QNNP_T(6), f0); mma(QNNP_T(5), f1); piece(4);
+      read_a(QNNP_T(7), f1); mma(QNNP_T(6), f0); piece(5);
+      read_a(QNNP_T(8), f0); mma(QNNP_T(7), f1); piece(6);
+      mma(QNNP_T(8), f0);
+#undef QNNP_T
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- fused epilogue: requantization, one lane transpose per position tile, 16-byte stores of whole pixels ----
+    {
+      const int32_t rowterm = with_rq_offset<SEQ>(0);
+      uint64_t row_addend = 0;                       // lane forms: the (constant) row term rides in the multiply-add's addend
+      if constexpr (rq_is_lane<SEQ>()) row_addend = lane_addend(rowterm, p.lane);
+#pragma unroll
+      for (int tm = 0; tm < 2; tm++) {
+        uint32_t q[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int tn = 0; tn < TN16; tn++) {
+          if constexpr (rq_is_lane<SEQ>()) {
+            q[tn] = q31_requantize_pack4_lane<SEQ, FULL>(
+                static_cast<uint32_t>(acc[tm][tn][0]), static_cast<uint32_t>(acc[tm][tn][1]),
+                static_cast<uint32_t>(acc[tm][tn][2]), static_cast<uint32_t>(acc[tm][tn][3]), row_addend, p.lane, p.rq);
+          } else {
+            q[tn] = q31_requantize_pack4<SEQ, FULL, false>(
+                add_wrap(acc[tm][tn][0], rowterm), add_wrap(acc[tm][tn][1], rowterm),
+                add_wrap(acc[tm][tn][2], rowterm), add_wrap(acc[tm][tn][3], rowterm), p.rq);
+          }
+        }
+        // 4 x 4 dword transpose over the four 16-lane rows: lane (position, g) then holds channels 16 g .. 16 g + 15
+        const auto s02 = __builtin_amdgcn_permlane32_swap(q[0], q[2], false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(q[1], q[3], false, false);
+        const auto tlo = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+        const auto thi = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+        const v4i outv = {static_cast<int>(tlo[0]), static_cast<int>(tlo[1]), static_cast<int>(thi[0]), static_cast<int>(thi[1])};
+        const uint32_t oy = here.oy0 + tm * 2u + tyl;
+        const uint32_t ox = here.ox0 + (fpos & 7u);
+        const bool ok = oy < g.OH && ox < g.OW && fg < static_cast<uint32_t>(TN16);
+        const uint32_t off = ok ? here.out_img + (oy * g.OW + ox) * p.n + fg * 16u : 0xFFFFFFF0u;
+        const auto bits = __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, outv);
+        // (64 output channels: a store instruction writes two runs of eight whole 64-byte pixels, every line exactly once)
+        if (TN16 == 4 && p.stream_out != 0) __builtin_amdgcn_raw_buffer_store_b128(bits, out_rsrc, off, 0, 2);
+        else __builtin_amdgcn_raw_buffer_store_b128(bits, out_rsrc, off, 0, 0);
+      }
+    }
+    // ---- the next unit's patch (fetched between the taps) into the patch buffer ----
+    fix_up(raw, next);
+    here = next;
+    cur += kWsWaves;
+  }
+}
+
+template <int TN16, int SEQ, bool FULL>
+int launch_ws16_as(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hipStream_t stream)
+{
+  static qnnp::PerDeviceOnce attr_once;   // function attributes are per device
+  if (auto once_scope = attr_once.begin()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&q8_conv_wave_ws16_kernel<TN16, SEQ, FULL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      (void) hipGetLastError();
+    }
+  }
+  const uint32_t want = (a.units + kWsWaves - 1) / kWsWaves;
+  const uint32_t grid = want < p.cu_count ? want : p.cu_count;
+  hipLaunchKernelGGL((q8_conv_wave_ws16_kernel<TN16, SEQ, FULL>), dim3(grid), dim3(kWsWaves * 64), ws_lds_bytes(a), stream, p, g, a);
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+template <int TN16>
+int launch_ws16(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hipStream_t stream)
+{
+  int rc = QNNP_HIP_EINVAL;
+  requant_dispatch_lane(p.rq, p.lane, [&](auto seq, auto full) {
+    rc = launch_ws16_as<TN16, decltype(seq)::value, decltype(full)::value>(p, g, a, stream);
+  });
+  return rc;
+}
+
+
 template <int TN, int CB, int SEQ, bool FULL, bool CEN>
 int launch_ws_as(const IgemmParams& p, const ConvGeom& g, const WaveArgs& a, hipStream_t stream)
 {
@@ -1294,6 +1560,11 @@ int convwave_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hip
     const uint64_t in_bytes = static_cast<uint64_t>(batch) * p.image_stride;    // (32-bit buffer offsets)
     if (ok && in_bytes < (UINT64_C(1) << 31) && ws_lds_bytes(ar) <= kLdsLimit) {
       const IgemmParams& pw = centred != nullptr ? *centred : p;
+      // round 6: 64 input channels with a centred image on the 16x16x64 shape; flavour 2 ("gemm_kernel" 27) keeps the 32x32x32 one
+      if (centred != nullptr && p.kc == 64 && flavour != 2) {
+        *name = "q8_conv_wave_ws_c16_mfma";
+        return p.n == 32 ? launch_ws16<2>(pw, g, ar, stream) : launch_ws16<4>(pw, g, ar, stream);
+      }
       *name = centred != nullptr ? "q8_conv_wave_ws_c_mfma" : "q8_conv_wave_ws_mfma";
       if (p.kc == 32) return p.n == 32 ? launch_ws<1, 1>(pw, g, ar, stream) : launch_ws<2, 1>(pw, g, ar, stream);
       return p.n == 32 ? launch_ws<1, 2>(pw, g, ar, stream) : launch_ws<2, 2>(pw, g, ar, stream);

@@ -640,7 +640,7 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
       qnnp::convwave_supported(p, geom, a->groups, vec, a->rows / a->rows_per_image);
   const bool wave_k33 = geom.KH == 3 && geom.KW == 3 && geom.sh == 1 && geom.sw == 1 && geom.dh == 1 && geom.dw == 1;
   // ("gemm_kernel" = 12: the same family with the round-2 register-path kernel instead of the weight-stationary one)
-  const bool wave_forced = a->variant == 8 || a->variant == 12;
+  const bool wave_forced = a->variant == 8 || a->variant == 12 || a->variant == 27;   // 27: the 32x32x32 weight-stationary kernel (A/B)
   const bool wave_ok = wave_shape && (wave_forced || (a->variant == 0 && wave_k33 && a->rows >= 16384u));
   if (wave_forced && !wave_ok) return QNNP_HIP_EINVAL;
   if (wave_ok) {
@@ -656,7 +656,7 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
       pc.a_flip = (a->centre_flip & 0xFFu) * 0x01010101u;
       pc.row_coeff = 0;
     }
-    const int rc_wave = qnnp::convwave_launch(p, geom, a->rows / a->rows_per_image, stream, &name, a->variant == 12 ? 1 : 0,
+    const int rc_wave = qnnp::convwave_launch(p, geom, a->rows / a->rows_per_image, stream, &name, a->variant == 12 ? 1 : (a->variant == 27 ? 2 : 0),
                                               centred ? &pc : nullptr);
     if (kernel_name != nullptr) *kernel_name = name;
     return rc_wave;

@@ -169,7 +169,7 @@ enum qnnp_status qnnp_gfx950_memset(void* dst_device, int value, size_t bytes)
 enum qnnp_status qnnp_gfx950_set_option(const char* key, int value)
 {
   if (key == NULL) return qnnp_status_invalid_parameter;
-  if (strcmp(key, "gemm_kernel") == 0 && value >= 0 && value <= 26 && !(value >= 17 && value <= 19)) {
+  if (strcmp(key, "gemm_kernel") == 0 && value >= 0 && value <= 27 && !(value >= 17 && value <= 19)) {
     qnnp_state.opt_gemm_kernel = value;
     return qnnp_status_success;
   }

@@ -61,7 +61,8 @@ def test_wave_convolution_matches_oracle(waveconv, case, kzp):
         case = dataclasses.replace(case, kzp=kzp)
     expected, quant, out_hw = conv_expected(case)
     out, kname = conv_run(waveconv, case, quant, out_hw, to_device=to_device, from_device=from_device)
-    ws = "q8_conv_wave_ws_c_mfma" if case.kzp in (127, 128) else "q8_conv_wave_ws_mfma"
+    # (round 6: 64 input channels with a centred image run on the 16x16x64 flavour, q8_conv_wave_ws16_kernel)
+    ws = ("q8_conv_wave_ws_c16_mfma" if case.gic == 64 else "q8_conv_wave_ws_c_mfma") if case.kzp in (127, 128) else "q8_conv_wave_ws_mfma"
     want = ws if (waveconv._variant == 8 and _is_k33(case)) else "q8_conv_wave_mfma"
     assert kname == want, kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}, kzp {case.kzp}]")

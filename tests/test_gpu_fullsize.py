@@ -59,10 +59,11 @@ def test_c2_q8gemm_4096_cubed(qnnp, variant, kernel):
         qnnp.delete_operator(op)
 
 
-@pytest.mark.parametrize("variant,kzp,kernel_name", [(0, 127, "q8_conv_wave_ws_c_mfma"), (0, 128, "q8_conv_wave_ws_c_mfma"),
+@pytest.mark.parametrize("variant,kzp,kernel_name", [(0, 127, "q8_conv_wave_ws_c16_mfma"), (0, 128, "q8_conv_wave_ws_c16_mfma"),
+                                                     (27, 127, "q8_conv_wave_ws_c_mfma"),
                                                      (0, 126, "q8_conv_wave_ws_mfma"), (1, 127, None),
                                                      (2, 127, "q8_gemm_mfma_256x256_conv")],
-                         ids=["auto_kzp127", "auto_kzp128", "auto_kzp126", "offset_table_generic", "offset_table_256x256"])
+                         ids=["auto_kzp127", "auto_kzp128", "centred_32x32x32", "auto_kzp126", "offset_table_generic", "offset_table_256x256"])
 def test_c3_q8conv_3x3_56x56x64_batch128(qnnp, variant, kzp, kernel_name):
     """configs[2]: 3x3 s1 pad1 conv, 56x56x64 -> 64, batch 128. "auto" is the weight-stationary wave kernel, which
     computes its patch addresses arithmetically (q8convwave.hip) -- with the zero-point-centred image for kernel zero

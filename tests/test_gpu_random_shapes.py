@@ -167,7 +167,8 @@ def test_random_3x3_convolution_weight_stationary(qnnp, seed):
         out, kname = conv_run(qnnp, case, quant, out_hw, inp, kernel, bias, to_device, from_device)
     finally:
         qnnp.set_option("gemm_kernel", 0)
-    assert kname == ("q8_conv_wave_ws_c_mfma" if kzp in (127, 128) else "q8_conv_wave_ws_mfma"), (kname, case)
+    centred = "q8_conv_wave_ws_c16_mfma" if cin == 64 else "q8_conv_wave_ws_c_mfma"      # (64 channels in: the 16x16x64 flavour)
+    assert kname == (centred if kzp in (127, 128) else "q8_conv_wave_ws_mfma"), (kname, case)
     assert_bytes_equal(out, expected, f"{kname} [{case}]")
 
 
