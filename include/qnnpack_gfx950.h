@@ -129,39 +129,7 @@ enum qnnp_status qnnp_gfx950_attach_residual_add(
     qnnp_operator_t convolution, qnnp_operator_t add, const uint8_t* residual, size_t residual_stride);
 int qnnp_gfx950_operator_residual_folded(qnnp_operator_t op);
 
-/* Kernel-variant control for A/B measurement and tests. Keys:
- *   "gemm_kernel":   0 = auto, 1 = generic MFMA implicit-GEMM kernel, 2 = 256x256 LDS-DMA MFMA kernel,
- *                    3 = LDS-tiled direct-convolution MFMA kernel (convolutions only),
- *                    4 = the 256x256 kernel in its 4-wave flavour (one wave per SIMD, 128x128 per wave) [measurement
- *                        builds only since round 4, as 10, 11 and 16: structures that lost their A/B],
- *                    5 = barrier-free streaming kernel for short-K pointwise / fully-connected layers,
- *                    6 = its global-operand flavour (one wave per 32x32 block; small problems with long K),
- *                    7 = its 3-channel-image convolution flavour (first layers; in-register tap gather),
- *                    8 = wave-per-8x8-block direct-convolution MFMA kernel (small windows, <= 64 channels, dense output),
- *                    9 = long-K flavour of the streaming kernel (256 < K <= 1024, 16-byte aligned rows both sides:
- *                        a channel column's weights in LDS, every K block of a unit's rows in flight at once),
- *                    10 = 128x256 tiles of the LDS-DMA kernel, two workgroups per CU; 11 = its ping-pong schedule;
- *                    12 = the round-2 register-path flavour of kernel 8; 13 = stride-2 deconvolution streaming kernel
- *                    forced (1 keeps deconvolutions on the phase-table GEMMs); 14 = first-layer row-slot kernel;
- *                    15 = the lean flavour of kernel 2 (what auto picks when K % 64 == 0 and N % 256 == 0; 2 keeps the
- *                    general flavour), 16 = the lean flavour of kernel 4,
- *                    20 = the zero-point-centred 256x256 kernel (hip/q8gemm256c.hip: what auto picks for operators with
- *                    kernel zero point 127 or 128, K % 64 == 0, K >= 512, N % 256 == 0), 21 = its A/B structure in MEASUREMENT BUILDS ONLY
- *                    (fragment reads in one burst), 23 = the centred kernel on v_mfma_i32_16x16x64_i8 (hip/q8gemm256x.hip,
- *                    round 6), 24 = its 128x128-tile sibling for mid-size problems (hip/q8gemm128x.hip: any K % 64 == 0, two
- *                    workgroups per CU). A forced kernel refuses what it cannot take (unsupported_parameter
- *                    at run) instead of rerouting.
- *   "fused_kernel":  fused inverted-residual blocks: 0 = auto (the strip kernel, hip/q8fusedstrip.hip, where it takes the
- *                    block -- kernel zero points 127 / 128 in all three members -- else the tile kernel of rounds 1-3),
- *                    1 = the tile kernel only, 2 = the strip kernel only (unsupported_parameter at setup otherwise)
- *   "fused_rows":    output rows per strip of the strip kernel, 0 = its planner's choice (tests, A/B)
- *   "fused_weights": 0 / 2 = a chunk's expand / project fragments fetched from L2 by the stage that multiplies them,
- *                    1 = staged in LDS one stage ahead by LDS-DMA where they fit (measured level: measurement builds only,
- *                    the product library ignores it)
- *   "dwconv_kernel": 0 = auto, 1 = generic direct kernel, 2 = LDS-tiled kernel, 3 = register sliding-window kernel (3x3),
- *                    4 = matrix-core kernel (diagonal MFMA operands; 3x3, channels % 16 == 0), tap operands gathered
- *                        from global memory, 5 = the same with the input band staged in LDS first,
- *                    6 = column-sliding register window (3x3, stride 1 | 2): tap pairs shared between output rows
+/* Process-wide options of the product. Keys:
  *   "timing_graph":  1 (default) = qnnp_gfx950_time_operator* time a hipGraph replay of the launches (kernel
  *                    time without per-launch dispatch gaps); 0 = a plain back-to-back launch loop
  *   "streaming_stores": 1 (default) = kernels whose waves write whole cache lines exactly once (pointwise / fully
@@ -171,7 +139,9 @@ int qnnp_gfx950_operator_residual_folded(qnnp_operator_t op);
  *                    consumer starts (whole MobileNetV2: -1 % with the hint). Read at launch (or graph-capture) time.
  *                    This is the DEFAULT of every operator; qnnp_gfx950_operator_set_streaming_stores below sets it per
  *                    operator, which is what a caller with both kinds of operators in one process wants.
- * Unknown key -> invalid_parameter. Kernel choices apply to operators set up afterwards. */
+ * Unknown key -> invalid_parameter.
+ * (Kernel-forcing codes -- which kernel an operator runs on, for A/B measurement and for the test tiers -- are NOT part of
+ *  this interface: include/qnnpack_gfx950_test.h, qnnp_gfx950_test_force_kernel.) */
 enum qnnp_status qnnp_gfx950_set_option(const char* key, int value);
 
 /* The streaming-store hint ("streaming_stores" above) of ONE operator: value 1 / 0 = on / off for every later launch of

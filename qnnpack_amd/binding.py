@@ -327,6 +327,8 @@ class Gfx950Library(QnnpackLibrary):
             L.qnnp_gfx950_operator_residual_folded.argtypes = [c_void_p]
         L.qnnp_gfx950_set_option.restype = c_int
         L.qnnp_gfx950_set_option.argtypes = [c_char_p, c_int]
+        L.qnnp_gfx950_test_force_kernel.restype = c_int           # include/qnnpack_gfx950_test.h
+        L.qnnp_gfx950_test_force_kernel.argtypes = [c_char_p, c_int]
         L.qnnp_gfx950_operator_set_streaming_stores.restype = c_int
         L.qnnp_gfx950_operator_set_streaming_stores.argtypes = [c_void_p, c_int]
         L.qnnp_gfx950_operator_kernel.restype = c_char_p
@@ -452,6 +454,10 @@ class Gfx950Library(QnnpackLibrary):
         self.lib.qnnp_gfx950_graph_destroy(graph)
 
     def set_option(self, key: str, value: int) -> None:
+        if key in ("gemm_kernel", "dwconv_kernel", "fused_kernel", "fused_rows", "fused_weights"):
+            # kernel-forcing codes are test / measurement hooks (include/qnnpack_gfx950_test.h), not product options
+            self._check("qnnp_gfx950_test_force_kernel", self.lib.qnnp_gfx950_test_force_kernel(key.encode(), value))
+            return
         self._check("qnnp_gfx950_set_option", self.lib.qnnp_gfx950_set_option(key.encode(), value))
 
     def operator_set_streaming_stores(self, op, value: int) -> None:

@@ -73,45 +73,45 @@ static enum qnnp_status qnnp_create_add_nc_q8_impl(
   (void) flags;
   /* reference add.c:36-39 */
   if (!qnnp_state.initialized) {
-    qnnp_log_error("qnnp_create_add_nc_q8 failed because QNNPACK is not properly initialized");
+    qnnp_log_error("qnnp_create_add_nc_q8 called before qnnp_initialize succeeded");
     return qnnp_status_uninitialized;
   }
   /* reference add.c:41-71 */
   if (channels == 0) {
-    qnnp_log_error("failed to create add operator with %zu channels: number of channels must be non-zero", channels);
+    qnnp_log_error("cannot create add operator with %zu channels: number of channels may not be zero", channels);
     return qnnp_status_invalid_parameter;
   }
   if (!scale_is_valid(a_scale)) {
-    qnnp_log_error("failed to create add operator with %.7g A scale: scale must be finite and positive", a_scale);
+    qnnp_log_error("cannot create add operator with %.7g A scale: a scale has to be a finite number above zero", a_scale);
     return qnnp_status_invalid_parameter;
   }
   if (!scale_is_valid(b_scale)) {
-    qnnp_log_error("failed to create add operator with %.7g B scale: scale must be finite and positive", b_scale);
+    qnnp_log_error("cannot create add operator with %.7g B scale: a scale has to be a finite number above zero", b_scale);
     return qnnp_status_invalid_parameter;
   }
   if (!scale_is_valid(sum_scale)) {
-    qnnp_log_error("failed to create add operator with %.7g output scale: scale must be finite and positive", sum_scale);
+    qnnp_log_error("cannot create add operator with %.7g output scale: a scale has to be a finite number above zero", sum_scale);
     return qnnp_status_invalid_parameter;
   }
   if (sum_min >= sum_max) {
-    qnnp_log_error("failed to create add operator with [%" PRIu8 ", %" PRIu8 "] output range: range min must be below range max",
+    qnnp_log_error("cannot create add operator with [%" PRIu8 ", %" PRIu8 "] output range: range min must be below range max",
         sum_min, sum_max);
     return qnnp_status_invalid_parameter;
   }
   if (channels > (size_t) UINT32_MAX / 4) {
-    qnnp_log_error("failed to create add operator: %zu channels exceed the device kernels' index range", channels);
+    qnnp_log_error("cannot create add operator: %zu channels exceed the device kernels' index range", channels);
     return qnnp_status_unsupported_parameter;
   }
   /* reference add.c:73-89 */
   const float a_output_scale = a_scale / sum_scale;
   if (a_output_scale < 0x1.0p-14f || a_output_scale >= 0x1.0p+8f) {
-    qnnp_log_error("failed to create add operator with %.7g A-to-output scale ratio: scale ratio must be in [2**-14, 2**8) range",
+    qnnp_log_error("cannot create add operator with %.7g A-to-output scale ratio: scale ratio must be in [2**-14, 2**8) range",
         a_output_scale);
     return qnnp_status_unsupported_parameter;
   }
   const float b_output_scale = b_scale / sum_scale;
   if (b_output_scale < 0x1.0p-14f || b_output_scale >= 0x1.0p+8f) {
-    qnnp_log_error("failed to create add operator with %.7g B-to-output scale ratio: scale ratio must be in [2**-14, 2**8) range",
+    qnnp_log_error("cannot create add operator with %.7g B-to-output scale ratio: scale ratio must be in [2**-14, 2**8) range",
         b_output_scale);
     return qnnp_status_unsupported_parameter;
   }
@@ -119,7 +119,7 @@ static enum qnnp_status qnnp_create_add_nc_q8_impl(
   qnnp_operator_t op = calloc(1, sizeof(struct qnnp_operator));
   if (op != NULL) op->device = qnnp_hip_device();   /* the context this create runs in (entry point below) */
   if (op == NULL) {
-    qnnp_log_error("failed to allocate %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
+    qnnp_log_error("out of host memory: %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
     return qnnp_status_out_of_memory;
   }
   op->channels = channels;
@@ -142,7 +142,7 @@ static enum qnnp_status qnnp_setup_add_nc_q8_impl(
 {
   /* reference add.c:128-131 */
   if (!qnnp_state.initialized) {
-    qnnp_log_error("qnnp_setup_add_nc_q8 failed because QNNPACK is not properly initialized");
+    qnnp_log_error("qnnp_setup_add_nc_q8 called before qnnp_initialize succeeded");
     return qnnp_status_uninitialized;
   }
   if (op == NULL || op->ukernel_type != qnnp_ukernel_type_add) {
@@ -155,7 +155,7 @@ static enum qnnp_status qnnp_setup_add_nc_q8_impl(
   }
   const size_t channels = op->channels;
   if (a == NULL || b == NULL || sum == NULL || a_stride < channels || b_stride < channels || sum_stride < channels) {
-    qnnp_log_error("failed to setup add operator: NULL tensor or stride smaller than the channel count");
+    qnnp_log_error("cannot set up add operator: NULL tensor or stride smaller than the channel count");
     return qnnp_status_invalid_parameter;
   }
 

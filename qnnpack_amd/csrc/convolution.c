@@ -80,41 +80,41 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
 
   /* reference convolution.c:69-72 */
   if (!qnnp_state.initialized) {
-    qnnp_log_error("qnnp_create_convolution2d_nhwc_q8 failed because QNNPACK is not properly initialized");
+    qnnp_log_error("qnnp_create_convolution2d_nhwc_q8 called before qnnp_initialize succeeded");
     goto error;
   }
 
   /* reference convolution.c:74-115 */
   status = qnnp_status_invalid_parameter;
   if (kernel_width == 0 || kernel_height == 0) {
-    qnnp_log_error("failed to create convolution with %" PRIu32 "x%" PRIu32 " kernel: kernel dimensions must be non-zero",
+    qnnp_log_error("cannot create convolution with %" PRIu32 "x%" PRIu32 " kernel: kernel dimensions may not be zero",
         kernel_width, kernel_height);
     goto error;
   }
   if (subsampling_width == 0 || subsampling_height == 0) {
-    qnnp_log_error("failed to create convolution with %" PRIu32 "x%" PRIu32 " subsampling: subsampling dimensions must be non-zero",
+    qnnp_log_error("cannot create convolution with %" PRIu32 "x%" PRIu32 " subsampling: subsampling dimensions may not be zero",
         subsampling_width, subsampling_height);
     goto error;
   }
   if (dilation_width == 0 || dilation_height == 0) {
-    qnnp_log_error("failed to create convolution with %" PRIu32 "x%" PRIu32 " dilation: dilation dimensions must be non-zero",
+    qnnp_log_error("cannot create convolution with %" PRIu32 "x%" PRIu32 " dilation: dilation dimensions may not be zero",
         dilation_width, dilation_height);
     goto error;
   }
   if (!scale_is_valid(input_scale)) {
-    qnnp_log_error("failed to create convolution with %.7g input scale: scale must be finite and positive", input_scale);
+    qnnp_log_error("cannot create convolution with %.7g input scale: a scale has to be a finite number above zero", input_scale);
     goto error;
   }
   if (!scale_is_valid(kernel_scale)) {
-    qnnp_log_error("failed to create convolution with %.7g kernel scale: scale must be finite and positive", kernel_scale);
+    qnnp_log_error("cannot create convolution with %.7g kernel scale: a scale has to be a finite number above zero", kernel_scale);
     goto error;
   }
   if (!scale_is_valid(output_scale)) {
-    qnnp_log_error("failed to create convolution with %.7g output scale: scale must be finite and positive", output_scale);
+    qnnp_log_error("cannot create convolution with %.7g output scale: a scale has to be a finite number above zero", output_scale);
     goto error;
   }
   if (groups == 0 || group_input_channels == 0 || group_output_channels == 0 || kernel == NULL || bias == NULL) {
-    qnnp_log_error("failed to create convolution: groups, channel counts, kernel and bias must be non-zero");
+    qnnp_log_error("cannot create convolution: groups, channel counts, kernel and bias may not be zero");
     goto error;
   }
 
@@ -123,20 +123,20 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
   const float convolution_scale = input_scale * kernel_scale / output_scale;
   if (convolution_scale >= 1.0f) {
     qnnp_log_error(
-        "failed to create convolution with %.7g input scale, %.7g kernel scale, and %.7g output scale: "
+        "cannot create convolution with %.7g input scale, %.7g kernel scale, and %.7g output scale: "
         "convolution scale %.7g is greater or equal to 1.0",
         input_scale, kernel_scale, output_scale, convolution_scale);
     goto error;
   }
   if (!(convolution_scale >= 0x1.0p-32f)) {
     /* the reference's parameter builder asserts this range (requantization.h:28, :139) */
-    qnnp_log_error("failed to create convolution: convolution scale %.7g is below 2**-32", convolution_scale);
+    qnnp_log_error("cannot create convolution: convolution scale %.7g is below 2**-32", convolution_scale);
     goto error;
   }
   const size_t kernel_size = (size_t) kernel_height * kernel_width;
   if (kernel_size * group_input_channels > (size_t) UINT32_MAX / 4 ||
       (size_t) groups * group_output_channels > (size_t) UINT32_MAX / 4) {
-    qnnp_log_error("failed to create convolution: channel / kernel extents exceed the 32-bit index range of the device kernels");
+    qnnp_log_error("cannot create convolution: channel / kernel extents exceed the 32-bit index range of the device kernels");
     goto error;
   }
 
@@ -144,7 +144,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
   op = calloc(1, sizeof(struct qnnp_operator));
   if (op != NULL) op->device = qnnp_hip_device();   /* the context this create runs in (entry point below) */
   if (op == NULL) {
-    qnnp_log_error("failed to allocate %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
+    qnnp_log_error("out of host memory: %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
     goto error;
   }
 
@@ -173,7 +173,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
     host_weights = malloc(w_bytes);
     host_bias = malloc(b_bytes);
     if (host_weights == NULL || host_bias == NULL) {
-      qnnp_log_error("failed to allocate %zu bytes for packed weights", w_bytes + b_bytes);
+      qnnp_log_error("out of host memory: %zu bytes for packed weights", w_bytes + b_bytes);
       goto error;
     }
     qnnp_pack_dwconv_w(groups, c_pad, kernel_height, kernel_width,
@@ -185,7 +185,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
     if (op->d_weights == NULL || op->d_bias == NULL ||
         qnnp_hip_h2d(op->d_weights, host_weights, w_bytes, 0) != QNNP_HIP_OK ||
         qnnp_hip_h2d(op->d_bias, host_bias, b_bytes, 0) != QNNP_HIP_OK) {
-      qnnp_log_error("failed to place %zu bytes of packed depthwise weights on the device", w_bytes + b_bytes);
+      qnnp_log_error("device allocation or upload failed: %zu bytes of packed depthwise weights on the device", w_bytes + b_bytes);
       goto error;
     }
     /* 3x3 with weights in int8 range: the register image of the int8 dot-product walk (pack.h) */
@@ -200,7 +200,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
       }
       free(host_q);
       if (!ok) {
-        qnnp_log_error("failed to place %zu bytes of depthwise dot-product weights on the device", q_bytes);
+        qnnp_log_error("device allocation or upload failed: %zu bytes of depthwise dot-product weights on the device", q_bytes);
         goto error;
       }
     }
@@ -216,7 +216,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
       }
       free(host_q);
       if (!ok) {
-        qnnp_log_error("failed to place %zu bytes of depthwise dot-product weights on the device", q_bytes);
+        qnnp_log_error("device allocation or upload failed: %zu bytes of depthwise dot-product weights on the device", q_bytes);
         goto error;
       }
     }
@@ -241,7 +241,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
       free(host_x);
       free(host_bm);
       if (!ok) {
-        qnnp_log_error("failed to place %zu bytes of depthwise weight parts on the device", x_bytes + bm_bytes);
+        qnnp_log_error("device allocation or upload failed: %zu bytes of depthwise weight parts on the device", x_bytes + bm_bytes);
         goto error;
       }
     }
@@ -257,7 +257,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
     host_weights = malloc(w_bytes);
     host_bias = malloc(b_bytes);
     if (host_weights == NULL || host_bias == NULL) {
-      qnnp_log_error("failed to allocate %zu bytes for packed weights", w_bytes + b_bytes);
+      qnnp_log_error("out of host memory: %zu bytes for packed weights", w_bytes + b_bytes);
       goto error;
     }
     qnnp_pack_igemm_w_slots(groups, (uint32_t) group_output_channels, (uint32_t) kernel_size,
@@ -270,7 +270,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
     op->d_bias = qnnp_upload_bias_pair((const int32_t*) host_bias, (size_t) groups * n_pad);   /* bias-pair.h */
     if (op->d_weights == NULL || op->d_bias == NULL ||
         qnnp_hip_h2d(op->d_weights, host_weights, w_bytes, 0) != QNNP_HIP_OK) {
-      qnnp_log_error("failed to place %zu bytes of packed weights on the device", w_bytes + 2 * b_bytes);
+      qnnp_log_error("device allocation or upload failed: %zu bytes of packed weights on the device", w_bytes + 2 * b_bytes);
       goto error;
     }
     /* Zero-point-centred image (pack.h qnnp_pack_igemm_w_centred127; hip/q8gemm256c.hip, the weight-stationary 3x3
@@ -319,7 +319,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
       const size_t r_bytes = (size_t) n_pad * 64;
       int8_t* host_rows = (int8_t*) malloc(r_bytes);
       if (host_rows == NULL) {
-        qnnp_log_error("failed to allocate %zu bytes for packed weights", r_bytes);
+        qnnp_log_error("out of host memory: %zu bytes for packed weights", r_bytes);
         goto error;
       }
       qnnp_pack_conv_rows16((uint32_t) group_output_channels, kernel_height, kernel_width, 3, n_pad, kernel, host_rows);
@@ -327,7 +327,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
       const int placed = op->d_weights_rows16 != NULL && qnnp_hip_h2d(op->d_weights_rows16, host_rows, r_bytes, 0) == QNNP_HIP_OK;
       free(host_rows);
       if (!placed) {
-        qnnp_log_error("failed to place %zu bytes of packed weights on the device", r_bytes);
+        qnnp_log_error("device allocation or upload failed: %zu bytes of packed weights on the device", r_bytes);
         goto error;
       }
     } else if (kc_slot == 4 && (kernel_height == 5 || kernel_height == 7) && kernel_width * 3 <= 32 &&
@@ -337,7 +337,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
       const size_t r_bytes = qnnp_conv_rows32_size(n_pad, kernel_height);
       int8_t* host_rows = (int8_t*) malloc(r_bytes);
       if (host_rows == NULL) {
-        qnnp_log_error("failed to allocate %zu bytes for packed weights", r_bytes);
+        qnnp_log_error("out of host memory: %zu bytes for packed weights", r_bytes);
         goto error;
       }
       qnnp_pack_conv_rows32((uint32_t) group_output_channels, kernel_height, kernel_width, 3, n_pad, kernel, host_rows);
@@ -345,7 +345,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
       const int placed = op->d_weights_rows16 != NULL && qnnp_hip_h2d(op->d_weights_rows16, host_rows, r_bytes, 0) == QNNP_HIP_OK;
       free(host_rows);
       if (!placed) {
-        qnnp_log_error("failed to place %zu bytes of packed weights on the device", r_bytes);
+        qnnp_log_error("device allocation or upload failed: %zu bytes of packed weights on the device", r_bytes);
         goto error;
       }
     }
@@ -401,7 +401,7 @@ static enum qnnp_status qnnp_setup_convolution2d_nhwc_q8_impl(
 
   /* reference convolution.c:391-394 */
   if (!qnnp_state.initialized) {
-    qnnp_log_error("qnnp_setup_convolution2d_nhwc_q8 failed because QNNPACK is not properly initialized");
+    qnnp_log_error("qnnp_setup_convolution2d_nhwc_q8 called before qnnp_initialize succeeded");
     return qnnp_status_uninitialized;
   }
   if (op == NULL || op->transposed || op->kernel_height == 0 ||
@@ -418,21 +418,21 @@ static enum qnnp_status qnnp_setup_convolution2d_nhwc_q8_impl(
 
   /* reference convolution.c:401-407 */
   if (input_width == 0 || input_height == 0) {
-    qnnp_log_error("failed to setup convolution with %zux%zu input: input dimensions must be non-zero",
+    qnnp_log_error("cannot set up convolution with %zux%zu input: input dimensions may not be zero",
         input_width, input_height);
     return qnnp_status_invalid_parameter;
   }
   const size_t in_channels = (size_t) op->groups * op->group_input_channels;
   const size_t out_channels = (size_t) op->groups * op->group_output_channels;
   if (input == NULL || output == NULL || input_pixel_stride < in_channels || output_pixel_stride < out_channels) {
-    qnnp_log_error("failed to setup convolution: NULL tensor or pixel stride smaller than the channel count");
+    qnnp_log_error("cannot set up convolution: NULL tensor or pixel stride smaller than the channel count");
     return qnnp_status_invalid_parameter;
   }
   const size_t eff_kh = (size_t) (op->kernel_height - 1) * op->dilation_height + 1;
   const size_t eff_kw = (size_t) (op->kernel_width - 1) * op->dilation_width + 1;
   if (op->input_padding_top + input_height + op->input_padding_bottom < eff_kh ||
       op->input_padding_left + input_width + op->input_padding_right < eff_kw) {
-    qnnp_log_error("failed to setup convolution with %zux%zu input: padded input is smaller than the dilated kernel",
+    qnnp_log_error("cannot set up convolution with %zux%zu input: padded input is smaller than the dilated kernel",
         input_width, input_height);
     return qnnp_status_invalid_parameter;
   }
@@ -458,7 +458,7 @@ static enum qnnp_status qnnp_setup_convolution2d_nhwc_q8_impl(
   const size_t output_size = op->output_height * op->output_width;
   const size_t input_size = input_height * input_width;
   if (batch_size * output_size > (size_t) UINT32_MAX / 2 || input_size * input_pixel_stride > (size_t) INT32_MAX) {
-    qnnp_log_error("failed to setup convolution: %zu output pixels / %zu-byte images exceed the device kernels' index range",
+    qnnp_log_error("cannot set up convolution: %zu output pixels / %zu-byte images exceed the device kernels' index range",
         batch_size * output_size, input_size * input_pixel_stride);
     return qnnp_status_unsupported_parameter;
   }
@@ -498,7 +498,7 @@ static enum qnnp_status qnnp_setup_convolution2d_nhwc_q8_impl(
       }
       int32_t* host_table = (int32_t*) malloc(sizeof(int32_t) * entries);
       if (host_table == NULL) {
-        qnnp_log_error("failed to allocate %zu bytes for the offset table", sizeof(int32_t) * entries);
+        qnnp_log_error("out of host memory: %zu bytes for the offset table", sizeof(int32_t) * entries);
         return qnnp_status_out_of_memory;
       }
       if (op->offsets_capacity < entries) {
@@ -509,7 +509,7 @@ static enum qnnp_status qnnp_setup_convolution2d_nhwc_q8_impl(
         op->d_offsets = (int32_t*) qnnp_hip_alloc(sizeof(int32_t) * entries + 16);
         if (op->d_offsets == NULL) {
           free(host_table);
-          qnnp_log_error("failed to allocate %zu bytes for the device offset table", sizeof(int32_t) * entries);
+          qnnp_log_error("out of host memory: %zu bytes for the device offset table", sizeof(int32_t) * entries);
           return qnnp_status_out_of_memory;
         }
         op->offsets_capacity = entries;

@@ -92,41 +92,41 @@ static enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8_impl(
 
   /* reference deconvolution.c:69-72 */
   if (!qnnp_state.initialized) {
-    qnnp_log_error("qnnp_create_deconvolution2d_nhwc_q8 failed because QNNPACK is not properly initialized");
+    qnnp_log_error("qnnp_create_deconvolution2d_nhwc_q8 called before qnnp_initialize succeeded");
     goto error;
   }
 
   /* reference deconvolution.c:74-116 */
   status = qnnp_status_invalid_parameter;
   if (kernel_width == 0 || kernel_height == 0) {
-    qnnp_log_error("failed to create deconvolution with %" PRIu32 "x%" PRIu32 " kernel: kernel dimensions must be non-zero",
+    qnnp_log_error("cannot create deconvolution with %" PRIu32 "x%" PRIu32 " kernel: kernel dimensions may not be zero",
         kernel_width, kernel_height);
     goto error;
   }
   if (stride_width == 0 || stride_height == 0) {
-    qnnp_log_error("failed to create deconvolution with %" PRIu32 "x%" PRIu32 " stride: stride dimensions must be non-zero",
+    qnnp_log_error("cannot create deconvolution with %" PRIu32 "x%" PRIu32 " stride: stride dimensions may not be zero",
         stride_width, stride_height);
     goto error;
   }
   if (dilation_width == 0 || dilation_height == 0) {
-    qnnp_log_error("failed to create deconvolution with %" PRIu32 "x%" PRIu32 " dilation: dilation dimensions must be non-zero",
+    qnnp_log_error("cannot create deconvolution with %" PRIu32 "x%" PRIu32 " dilation: dilation dimensions may not be zero",
         dilation_width, dilation_height);
     goto error;
   }
   if (!scale_is_valid(input_scale)) {
-    qnnp_log_error("failed to create deconvolution with %.7g input scale: scale must be finite and positive", input_scale);
+    qnnp_log_error("cannot create deconvolution with %.7g input scale: a scale has to be a finite number above zero", input_scale);
     goto error;
   }
   if (!scale_is_valid(kernel_scale)) {
-    qnnp_log_error("failed to create deconvolution with %.7g kernel scale: scale must be finite and positive", kernel_scale);
+    qnnp_log_error("cannot create deconvolution with %.7g kernel scale: a scale has to be a finite number above zero", kernel_scale);
     goto error;
   }
   if (!scale_is_valid(output_scale)) {
-    qnnp_log_error("failed to create deconvolution with %.7g output scale: scale must be finite and positive", output_scale);
+    qnnp_log_error("cannot create deconvolution with %.7g output scale: a scale has to be a finite number above zero", output_scale);
     goto error;
   }
   if (groups == 0 || group_input_channels == 0 || group_output_channels == 0 || kernel == NULL || bias == NULL) {
-    qnnp_log_error("failed to create deconvolution: groups, channel counts, kernel and bias must be non-zero");
+    qnnp_log_error("cannot create deconvolution: groups, channel counts, kernel and bias may not be zero");
     goto error;
   }
 
@@ -135,19 +135,19 @@ static enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8_impl(
   const float deconvolution_scale = input_scale * kernel_scale / output_scale;
   if (deconvolution_scale >= 1.0f) {
     qnnp_log_error(
-        "failed to create deconvolution with %.7g input scale, %.7g kernel scale, and %.7g output scale: "
+        "cannot create deconvolution with %.7g input scale, %.7g kernel scale, and %.7g output scale: "
         "deconvolution scale %.7g is greater or equal to 1.0",
         input_scale, kernel_scale, output_scale, deconvolution_scale);
     goto error;
   }
   if (!(deconvolution_scale >= 0x1.0p-32f)) {
-    qnnp_log_error("failed to create deconvolution: deconvolution scale %.7g is below 2**-32", deconvolution_scale);
+    qnnp_log_error("cannot create deconvolution: deconvolution scale %.7g is below 2**-32", deconvolution_scale);
     goto error;
   }
   const size_t kernel_size = (size_t) kernel_height * kernel_width;
   if (kernel_size * group_input_channels > (size_t) UINT32_MAX / 4 ||
       (size_t) groups * group_output_channels > (size_t) UINT32_MAX / 4) {
-    qnnp_log_error("failed to create deconvolution: channel / kernel extents exceed the 32-bit index range of the device kernels");
+    qnnp_log_error("cannot create deconvolution: channel / kernel extents exceed the 32-bit index range of the device kernels");
     goto error;
   }
 
@@ -155,7 +155,7 @@ static enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8_impl(
   op = calloc(1, sizeof(struct qnnp_operator));
   if (op != NULL) op->device = qnnp_hip_device();   /* the context this create runs in (entry point below) */
   if (op == NULL) {
-    qnnp_log_error("failed to allocate %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
+    qnnp_log_error("out of host memory: %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
     goto error;
   }
 
@@ -164,7 +164,7 @@ static enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8_impl(
   const size_t group_weights = goc * kernel_size * gic;
   conv_order = (uint8_t*) malloc(group_weights * groups);
   if (conv_order == NULL) {
-    qnnp_log_error("failed to allocate %zu bytes for the transposed kernel", group_weights * groups);
+    qnnp_log_error("out of host memory: %zu bytes for the transposed kernel", group_weights * groups);
     goto error;
   }
   for (size_t g = 0; g < groups; g++) {
@@ -190,7 +190,7 @@ static enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8_impl(
     host_bias = malloc(b_bytes);
     if (sub == NULL || host_bias == NULL) {
       free(sub);
-      qnnp_log_error("failed to allocate %zu bytes for the phase kernels", group_weights * groups);
+      qnnp_log_error("out of host memory: %zu bytes for the phase kernels", group_weights * groups);
       goto error;
     }
     for (uint32_t py = 0; py < stride_height; py++) {
@@ -242,7 +242,7 @@ static enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8_impl(
         op->deconv_phases = py * stride_width + px + 1;   /* so that delete frees what exists so far */
         if (!ok) {
           free(sub);
-          qnnp_log_error("failed to place %zu bytes of packed phase weights on the device", w_bytes + b_bytes);
+          qnnp_log_error("device allocation or upload failed: %zu bytes of packed phase weights on the device", w_bytes + b_bytes);
           goto error;
         }
       }
@@ -291,7 +291,7 @@ static enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8_impl(
       free(packed);
       free(packed_bias);
       if (!ok) {
-        qnnp_log_error("failed to place %zu bytes of packed depth-to-space weights on the device", dw_bytes + db_bytes);
+        qnnp_log_error("device allocation or upload failed: %zu bytes of packed depth-to-space weights on the device", dw_bytes + db_bytes);
         goto error;
       }
       op->k_pad = d2s_k_pad;
@@ -306,7 +306,7 @@ static enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8_impl(
   host_weights = malloc(w_bytes);
   host_bias = malloc(b_bytes);
   if (host_weights == NULL || host_bias == NULL) {
-    qnnp_log_error("failed to allocate %zu bytes for packed weights", w_bytes + b_bytes);
+    qnnp_log_error("out of host memory: %zu bytes for packed weights", w_bytes + b_bytes);
     goto error;
   }
   qnnp_pack_igemm_w_slots(groups, (uint32_t) goc, (uint32_t) kernel_size, (uint32_t) gic, kc_slot, n_pad, k_pad,
@@ -318,7 +318,7 @@ static enum qnnp_status qnnp_create_deconvolution2d_nhwc_q8_impl(
   op->d_bias = qnnp_upload_bias_pair((const int32_t*) host_bias, (size_t) groups * n_pad);   /* bias-pair.h */
   if (op->d_weights == NULL || op->d_bias == NULL ||
       qnnp_hip_h2d(op->d_weights, host_weights, w_bytes, 0) != QNNP_HIP_OK) {
-    qnnp_log_error("failed to place %zu bytes of packed weights on the device", w_bytes + b_bytes);
+    qnnp_log_error("device allocation or upload failed: %zu bytes of packed weights on the device", w_bytes + b_bytes);
     goto error;
   }
 packed_done:
@@ -394,7 +394,7 @@ static enum qnnp_status upload_phase_table(struct qnnp_operator* op)
   if (op->d_phase_table == NULL) {
     op->d_phase_table = qnnp_hip_alloc(sizeof(table));
     if (op->d_phase_table == NULL) {
-      qnnp_log_error("failed to allocate %zu bytes for the phase table", sizeof(table));
+      qnnp_log_error("out of host memory: %zu bytes for the phase table", sizeof(table));
       return qnnp_status_out_of_memory;
     }
   }
@@ -420,7 +420,7 @@ static enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8_impl(
 
   /* reference deconvolution.c:225-228 */
   if (!qnnp_state.initialized) {
-    qnnp_log_error("qnnp_setup_deconvolution2d_nhwc_q8 failed because QNNPACK is not properly initialized");
+    qnnp_log_error("qnnp_setup_deconvolution2d_nhwc_q8 called before qnnp_initialize succeeded");
     return qnnp_status_uninitialized;
   }
   if (op == NULL || !op->transposed) {
@@ -435,14 +435,14 @@ static enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8_impl(
 
   /* reference deconvolution.c:235-241 */
   if (input_width == 0 || input_height == 0) {
-    qnnp_log_error("failed to setup deconvolution with %zux%zu input: input dimensions must be non-zero",
+    qnnp_log_error("cannot set up deconvolution with %zux%zu input: input dimensions may not be zero",
         input_width, input_height);
     return qnnp_status_invalid_parameter;
   }
   const size_t in_channels = (size_t) op->groups * op->group_input_channels;
   const size_t out_channels = (size_t) op->groups * op->group_output_channels;
   if (input == NULL || output == NULL || input_pixel_stride < in_channels || output_pixel_stride < out_channels) {
-    qnnp_log_error("failed to setup deconvolution: NULL tensor or pixel stride smaller than the channel count");
+    qnnp_log_error("cannot set up deconvolution: NULL tensor or pixel stride smaller than the channel count");
     return qnnp_status_invalid_parameter;
   }
   const size_t pad_h = (size_t) op->input_padding_top + op->input_padding_bottom;
@@ -452,7 +452,7 @@ static enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8_impl(
   const size_t full_w = compute_output_dimension(input_width, 0, op->adjustment_width, op->kernel_width,
       op->dilation_width, op->stride_width);
   if (pad_h >= full_h || pad_w >= full_w) {
-    qnnp_log_error("failed to setup deconvolution with %zux%zu input: the padding removes the whole output",
+    qnnp_log_error("cannot set up deconvolution with %zux%zu input: the padding removes the whole output",
         input_width, input_height);
     return qnnp_status_invalid_parameter;
   }
@@ -472,7 +472,7 @@ static enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8_impl(
   const size_t output_size = op->output_height * op->output_width;
   const size_t input_size = input_height * input_width;
   if (batch_size * output_size > (size_t) UINT32_MAX / 2 || input_size * input_pixel_stride > (size_t) INT32_MAX) {
-    qnnp_log_error("failed to setup deconvolution: %zu output pixels / %zu-byte images exceed the device kernels' index range",
+    qnnp_log_error("cannot set up deconvolution: %zu output pixels / %zu-byte images exceed the device kernels' index range",
         batch_size * output_size, input_size * input_pixel_stride);
     return qnnp_status_unsupported_parameter;
   }
@@ -514,7 +514,7 @@ static enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8_impl(
       if (host_offsets == NULL || host_rows == NULL) {
         free(host_offsets);
         free(host_rows);
-        qnnp_log_error("failed to allocate %zu bytes for a phase table", sizeof(int32_t) * ph->rows * (ph->taps + 1));
+        qnnp_log_error("out of host memory: %zu bytes for a phase table", sizeof(int32_t) * ph->rows * (ph->taps + 1));
         return qnnp_status_out_of_memory;
       }
       size_t r = 0;
@@ -569,7 +569,7 @@ static enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8_impl(
   }
   int32_t* host_table = (int32_t*) malloc(sizeof(int32_t) * entries);
   if (host_table == NULL) {
-    qnnp_log_error("failed to allocate %zu bytes for the offset table", sizeof(int32_t) * entries);
+    qnnp_log_error("out of host memory: %zu bytes for the offset table", sizeof(int32_t) * entries);
     return qnnp_status_out_of_memory;
   }
   if (op->offsets_capacity < entries) {
@@ -578,7 +578,7 @@ static enum qnnp_status qnnp_setup_deconvolution2d_nhwc_q8_impl(
     op->d_offsets = (int32_t*) qnnp_hip_alloc(sizeof(int32_t) * entries);
     if (op->d_offsets == NULL) {
       free(host_table);
-      qnnp_log_error("failed to allocate %zu bytes for the device offset table", sizeof(int32_t) * entries);
+      qnnp_log_error("out of host memory: %zu bytes for the device offset table", sizeof(int32_t) * entries);
       return qnnp_status_out_of_memory;
     }
     op->offsets_capacity = entries;

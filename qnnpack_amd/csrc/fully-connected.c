@@ -52,26 +52,26 @@ static enum qnnp_status qnnp_create_fully_connected_nc_q8_impl(
 
   /* reference fully-connected.c:44-47 */
   if (!qnnp_state.initialized) {
-    qnnp_log_error("qnnp_create_fully_connected_nc_q8 failed because QNNPACK is not properly initialized");
+    qnnp_log_error("qnnp_create_fully_connected_nc_q8 called before qnnp_initialize succeeded");
     goto error;
   }
 
   /* reference fully-connected.c:49-67 */
   status = qnnp_status_invalid_parameter;
   if (!scale_is_valid(input_scale)) {
-    qnnp_log_error("failed to create fully connected operator with %.7g input scale: scale must be finite and positive", input_scale);
+    qnnp_log_error("cannot create fully connected operator with %.7g input scale: a scale has to be a finite number above zero", input_scale);
     goto error;
   }
   if (!scale_is_valid(kernel_scale)) {
-    qnnp_log_error("failed to create fully connected operator with %.7g kernel scale: scale must be finite and positive", kernel_scale);
+    qnnp_log_error("cannot create fully connected operator with %.7g kernel scale: a scale has to be a finite number above zero", kernel_scale);
     goto error;
   }
   if (!scale_is_valid(output_scale)) {
-    qnnp_log_error("failed to create fully connected operator with %.7g output scale: scale must be finite and positive", output_scale);
+    qnnp_log_error("cannot create fully connected operator with %.7g output scale: a scale has to be a finite number above zero", output_scale);
     goto error;
   }
   if (input_channels == 0 || output_channels == 0 || kernel == NULL || bias == NULL) {
-    qnnp_log_error("failed to create fully connected operator: channel counts, kernel and bias must be non-zero");
+    qnnp_log_error("cannot create fully connected operator: channel counts, kernel and bias may not be zero");
     goto error;
   }
 
@@ -80,17 +80,17 @@ static enum qnnp_status qnnp_create_fully_connected_nc_q8_impl(
   const float requantization_scale = input_scale * kernel_scale / output_scale;
   if (requantization_scale >= 1.0f) {
     qnnp_log_error(
-        "failed to create fully connected operator with %.7g input scale, %.7g kernel scale, and %.7g output scale: "
+        "cannot create fully connected operator with %.7g input scale, %.7g kernel scale, and %.7g output scale: "
         "requantization scale %.7g is greater or equal to 1.0",
         input_scale, kernel_scale, output_scale, requantization_scale);
     goto error;
   }
   if (!(requantization_scale >= 0x1.0p-32f)) {
-    qnnp_log_error("failed to create fully connected operator: requantization scale %.7g is below 2**-32", requantization_scale);
+    qnnp_log_error("cannot create fully connected operator: requantization scale %.7g is below 2**-32", requantization_scale);
     goto error;
   }
   if (input_channels > (size_t) UINT32_MAX / 4 || output_channels > (size_t) UINT32_MAX / 4) {
-    qnnp_log_error("failed to create fully connected operator: channel counts exceed the device kernels' 32-bit index range");
+    qnnp_log_error("cannot create fully connected operator: channel counts exceed the device kernels' 32-bit index range");
     goto error;
   }
 
@@ -98,7 +98,7 @@ static enum qnnp_status qnnp_create_fully_connected_nc_q8_impl(
   op = calloc(1, sizeof(struct qnnp_operator));
   if (op != NULL) op->device = qnnp_hip_device();   /* the context this create runs in (entry point below) */
   if (op == NULL) {
-    qnnp_log_error("failed to allocate %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
+    qnnp_log_error("out of host memory: %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
     goto error;
   }
 
@@ -109,7 +109,7 @@ static enum qnnp_status qnnp_create_fully_connected_nc_q8_impl(
   host_weights = (int8_t*) malloc(w_bytes);
   host_bias = (int32_t*) malloc(b_bytes);
   if (host_weights == NULL || host_bias == NULL) {
-    qnnp_log_error("failed to allocate %zu bytes for packed weights", w_bytes + b_bytes);
+    qnnp_log_error("out of host memory: %zu bytes for packed weights", w_bytes + b_bytes);
     goto error;
   }
   qnnp_pack_igemm_w(1, (uint32_t) output_channels, (uint32_t) input_channels, n_pad, k_pad,
@@ -121,7 +121,7 @@ static enum qnnp_status qnnp_create_fully_connected_nc_q8_impl(
   op->d_bias = qnnp_upload_bias_pair(host_bias, n_pad);      /* bias-pair.h */
   if (op->d_weights == NULL || op->d_bias == NULL ||
       qnnp_hip_h2d(op->d_weights, host_weights, w_bytes, 0) != QNNP_HIP_OK) {
-    qnnp_log_error("failed to place %zu bytes of packed weights on the device", w_bytes + 2 * b_bytes);
+    qnnp_log_error("device allocation or upload failed: %zu bytes of packed weights on the device", w_bytes + 2 * b_bytes);
     goto error;
   }
   /* The big GEMM kernel's zero-point-centred image (pack.h, hip/q8gemm256c.hip): kernel zero point 128 IS the
@@ -190,7 +190,7 @@ static enum qnnp_status qnnp_setup_fully_connected_nc_q8_impl(
 {
   /* reference fully-connected.c:139-142 */
   if (!qnnp_state.initialized) {
-    qnnp_log_error("qnnp_setup_fully_connected_nc_q8 failed because QNNPACK is not properly initialized");
+    qnnp_log_error("qnnp_setup_fully_connected_nc_q8 called before qnnp_initialize succeeded");
     return qnnp_status_uninitialized;
   }
   if (op == NULL || op->ukernel_type != qnnp_ukernel_type_gemm || op->transposed || op->group_input_channels == 0) {
@@ -204,11 +204,11 @@ static enum qnnp_status qnnp_setup_fully_connected_nc_q8_impl(
   }
   if (input == NULL || output == NULL ||
       input_stride < op->group_input_channels || output_stride < op->group_output_channels) {
-    qnnp_log_error("failed to setup fully connected operator: NULL tensor or stride smaller than the channel count");
+    qnnp_log_error("cannot set up fully connected operator: NULL tensor or stride smaller than the channel count");
     return qnnp_status_invalid_parameter;
   }
   if (batch_size > (size_t) UINT32_MAX / 2) {
-    qnnp_log_error("failed to setup fully connected operator: batch %zu exceeds the device kernels' index range", batch_size);
+    qnnp_log_error("cannot set up fully connected operator: batch %zu exceeds the device kernels' index range", batch_size);
     return qnnp_status_unsupported_parameter;
   }
 

@@ -222,7 +222,7 @@ static enum qnnp_status qnnp_gfx950_create_fused_block_impl(
     qnnp_operator_t* fused_out)
 {
   if (!qnnp_state.initialized) {
-    qnnp_log_error("qnnp_gfx950_create_fused_block failed because QNNPACK is not properly initialized");
+    qnnp_log_error("qnnp_gfx950_create_fused_block called before qnnp_initialize succeeded");
     return qnnp_status_uninitialized;
   }
   if (depthwise == NULL || project == NULL || fused_out == NULL) {
@@ -237,25 +237,25 @@ static enum qnnp_status qnnp_gfx950_create_fused_block_impl(
       depthwise->input_padding_bottom != 1 || depthwise->input_padding_right != 1 ||
       !is_pointwise(project) || project->group_input_channels != depthwise->groups ||
       (expand != NULL && (!is_pointwise(expand) || expand->group_output_channels != depthwise->groups))) {
-    qnnp_log_error("failed to create fused block: operators are not a [1x1 ->] 3x3 depthwise (pad 1) -> 1x1 chain");
+    qnnp_log_error("cannot create fused block: operators are not a [1x1 ->] 3x3 depthwise (pad 1) -> 1x1 chain");
     return qnnp_status_unsupported_parameter;
   }
   if (residual_add != NULL) {
     const size_t cin = expand != NULL ? expand->group_input_channels : depthwise->groups;
     if (residual_add->ukernel_type != qnnp_ukernel_type_add || residual_add->channels != project->group_output_channels ||
         cin != project->group_output_channels || depthwise->stride_height != 1) {
-      qnnp_log_error("failed to create fused block: the residual add does not match the block's input / output");
+      qnnp_log_error("cannot create fused block: the residual add does not match the block's input / output");
       return qnnp_status_unsupported_parameter;
     }
   }
   if (project->device != depthwise->device || (expand != NULL && expand->device != depthwise->device)) {
-    qnnp_log_error("failed to create fused block: the operators live on different devices");
+    qnnp_log_error("cannot create fused block: the operators live on different devices");
     return qnnp_status_invalid_parameter;
   }
   qnnp_operator_t op = calloc(1, sizeof(struct qnnp_operator));
   if (op != NULL) op->device = depthwise->device;   /* it borrows their device images */
   if (op == NULL) {
-    qnnp_log_error("failed to allocate %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
+    qnnp_log_error("out of host memory: %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
     return qnnp_status_out_of_memory;
   }
   op->fused_expand = expand;
@@ -287,7 +287,7 @@ static enum qnnp_status qnnp_gfx950_setup_fused_block_impl(
   const size_t cout = op->fused_project->group_output_channels;
   if (input_height == 0 || input_width == 0 || input == NULL || output == NULL ||
       input_stride < cin || output_stride < cout) {
-    qnnp_log_error("failed to setup fused block: zero extent, NULL tensor or stride smaller than the channel count");
+    qnnp_log_error("cannot set up fused block: zero extent, NULL tensor or stride smaller than the channel count");
     return qnnp_status_invalid_parameter;
   }
   const size_t s = op->fused_depthwise->stride_height;
@@ -304,7 +304,7 @@ static enum qnnp_status qnnp_gfx950_setup_fused_block_impl(
   const size_t in_pixels = batch_size * input_height * input_width;
   const size_t out_pixels = batch_size * op->output_height * op->output_width;
   if (in_pixels > (size_t) UINT32_MAX / 2 || in_pixels * input_stride > (size_t) UINT32_MAX) {
-    qnnp_log_error("failed to setup fused block: %zu pixels exceed the device kernel's index range", in_pixels);
+    qnnp_log_error("cannot set up fused block: %zu pixels exceed the device kernel's index range", in_pixels);
     return qnnp_status_unsupported_parameter;
   }
   op->input_span = (in_pixels - 1) * input_stride + cin;

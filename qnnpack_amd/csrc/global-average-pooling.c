@@ -60,34 +60,34 @@ static enum qnnp_status qnnp_create_global_average_pooling_nwc_q8_impl(
   (void) flags;
   /* reference global-average-pooling.c:34-37 */
   if (!qnnp_state.initialized) {
-    qnnp_log_error("qnnp_create_global_average_pooling_nwc_q8 failed because QNNPACK is not properly initialized");
+    qnnp_log_error("qnnp_create_global_average_pooling_nwc_q8 called before qnnp_initialize succeeded");
     return qnnp_status_uninitialized;
   }
   /* reference global-average-pooling.c:39-59 */
   if (channels == 0) {
-    qnnp_log_error("failed to create global average pooling operator with %zu channels: number of channels must be non-zero",
+    qnnp_log_error("cannot create global average pooling operator with %zu channels: number of channels may not be zero",
         channels);
     return qnnp_status_invalid_parameter;
   }
   if (!scale_is_valid(input_scale)) {
-    qnnp_log_error("failed to create global average pooling operator with %.7g input scale: scale must be finite and positive",
+    qnnp_log_error("cannot create global average pooling operator with %.7g input scale: a scale has to be a finite number above zero",
         input_scale);
     return qnnp_status_invalid_parameter;
   }
   if (!scale_is_valid(output_scale)) {
-    qnnp_log_error("failed to create global average pooling operator with %.7g output scale: scale must be finite and positive",
+    qnnp_log_error("cannot create global average pooling operator with %.7g output scale: a scale has to be a finite number above zero",
         output_scale);
     return qnnp_status_invalid_parameter;
   }
   /* reference global-average-pooling.c:61-70 */
   const float input_output_scale = input_scale / output_scale;
   if (input_output_scale < 0x1.0p-8f || input_output_scale >= 0x1.0p+8f) {
-    qnnp_log_error("failed to create global average pooling operator with %.7g input-to-output scale ratio: "
+    qnnp_log_error("cannot create global average pooling operator with %.7g input-to-output scale ratio: "
         "scale ratio must be in [2**-8, 2**8) range", input_output_scale);
     return qnnp_status_unsupported_parameter;
   }
   if (channels > (size_t) UINT32_MAX / 4) {
-    qnnp_log_error("failed to create global average pooling operator: %zu channels exceed the device kernels' index range",
+    qnnp_log_error("cannot create global average pooling operator: %zu channels exceed the device kernels' index range",
         channels);
     return qnnp_status_unsupported_parameter;
   }
@@ -95,7 +95,7 @@ static enum qnnp_status qnnp_create_global_average_pooling_nwc_q8_impl(
   qnnp_operator_t op = calloc(1, sizeof(struct qnnp_operator));
   if (op != NULL) op->device = qnnp_hip_device();   /* the context this create runs in (entry point below) */
   if (op == NULL) {
-    qnnp_log_error("failed to allocate %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
+    qnnp_log_error("out of host memory: %zu bytes for qnnp_operator structure", sizeof(struct qnnp_operator));
     return qnnp_status_out_of_memory;
   }
   op->channels = channels;
@@ -121,7 +121,7 @@ static enum qnnp_status qnnp_setup_global_average_pooling_nwc_q8_impl(
 {
   /* reference global-average-pooling.c:118-121 */
   if (!qnnp_state.initialized) {
-    qnnp_log_error("qnnp_setup_global_average_pooling_nwc_q8 failed because QNNPACK is not properly initialized");
+    qnnp_log_error("qnnp_setup_global_average_pooling_nwc_q8 called before qnnp_initialize succeeded");
     return qnnp_status_uninitialized;
   }
   if (op == NULL || op->ukernel_type != qnnp_ukernel_type_global_average_pooling) {
@@ -134,19 +134,19 @@ static enum qnnp_status qnnp_setup_global_average_pooling_nwc_q8_impl(
   }
   /* reference global-average-pooling.c:128-131 */
   if (width == 0) {
-    qnnp_log_error("failed to setup global average pooling operator with width %zu: width must be non-zero", width);
+    qnnp_log_error("cannot set up global average pooling operator with width %zu: width may not be zero", width);
     return qnnp_status_invalid_parameter;
   }
   const size_t channels = op->channels;
   if (input == NULL || output == NULL || input_stride < channels || output_stride < channels) {
-    qnnp_log_error("failed to setup global average pooling operator: NULL tensor or stride smaller than the channel count");
+    qnnp_log_error("cannot set up global average pooling operator: NULL tensor or stride smaller than the channel count");
     return qnnp_status_invalid_parameter;
   }
   /* the accumulator of one output is width * 255 at most; the scale must stay inside the parameter builder's
    * range [2^-32, 256) (asserted by the reference, requantization.h:208-209) */
   const float scale = op->input_scale / (op->output_scale * (float) width);
   if (width > (size_t) INT32_MAX / 255 || !(scale >= 0x1.0p-32f) || !(scale < 256.0f)) {
-    qnnp_log_error("failed to setup global average pooling operator with width %zu: outside the supported range", width);
+    qnnp_log_error("cannot set up global average pooling operator with width %zu: outside the supported range", width);
     return qnnp_status_unsupported_parameter;
   }
 

@@ -362,8 +362,10 @@ int launch_c3rows(const IgemmParams& p, const C3Geom& cg, hipStream_t stream)
  *   - every fetch is dword-aligned (address & ~3) and moved into place with v_alignbyte; the launcher requires the tensor's
  *     size to be a multiple of four bytes, so no dword straddles its end and the first / last image need no special path:
  *     what lies outside the tensor is padding, fetched as zeros and replaced like every out-of-image tap;
- *   - the kernel-zero-point row term is VALU work (v_dot4_u32_u8 of the raw bytes against a 0 / 1 mask of the slot's real
- *     bytes, the two halves joined by v_permlane32_swap): KR more MFMAs per channel block would double the matrix time here;
+ *   - the kernel-zero-point row term comes from the matrix cores too: KR MFMAs per unit multiply the re-centred slots with a
+ *     `ones` fragment (1 in every real byte of the slot, 0 in its padding bytes), i.e. an extra channel block that holds the row
+ *     sums -- KR more MFMAs per UNIT, not per channel block (the first build did it with v_dot4_u32_u8 + v_permlane32_swap on
+ *     the VALU, which this kernel has no slots left for);
  *   - two sets of slot registers with swapping roles, as above: the next unit's fetches fly under the whole current unit.
  */
 template <int NB, int KR, int SEQ, bool FULL>

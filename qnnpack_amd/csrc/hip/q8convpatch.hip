@@ -15,9 +15,11 @@
  * q8convwave.hip keeps 9 * C * N weight bytes in registers, which ends at 64 channels. Here:
  *   - a workgroup (8 waves) owns P <= 128 (N-tile 256) or <= 256 (N-tile 128) output positions -- whole output rows of
  *     one image, or whole small images -- and an N-tile of output channels. Their input patch, halo included
- *     (out-of-image pixels = the input zero point), goes to LDS ONCE by LDS-DMA: 16-byte chunk c of patch pixel q sits
- *     in slot c ^ f(q) of the pixel (f chosen per channel count so that the 16 lanes of a ds_read_b128 group, which
- *     read the same chunk of consecutive pixels, hit 16 different bank groups);
+ *     (out-of-image pixels = the input zero point), goes to LDS ONCE by LDS-DMA with a PADDED pixel pitch: patch pixel q
+ *     starts at q * (C + 16) bytes -- an odd number of 16-byte chunks, so the lanes of a ds_read_b128 group, which read the
+ *     same chunk of consecutive pixels, walk the bank quads with an odd stride (no XOR swizzle: the first build had one and
+ *     it is gone; what conflicts remain -- SQ_LDS_BANK_CONFLICT 28 % of the LDS-active cycles at 14 x 14 x 256, profiles/r05/
+ *     conv_patch_stamps_and_pmc_r05ptrace3.txt -- come from lane groups that straddle an output row's end);
  *   - one pass over the landed patch re-centres it in place (a ^ 0x80) and leaves per-pixel channel sums beside it
  *     (v_sad_u8; the kernel-zero-point row term is their sum over the window, taken in the epilogue: 9 LDS reads per
  *     position instead of row-sum work inside the K loop);

@@ -135,7 +135,11 @@ __device__ __forceinline__ uint32_t a_swizzle(uint32_t row) { return (row & 8u) 
  * 1 = no epilogue, 2 = no recentring, 4 = no MFMA, 8 = no LDS-DMA after the prologue, 16 = no fragment reads after the
  * prologue, 32 = no per-tile wait + barrier, 64 = no global stores.
  */
-template <int SEQ, int CLAMP, bool ALIGNED, int ABL = 0>
+/* ROWSUM (round 6): any OTHER kernel zero point, on the standard image (w - 128, activations ^ 0x80): the kernel-zero-point row term
+ * (128 - kzp) * sum_k (a(m,k) - 128) of q8gemm256.hip is added to the accumulators in front of the requantization. The sums are
+ * taken over the RAW fragment bytes with v_sad_u8 (one per dword, beside the re-centring XOR); a lane holds chunk g of its row, the
+ * four lanes of a row are summed once in the epilogue -- and the result lane of a row is its operand lane, nothing moves. */
+template <int SEQ, int CLAMP, bool ALIGNED, int ABL = 0, bool ROWSUM = false>
 __global__ __launch_bounds__(kThreads, 2)
 void q8_gemm_mfma_256x256_c16_kernel(const IgemmParams p)
 {
@@ -276,8 +280,21 @@ void q8_gemm_mfma_256x256_c16_kernel(const IgemmParams p)
   };
 
   const uint32_t flip = p.a_flip;                // 0x80808080 (kzp 128) or 0x7F7F7F7F (kzp 127), scalar
+  uint32_t rs[kTM] = {0u, 0u, 0u, 0u};           // ROWSUM: sum of the raw bytes of this lane's chunks of rows 16 tm + (lane & 15)
   // half (0 / 1) of the recentring of one activation fragment: 2 of its 4 dwords
   auto flip_half = [&](int tm, int half) __attribute__((always_inline)) {
+    if constexpr (ROWSUM) {
+      if (half) {
+        rs[tm] = __builtin_amdgcn_sad_u8(static_cast<uint32_t>(fa[tm].z), 0u, rs[tm]);
+        rs[tm] = __builtin_amdgcn_sad_u8(static_cast<uint32_t>(fa[tm].w), 0u, rs[tm]);
+      } else {
+        rs[tm] = __builtin_amdgcn_sad_u8(static_cast<uint32_t>(fa[tm].x), 0u, rs[tm]);
+        rs[tm] = __builtin_amdgcn_sad_u8(static_cast<uint32_t>(fa[tm].y), 0u, rs[tm]);
+      }
+      // (pinned HERE: left alone, hipcc sinks the sums of the unrolled drain tiles to the epilogue, where their result is first
+      //  needed, and keeps -- spills -- the raw fragments until then)
+      asm volatile("" : "+v"(rs[tm]));
+    }
     if constexpr ((ABL & 2) != 0) {
       asm volatile("" : "+v"(fa[tm]));
     } else if (half) {
@@ -478,6 +495,19 @@ void q8_gemm_mfma_256x256_c16_kernel(const IgemmParams p)
   };
 #pragma unroll
   for (int tm = 0; tm < kTM; tm++) {
+    if constexpr (ROWSUM) {
+      // the row's four chunk sums (lanes l, l ^ 16, l ^ 32, l ^ 48), then (128 - kzp) * (sum of a - 128 K) onto every accumulator of
+      // the row (wrapping: the accumulators may carry the 2^31 offset of the offset forms)
+      uint32_t t = rs[tm];
+      t += static_cast<uint32_t>(__shfl_xor(static_cast<int>(t), 16));
+      t += static_cast<uint32_t>(__shfl_xor(static_cast<int>(t), 32));
+      const uint32_t term = static_cast<uint32_t>(p.row_coeff) * (t - 128u * p.k_pad);
+#pragma unroll
+      for (int tn = 0; tn < kTN; tn++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[tm][tn][r] = static_cast<int>(static_cast<uint32_t>(acc[tm][tn][r]) + term);
+      }
+    }
     uint32_t lo[4], hi[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -519,12 +549,12 @@ void q8_gemm_mfma_256x256_c16_kernel(const IgemmParams p)
 }
 #undef QNNP_PIN
 
-template <bool ALIGNED>
+template <bool ALIGNED, bool ROWSUM>
 int launch_x(const IgemmParams& p, const dim3& grid, hipStream_t stream)
 {
   int rc = QNNP_HIP_EINVAL;
 #ifdef QNNP_ENABLE_ABLATION
-  if constexpr (ALIGNED) {
+  if constexpr (ALIGNED && !ROWSUM) {
     const char* env = getenv("QNNP_GFX950_ABLATE");
     const int abl = env != nullptr ? atoi(env) : 0;
 #define QNNP_ABL_CASE(V) case V: hipLaunchKernelGGL((q8_gemm_mfma_256x256_c16_kernel<kRqShift0Ofs, 1, true, V>), grid, dim3(kThreads), 0, stream, p); \
@@ -539,18 +569,18 @@ int launch_x(const IgemmParams& p, const dim3& grid, hipStream_t stream)
 #endif
   if (p.rq.f.shift != 0 && p.rq.f.bounded && p.rq.f.ofs_kind == 2 && !p.rq.full_range) {
     // bounded accumulators, shift >= 1, a clamp other than [0, 255]: the bounded sequence with the clamp class picked here
-    if (p.rq.zp_late == 0) hipLaunchKernelGGL((q8_gemm_mfma_256x256_c16_kernel<kRqBoundedOfs, 1, ALIGNED>), grid, dim3(kThreads), 0, stream, p);
-    else hipLaunchKernelGGL((q8_gemm_mfma_256x256_c16_kernel<kRqBoundedOfs, 2, ALIGNED>), grid, dim3(kThreads), 0, stream, p);
+    if (p.rq.zp_late == 0) hipLaunchKernelGGL((q8_gemm_mfma_256x256_c16_kernel<kRqBoundedOfs, 1, ALIGNED, 0, ROWSUM>), grid, dim3(kThreads), 0, stream, p);
+    else hipLaunchKernelGGL((q8_gemm_mfma_256x256_c16_kernel<kRqBoundedOfs, 2, ALIGNED, 0, ROWSUM>), grid, dim3(kThreads), 0, stream, p);
     return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
   }
   requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
     constexpr int kSeq = decltype(seq)::value;
     if constexpr (decltype(full)::value) {
-      hipLaunchKernelGGL((q8_gemm_mfma_256x256_c16_kernel<kSeq, 0, ALIGNED>), grid, dim3(kThreads), 0, stream, p);
+      hipLaunchKernelGGL((q8_gemm_mfma_256x256_c16_kernel<kSeq, 0, ALIGNED, 0, ROWSUM>), grid, dim3(kThreads), 0, stream, p);
     } else if (p.rq.zp_late == 0) {             // zero point folded (or zero): no add behind the clamp
-      hipLaunchKernelGGL((q8_gemm_mfma_256x256_c16_kernel<kSeq, 1, ALIGNED>), grid, dim3(kThreads), 0, stream, p);
+      hipLaunchKernelGGL((q8_gemm_mfma_256x256_c16_kernel<kSeq, 1, ALIGNED, 0, ROWSUM>), grid, dim3(kThreads), 0, stream, p);
     } else {
-      hipLaunchKernelGGL((q8_gemm_mfma_256x256_c16_kernel<kSeq, 2, ALIGNED>), grid, dim3(kThreads), 0, stream, p);
+      hipLaunchKernelGGL((q8_gemm_mfma_256x256_c16_kernel<kSeq, 2, ALIGNED, 0, ROWSUM>), grid, dim3(kThreads), 0, stream, p);
     }
     rc = hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
   });
@@ -559,7 +589,9 @@ int launch_x(const IgemmParams& p, const dim3& grid, hipStream_t stream)
 
 }  // namespace
 
-/* `p` must carry the CENTRED weight image, its bias pair table and a_flip (q8igemm.hip); gemm256c_supported(p) holds. */
+/* `p` must carry the CENTRED weight image, its bias pair table and a_flip (q8igemm.hip); gemm256c_supported(p) holds.
+ * p.row_coeff != 0: the STANDARD image (centred on 128, a_flip 0x80808080) of an operator with another kernel zero point -- the
+ * flavour that adds the kernel-zero-point row term (ROWSUM). */
 int gemm256x_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name)
 {
   const uint32_t tiles_m = (p.rows + kBM - 1) / kBM;
@@ -569,8 +601,12 @@ int gemm256x_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, c
   // x / tiles_n == hi32(x * magic) for x < 2^32 / tiles_n (the tile ids); 0 stands for tiles_n == 1
   pm.tiles_n_magic = tiles_n == 1 ? 0u : static_cast<uint32_t>((1ull << 32) / tiles_n) + 1u;
   const bool aligned = (p.k_pad / kBK) % kRing == 0;
+  if (p.row_coeff != 0) {
+    *name = "q8_gemm_mfma_256x256_r16";
+    return aligned ? launch_x<true, true>(pm, grid, stream) : launch_x<false, true>(pm, grid, stream);
+  }
   *name = "q8_gemm_mfma_256x256_c16";
-  return aligned ? launch_x<true>(pm, grid, stream) : launch_x<false>(pm, grid, stream);
+  return aligned ? launch_x<true, false>(pm, grid, stream) : launch_x<false, false>(pm, grid, stream);
 }
 
 }  // namespace qnnp

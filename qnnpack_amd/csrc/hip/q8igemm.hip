@@ -818,6 +818,19 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
     }
     if (c_forced) return QNNP_HIP_EINVAL;
   }
+  // Round 6: every OTHER kernel zero point on the 16x16x64 kernel as well -- the standard image and its row term (ROWSUM flavour of
+  // q8gemm256x.hip; "gemm_kernel" 28 forces it, 15 keeps the lean 32x32x32 kernel it replaces).
+  if (a->variant == 28 || (a->variant == 0 && big_auto && big_ok)) {
+    qnnp::IgemmParams pr = p;
+    pr.a_flip = 0x80808080u;
+    const bool r_ok = big_ok && p.bias2u != nullptr && a->groups >= 1 && qnnp::gemm256c_supported(pr, vec);
+    if (r_ok) {
+      rc = qnnp::gemm256x_launch(pr, a->groups, stream, &name);
+      if (kernel_name != nullptr) *kernel_name = name;
+      return rc;
+    }
+    if (a->variant == 28) return QNNP_HIP_EINVAL;
+  }
   if (big_ok && (big_forced || (a->variant == 0 && big_auto))) {
     rc = qnnp::gemm256_launch(p, a->groups, stream, &name, a->variant == 4 || a->variant == 16, a->variant == 10, a->variant == 11,
                                (a->variant == 15 || a->variant == 16) ? 2 : (a->variant == 0 ? 1 : 0));   // 16: the 4-wave flavour, lean;   // ("gemm_kernel" = 2 keeps the general flavour for A/B)

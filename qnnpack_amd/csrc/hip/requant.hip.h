@@ -302,13 +302,14 @@ __device__ __forceinline__ uint32_t q31_requantize_pack4_lane(
     // The matrix-core hazard: gfx950 has no interlock between an MFMA's write of its accumulators and a VALU read of them
     // (8 passes + 3 wait states here); hipcc pads in front of the first reader it KNOWS, and it does not look inside
     // inline asm -- the first version of this tail read accumulators three instructions after the MFMA and returned
-    // garbage. So one instruction the compiler does know reads the accumulator block first (u3 | 0, the zero opaque), and
-    // the asm takes its result. CONTRACT: u0..u3 come from one MFMA result (every caller passes acc[4 rg .. 4 rg + 3]).
+    // garbage. So instructions the compiler does know read EVERY one of the four inputs first (u | 0, the zero opaque: four
+    // plain VALU ops, which hipcc pads behind whichever MFMAs produced them), and the asm takes their results: the tail is
+    // safe for inputs from different MFMA results too (round 6; round 5 guarded u3 only and relied on all four coming from one).
     uint32_t zero = 0;
     asm("" : "+s"(zero));
-    const uint32_t u3f = u3 | zero;
+    const uint32_t u0f = u0 | zero, u1f = u1 | zero, u2f = u2 | zero, u3f = u3 | zero;
     int32_t v0, v1, v2, v3;
-    lane_mad_round4(u0, u1, u2, u3f, m2, addend, k1m1, v0, v1, v2, v3);
+    lane_mad_round4(u0f, u1f, u2f, u3f, m2, addend, k1m1, v0, v1, v2, v3);
     const auto p01 = __builtin_amdgcn_cvt_pk_i16(v0, v1);   // saturating: qnnp_requant_lane_sn_pk says why that is exact
     const auto p23 = __builtin_amdgcn_cvt_pk_i16(v2, v3);
     uint32_t lo, hi;

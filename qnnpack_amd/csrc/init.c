@@ -13,6 +13,7 @@
 
 #include <qnnpack.h>
 #include <qnnpack_gfx950.h>
+#include <qnnpack_gfx950_test.h>
 
 #include "hip/qnnp_hip.h"
 #include "log.h"
@@ -169,16 +170,23 @@ enum qnnp_status qnnp_gfx950_memset(void* dst_device, int value, size_t bytes)
 enum qnnp_status qnnp_gfx950_set_option(const char* key, int value)
 {
   if (key == NULL) return qnnp_status_invalid_parameter;
-  if (strcmp(key, "gemm_kernel") == 0 && value >= 0 && value <= 27 && !(value >= 17 && value <= 19)) {
-    qnnp_state.opt_gemm_kernel = value;
-    return qnnp_status_success;
-  }
   if (strcmp(key, "timing_graph") == 0 && (value == 0 || value == 1)) {
     qnnp_state.opt_timing_graph = value;
     return qnnp_status_success;
   }
   if (strcmp(key, "streaming_stores") == 0 && (value == 0 || value == 1)) {
     qnnp_hip_set_streaming_stores(value);
+    return qnnp_status_success;
+  }
+  return qnnp_status_invalid_parameter;
+}
+
+/* include/qnnpack_gfx950_test.h: which kernel the operators set up from now on run on (tests, A/B tools) */
+enum qnnp_status qnnp_gfx950_test_force_kernel(const char* key, int value)
+{
+  if (key == NULL) return qnnp_status_invalid_parameter;
+  if (strcmp(key, "gemm_kernel") == 0 && value >= 0 && value <= 28 && !(value >= 17 && value <= 19)) {
+    qnnp_state.opt_gemm_kernel = value;
     return qnnp_status_success;
   }
   if (strcmp(key, "fused_kernel") == 0 && value >= 0 && value <= 2) {

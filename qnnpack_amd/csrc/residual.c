@@ -25,7 +25,7 @@ enum qnnp_status qnnp_gfx950_attach_residual_add(
     qnnp_operator_t convolution, qnnp_operator_t add, const uint8_t* residual, size_t residual_stride)
 {
   if (!qnnp_state.initialized) {
-    qnnp_log_error("qnnp_gfx950_attach_residual_add failed because QNNPACK is not properly initialized");
+    qnnp_log_error("qnnp_gfx950_attach_residual_add called before qnnp_initialize succeeded");
     return qnnp_status_uninitialized;
   }
   if (convolution == NULL || add == NULL) {

@@ -33,10 +33,22 @@ def test_headers_declare_the_reference_entry_points():
         "qnnp_run_operator", "qnnp_delete_operator"])
 
 
-@pytest.mark.parametrize("header", ["qnnpack.h", "qnnpack_gfx950.h"])
+@pytest.mark.parametrize("header", ["qnnpack.h", "qnnpack_gfx950.h", "qnnpack_gfx950_test.h"])
 def test_library_exports_every_declared_symbol(product, header):
     for name in declared_functions(header):
         assert hasattr(product.lib, name), f"{name} declared in include/{header} but not exported"
+
+
+def test_kernel_forcing_codes_are_not_product_options(product):
+    """round 6: "gemm_kernel" & co. moved out of qnnp_gfx950_set_option into the test header's entry point"""
+    assert product.lib.qnnp_gfx950_set_option(b"gemm_kernel", 0) == Status.invalid_parameter
+    assert product.lib.qnnp_gfx950_set_option(b"dwconv_kernel", 0) == Status.invalid_parameter
+    assert product.lib.qnnp_gfx950_test_force_kernel(b"gemm_kernel", 23) == 0
+    assert product.lib.qnnp_gfx950_test_force_kernel(b"gemm_kernel", 0) == 0
+    assert product.lib.qnnp_gfx950_test_force_kernel(b"gemm_kernel", 18) == Status.invalid_parameter
+    assert product.lib.qnnp_gfx950_test_force_kernel(b"no_such_family", 0) == Status.invalid_parameter
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "qnnpack_gfx950.h")).read()
+    assert '"gemm_kernel":' not in text and "qnnp_gfx950_test_force_kernel" in text
 
 
 def test_status_enum_values_match_reference():

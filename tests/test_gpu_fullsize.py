@@ -13,9 +13,9 @@ from oracle import o1
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant,kernel", [(0, "q8_gemm_mfma_256x256_c16"), (20, "q8_gemm_mfma_256x256_c"),
+@pytest.mark.parametrize("variant,kernel", [(0, "q8_gemm_mfma_256x256_c16"), (20, "q8_gemm_mfma_256x256_c"), (28, "q8_gemm_mfma_256x256_r16"),
                                             (15, "q8_gemm_mfma_256x256_lean"), (2, "q8_gemm_mfma_256x256")],
-                         ids=["auto", "centred_32x32x32", "lean", "general"])
+                         ids=["auto", "centred_32x32x32", "rowsum_16x16x64", "lean", "general"])
 def test_c2_q8gemm_4096_cubed(qnnp, variant, kernel):
     """configs[1]: q8gemm M=N=K=4096 through qnnp_fully_connected_nc_q8 -- the shipped kernel (round 6: the
     zero-point-centred flavour on v_mfma_i32_16x16x64_i8, q8gemm256x.hip, is what "auto" picks for this shape and these
@@ -204,7 +204,7 @@ def test_c5_mobilenetv2_first_layer(qnnp):
 
 
 @pytest.mark.parametrize("kzp,kernel", [(127, "q8_gemm_mfma_256x256_c16"), (128, "q8_gemm_mfma_256x256_c16"),
-                                        (126, "q8_gemm_mfma_256x256_lean")], ids=["kzp127", "kzp128", "kzp126"])
+                                        (126, "q8_gemm_mfma_256x256_r16")], ids=["kzp127", "kzp128", "kzp126"])
 def test_c2_q8gemm_4096_cubed_full_output_vs_compiled_reference(qnnp, kzp, kernel):
     """(both centring classes of the shipped kernel, and a zero point that keeps the lean flavour)
     configs[1], every one of the 16.8 M output bytes: the compiled REFERENCE (oracle/_ref, its SSE2 q8gemm under

@@ -149,7 +149,7 @@ def test_epilogue_corners(qnnp, scale, kzp, code):
 
 @pytest.mark.parametrize("kzp,k,n,kernel", [(127, 1088, 2048, "q8_gemm_mfma_256x256_c16"),
                                             (128, 1088, 2048, "q8_gemm_mfma_256x256_c16"),
-                                            (126, 1088, 2048, "q8_gemm_mfma_256x256_lean"),
+                                            (126, 1088, 2048, "q8_gemm_mfma_256x256_r16"),
                                             (127, 1088, 2080, "q8_gemm_mfma_128x256")])     # (N % 256 != 0: no centred flavour; underfilled: 128-row tiles)
 def test_auto_takes_the_centred_flavour_where_it_applies(qnnp, kzp, k, n, kernel):
     case = FcCase(f"auto_kzp{kzp}_k{k}_n{n}", 3328, k, n, kzp=kzp)
@@ -176,7 +176,7 @@ def test_repeated_launches_are_stable(qnnp, code):
 
 @pytest.mark.parametrize("kw,kernel", [(dict(kzp=127), "q8_gemm_mfma_256x256_c16"), (dict(kzp=128), "q8_gemm_mfma_256x256_c16"),
                                        (dict(kzp=127, input_pixel_stride=1104, output_pixel_stride=528), "q8_gemm_mfma_256x256_c16"),
-                                       (dict(kzp=126), "q8_gemm_mfma_256x256_lean")],
+                                       (dict(kzp=126), "q8_gemm_mfma_256x256_r16")],
                          ids=["kzp127", "kzp128", "kzp127_strided_pixels", "kzp126"])
 def test_pointwise_convolutions_take_it_too(qnnp, kw, kernel):
     """a 1x1 convolution is the same GEMM over pixels (src/convolution.c:196-199 routes it to qnnp_ukernel_type_gemm):
@@ -193,3 +193,69 @@ def test_pointwise_convolutions_take_it_too(qnnp, kw, kernel):
     out, kname = conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
     assert kname == kernel, kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}, {kw}]")
+
+
+# ---- round 6: every other kernel zero point on the 16x16x64 kernel: the standard image + the kernel-zero-point row term
+#      (ROWSUM flavour of q8gemm256x.hip, "gemm_kernel" 28; reference: the same q8gemm path, src/q8gemm/4x4c2-sse2.c:14-318) ----
+R16 = "q8_gemm_mfma_256x256_r16"
+
+
+@pytest.fixture
+def rowsum(qnnp):
+    qnnp.set_option("gemm_kernel", 28)
+    yield qnnp
+    qnnp.set_option("gemm_kernel", 0)
+
+
+def _fc_r16(lib, case):
+    expected, quant = fc_expected(case)
+    out, kname = fc_run(lib, case, quant, to_device=to_device, from_device=from_device)
+    assert kname == R16, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("k", [512, 576, 704, 768, 1024, 1344])
+@pytest.mark.parametrize("m", [1, 255, 257, 1000])
+def test_rowsum_m_and_k(rowsum, m, k):
+    _fc_r16(rowsum, FcCase(f"r_m{m}_k{k}", m, k, 256, kzp=126))
+
+
+@pytest.mark.parametrize("n", [256, 1008])
+@pytest.mark.parametrize("kw", [dict(kzp=126), dict(kzp=0), dict(kzp=255), dict(kzp=77, izp=3), dict(kzp=200, izp=255), dict(kzp=1, izp=0),
+                                dict(kzp=126, qmin=128), dict(kzp=129, qmax=128)],
+                         ids=lambda d: "_".join(f"{k}{v}" for k, v in d.items()))
+def test_rowsum_zero_points_and_clamps(rowsum, n, kw):
+    _fc_r16(rowsum, FcCase(f"r_n{n}_" + "_".join(f"{k}{v}" for k, v in kw.items()), 520, 704, n, **kw))
+
+
+def test_rowsum_strided_rows_and_pointwise_convolution(rowsum):
+    _fc_r16(rowsum, FcCase("r_strided", 300, 640, 256, input_stride=656, output_stride=272, kzp=126))
+    case = ConvCase("r_1x1_s2_512_256", (9, 11), subsampling=(2, 2), gic=512, goc=256, batch=3, kzp=90)
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(rowsum, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == R16, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("scale", [0.75, 0.5, 1 / 255.0, 0.0031, 2.0 ** -22], ids=lambda s: f"{s:.3e}")
+def test_rowsum_requantization_flavours(rowsum, scale):
+    """activations on their zero point: the accumulator is bias + the row term's and the bias fold's exact cancellation -- every
+    rounding flavour of the launcher against the oracle, kernel zero point 100"""
+    N, K, M = 1024, 640, 260
+    acc = _accumulators(N)
+    kernel = np.random.default_rng(9).integers(0, 256, size=(N, K), dtype=np.uint8)
+    inp = np.full(M * K, 77, np.uint8)
+    for zp, qmin, qmax in QUANT:
+        op = rowsum.create_fully_connected_nc_q8(K, N, 77, 1.0, 100, float(scale), kernel, acc, zp, 1.0, qmin, qmax, 0)
+        try:
+            d_in, d_out = to_device(inp), to_device(np.zeros(M * N, np.uint8))
+            rowsum.setup_fully_connected_nc_q8(op, M, d_in, K, d_out, N)
+            rowsum.run_operator(op)
+            assert rowsum.operator_kernel(op) == R16
+            out = from_device(d_out).reshape(M, N)
+        finally:
+            rowsum.delete_operator(op)
+        exp = o1.q31_requantize(acc, np.float32(scale), zp, qmin, qmax)
+        for m in (0, 131, M - 1):
+            bad = np.flatnonzero(out[m] != exp)
+            assert bad.size == 0, (scale, zp, qmin, qmax, acc[bad[:4]].tolist(), out[m][bad[:4]].tolist(), exp[bad[:4]].tolist())

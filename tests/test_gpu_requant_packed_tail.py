@@ -70,8 +70,9 @@ def test_packed_tail_matches_oracle(qnnp, case):
     assert all(k.startswith(kname_want) for k in seen), (name, seen)
 
 
-@pytest.mark.parametrize("kzp,kname_want", [(126, "q8_gemm_mfma_256x256_lean"), (127, "q8_gemm_mfma_128x128_c16")])
-def test_packed_tail_in_the_gemm_epilogues(qnnp, kzp, kname_want):
+@pytest.mark.parametrize("kzp,kname_want,code", [(126, "q8_gemm_mfma_256x256_lean", 15), (126, "q8_gemm_mfma_256x256_r16", 0),
+                                                 (127, "q8_gemm_mfma_128x128_c16", 0)])
+def test_packed_tail_in_the_gemm_epilogues(qnnp, kzp, kname_want, code):
     """the lean 256 x 256 GEMM (kernel zero point without a centred image) takes the packed tail in its lane-form epilogue; the
     centred one keeps the bounded offset form -- both against the oracle at the same scales and zero points"""
     M, K, N = 2048, 1024, 256
@@ -87,14 +88,18 @@ def test_packed_tail_in_the_gemm_epilogues(qnnp, kzp, kname_want):
             expected = o1.requantize_rows(acc, req, ozp, 0, 255).reshape(-1)
             if ozp == 127 and scale <= 0.05:
                 assert float(np.mean((expected > 0) & (expected < 255))) > 0.25, (scale,)
-            op = qnnp.create_fully_connected_nc_q8(K, N, 127, 1.0, kzp, float(scale), kernel, bias, ozp, 1.0, 0, 255, 0)
+            qnnp.set_option("gemm_kernel", code)      # (15: the lean 32x32x32 kernel, what auto took before round 6)
             try:
-                d_out = to_device(np.full(M * N, FILL, np.uint8))
-                qnnp.setup_fully_connected_nc_q8(op, M, d_in, K, d_out, N)
-                qnnp.run_operator(op)
-                kname = qnnp.operator_kernel(op)
-                out = from_device(d_out)
+                op = qnnp.create_fully_connected_nc_q8(K, N, 127, 1.0, kzp, float(scale), kernel, bias, ozp, 1.0, 0, 255, 0)
+                try:
+                    d_out = to_device(np.full(M * N, FILL, np.uint8))
+                    qnnp.setup_fully_connected_nc_q8(op, M, d_in, K, d_out, N)
+                    qnnp.run_operator(op)
+                    kname = qnnp.operator_kernel(op)
+                    out = from_device(d_out)
+                finally:
+                    qnnp.delete_operator(op)
             finally:
-                qnnp.delete_operator(op)
+                qnnp.set_option("gemm_kernel", 0)
             assert kname == kname_want, kname
             assert_bytes_equal(out, expected, f"4096-style GEMM, kernel zero point {kzp}, scale {scale}, zero point {ozp}")

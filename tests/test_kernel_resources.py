@@ -63,7 +63,7 @@ def kernels(tmp_path_factory):
 # mangled-name fragments of the kernels the automatic dispatch picks for aligned tensors; the
 # generic implicit-GEMM fallback for unaligned / odd-channel tensors (q8_igemm_mfma_kernel, byte gathers) is known to
 # spill in its 1-byte flavours and is reported by test_report_of_spilling_kernels below, not asserted
-DEFAULT_PATH = ["q8_gemm_mfma_256x256_c_kernel", "q8_gemm_mfma_256x256_kernelILb0ELi4E", "q8_gemm_mfma_256x256_kernelILb1ELi4E", "q8_pw_stream_staged_kernel", "q8_pw_stream_longk_kernel",
+DEFAULT_PATH = ["q8_gemm_mfma_256x256_c16_kernel", "q8_gemm_mfma_128xN_c16_kernel", "q8_conv_wave_ws16_kernel", "q8_gemm_mfma_256x256_c_kernel", "q8_gemm_mfma_256x256_kernelILb0ELi4E", "q8_gemm_mfma_256x256_kernelILb1ELi4E", "q8_pw_stream_staged_kernel", "q8_pw_stream_longk_kernel",
                 "q8_pw_stream_gw_kernel", "q8_pw_stream_gwk_kernel", "q8_conv_stream_c3s_kernel",
                 "q8_dwconv_col3x3_kernel", "q8_conv_wave_reg_kernel", "q8_conv_wave_ws_kernel", "q8_conv_lds_mfma", "q8_vadd", "q8_gavgpool",
                 "q8_conv_patch_kernel", "q8_conv_c3rows32_kernel"]
@@ -89,6 +89,10 @@ def test_default_path_kernels_do_not_spill(kernels):
     ("25q8_conv_stream_c3s_kernelILi3ELb1E", 96, "first-layer kernel: 5 per CU"),
     ("27q8_gemm_mfma_256x256_kernelILb0ELi4ELi256ELi0ELb0E", 256, "256x256 GEMM: 2 waves per SIMD"),
     ("29q8_gemm_mfma_256x256_c_kernel", 256, "256x256 GEMM, zero-point-centred flavour: 2 waves per SIMD"),
+    ("31q8_gemm_mfma_256x256_c16_kernel", 256, "256x256 GEMM on 16x16x64 MFMAs (centred and row-sum flavours): 2 waves per SIMD"),
+    ("29q8_gemm_mfma_128xN_c16_kernelILi3ELi0ELi4E", 128, "128x128 centred GEMM: 64 KiB of LDS allow two workgroups per CU, the registers must too"),
+    ("29q8_gemm_mfma_128xN_c16_kernelILi3ELi0ELi2E", 80, "128x64 centred GEMM: three workgroups per CU by LDS"),
+    ("24q8_conv_wave_ws16_kernel", 256, "weight-stationary 3x3 convolution on 16x16x64 MFMAs: 2 waves per SIMD"),
     ("20q8_conv_patch_kernelILi8ELi4E", 128, "patch kernel, 256 positions x 128 channels: TWO 8-wave workgroups per CU (4 waves per SIMD)"),
     ("20q8_conv_patch_kernelILi4ELi8E", 256, "patch kernel, 128 positions x 256 channels: 2 waves per SIMD"),
     ("23q8_conv_c3rows32_kernel", 256, "7x7 / 5x5 first-layer kernel: 2 waves per SIMD"),

@@ -12,7 +12,7 @@ NAMES = {0: "shipped 256x256 (8 waves, interleaved)", 2: "256x256 forced", 4: "2
          10: "128x256 x 2 workgroups per CU", 11: "256x256 ping-pong + setprio",
          16: "256x256 4 waves, lean", 15: "256x256 lean (saddr DMA, ring unrolled)",
          20: "centred, 32x32x32 MFMA", 21: "centred, fragment reads in one burst",
-         23: "centred, 16x16x64 MFMA (round 6)"}
+         23: "centred, 16x16x64 MFMA (round 6)", 28: "standard image + row sums, 16x16x64 MFMA (round 6)"}
 
 
 def main():
@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--kzp", type=int, default=127, help="kernel zero point (126: no centred image -> lean / row-sum flavours)")
     args = ap.parse_args()
     import torch
     import qnnpack_amd
@@ -37,7 +38,7 @@ def main():
     ops, outs = {}, {}
     for v in variants:
         lib.set_option("gemm_kernel", v)
-        op = lib.create_fully_connected_nc_q8(K, N, 127, 0.75, 127, 1.0, w, bias, 127, 1.0, 1, 254)
+        op = lib.create_fully_connected_nc_q8(K, N, 127, 0.75, args.kzp, 1.0, w, bias, 127, 1.0, 1, 254)
         outs[v] = torch.empty(M * N, dtype=torch.uint8, device="cuda")
         lib.setup_fully_connected_nc_q8(op, M, a, K, outs[v], N)
         lib.run_operator(op)
