@@ -82,7 +82,8 @@ def test_lean_strided_rows(lean):
 
 # (shapes the dispatcher hands to this kernel by itself: K beyond the streaming kernels' 1024, more than 400 generic tiles)
 # (kernel zero point 126: 127 and 128 go to the centred flavour, tests/test_gpu_gemm256c.py)
-@pytest.mark.parametrize("k,n,kernel", [(1088, 2048, "q8_gemm_mfma_256x256_lean"), (1104, 2048, "q8_gemm_mfma_128x256"),
+# (round 6: where K % 64 == 0 and N % 256 == 0 the row-sum flavour of the 16x16x64 kernel, q8gemm256x.hip, takes what the lean one took)
+@pytest.mark.parametrize("k,n,kernel", [(1088, 2048, "q8_gemm_mfma_256x256_r16"), (1104, 2048, "q8_gemm_mfma_128x256"),
                                         (1088, 2080, "q8_gemm_mfma_128x256")])      # (13 x 9 tiles of 256 rows on 256 CUs: the 128-row tiling, round 5)
 def test_auto_takes_the_lean_flavour_where_it_applies(qnnp, k, n, kernel):
     case = FcCase(f"auto_k{k}_n{n}", 3328, k, n, kzp=126)
