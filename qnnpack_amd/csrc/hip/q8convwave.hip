@@ -1354,8 +1354,10 @@ void q8_conv_wave_ws16_kernel(const IgemmParams p, const ConvGeom g, const WaveA
 #pragma unroll
         for (int tm = 0; tm < 2; tm++)
 #pragma unroll
-          for (int tn = 0; tn < TN16; tn++)
+          for (int j = 0; j < TN16; j++) {
+            const int tn = tm == 0 ? j : TN16 - 1 - j;       // snake: one operand changes per MFMA (q8gemm256x.hip)
             acc[tm][tn] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wreg[t][tn], f.a[tm], acc[tm][tn], 0, 0, 0);
+          }
       };
       // the next unit's patch is requested piece by piece between the taps
       auto piece = [&](int u) __attribute__((always_inline)) { if (u < NP) fetch_piece(next, u, raw); };

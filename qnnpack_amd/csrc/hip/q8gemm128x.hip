@@ -250,7 +250,7 @@ void q8_gemm_mfma_128xN_c16_kernel(const IgemmParams p)
     //      and it counts them) ----
 #pragma unroll
     for (int i = 0; i < kMma; i++) {
-      const int tm = i / kHalf, tn = i % kHalf;
+      const int tm = i / kHalf, tn = (tm & 1) != 0 ? kHalf - 1 - i % kHalf : i % kHalf;   // snake: one operand changes per MFMA (q8gemm256x.hip)
       mma(wl[tn], tm, tn);
       QNNP_PIN();
       if (i == 0) { flip_a(2); QNNP_PIN(); }                       // read behind MFMA 3 kHalf - 1 of the previous phase 2; first use: MFMA 2 kHalf
@@ -274,11 +274,11 @@ void q8_gemm_mfma_128xN_c16_kernel(const IgemmParams p)
     // ---- phase 2 (the reads of a tile that does not exist fetch stale LDS into registers nobody multiplies) ----
 #pragma unroll
     for (int i = 0; i < kMma; i++) {
-      const int tm = i / kHalf, tn = i % kHalf;
+      const int tm = i / kHalf, tn = (tm & 1) != 0 ? kHalf - 1 - i % kHalf : i % kHalf;   // snake: one operand changes per MFMA (q8gemm256x.hip)
       mma(wh[tn], tm, kHalf + tn);
       QNNP_PIN();
       if (tm == 0) { read_w(next_slot, tn, wl[tn]); QNNP_PIN(); }
-      if (tn == kHalf - 1) {
+      if (i % kHalf == kHalf - 1) {
         if (tm >= 2) { flip_a(tm - 2); QNNP_PIN(); }               // fa[0], fa[1]: read two row tiles ago
         read_a(next_slot, tm);
         QNNP_PIN();

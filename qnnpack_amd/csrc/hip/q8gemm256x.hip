@@ -31,7 +31,7 @@
  *   phase 2: 16 MFMAs  a[0..3] x wh[0..3]   | read wl[0..3], a[0..3] of tile kt + 1, a[tm] right behind its last use
  *                                           | re-centre them | LDS-DMA pieces 0, 1 of tile kt + RING
  * 48 fragment registers, no double buffer: in both phases the activation operand stays for four MFMAs and the weight operand
- * rotates (the order the microbenchmark prices highest).
+ * walks 0123 3210 ... (one operand changes per MFMA: the order the microbenchmark prices highest).
  *
  * Epilogue without LDS: requantize four accumulators -> one dword; two 4 x 4 dword transposes over the four 16-lane rows
  * (v_permlane32_swap + v_permlane16_swap, 8 instructions per 16-row block) give every lane 16 consecutive channels of its
@@ -139,7 +139,11 @@ __device__ __forceinline__ uint32_t a_swizzle(uint32_t row) { return (row & 8u) 
  * (128 - kzp) * sum_k (a(m,k) - 128) of q8gemm256.hip is added to the accumulators in front of the requantization. The sums are
  * taken over the RAW fragment bytes with v_sad_u8 (one per dword, beside the re-centring XOR); a lane holds chunk g of its row, the
  * four lanes of a row are summed once in the epilogue -- and the result lane of a row is its operand lane, nothing moves. */
-template <int SEQ, int CLAMP, bool ALIGNED, int ABL = 0, bool ROWSUM = false>
+/* Inside a phase the weight operand walks its four fragments in SNAKE order (0123 3210 0123 3210): only ONE operand changes per MFMA.
+ * tools/ubench_mfma2.hip: 4.27 POP/s against 4.18 for "activation held for four, weights 0123 0123" (and 4.20 for holding it for eight);
+ * this kernel, interleaved on one box: 49.96 -> 49.36 us (profiles/r06/gemm_ab_c16_snake_r06k.txt).
+ * OPT (measurement builds, env QNNP_C16_OPT; 0 in the product): 1 = the plain order, for that A/B. */
+template <int SEQ, int CLAMP, bool ALIGNED, int ABL = 0, bool ROWSUM = false, int OPT = 0>
 __global__ __launch_bounds__(kThreads, 2)
 void q8_gemm_mfma_256x256_c16_kernel(const IgemmParams p)
 {
@@ -357,7 +361,7 @@ void q8_gemm_mfma_256x256_c16_kernel(const IgemmParams p)
     QNNP_PIN();
 #pragma unroll
     for (int i = 0; i < kMma; i++) {
-      const int tm = i / kHalf, tn = i % kHalf;
+      const int tm = i / kHalf, tn = ((OPT & 1) == 0 && (tm & 1) != 0) ? kHalf - 1 - i % kHalf : i % kHalf;
       if constexpr (P1F && KNOWN) {
         if (i % 8 == 0) { dma16_set_m0(piece_dst(2 + i / 8, prev_slot)); QNNP_PIN(); }
       }
@@ -396,7 +400,7 @@ void q8_gemm_mfma_256x256_c16_kernel(const IgemmParams p)
     //      behind the last MFMA that reads the old one ----
 #pragma unroll
     for (int i = 0; i < kMma; i++) {
-      const int tm = i / kHalf, tn = i % kHalf;
+      const int tm = i / kHalf, tn = ((OPT & 1) == 0 && (tm & 1) != 0) ? kHalf - 1 - i % kHalf : i % kHalf;
       if constexpr (P2F && KNOWN) {
         if (i % 8 == 0) { dma16_set_m0(piece_dst(i / 8, slot)); QNNP_PIN(); }
       }
@@ -404,7 +408,7 @@ void q8_gemm_mfma_256x256_c16_kernel(const IgemmParams p)
       QNNP_PIN();
       if constexpr (MORE && READS) {
         if (tm == 0) { read_w(known_c, next_slot, tn, wl[tn]); QNNP_PIN(); }
-        if (tn == kHalf - 1) { read_a(known_c, next_slot, tm); QNNP_PIN(); }
+        if (i % kHalf == kHalf - 1) { read_a(known_c, next_slot, tm); QNNP_PIN(); }
       }
       if constexpr (P2F && KNOWN) {
         if (i % 8 == 0) { dma16_saddr_m0_set(piece_src(kt + RING, i / 8), piece_off(i / 8)); QNNP_PIN(); }
@@ -565,6 +569,11 @@ int launch_x(const IgemmParams& p, const dim3& grid, hipStream_t stream)
       default: break;
     }
 #undef QNNP_ABL_CASE
+    const char* oenv = getenv("QNNP_C16_OPT");
+    if (oenv != nullptr && atoi(oenv) == 1) {
+      hipLaunchKernelGGL((q8_gemm_mfma_256x256_c16_kernel<kRqShift0Ofs, 1, true, 0, false, 1>), grid, dim3(kThreads), 0, stream, p);
+      return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+    }
   }
 #endif
   if (p.rq.f.shift != 0 && p.rq.f.bounded && p.rq.f.ofs_kind == 2 && !p.rq.full_range) {

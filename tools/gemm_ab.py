@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--c16-opts", default="", help="measurement builds: time variant 23 once per QNNP_C16_OPT value of this comma list")
     ap.add_argument("--kzp", type=int, default=127, help="kernel zero point (126: no centred image -> lean / row-sum flavours)")
     args = ap.parse_args()
     import torch
@@ -55,8 +56,23 @@ def main():
         torch.cuda.synchronize()
         print(json.dumps({"only": args.only, "kernel": lib.operator_kernel(ops[args.only])}))
         return
+    if args.c16_opts:
+        # the same operator (code 23), one graph per value of QNNP_C16_OPT: the launcher reads it when the launches are captured
+        base = ops[variants[0]]
+        keys = [f"opt{o}" for o in args.c16_opts.split(",")]
+        for key, o in zip(keys, args.c16_opts.split(",")):
+            os.environ["QNNP_C16_OPT"] = o
+            outs[key] = torch.empty(M * N, dtype=torch.uint8, device="cuda")
+            lib.setup_fully_connected_nc_q8(base, M, a, K, outs[key], N)
+            lib.run_operator(base); torch.cuda.synchronize()
+            assert torch.equal(outs[key], ref), key
+            ops[key] = base
+        variants = keys
+        NAMES.update({k: "c16 with QNNP_C16_OPT=" + k[3:] for k in keys})
     graphs = {}
     for v in variants:
+        if args.c16_opts:
+            os.environ["QNNP_C16_OPT"] = v[3:]
         lib.graph_begin()
         for _ in range(32):
             lib.run_operator(ops[v])

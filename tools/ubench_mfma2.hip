@@ -18,6 +18,11 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 __device__ unsigned long long g_ticks[2];
 
+// operand rotation: ORDER 0 = b held for 4 MFMAs, a rotates; 1 = both change every MFMA; 2 = snake (b held for 4, a walks 0123 3210 ...:
+// only ONE operand changes per step); 3 = b held for 8 MFMAs, a rotates
+template <int ORDER> __device__ constexpr int order_a(int i) { return ORDER == 2 ? (((i >> 2) & 1) ? 3 - (i & 3) : (i & 3)) : (i & 3); }
+template <int ORDER> __device__ constexpr int order_b(int i) { return ORDER == 1 ? (i + (i >> 2)) & 3 : (ORDER == 3 ? (i >> 3) & 3 : (i >> 2) & 3); }
+
 // SHAPE 0: 32x32x32 (16 acc regs), 1: 16x16x64 (4 acc regs; NACC counts 32x32-equivalents: 4 small tiles each, 2 MFMAs per tile per step
 // so that one "step" is the same 32768 MACs). ORDER 0: b fixed over 4 MFMAs, 1: both rotate.
 template <int NACC, int SHAPE, int ORDER, int THREADS>
@@ -37,7 +42,7 @@ __global__ __launch_bounds__(THREADS) void k(const v4i* in, int* out, int iters,
     for (int it = 0; it < iters; it++) {
 #pragma unroll
       for (int i = 0; i < NACC; i++) {
-        const int ia = i & 3, ib = ORDER == 0 ? (i >> 2) & 3 : (i + (i >> 2)) & 3;
+        const int ia = order_a<ORDER>(i), ib = order_b<ORDER>(i);
         acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ia], b[ib], acc[i], 0, 0, 0);
       }
     }
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(THREADS) void k(const v4i* in, int* out, int iters,
       for (int i = 0; i < NACC * 4; i++) {
         // a 32x32 block over K = 32 == four 16x16 tiles over K = 32; with K = 64 per instruction: two instructions per tile per
         // TWO steps -> per step, 2 instructions for each of ... keep it simple: NACC*4 tiles x 1 instruction x K=64 = NACC x 2 x 32768 MACs / 2
-        const int ia = i & 3, ib = ORDER == 0 ? (i >> 2) & 3 : (i + (i >> 2)) & 3;
+        const int ia = order_a<ORDER>(i), ib = order_b<ORDER>(i);
         acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ia], b[ib], acc[i], 0, 0, 0);
       }
     }
@@ -103,12 +108,14 @@ int main() {
     printf("--- operands: %s\n", pass == 0 ? "zero" : "random");
     const int it = 3200;   // ~50 us per launch at the random-operand rate
     for (int round = 0; round < 2; round++) {
-      for (int acc0 : {0, (int) 0x80000000u}) {
+      for (int acc0 : {(int) 0x80000000u}) {
         run<8, 0, 0, 512>("32x32x32  8 waves/CU x 8 tiles   b fixed over 4", d_in, d_out, it, acc0);
         run<8, 0, 1, 512>("32x32x32  8 waves/CU x 8 tiles   both operands rotate", d_in, d_out, it, acc0);
         run<16, 0, 0, 256>("32x32x32  4 waves/CU x 16 tiles  b fixed over 4", d_in, d_out, it, acc0);
         run<8, 1, 0, 512>("16x16x64  8 waves/CU x 32 tiles  b fixed over 4", d_in, d_out, it / 2, acc0);
         run<8, 1, 1, 512>("16x16x64  8 waves/CU x 32 tiles  both operands rotate", d_in, d_out, it / 2, acc0);
+        run<8, 1, 2, 512>("16x16x64  8 waves/CU x 32 tiles  snake: one operand changes per step", d_in, d_out, it / 2, acc0);
+        run<8, 1, 3, 512>("16x16x64  8 waves/CU x 32 tiles  b fixed over 8", d_in, d_out, it / 2, acc0);
       }
     }
   }
