@@ -331,7 +331,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
         goto error;
       }
     } else if (kc_slot == 4 && (kernel_height == 5 || kernel_height == 7) && kernel_width * 3 <= 32 &&
-               dilation_height == 1 && dilation_width == 1 && n_pad <= 64) {
+               dilation_height == 1 && dilation_width == 1 && n_pad <= (kernel_height == 7 ? 96u : 64u)) {
       /* ... and with 32-byte row slots for the larger windows (5x5, ResNet's 7x7 entry layer): same pointer, the window
        * decides which image it is (hip/q8convc3.hip) */
       const size_t r_bytes = qnnp_conv_rows32_size(n_pad, kernel_height);

@@ -629,7 +629,8 @@ bool conv_c3rows32_supported(const IgemmParams& p, const ConvGeom& g, uint32_t g
 {
   if (w_rows32 == nullptr || groups != 1 || real_kc != 3 || p.input_stride != 3) return false;
   if (g.KW * 3u > 32u || !(g.KH == 5 || g.KH == 7) || g.dh != 1 || g.dw != 1) return false;
-  if (p.n_pad > 64 || p.n % 16u != 0 || p.output_stride % 16u != 0 || (reinterpret_cast<uintptr_t>(p.output) & 15u) != 0) return false;
+  // (round 6: three channel blocks for the 7-row window -- SqueezeNet 1.0's 7x7 stride-2 3 -> 96 entry layer, bench/convolution.cc:541)
+  if (p.n_pad > (g.KH == 7 ? 96u : 64u) || p.n % 16u != 0 || p.output_stride % 16u != 0 || (reinterpret_cast<uintptr_t>(p.output) & 15u) != 0) return false;
   if (p.rows == 0 || p.rows_per_image == 0 || g.OW == 0 || g.OH == 0 || p.rows_per_image != g.OH * g.OW) return false;
   if (p.rows % p.rows_per_image != 0) return false;
   const uint64_t in_bytes = static_cast<uint64_t>(p.input_end - p.input);
@@ -656,6 +657,7 @@ int conv_c3rows32_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* 
   cg.abl = 0;
   *name = "q8_conv_c3rows32_mfma";
   const bool two = p.n_pad > 32;
+  if (g.KH == 7 && p.n_pad > 64) return launch_c3rows32<3, 7>(p, cg, stream);
   if (g.KH == 7) return two ? launch_c3rows32<2, 7>(p, cg, stream) : launch_c3rows32<1, 7>(p, cg, stream);
   return two ? launch_c3rows32<2, 5>(p, cg, stream) : launch_c3rows32<1, 5>(p, cg, stream);
 }

@@ -114,6 +114,10 @@ CASES32 = [
     ConvCase("w_7x7_kzp128_no_row_term", (10, 10), (7, 7), _pad(3, 3), gic=3, goc=64, kzp=128, batch=2),
     ConvCase("w_7x7_clamp", (10, 10), (7, 7), _pad(3, 3), gic=3, goc=64, qmin=90, qmax=160, batch=2),
     ConvCase("w_7x7_many_units", (64, 48), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=64, batch=40),
+    # round 6: three channel blocks (SqueezeNet 1.0's 3 -> 96 entry layer, bench/convolution.cc:541)
+    ConvCase("w_7x7_s2_96_channels", (48, 40), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=96, batch=3),
+    ConvCase("w_7x7_80_channels_zp", (10, 12), (7, 7), _pad(3, 3), gic=3, goc=80, izp=9, kzp=200, batch=2),
+    ConvCase("w_7x7_nopad_96", (64, 64), (7, 7), subsampling=(2, 2), gic=3, goc=96, batch=2),
 ]
 
 
