@@ -2118,7 +2118,341 @@ int launch_lds(const DwParams& p, bool vec16, hipStream_t stream)
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
-enum : uint32_t { kPlanDirect = 1, kPlanLds33, kPlanLds55, kPlanRow, kPlanMfma, kPlanMfmaLds, kPlanCol, kPlanCol5 };
+// --------------------------------------------------------------------------
+// Kernel M16 (round 6): 3x3, stride 1, dilation 1, channels % 16 == 0, weights in int8 range -- the window on v_mfma_i32_16x16x64_i8
+// --------------------------------------------------------------------------
+/*
+ * Replaces q8dwconv_ukernel_up8x9__sse2 (reference src/q8dwconv/up8x9-sse2.c:14-372) for the stride-1 layers whose column walk
+ * (kernel G) is bound by instruction issue: 33 VALU per output dword, of which 18 are the multiplies (6 v_perm + 12 v_dot4).
+ * Here the multiplies go to the matrix cores with NO transposition of the data:
+ *   D[c][p] = sum_k A[c][k] B[k][p],   K = 64 = 4 tap slots x 16 channels,
+ *   B[(g, c')][p] = a'(pixel of position p shifted by tap g)[c0 + c']   -- the 16 contiguous channel bytes of an NHWC pixel:
+ *                   operand lane (p = l & 15, g = l >> 4) LOADS its fragment with one 16-byte load, re-centres it, done;
+ *   A[c][(g, c')] = x[ky][kx = g][c] if c' == c else 0                   -- a diagonal: lane (c, g) holds one non-zero byte.
+ * One instruction = one kernel ROW (kx = 0, 1, 2 in slots g = 0, 1, 2; slot 3 multiplies by zero) of 16 positions x 16 channels.
+ * A wave owns a strip of 16 output columns x TN channel blocks and walks DOWN a segment of rows like kernel G: an input row is
+ * loaded ONCE (TN fragments) and feeds three MFMAs per block -- kernel row 0 of output row t (its first product: the bias is the
+ * C operand), row 1 of t - 1, row 2 of t - 2, which completes it: requantize 4 accumulators -> one dword, a 4 x 4 lane transpose,
+ * one 16-byte store per lane (a pixel's 16 TN contiguous channels). Three accumulator sets rotate; a trip of the loop is three
+ * rows, so the rotation is compile-time. Per output dword: 4 v_xor + the requantization + 0.4 other VALU against 33 in kernel G.
+ * Padding as kernel G's late scheme: out-of-image COLUMNS are never loaded (offset beyond the descriptor: 0) and their constant
+ * izp * x goes into the lane's bias once; out-of-image ROWS are replaced where they are consumed (checked trips only).
+ * Weights and bias come from the dot-product image of pack.h (qnnp_pack_dwconv_dot4: x = +-(w - kzp), activations ^ 0x80 | 0x7f).
+ *
+ * STATUS (round 6): parity-green (tests/test_gpu_dwmfma16.py) and SLOWER than kernel G on every stride-1 MobileNetV2 layer -- 26-32
+ * against 25 us (layer 2), 59 against 28 (layer 8), 15-19 against 11 (layer 13), 10-13 against 7-9.5 (layers 18 / 22 / 27): kept as
+ * "dwconv_kernel" 7 for the record, never chosen automatically. Four builds (profiles/r06/dw_mfma16_walk_negative_result_r06n.txt):
+ * fragments loaded in the operand pattern (16 pixels at the pixel stride per 16-lane group: bound by address processing), one
+ * coalesced 16-byte load per lane + a wave-private LDS transposition, six rows in flight + stores in pixel order, and the finish of a
+ * row deferred by one step. Counters on layer 8 (pmc_dw_mfma16_vs_col_walk_layer8_r06o.txt): 5.66 M VALU + MFMA instructions per launch
+ * against kernel G's 7.52 M -- a quarter fewer, as planned -- but 174-190 registers leave two waves per SIMD where kernel G runs six
+ * or seven, and a step is one chain (row -> LDS -> fragments -> MFMAs -> requantize -> LDS -> store): waves parked on s_waitcnt 45 % of
+ * their cycles and stalled at issue another 35 %. The diagonal weight fragments (one non-zero byte in sixteen per lane) are what
+ * the registers go to; a form with <= 96 registers would be needed to compete.
+ */
+constexpr int kM16Threads = 256;
+
+template <int TN, int SEQ, bool FULL>
+__global__ __launch_bounds__(kM16Threads, TN >= 3 ? 2 : 3)
+void q8_dwconv_mfma16_3x3_kernel(const DwParams p)
+{
+  typedef int m16_v4i __attribute__((ext_vector_type(4)));
+  // wave-private row buffers: a row of the wave's 18 pixels x TN chunks is fetched with ONE 16-byte load per lane -- lane i takes
+  // chunk i % TN of pixel i / TN: a pixel's 16 TN bytes are contiguous, so the load touches ~6 lines per 16-lane group where the
+  // fragment pattern itself (16 pixels at the pixel stride per group) touched 16-18 and bound the first build by address processing
+  // (layer 8: 64 us) -- re-centred, written to LDS lane-linearly and read back in the fragment pattern. Pixel pitch in LDS: 3 chunks
+  // (an odd number: the sixteen pixels of a ds_read_b128 lane group fall into sixteen different bank quads).
+  constexpr uint32_t kPitch = 3u;                  // 16-byte chunks per pixel in LDS
+  constexpr uint32_t kRowBytes = 18u * kPitch * 16u;              // 864
+  __shared__ __attribute__((aligned(16))) uint8_t lds[(kM16Threads / 64) * 4 * 1024];      // per wave: 3 row buffers + the output row image
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t fp = lane & 15u;                 // operand: position; result: position
+  const uint32_t fg = lane >> 4;                  // operand: tap slot (kernel column); result: channel quad
+  auto div_by = [](uint32_t x, uint32_t inv) __attribute__((always_inline)) { return inv != 0u ? __umulhi(x, inv) : x; };
+  // wave -> (image, row segment, strip of 16 columns, channel group): channel groups fastest, so that the waves of a workgroup
+  // read the same pixels' lines
+  const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kM16Threads / 64) + wave_in_wg);
+  const uint32_t cgroups = p.IR, strips = p.bands;
+  const uint32_t w1 = div_by(w, p.inv_q4);        // / cgroups
+  const uint32_t cgrp = w - w1 * cgroups;
+  const uint32_t w2 = div_by(w1, p.inv_bands);    // / strips
+  const uint32_t strip = w1 - w2 * strips;
+  const uint32_t n = div_by(w2, p.inv_slabs);     // / segments
+  const uint32_t seg = w2 - n * p.slabs;
+  if (n >= p.batch) return;
+  const uint32_t c0 = cgrp * (16u * TN);
+  const uint32_t x0 = strip * 16u;
+  const uint32_t oy0 = seg * p.TOH;
+  const uint32_t oy1 = min(p.OH, oy0 + p.TOH);
+  const uint32_t flip = p.wrange == 2u ? 0x7f7f7f7fu : 0x80808080u;    // wave-uniform
+  uint8_t* rowbuf = lds + wave_in_wg * (4u * 1024u);
+  uint8_t* outbuf = rowbuf + 3u * 1024u;
+
+  // ---- loader role: lane i < 18 TN fetches chunk i % TN of strip pixel i / TN (input column x0 - pad_left + i / TN) ----
+  const uint32_t lpix = lane / TN, lchunk = lane - lpix * TN;
+  const bool loader = lane < 18u * TN;
+  const int32_t lix = static_cast<int32_t>(x0 + lpix) - static_cast<int32_t>(p.pad_left);
+  const bool lcol_ok = loader && lix >= 0 && lix < static_cast<int32_t>(p.W);
+  const uint32_t row_bytes = p.W * p.in_stride;
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.input), 0, static_cast<int>(p.batch * p.H * row_bytes), 0x00020000);
+  // (an offset beyond the descriptor's extent: the load returns 0 -- plan_m16 keeps the tensor below 2^31 bytes)
+  const uint32_t coff = lcol_ok ? static_cast<uint32_t>(lix) * p.in_stride + c0 + 16u * lchunk : 0x80000000u;
+  const uint32_t fillraw = lcol_ok ? p.izp * 0x01010101u : 0u;                     // what a padding ROW holds at this lane's column
+  const uint32_t img_off = n * p.H * row_bytes;
+  const uint32_t wr_off = (lpix * kPitch + lchunk) * 16u;                          // this lane's chunk inside a row buffer
+  // ---- operand role: position fp, tap slot fg (slot 3 repeats slot 2: its weights are zero) ----
+  const uint32_t rd_off = ((fp + min(fg, 2u)) * kPitch) * 16u;                     // + tn * 16
+
+  // ---- weights: the diagonal fragments, from the dot-product image ((x_r0, x_r1, x_r2, 0) per channel) ----
+  m16_v4i wf[3][TN];
+#pragma unroll
+  for (int ky = 0; ky < 3; ky++) {
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+      const uint32_t word = p.dot4[ky * p.c_pad + c0 + 16u * tn + fp];
+      const uint32_t b = ((word >> (8u * fg)) & 0xFFu) << (8u * (fp & 3u));        // (slot 3: the image's fourth byte is 0)
+      const uint32_t q = fp >> 2;
+      wf[ky][tn] = m16_v4i{static_cast<int>(q == 0u ? b : 0u), static_cast<int>(q == 1u ? b : 0u),
+                           static_cast<int>(q == 2u ? b : 0u), static_cast<int>(q == 3u ? b : 0u)};
+    }
+  }
+  // ---- bias of this lane's result channels 16 tn + 4 fg + r (+ 2^31 for the offset rounding forms) ----
+  const uint32_t ox = x0 + fp;
+  const bool pos_ok = ox < p.OW;
+  m16_v4i bias[TN];
+  {
+    // taps of this lane's POSITION that read outside the image: 0 was multiplied where the zero point belongs
+    const int32_t ixb = static_cast<int32_t>(ox) - static_cast<int32_t>(p.pad_left);
+    bool tap_out[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) tap_out[k] = (ixb + k) < 0 || (ixb + k) >= static_cast<int32_t>(p.W);
+    const bool any_out = __builtin_amdgcn_ballot_w64(tap_out[0] || tap_out[1] || tap_out[2]) != 0;
+    const int32_t step = p.wrange == 2u ? -static_cast<int32_t>(p.izp) : static_cast<int32_t>(p.izp);
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+      const uint32_t cq = c0 + 16u * tn + 4u * fg;
+      const int4 bv = *reinterpret_cast<const int4*>(p.dot4 + 3u * p.c_pad + cq);
+      int32_t b[4] = {bv.x, bv.y, bv.z, bv.w};
+      if (any_out) {                                                               // (border strips only: wave-uniform)
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+          const uint4 xv = *reinterpret_cast<const uint4*>(p.dot4 + ky * p.c_pad + cq);
+          const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            int32_t sum = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) sum += tap_out[k] ? static_cast<int8_t>(xw[r] >> (8 * k)) : 0;
+            b[r] = qnnp::add_wrap(b[r], step * sum);
+          }
+        }
+      }
+      bias[tn] = m16_v4i{qnnp::with_rq_offset<SEQ>(b[0]), qnnp::with_rq_offset<SEQ>(b[1]),
+                         qnnp::with_rq_offset<SEQ>(b[2]), qnnp::with_rq_offset<SEQ>(b[3])};
+    }
+  }
+
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.output, 0, static_cast<int>(p.batch * p.OH * p.OW * p.out_stride), 0x00020000);
+  // after the lane transpose lane (position, g) holds channel block g: 16 bytes (lanes with g >= TN hold nothing). Stored like that,
+  // a pixel's 16 TN bytes would leave in TN separate 16-byte pieces from lanes 16 apart (the first build: layer 8 at 65 us); they go
+  // through the wave's LDS image once more and leave in the LOADER's lane order -- lane i = chunk i % TN of position i / TN, a
+  // pixel's bytes from adjacent lanes.
+  const uint32_t st_pos = lane / TN, st_chunk = lane - st_pos * TN;
+  const bool st_ok = lane < 16u * TN && x0 + st_pos < p.OW;
+  const uint32_t out_voff = st_ok ? (x0 + st_pos) * p.out_stride + c0 + 16u * st_chunk : 0x80000000u;
+  const uint32_t ow_off = (fp * TN + min(fg, static_cast<uint32_t>(TN - 1))) * 16u;   // where lane (position, g) puts its block
+  (void) pos_ok;
+  const uint32_t out_row = p.OW * p.out_stride;
+  const uint32_t out_img = n * p.OH * out_row;
+
+  // ---- the walk: t = input row + pad_top; row t feeds kernel row 0 of output row t, row 1 of t - 1, row 2 of t - 2 ----
+  m16_v4i raw[6];                                 // SIX rows in flight (this lane's chunk): row t lives in raw[t % 6]
+  m16_v4i acc[3][TN];                             // output row oy accumulates in set oy % 3
+  auto request = [&](auto ph_c, int32_t t) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph_c)::value;                                        // 0 .. 5
+    int32_t iy = t - static_cast<int32_t>(p.pad_top);
+    iy = iy < 0 ? 0 : (iy >= static_cast<int32_t>(p.H) ? static_cast<int32_t>(p.H) - 1 : iy);      // (scalar; replaced where consumed)
+    const uint32_t ro = img_off + static_cast<uint32_t>(iy) * row_bytes;
+    raw[PH] = __builtin_bit_cast(m16_v4i, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, coff, ro, 0));
+  };
+  // The row an earlier step completed is finished one step LATER, in two halves around the next row's LDS round trip and MFMAs, so
+  // that nothing in a step waits for what the step itself started (the first build ran write -> read -> MFMA -> requantize -> write
+  // -> read -> store as one chain per step: waves parked 45 % of their cycles, two per SIMD).
+  auto finish_a = [&](auto slot_c) __attribute__((always_inline)) {                // requantize set S, lane transpose, into the image
+    constexpr int S = decltype(slot_c)::value;
+    uint32_t q[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+      q[tn] = qnnp::q31_requantize_pack4<SEQ, FULL>(acc[S][tn][0], acc[S][tn][1], acc[S][tn][2], acc[S][tn][3], p.rq);
+    }
+    const auto s02 = __builtin_amdgcn_permlane32_swap(q[0], q[2], false, false);
+    const auto s13 = __builtin_amdgcn_permlane32_swap(q[1], q[3], false, false);
+    const auto tlo = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+    const auto thi = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+    const m16_v4i blk = {static_cast<int>(tlo[0]), static_cast<int>(tlo[1]), static_cast<int>(thi[0]), static_cast<int>(thi[1])};
+    if (fg < static_cast<uint32_t>(TN)) *reinterpret_cast<m16_v4i*>(outbuf + ow_off) = blk;
+  };
+  auto finish_b = [&](const m16_v4i& outv, uint32_t oy) __attribute__((always_inline)) {
+    const auto bits = __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, outv);
+    const uint32_t soff = out_img + oy * out_row;
+    if (p.stream_out) __builtin_amdgcn_raw_buffer_store_b128(bits, out_rsrc, out_voff, soff, 2);
+    else __builtin_amdgcn_raw_buffer_store_b128(bits, out_rsrc, out_voff, soff, 0);
+  };
+  // one row: PH6 = t % 6 (the raw row register), accumulator phase PH = t % 3. CHECK: the row may lie outside the image (then it
+  // holds the zero point / 0 at this lane's column). Output row t - 3 was completed by the previous step in set PH -- the set this
+  // step's first product overwrites: it is requantized first.
+  auto step = [&](auto ph_c, auto check_c, int32_t t, int32_t t_next) __attribute__((always_inline)) {
+    constexpr int PH6 = decltype(ph_c)::value;
+    constexpr int PH = PH6 % 3;
+    constexpr bool CHECK = decltype(check_c)::value;
+    m16_v4i x = raw[PH6];
+    if constexpr (CHECK) {
+      const int32_t iy = t - static_cast<int32_t>(p.pad_top);
+      if (iy < 0 || iy >= static_cast<int32_t>(p.H)) {                             // (wave-uniform)
+        x = m16_v4i{static_cast<int>(fillraw), static_cast<int>(fillraw), static_cast<int>(fillraw), static_cast<int>(fillraw)};
+      }
+    }
+    x.x ^= static_cast<int>(flip); x.y ^= static_cast<int>(flip); x.z ^= static_cast<int>(flip); x.w ^= static_cast<int>(flip);
+    uint8_t* buf = rowbuf + PH * 1024u;
+    if (loader) *reinterpret_cast<m16_v4i*>(buf + wr_off) = x;
+    request(ph_c, t_next);                                                          // the row a trip ahead, into the register just consumed
+    const int32_t oy_done = t - 3;
+    const bool done = oy_done >= static_cast<int32_t>(oy0) && oy_done < static_cast<int32_t>(oy1);   // (wave-uniform)
+    if (done) finish_a(std::integral_constant<int, PH>{});
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                         // the wave's own LDS writes before its reads
+    m16_v4i xf[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) xf[tn] = *reinterpret_cast<const m16_v4i*>(buf + rd_off + tn * 16);
+    const m16_v4i outv = *reinterpret_cast<const m16_v4i*>(outbuf + lane * 16u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+      acc[PH][tn] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[0][tn], xf[tn], bias[tn], 0, 0, 0);
+      acc[(PH + 2) % 3][tn] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[1][tn], xf[tn], acc[(PH + 2) % 3][tn], 0, 0, 0);
+      acc[(PH + 1) % 3][tn] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[2][tn], xf[tn], acc[(PH + 1) % 3][tn], 0, 0, 0);
+    }
+    if (done) finish_b(outv, static_cast<uint32_t>(oy_done));
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  using P3 = std::integral_constant<int, 3>;
+  using P4 = std::integral_constant<int, 4>;
+  using P5 = std::integral_constant<int, 5>;
+  // (segments start at multiples of SIX rows: plan_m16)
+  int32_t t = static_cast<int32_t>(oy0);
+  const int32_t t_end = static_cast<int32_t>(oy1) + 2;                              // rows oy0 .. oy1 + 1 are consumed
+  request(P0{}, t);
+  request(P1{}, t + 1);
+  request(P2{}, t + 2);
+  request(P3{}, t + 3);
+  request(P4{}, t + 4);
+  request(P5{}, t + 5);
+  // sets 1 and 2 are accumulated into before their first bias product on the first two rows (output rows before the segment,
+  // never stored): give them a defined value
+#pragma unroll
+  for (int tn = 0; tn < TN; tn++) { acc[1][tn] = bias[tn]; acc[2][tn] = bias[tn]; }
+  for (; t < t_end; t += 6) {
+    const int32_t iy_lo = t - static_cast<int32_t>(p.pad_top);
+    if (iy_lo >= 0 && iy_lo + 5 < static_cast<int32_t>(p.H)) {
+      step(P0{}, std::false_type{}, t, t + 6);
+      step(P1{}, std::false_type{}, t + 1, t + 7);
+      step(P2{}, std::false_type{}, t + 2, t + 8);
+      if (t + 3 < t_end) {
+        step(P3{}, std::false_type{}, t + 3, t + 9);
+        step(P4{}, std::false_type{}, t + 4, t + 10);
+        step(P5{}, std::false_type{}, t + 5, t + 11);
+      }
+    } else {
+      step(P0{}, std::true_type{}, t, t + 6);
+      step(P1{}, std::true_type{}, t + 1, t + 7);
+      step(P2{}, std::true_type{}, t + 2, t + 8);
+      if (t + 3 < t_end) {
+        step(P3{}, std::true_type{}, t + 3, t + 9);
+        step(P4{}, std::true_type{}, t + 4, t + 10);
+        step(P5{}, std::true_type{}, t + 5, t + 11);
+      }
+    }
+  }
+  // the segment's last row is completed by step t_end - 1 (in set t_end % 3) and finished by step t_end -- which exists only when
+  // the last half trip does not end at t_end - 1: then it is finished here
+  if ((t_end - static_cast<int32_t>(oy0)) % 3 == 0) {
+    const uint32_t last = static_cast<uint32_t>(t_end) % 3u;
+    if (last == 0u) finish_a(P0{}); else if (last == 1u) finish_a(P1{}); else finish_a(P2{});
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const m16_v4i outv = *reinterpret_cast<const m16_v4i*>(outbuf + lane * 16u);
+    finish_b(outv, oy1 - 1u);
+  }
+}
+
+// geometry of kernel M16: `bands` = strips of 16 output columns, `slabs` = row segments (TOH rows each),
+// `CS` = channel blocks per wave (TN), `IR` = channel groups (C / (16 TN)); TOH a multiple of six (the walk's trip)
+bool plan_m16(DwParams& p, uintptr_t in_addr, uintptr_t out_addr)
+{
+  if (p.KH != 3 || p.KW != 3 || p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1) return false;
+  if (p.C % 16 != 0 || p.in_stride % 16 != 0 || p.out_stride % 16 != 0 || in_addr % 16 != 0 || out_addr % 16 != 0) return false;
+  if (!(p.wrange == 1u || p.wrange == 2u) || p.dot4 == nullptr) return false;
+  if (p.pad_top > 2 || p.pad_left > 2) return false;
+  const uint64_t in_bytes = static_cast<uint64_t>(p.batch) * p.H * p.W * p.in_stride;
+  const uint64_t out_bytes = static_cast<uint64_t>(p.batch) * p.OH * p.OW * p.out_stride;
+  if (in_bytes >= (UINT64_C(1) << 31) || out_bytes >= (UINT64_C(1) << 31)) return false;
+  const uint32_t blocks = p.C / 16u;
+  // (three blocks per wave where they divide the channels: 140 registers, three waves per SIMD; four would leave one)
+  uint32_t tn = blocks % 3u == 0 ? 3u : (blocks % 2u == 0 ? 2u : 1u);
+#ifdef QNNP_ENABLE_ABLATION
+  if (const char* env = getenv("QNNP_DW_M16_TN")) {            // measurement builds: blocks per wave
+    const uint32_t v = static_cast<uint32_t>(atoi(env));
+    if (v >= 1u && v <= 3u && blocks % v == 0u) tn = v;
+  }
+#endif
+  const uint32_t cgroups = blocks / tn;
+  const uint32_t strips = (p.OW + 15u) / 16u;
+  const uint64_t per_seg = static_cast<uint64_t>(p.batch) * strips * cgroups;
+  // ~3 waves per SIMD in all; segments of at least 9 rows, in multiples of three
+  const uint64_t target = static_cast<uint64_t>(p.cu_count) * 4u * 3u;
+  uint32_t segs = static_cast<uint32_t>((target + per_seg - 1) / per_seg);
+  uint32_t max_segs = p.OH / 9u;
+  if (max_segs < 1u) max_segs = 1u;
+  if (segs > max_segs) segs = max_segs;
+  if (segs < 1u) segs = 1u;
+  uint32_t toh = (p.OH + segs - 1u) / segs;
+  toh = (toh + 5u) / 6u * 6u;
+  if (const uint32_t forced = col_rows_override()) toh = (forced + 5u) / 6u * 6u;
+  p.TOH = toh;
+  p.slabs = (p.OH + toh - 1u) / toh;
+  p.bands = strips;
+  p.CS = tn;
+  p.IR = cgroups;
+  const uint64_t waves = per_seg * p.slabs;
+  const uint64_t dmax = strips > p.slabs ? (strips > cgroups ? strips : cgroups) : (p.slabs > cgroups ? p.slabs : cgroups);
+  return (waves + 8u) * dmax < (UINT64_C(1) << 32);
+}
+
+int launch_m16(const DwParams& geometry, hipStream_t stream)
+{
+  DwParams p = geometry;
+  auto reciprocal = [](uint32_t d) { return d > 1u ? static_cast<uint32_t>(((UINT64_C(1) << 32) + d - 1u) / d) : 0u; };
+  p.inv_q4 = reciprocal(p.IR);
+  p.inv_bands = reciprocal(p.bands);
+  p.inv_slabs = reciprocal(p.slabs);
+  const uint64_t waves = static_cast<uint64_t>(p.batch) * p.slabs * p.bands * p.IR;
+  const uint32_t blocks = static_cast<uint32_t>((waves + (kM16Threads / 64) - 1) / (kM16Threads / 64));
+  qnnp::requant_dispatch_ofs(p.rq, [&](auto seq, auto full) {
+    constexpr int kSeq = decltype(seq)::value;
+    constexpr bool kFull = decltype(full)::value;
+    switch (p.CS) {
+      case 3: hipLaunchKernelGGL((q8_dwconv_mfma16_3x3_kernel<3, kSeq, kFull>), dim3(blocks), dim3(kM16Threads), 0, stream, p); break;
+      case 2: hipLaunchKernelGGL((q8_dwconv_mfma16_3x3_kernel<2, kSeq, kFull>), dim3(blocks), dim3(kM16Threads), 0, stream, p); break;
+      default: hipLaunchKernelGGL((q8_dwconv_mfma16_3x3_kernel<1, kSeq, kFull>), dim3(blocks), dim3(kM16Threads), 0, stream, p); break;
+    }
+  });
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+enum : uint32_t { kPlanDirect = 1, kPlanLds33, kPlanLds55, kPlanRow, kPlanMfma, kPlanMfmaLds, kPlanCol, kPlanCol5, kPlanM16 };
 
 // measurement knob, read once: LDS budget per workgroup of the LDS-tiled kernel in KiB
 uint32_t lds_budget()
@@ -2145,7 +2479,11 @@ int make_plan(DwParams& p, const struct qnnp_hip_dwconv_args* a, uintptr_t in_ad
   else if (p.C % 4 == 0 && p.out_stride % 4 == 0 && out_addr % 4 == 0) p.store_mode = 1;
   plan->vec16 = 0;
   plan->kernel = 0;
-  if (a->variant == 6 && k55) {
+  if (a->variant == 7) {
+    // (round 6) the 16x16x64 matrix-core walk, forced
+    if (!k33 || !plan_m16(p, in_addr, out_addr)) return QNNP_HIP_EINVAL;
+    plan->kernel = kPlanM16;
+  } else if (a->variant == 6 && k55) {
     if (!aligned4 || !plan_col5(p)) return QNNP_HIP_EINVAL;
     plan->kernel = kPlanCol5;
   } else if (a->variant == 6) {
@@ -2267,6 +2605,9 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
     case kPlanCol5:
       if (kernel_name != nullptr) *kernel_name = "q8_dwconv_col_5x5_dot4";
       return launch_col5(p, stream);
+    case kPlanM16:
+      if (kernel_name != nullptr) *kernel_name = "q8_dwconv_mfma16_3x3";
+      return launch_m16(p, stream);
     case kPlanLds33:
       if (kernel_name != nullptr) *kernel_name = "q8_dwconv_lds_3x3";
       return launch_lds<3, 3>(p, plan->vec16 != 0, stream);
