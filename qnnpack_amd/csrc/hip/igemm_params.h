@@ -134,6 +134,9 @@ bool gemm256c_supported(const IgemmParams& p, uint32_t vec);
 int gemm256c_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, uint32_t opt);
 /* q8gemm256x.hip: the same GEMM on v_mfma_i32_16x16x64_i8 (round 6); takes what gemm256c_supported accepts */
 int gemm256x_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name);
+/* q8gemm128u.hip: the same matrix side for ANY channel counts / groups / alignment (activations staged by the threads, standard image) */
+bool gemm128u_supported(const IgemmParams& p);
+int gemm128u_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, uint32_t tile_n);
 /* q8gemm128x.hip: 128 x 128 tiles of four waves on the same operand path -- mid-size problems, any K tile count */
 bool gemm128x_supported(const IgemmParams& p, uint32_t vec);
 int gemm128x_launch(const IgemmParams& p, uint32_t groups, hipStream_t stream, const char** name, uint32_t tile_n);

@@ -726,6 +726,13 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   // (strided 1x1 convolutions over few rows -- ResNet-18's 28x28 128 -> 256 and 14x14 256 -> 512 shortcuts, 25 k / 6 k output pixels:
   //  7.9 -> 6.1 us and 8.2 -> 5.4 against the streaming kernel's table rows; with 100 k rows the streaming kernel keeps them)
   if (a->variant == 0 && mid_ok && a->offsets != nullptr && a->rows <= 32768u && a->k_total >= 128u && a->k_total <= 256u && a->rows >= 2048u) return launch_mid();
+  // (round 6: pointwise layers whose channel count forces BYTE stores on the streaming kernel -- ShuffleNet v2's 24 -> 58 / 122 at 56 x 56:
+  //  56.3 / 122.1 us -- run on the register-staged 128-row GEMM instead: 36.3 / 78.6 us, profiles/r06/ugemm_by_forced_kernel_r06p.txt)
+  if (a->variant == 0 && !pad3 && p.store_mode == 0 && a->rows >= 2048u && p.d2s_sh == 0 && qnnp::gemm128u_supported(p)) {
+    const int rc_u = qnnp::gemm128u_launch(p, a->groups, stream, &name, 0u);
+    if (kernel_name != nullptr) *kernel_name = name;
+    return rc_u;
+  }
   // Short-K pointwise / fully-connected layers over many rows: barrier-free streaming kernel.
   const bool pw_ok = !pad3 && qnnp::pwstream_supported(p, a->groups, vec) && (p.d2s_sh == 0 || vec == 16);
   if ((a->variant == 5 || p.d2s_sh != 0) && !pw_ok) return QNNP_HIP_EINVAL;   /* depth-to-space exists in this kernel only */
@@ -830,6 +837,17 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
       return rc;
     }
     if (a->variant == 28) return QNNP_HIP_EINVAL;
+  }
+  // Round 6: what is left of the 1x1 / fully connected class -- grouped, odd channel counts, unaligned rows -- on the 128 x 128 kernel
+  // that stages its activation tile through registers (q8gemm128u.hip; "gemm_kernel" 29 forces it, 1 keeps the generic tile kernel).
+  {
+    const bool u_ok = !pad3 && qnnp::gemm128u_supported(p);
+    if (a->variant == 29 && !u_ok) return QNNP_HIP_EINVAL;
+    if (u_ok && (a->variant == 29 || (a->variant == 0 && !(big_ok && big_auto)))) {
+      rc = qnnp::gemm128u_launch(p, a->groups, stream, &name, 0u);
+      if (kernel_name != nullptr) *kernel_name = name;
+      return rc;
+    }
   }
   if (big_ok && (big_forced || (a->variant == 0 && big_auto))) {
     rc = qnnp::gemm256_launch(p, a->groups, stream, &name, a->variant == 4 || a->variant == 16, a->variant == 10, a->variant == 11,

@@ -63,7 +63,7 @@ def kernels(tmp_path_factory):
 # mangled-name fragments of the kernels the automatic dispatch picks for aligned tensors; the
 # generic implicit-GEMM fallback for unaligned / odd-channel tensors (q8_igemm_mfma_kernel, byte gathers) is known to
 # spill in its 1-byte flavours and is reported by test_report_of_spilling_kernels below, not asserted
-DEFAULT_PATH = ["q8_gemm_mfma_256x256_c16_kernel", "q8_gemm_mfma_128xN_c16_kernel", "q8_conv_wave_ws16_kernel", "q8_gemm_mfma_256x256_c_kernel", "q8_gemm_mfma_256x256_kernelILb0ELi4E", "q8_gemm_mfma_256x256_kernelILb1ELi4E", "q8_pw_stream_staged_kernel", "q8_pw_stream_longk_kernel",
+DEFAULT_PATH = ["q8_gemm_mfma_256x256_c16_kernel", "q8_gemm_mfma_128xN_c16_kernel", "q8_gemm_mfma_128xN_u16_kernel", "q8_conv_wave_ws16_kernel", "q8_gemm_mfma_256x256_c_kernel", "q8_gemm_mfma_256x256_kernelILb0ELi4E", "q8_gemm_mfma_256x256_kernelILb1ELi4E", "q8_pw_stream_staged_kernel", "q8_pw_stream_longk_kernel",
                 "q8_pw_stream_gw_kernel", "q8_pw_stream_gwk_kernel", "q8_conv_stream_c3s_kernel",
                 "q8_dwconv_col3x3_kernel", "q8_conv_wave_reg_kernel", "q8_conv_wave_ws_kernel", "q8_conv_lds_mfma", "q8_vadd", "q8_gavgpool",
                 "q8_conv_patch_kernel", "q8_conv_c3rows32_kernel"]
