@@ -299,10 +299,18 @@ void q8_conv_c3rows_kernel(const IgemmParams p, const C3Geom cg)
       const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
       const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
       const v4i v = {static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
-      bool ok = pixel_ok && nb * 32u + h * 16u < p.n;          // (n % 16 == 0: launcher)
+      bool ok = pixel_ok && nb * 32u + h * 16u + 16u <= p.n;   // (n % 8 == 0: launcher)
 #ifdef QNNP_ENABLE_ABLATION
       if (cg.abl & 2u) ok = ok && v.x == 0x12345678;
 #endif
+      if ((p.n & 8u) != 0u) {
+        // (round 6: channel counts that end on half a 16-byte piece -- ShuffleNet's 3 -> 24 first layer, bench/convolution.cc:112 --
+        //  store that half with an 8-byte store; wave-uniform test, nothing changes for multiples of 16)
+        const bool ok8 = pixel_ok && nb * 32u + h * 16u + 8u == p.n;
+        typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+        const u2 lo = {static_cast<unsigned int>(v.x), static_cast<unsigned int>(v.y)};
+        __builtin_amdgcn_raw_buffer_store_b64(lo, out_rsrc, ok8 ? out_off + nb * 32u : 0xFFFFFFF0u, 0, 0);
+      }
       // (a unit's sixteen pixels of a row x 32 channels are 512 contiguous bytes, written once: the streaming hint, under
       //  the operator's "streaming_stores" setting -- the two builtins differ in an immediate, so hipcc cannot merge them)
       if (p.stream_out) {
@@ -585,7 +593,9 @@ bool conv_c3rows_supported(const IgemmParams& p, const ConvGeom& g, uint32_t gro
 {
   if (w_rows16 == nullptr || groups != 1 || real_kc != 3 || p.input_stride != 3) return false;
   if (g.KW * 3u > 16u || g.KH == 0 || g.KH > 4 || g.dh != 1 || g.dw != 1) return false;
-  if (p.n_pad > 64 || p.n % 16u != 0 || p.output_stride % 16u != 0 || (reinterpret_cast<uintptr_t>(p.output) & 15u) != 0) return false;
+  // (channel counts in multiples of 8, pixels 8-byte aligned: the last half piece leaves by an 8-byte store -- round 6)
+  if (p.n_pad > 64 || p.n % 8u != 0 || p.output_stride % 8u != 0 || (reinterpret_cast<uintptr_t>(p.output) & 7u) != 0) return false;
+  if (p.n % 16u == 0 && (p.output_stride % 16u != 0 || (reinterpret_cast<uintptr_t>(p.output) & 15u) != 0)) return false;
   if (p.rows == 0 || p.rows_per_image == 0 || g.OW == 0 || g.OH == 0 || p.rows_per_image != g.OH * g.OW) return false;
   if (p.rows % p.rows_per_image != 0) return false;
   const uint64_t in_bytes = static_cast<uint64_t>(p.input_end - p.input);

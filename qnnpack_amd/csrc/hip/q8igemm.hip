@@ -679,7 +679,9 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   }
   // 3-channel images (first layers) with dense pixels: one 16-byte fetch per kernel row (q8convc3.hip);
   // "gemm_kernel" = 14 forces it, 7 keeps the tap-gather kernel below
-  const bool rows16_ok = pad3 && p.store_mode == 2 && qnnp::conv_c3rows_supported(p, geom, a->groups, a->packed_w_rows16, a->kc);
+  // (store_mode 1 with channels % 8 == 0: ShuffleNet's 3 -> 24 layer -- the kernel checks the 8-byte alignment it needs itself)
+  const bool rows16_ok = pad3 && (p.store_mode == 2 || (p.store_mode == 1 && a->n % 8u == 0)) &&
+      qnnp::conv_c3rows_supported(p, geom, a->groups, a->packed_w_rows16, a->kc);
   if (a->variant == 14 && !rows16_ok && !(pad3 && p.store_mode == 2 && qnnp::conv_c3rows32_supported(p, geom, a->groups, a->packed_w_rows16, a->kc))) return QNNP_HIP_EINVAL;
   if (rows16_ok && (a->variant == 14 || (a->variant == 0 && a->rows >= 2048))) {
     const int rc_r16 = qnnp::conv_c3rows_launch(p, geom, a->packed_w_rows16, stream, &name);

@@ -30,6 +30,10 @@ CASES = [
     ConvCase("r_3x3_s2x1", (16, 9), (3, 3), _pad(1, 1), subsampling=(2, 1), gic=3, goc=32),
     ConvCase("r_1x1_s2", (9, 9), (1, 1), subsampling=(2, 2), gic=3, goc=32),
     ConvCase("r_2x2_s2", (10, 12), (2, 2), subsampling=(2, 2), gic=3, goc=16, batch=3),
+    # round 6: channel counts in multiples of 8 (the last half piece leaves by an 8-byte store): ShuffleNet's 3 -> 24 first layer
+    ConvCase("r_3x3_s2_24_channels", (40, 36), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=24, batch=3),
+    ConvCase("r_3x3_s1_8_channels", (13, 11), (3, 3), _pad(1, 1), gic=3, goc=8, batch=2),
+    ConvCase("r_3x3_s2_56_channels_zp", (17, 19), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=56, izp=9, kzp=200, batch=2),
     ConvCase("r_4x4_pad", (11, 10), (4, 4), (1, 2, 2, 1), gic=3, goc=64),
     ConvCase("r_4x5_wide_window", (12, 14), (4, 5), (1, 2, 2, 2), gic=3, goc=48, batch=2),
     ConvCase("r_1x5", (6, 20), (1, 5), (0, 2, 0, 2), gic=3, goc=32),
@@ -69,7 +73,7 @@ def test_row_slot_kernel_matches_oracle(rows16, case):
     ConvCase("r_bad_7x7_tensor_not_whole_dwords", (9, 9), (7, 7), _pad(3, 3), gic=3, goc=64),        # 243 bytes
     ConvCase("r_bad_7x11", (16, 16), (7, 11), _pad(3, 5), gic=3, goc=32),                              # 33-byte window rows
     ConvCase("r_bad_dilated", (12, 12), (3, 3), _pad(2, 2), dilation=(2, 2), gic=3, goc=32),
-    ConvCase("r_bad_n24", (9, 9), (3, 3), _pad(1, 1), gic=3, goc=24),
+    ConvCase("r_bad_n20", (9, 9), (3, 3), _pad(1, 1), gic=3, goc=20),
     ConvCase("r_bad_n96", (9, 9), (3, 3), _pad(1, 1), gic=3, goc=96),
     ConvCase("r_bad_4_channels", (9, 9), (3, 3), _pad(1, 1), gic=4, goc=32),
 ], ids=lambda c: c.name)
