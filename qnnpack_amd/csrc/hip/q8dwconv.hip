@@ -127,6 +127,72 @@ void q8_dwconv_direct_kernel(const DwParams p)
 }
 
 // --------------------------------------------------------------------------
+// Kernel B4 (round 6): generic direct, four channels per thread
+// --------------------------------------------------------------------------
+/*
+ * What the shapes nothing else takes ran on until round 6 was kernel B: one output BYTE per thread, nine byte loads each -- ShuffleNet
+ * v2's depthwise layers with 58 / 122 channels (bench/convolution.cc:335-426) at 0.03-0.07 of their bounds (28 x 28 x 122: 102 us).
+ * Same arithmetic (reference: q8dwconv_ukernel_up8x9__sse2 / mp8x25, src/q8dwconv/up8x9-sse2.c:14-372), any window, stride, dilation,
+ * channel count and pixel stride; a thread owns four consecutive channels of one output pixel: per tap two DWORD-ALIGNED loads around
+ * its four bytes (a pixel of 58 bytes starts anywhere) joined by v_alignbyte, one 8-byte load of the four int16 tap weights. Bytes
+ * past the tensor read 0 (buffer descriptor) and channels past C are computed and not stored.
+ */
+__global__ __launch_bounds__(256)
+void q8_dwconv_direct4_kernel(const DwParams p)
+{
+  const uint32_t q4 = (p.C + 3u) / 4u;
+  const uint64_t total = static_cast<uint64_t>(p.batch) * p.OH * p.OW * q4;
+  // (the extent rounded up to whole dwords: the dword holding the tensor's last bytes must not read as out of range)
+  const uint64_t in_bytes = ((static_cast<uint64_t>(p.batch) * p.H * p.W - 1u) * p.in_stride + p.C + 3u) & ~static_cast<uint64_t>(3);
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.input), 0, static_cast<int>(in_bytes), 0x00020000);         // (make_plan: < 2^31 bytes)
+  // (32-bit index arithmetic -- make_plan: fewer than 2^32 channel groups in all -- a 64-bit division costs ~100 instructions)
+  const uint32_t total32 = static_cast<uint32_t>(total);
+  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total32; idx += gridDim.x * blockDim.x) {
+    const uint32_t pix = idx / q4;
+    const uint32_t cg = idx - pix * q4;
+    const uint32_t t = pix / p.OW;
+    const uint32_t ox = pix - t * p.OW;
+    const uint32_t n = t / p.OH;
+    const uint32_t oy = t - n * p.OH;
+    const uint32_t c0 = cg * 4u;
+    const int4 bv = *reinterpret_cast<const int4*>(p.bias1 + c0);                        // (c_pad is a multiple of four: pack.h)
+    int32_t acc[4] = {bv.x, bv.y, bv.z, bv.w};
+    for (uint32_t ky = 0; ky < p.KH; ky++) {
+      const uint32_t iy = oy * p.sh + ky * p.dh - p.pad_top;   // unsigned wrap = out of range
+      for (uint32_t kx = 0; kx < p.KW; kx++) {
+        const uint32_t ix = ox * p.sw + kx * p.dw - p.pad_left;
+        uint32_t a4 = p.izp * 0x01010101u;
+        if (iy < p.H && ix < p.W) {
+          const uint32_t off = ((n * p.H + iy) * p.W + ix) * p.in_stride + c0;
+          const uint32_t lo = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, off & ~3u, 0, 0);
+          const uint32_t hi = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (off & ~3u) + 4u, 0, 0);
+          a4 = __builtin_amdgcn_alignbyte(hi, lo, off & 3u);
+        }
+        const uint2 wv = *reinterpret_cast<const uint2*>(p.wadj + (ky * p.KW + kx) * p.c_pad + c0);
+        acc[0] += static_cast<int32_t>(a4 & 0xFFu) * static_cast<int16_t>(wv.x & 0xFFFFu);
+        acc[1] += static_cast<int32_t>((a4 >> 8) & 0xFFu) * static_cast<int16_t>(wv.x >> 16);
+        acc[2] += static_cast<int32_t>((a4 >> 16) & 0xFFu) * static_cast<int16_t>(wv.y & 0xFFFFu);
+        acc[3] += static_cast<int32_t>(a4 >> 24) * static_cast<int16_t>(wv.y >> 16);
+      }
+    }
+    uint8_t* out = p.output + static_cast<uint64_t>(pix) * p.out_stride + c0;
+    const uint32_t q = static_cast<uint32_t>(qnnp::q31_requantize(acc[0], p.rq)) | (static_cast<uint32_t>(qnnp::q31_requantize(acc[1], p.rq)) << 8) |
+                       (static_cast<uint32_t>(qnnp::q31_requantize(acc[2], p.rq)) << 16) | (static_cast<uint32_t>(qnnp::q31_requantize(acc[3], p.rq)) << 24);
+    const uint32_t nv = min(4u, p.C - c0);
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(out);
+    if (nv == 4u && (addr & 3u) == 0u) {
+      *reinterpret_cast<uint32_t*>(out) = q;
+    } else if (nv == 4u && (addr & 1u) == 0u) {
+      *reinterpret_cast<uint16_t*>(out) = static_cast<uint16_t>(q);
+      *reinterpret_cast<uint16_t*>(out + 2) = static_cast<uint16_t>(q >> 16);
+    } else {
+      for (uint32_t b = 0; b < nv; b++) out[b] = static_cast<uint8_t>(q >> (8 * b));
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
 // Kernel A: LDS-tiled
 // --------------------------------------------------------------------------
 #ifndef QNNP_DW_THREADS
@@ -2452,7 +2518,7 @@ int launch_m16(const DwParams& geometry, hipStream_t stream)
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
-enum : uint32_t { kPlanDirect = 1, kPlanLds33, kPlanLds55, kPlanRow, kPlanMfma, kPlanMfmaLds, kPlanCol, kPlanCol5, kPlanM16 };
+enum : uint32_t { kPlanDirect = 1, kPlanLds33, kPlanLds55, kPlanRow, kPlanMfma, kPlanMfmaLds, kPlanCol, kPlanCol5, kPlanM16, kPlanDirect4 };
 
 // measurement knob, read once: LDS budget per workgroup of the LDS-tiled kernel in KiB
 uint32_t lds_budget()
@@ -2521,7 +2587,11 @@ int make_plan(DwParams& p, const struct qnnp_hip_dwconv_args* a, uintptr_t in_ad
       plan->vec16 = (p.CS % 16 == 0 && p.in_stride % 16 == 0 && in_addr % 16 == 0) ? 1u : 0u;
       plan->kernel = k33 ? kPlanLds33 : kPlanLds55;
     } else {
-      plan->kernel = kPlanDirect;
+      // (round 6) four channels per thread where the tensors allow 32-bit offsets; "dwconv_kernel" 1 keeps the byte-per-thread kernel
+      const uint64_t ib = static_cast<uint64_t>(p.batch) * p.H * p.W * p.in_stride;
+      const uint64_t groups4 = static_cast<uint64_t>(p.batch) * p.OH * p.OW * ((p.C + 3u) / 4u);
+      plan->kernel = (a->variant != 1 && p.C >= 4 && ib + 8 < (UINT64_C(1) << 31) && groups4 + 256u * 8192u < (UINT64_C(1) << 32) && a->c_pad % 4 == 0)
+          ? kPlanDirect4 : kPlanDirect;
     }
   }
   plan->CS = p.CS; plan->TOH = p.TOH; plan->IR = p.IR; plan->IC = p.IC; plan->PP = p.PP;
@@ -2608,6 +2678,14 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
     case kPlanM16:
       if (kernel_name != nullptr) *kernel_name = "q8_dwconv_mfma16_3x3";
       return launch_m16(p, stream);
+    case kPlanDirect4: {
+      if (kernel_name != nullptr) *kernel_name = "q8_dwconv_direct4";
+      const uint64_t total4 = static_cast<uint64_t>(p.batch) * p.OH * p.OW * ((p.C + 3u) / 4u);
+      uint64_t blocks4 = (total4 + 255) / 256;
+      if (blocks4 > 256u * 32u) blocks4 = 256u * 32u;
+      hipLaunchKernelGGL(q8_dwconv_direct4_kernel, dim3(static_cast<uint32_t>(blocks4)), dim3(256), 0, stream, p);
+      return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+    }
     case kPlanLds33:
       if (kernel_name != nullptr) *kernel_name = "q8_dwconv_lds_3x3";
       return launch_lds<3, 3>(p, plan->vec16 != 0, stream);
