@@ -30,15 +30,9 @@ echo "== rocprofv3 kernel stats (whole bench)"
 for f in $(find $OUT/prof_all -name "*kernel_stats*.csv" | head -1); do cut -c1-160 $f | head -n 14; cp $f $OUT/rocprof_kernel_stats_all.csv; done
 rm -rf $OUT/prof $OUT/prof_all
 echo "== PMC: fabric traffic and SQ counters of the GEMM (auto = 16x16x64; 20 = 32x32x32)"
-for V in 0 20 28; do
+for V in 0 28; do
 bash scripts/gpu_pmc_cmd.sh $TAG gemm_tcc_$V "python tools/gemm_ab.py --only $V $( [ $V = 28 ] && echo --kzp 126 )" TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_EA0_WRREQ_64B_sum | tee $OUT/pmc_gemm_tcc_v$V.txt
 bash scripts/gpu_pmc_cmd.sh $TAG gemm_sq_$V "python tools/gemm_ab.py --only $V $( [ $V = 28 ] && echo --kzp 126 )" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU | tee $OUT/pmc_gemm_sq_v$V.txt
 bash scripts/gpu_pmc_cmd.sh $TAG gemm_lds_$V "python tools/gemm_ab.py --only $V $( [ $V = 28 ] && echo --kzp 126 )" SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS | tee $OUT/pmc_gemm_lds_v$V.txt
 rm -rf $OUT/pmc_gemm_tcc_$V $OUT/pmc_gemm_sq_$V $OUT/pmc_gemm_lds_$V
 done
-echo "== PMC: HBM-side traffic of the depthwise kernels (sweep layer 8: 3x3 s1 56x56x144; layer 5: 3x3 s2 112x112x96; 5x5 28x28x240)"
-bash scripts/gpu_pmc_cmd.sh $TAG dw8_tcc "python bench.py --layer 8 --steps 30 --warmup 3" TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_32B_sum | tee $OUT/pmc_dw8_tcc.txt
-bash scripts/gpu_pmc_cmd.sh $TAG dw5_tcc "python bench.py --layer 5 --steps 30 --warmup 3" TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_32B_sum | tee $OUT/pmc_dw5_tcc.txt
-bash scripts/gpu_pmc_cmd.sh $TAG dw5x5_tcc "python tools/dw5_time.py" TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_32B_sum | tee $OUT/pmc_dw5x5_tcc.txt
-bash scripts/gpu_pmc_cmd.sh $TAG dw8_sq "python bench.py --layer 8 --steps 30 --warmup 3" SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU | tee $OUT/pmc_dw8_sq.txt
-rm -rf $OUT/pmc_dw8_tcc $OUT/pmc_dw5_tcc $OUT/pmc_dw5x5_tcc $OUT/pmc_dw8_sq
