@@ -37,7 +37,9 @@ extern "C" {
  *                    workgroups per CU; tile width by the channel count), 25 / 26 = the same with 64- / 128-channel tiles,
  *                    27 = the 32x32x32 weight-stationary 3x3 convolution kernel for 64 input channels with a centred image (auto
  *                    takes its 16x16x64 flavour since round 6), 28 = the 16x16x64 GEMM with kernel-zero-point row sums (any kernel
- *                    zero point; what auto picks where 15 ran before).
+ *                    zero point; what auto picks where 15 ran before),
+ *                    29 = the 128-row GEMM for 1x1 / fully-connected shapes with NO alignment (hip/q8gemm128u.hip: grouped, odd channel
+ *                    counts, unaligned pixels; what auto picks where 1 ran for them).
  *   "fused_kernel":  fused inverted-residual blocks: 0 = auto (the strip kernel, hip/q8fusedstrip.hip, where it takes the
  *                    block -- kernel zero points 127 / 128 in all three members -- else the tile kernel of rounds 1-3),
  *                    1 = the tile kernel only, 2 = the strip kernel only (unsupported_parameter at setup otherwise)
@@ -48,7 +50,10 @@ extern "C" {
  *   "dwconv_kernel": 0 = auto, 1 = generic direct kernel, 2 = LDS-tiled kernel, 3 = register sliding-window kernel (3x3),
  *                    4 = matrix-core kernel (diagonal MFMA operands; 3x3, channels % 16 == 0), tap operands gathered
  *                        from global memory, 5 = the same with the input band staged in LDS first,
- *                    6 = column-sliding register window (3x3, stride 1 | 2): tap pairs shared between output rows
+ *                    6 = column-sliding register window (3x3, stride 1 | 2): tap pairs shared between output rows,
+ *                    7 = matrix-core kernel on v_mfma_i32_16x16x64_i8 without data transposition (3x3, stride 1, channels % 16 == 0;
+ *                        a negative result kept for its A/B: slower than 6 on every layer)
+ *                    (1 keeps the byte-per-thread direct kernel; auto takes its four-channel flavour for C >= 4)
  * Unknown family or code -> invalid_parameter. 0 = the automatic choice, always. */
 enum qnnp_status qnnp_gfx950_test_force_kernel(const char* family, int code);
 
