@@ -127,7 +127,7 @@ int pwstream_gw_launch(const IgemmParams& p, hipStream_t stream, const char** na
 bool conv_c3rows_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, const int8_t* w_rows16, uint32_t real_kc);
 int conv_c3rows_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_rows16, hipStream_t stream, const char** name);
 bool conv_c3rows32_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, const int8_t* w_rows32, uint32_t real_kc);
-int conv_c3rows32_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_rows32, hipStream_t stream, const char** name);
+int conv_c3rows32_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_rows32, hipStream_t stream, const char** name, int flavour);
 
 /* q8gemm256c.hip: the zero-point-centred flavour (p carries the centred image, its bias pair table and a_flip) */
 bool gemm256c_supported(const IgemmParams& p, uint32_t vec);

@@ -70,6 +70,37 @@ __device__ __forceinline__ uint32_t byte_range_mask(int32_t lo, int32_t hi)
   return upto_hi & ~upto_lo;
 }
 
+/* The stores of one unit (2 output rows x 16 columns) of the row-slot kernels with 16-byte channel pieces. After the requantization lane (pixel p = 16 prow + pcol, half h) holds channels
+ * 32 nb + 16 h .. + 15 of its pixel for every channel block nb: stored as they are, an instruction writes 32-byte pieces 64 (96) bytes
+ * apart. With two blocks the 16-lane rows exchange instead (v_permlane16_swap: row 1 of block 0 <-> row 0 of block 1, row 3 <-> row 2):
+ * the first instruction then writes the 16 pixels of the unit's FIRST output row whole -- 1 KiB of contiguous 128-byte lines -- and the
+ * second one the second row's (lane row r = 2 h + prow writes channels 16 h + 32 prow of pixel pcol). */
+template <int NB>
+__device__ __forceinline__ void c3_store_unit(v4i (&v)[NB], const __amdgpu_buffer_rsrc_t out_rsrc, uint32_t unit_out0, uint32_t row_pitch,
+                                              uint32_t ostride, uint32_t n, bool row0_ok, bool row1_ok, bool col_ok, uint32_t prow,
+                                              uint32_t pcol, uint32_t h, bool stream_out)
+{
+  auto put = [&](const v4i& x, uint32_t off, bool ok) __attribute__((always_inline)) {
+    const auto bits = __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, x);
+    if (stream_out) __builtin_amdgcn_raw_buffer_store_b128(bits, out_rsrc, ok ? off : 0xFFFFFFF0u, 0, 2);
+    else __builtin_amdgcn_raw_buffer_store_b128(bits, out_rsrc, ok ? off : 0xFFFFFFF0u, 0, 0);
+  };
+  const uint32_t pix = unit_out0 + pcol * ostride;
+  if constexpr (NB >= 2) {
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const auto sw = __builtin_amdgcn_permlane16_swap(static_cast<uint32_t>(v[0][d]), static_cast<uint32_t>(v[1][d]), false, false);
+      v[0][d] = static_cast<int>(sw[0]); v[1][d] = static_cast<int>(sw[1]);
+    }
+    const uint32_t ch = h * 16u + prow * 32u;
+    put(v[0], pix + ch, row0_ok && col_ok && ch < n);
+    put(v[1], pix + row_pitch + ch, row1_ok && col_ok && ch < n);
+  } else {
+    put(v[0], pix + prow * row_pitch + h * 16u, (prow != 0u ? row1_ok : row0_ok) && col_ok && h * 16u < n);
+  }
+  if constexpr (NB == 3) put(v[2], pix + prow * row_pitch + 64u + h * 16u, (prow != 0u ? row1_ok : row0_ok) && col_ok && 64u + h * 16u < n);
+}
+
 /* UNIT = 2 output rows x 16 output columns of one image (32 pixels; lane (p, h): row p >> 4, column p & 15 of the
  * unit, K half h). Everything that locates a unit is scalar arithmetic; a lane's byte offsets are constants of the
  * kernel plus one scalar per unit. Whether a unit touches the image border (some tap outside the image) or the tensor's
@@ -282,6 +313,10 @@ void q8_conv_c3rows_kernel(const IgemmParams p, const C3Geom cg)
     }
     const bool pixel_ok = prow < u.rows_left && pcol < u.cols_left;
     const uint32_t out_off = u.out0 + lane_out;
+    // (round 6) two whole channel blocks: the 16-lane rows trade pieces and each store instruction writes one output row's sixteen
+    // pixels whole (c3_store_unit) -- 224x224 3x3 3 -> 64, VGG's first layer, wrote 32-byte pieces 64 bytes apart
+    const bool whole_lines = NB == 2 && (p.n & 15u) == 0u && p.n > 32u;
+    v4i outv[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
       v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[nb][0], s.x[0], bias[nb], 0, 0, 0);
@@ -299,6 +334,8 @@ void q8_conv_c3rows_kernel(const IgemmParams p, const C3Geom cg)
       const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
       const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
       const v4i v = {static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
+      outv[nb] = v;
+      if (whole_lines) continue;                                // (wave-uniform)
       bool ok = pixel_ok && nb * 32u + h * 16u + 16u <= p.n;   // (n % 8 == 0: launcher)
 #ifdef QNNP_ENABLE_ABLATION
       if (cg.abl & 2u) ok = ok && v.x == 0x12345678;
@@ -321,6 +358,16 @@ void q8_conv_c3rows_kernel(const IgemmParams p, const C3Geom cg)
         __builtin_amdgcn_raw_buffer_store_b128(
             __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc,
             ok ? out_off + nb * 32u : 0xFFFFFFF0u, 0, 0);
+      }
+    }
+    if constexpr (NB == 2) {
+      if (whole_lines) {
+        bool col_ok = pcol < u.cols_left;
+#ifdef QNNP_ENABLE_ABLATION
+        if (cg.abl & 2u) col_ok = col_ok && outv[0].x == 0x12345678;
+#endif
+        c3_store_unit<2>(outv, out_rsrc, u.out0, cg.OW * p.output_stride, p.output_stride, p.n, u.rows_left > 0u, u.rows_left > 1u,
+                         col_ok, prow, pcol, h, p.stream_out != 0);
       }
     }
   };
@@ -417,8 +464,8 @@ void q8_conv_c3rows32_kernel(const IgemmParams p, const C3Geom cg)
 
   const uint32_t row_bytes = cg.W * 3u;
   const uint32_t lane_in = prow * cg.sh * row_bytes + pcol * cg.sw * 3u + h * 16u;   // this lane's half of row slot 0, relative to the unit's first window
-  const uint32_t lane_out = (prow * cg.OW + pcol) * p.output_stride + h * 16u;
   const uint32_t fill4 = (p.izp_fill & 0xFFu) * 0x01010101u;
+  const uint32_t flip = p.a_flip != 0u ? p.a_flip : kFlip;     // 0x7F7F7F7F: the image is centred on kernel zero point 127 (pack.h)
 
   struct Where { uint32_t origin, out0; int32_t iy0, ix0; uint32_t rows_left, cols_left; bool border, slow; };   // (wave-uniform)
   auto locate = [&](uint32_t unit) __attribute__((always_inline)) -> Where {
@@ -508,7 +555,7 @@ void q8_conv_c3rows32_kernel(const IgemmParams p, const C3Geom cg)
           x[d] = (x[d] & keep) | (fill4 & ~keep);
         }
       }
-      s.x[kb] = v4i{static_cast<int>(x[0] ^ kFlip), static_cast<int>(x[1] ^ kFlip), static_cast<int>(x[2] ^ kFlip), static_cast<int>(x[3] ^ kFlip)};
+      s.x[kb] = v4i{static_cast<int>(x[0] ^ flip), static_cast<int>(x[1] ^ flip), static_cast<int>(x[2] ^ flip), static_cast<int>(x[3] ^ flip)};
     }
     // ---- the multiplies (and the row sums, where the kernel zero point asks for them); then the next unit's fetches, into the
     //      registers they have just left
@@ -537,8 +584,7 @@ void q8_conv_c3rows32_kernel(const IgemmParams p, const C3Geom cg)
     //      requantization, 16-byte stores
     uint64_t row_addend = 0;
     if constexpr (rq_is_lane<SEQ>()) row_addend = lane_addend(rowterm, p.lane);
-    const bool pixel_ok = prow < done.rows_left && pcol < done.cols_left;
-    const uint32_t out_off = done.out0 + lane_out;
+    v4i outv[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
       uint32_t pk[4];
@@ -555,18 +601,10 @@ void q8_conv_c3rows32_kernel(const IgemmParams p, const C3Geom cg)
       }
       const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
       const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
-      const v4i v = {static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
-      const bool ok = pixel_ok && nb * 32u + h * 16u < p.n;          // (n % 16 == 0: launcher)
-      if (p.stream_out) {
-        __builtin_amdgcn_raw_buffer_store_b128(
-            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc,
-            ok ? out_off + nb * 32u : 0xFFFFFFF0u, 0, 2);
-      } else {
-        __builtin_amdgcn_raw_buffer_store_b128(
-            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc,
-            ok ? out_off + nb * 32u : 0xFFFFFFF0u, 0, 0);
-      }
+      outv[nb] = v4i{static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
     }
+    c3_store_unit<NB>(outv, out_rsrc, done.out0, cg.OW * p.output_stride, p.output_stride, p.n, done.rows_left > 0u, done.rows_left > 1u,
+                      pcol < done.cols_left, prow, pcol, h, p.stream_out != 0);     // (n % 16 == 0: launcher)
     if (!more) break;
   }
 }
@@ -581,6 +619,218 @@ int launch_c3rows32(const IgemmParams& p, const C3Geom& cg, hipStream_t stream)
   requant_dispatch_lane(p.rq, p.lane, [&](auto seq, auto full) {
     hipLaunchKernelGGL((q8_conv_c3rows32_kernel<NB, KR, decltype(seq)::value, decltype(full)::value>), dim3(grid),
                        dim3(kC3Threads), 0, stream, p, cg);
+  });
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
+
+/*
+ * The 32-byte-slot kernel with the input rows of a BAND staged in LDS (round 6). q8_conv_c3rows32_kernel above fetches every input
+ * byte ~12 times through the vector-memory path (a 7 x 7 stride-2 window: 18 KB of requests per unit for 1.1 KB of distinct bytes)
+ * and is bound by those requests. Here a workgroup owns `ppb` output-row PAIRS of one image, all column segments:
+ *   - its (2 ppb - 1) * stride + KH input rows go to LDS once, by coalesced 16-byte loads, already re-centred (a ^ 0x80) and WITH the
+ *     padding materialised -- rows above / below the image and the pad columns left and right of a row hold the re-centred zero point --
+ *     so a unit has no border path, no byte masks and no XOR;
+ *   - a lane's operand half of kernel row ky is 16 bytes at (row, column) of that image in LDS: five dwords from the dword below it
+ *     (ds_read2_b32 x 2 + ds_read_b32: LDS wants its reads aligned to their width) and four v_alignbyte;
+ *   - multiplies, row sums by the matrix cores, requantization and stores are the kernel's above.
+ * Needs 16-byte aligned image rows (W * 3 % 16 == 0, base and image stride with it); everything else stays on the kernel above.
+ */
+struct C3LdsGeom {
+  uint32_t ppb;               // output-row pairs per band
+  uint32_t bands, inv_bands;  // bands per image
+  uint32_t nrows;             // input rows of a band: (2 ppb - 1) * sh + KH
+  uint32_t pitch;             // bytes between rows in LDS (a multiple of 16, an odd number of 16-byte chunks)
+  uint32_t cpr, inv_cpr;      // chunks per row = pitch / 16
+  uint32_t c0, dchunks;       // first data chunk of a row (the chunks before it are left padding), data chunks = W * 3 / 16
+};
+
+template <int NB, int KR, int SEQ, bool FULL>
+__global__ __launch_bounds__(kC3Threads, NB == 1 ? 4 : (NB == 2 ? 3 : 2))
+void q8_conv_c3rows32_lds_kernel(const IgemmParams p, const C3Geom cg, const C3LdsGeom lg)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t c3lds[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t px = lane & 31u;
+  const uint32_t h = lane >> 5;
+  const uint32_t prow = px >> 4, pcol = px & 15u;
+  const uint32_t kbytes = cg.KW * 3u;
+  const int32_t nreal = static_cast<int32_t>(kbytes) - 16 * static_cast<int32_t>(h);
+
+  // (measurement builds: cycle stamps per wave -- entry, staged + barrier, first unit done, all units done; tools/trace_c3lds.py)
+  QNNP_TRACE_WAVE(p, blockIdx.x, wave, 0);
+  const uint32_t img = div_magic(blockIdx.x, lg.inv_bands);
+  const uint32_t band = blockIdx.x - img * lg.bands;
+  const uint32_t pair0 = band * lg.ppb;
+
+  // ---- staging requests first: chunk id = row * cpr + c, four per thread and trip, all loads of a trip in flight together
+  const uint32_t total = lg.nrows * lg.cpr;
+  const int32_t iy_first = static_cast<int32_t>(pair0 * 2u * cg.sh) - static_cast<int32_t>(cg.pad_top);
+  const uint8_t* img_base = p.input + static_cast<uint64_t>(img) * p.image_stride;
+  const uint32_t row_bytes = cg.W * 3u;
+  const int flip = static_cast<int>(p.a_flip != 0u ? p.a_flip : kFlip);     // 0x7F7F7F7F: the image is centred on kernel zero point 127
+  const int zp4 = static_cast<int>((p.izp_fill & 0xFFu) * 0x01010101u) ^ flip;
+  constexpr int kTrip = 4;
+  auto stage_trip = [&](uint32_t id0) __attribute__((always_inline)) {
+    v4i v[kTrip];
+    uint32_t dst[kTrip];
+    bool in[kTrip];
+#pragma unroll
+    for (int i = 0; i < kTrip; i++) {
+      const uint32_t id = id0 + static_cast<uint32_t>(i) * kC3Threads;
+      const uint32_t r = div_magic(id, lg.inv_cpr);
+      const uint32_t c = id - r * lg.cpr;
+      const int32_t iy = iy_first + static_cast<int32_t>(r);
+      in[i] = id < total && static_cast<uint32_t>(iy) < cg.H && c - lg.c0 < lg.dchunks;
+      dst[i] = id < total ? id * 16u : 0xFFFFFFFFu;
+      if (in[i]) v[i] = *reinterpret_cast<const v4i*>(img_base + static_cast<uint32_t>(iy) * row_bytes + (c - lg.c0) * 16u);
+    }
+#pragma unroll
+    for (int i = 0; i < kTrip; i++) {
+      v4i y = {zp4, zp4, zp4, zp4};
+      if (in[i]) y = v4i{v[i].x ^ flip, v[i].y ^ flip, v[i].z ^ flip, v[i].w ^ flip};
+      if (dst[i] != 0xFFFFFFFFu) *reinterpret_cast<v4i*>(c3lds + dst[i]) = y;
+    }
+  };
+
+  // ---- weights and bias to registers (L2-resident; their round trip runs under the staging)
+  v4i w[NB][KR];
+  v16i bias[NB];
+  {
+    const int32_t* bias_tab = rq_is_lane<SEQ>() ? p.bias2u : p.bias2;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+#pragma unroll
+      for (int kb = 0; kb < KR; kb++) w[nb][kb] = *reinterpret_cast<const v4i*>(cg.w_rows16 + ((nb * KR + kb) * 64u + lane) * 16u);
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const v4i b = *reinterpret_cast<const v4i*>(bias_tab + nb * 32 + rg * 8 + h * 4);
+        bias[nb][rg * 4 + 0] = b.x; bias[nb][rg * 4 + 1] = b.y; bias[nb][rg * 4 + 2] = b.z; bias[nb][rg * 4 + 3] = b.w;
+      }
+    }
+  }
+  for (uint32_t id0 = tid; id0 < total; id0 += kTrip * kC3Threads) stage_trip(id0);
+  QNNP_TRACE_WAVE(p, blockIdx.x, wave, 1);
+  __syncthreads();
+  QNNP_TRACE_WAVE(p, blockIdx.x, wave, 2);
+
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.output, 0, static_cast<int>((p.rows - 1u) * p.output_stride + p.n), 0x00020000);
+  // this lane's half of row slot 0 of the band's first unit, in LDS: row prow * sh, column pcol * sw - pad_left behind the data start
+  const uint32_t lane_lds = prow * cg.sh * lg.pitch + lg.c0 * 16u + pcol * cg.sw * 3u + h * 16u - cg.pad_left * 3u;
+
+  const uint32_t pairs_here = min(lg.ppb, cg.pairs - pair0);
+  const uint32_t nunits = pairs_here * cg.segs;
+  for (uint32_t unit = wave; unit < nunits; unit += kC3Waves) {
+    const uint32_t pl = div_magic(unit, cg.inv_segs);
+    const uint32_t seg = unit - pl * cg.segs;
+    const uint32_t oy = (pair0 + pl) * 2u, ox = seg * 16u;
+    const uint32_t off = lane_lds + pl * 2u * cg.sh * lg.pitch + ox * cg.sw * 3u;
+    const uint32_t shb = off & 3u;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(c3lds + (off & ~3u));
+    v4i x[KR];
+#pragma unroll
+    for (int kb = 0; kb < KR; kb++) {
+      const uint32_t* q = src + kb * (lg.pitch >> 2);
+      const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+      x[kb] = v4i{static_cast<int>(__builtin_amdgcn_alignbyte(d1, d0, shb)), static_cast<int>(__builtin_amdgcn_alignbyte(d2, d1, shb)),
+                  static_cast<int>(__builtin_amdgcn_alignbyte(d3, d2, shb)), static_cast<int>(__builtin_amdgcn_alignbyte(d4, d3, shb))};
+    }
+    // the row term first (kernel zero points other than 127 / 128), then channel block by channel block: multiply, requantize -- the
+    // next block's multiplies run under this block's requantization, and one set of accumulator registers serves all blocks
+    int32_t rowterm = with_rq_offset<SEQ>(0);
+    if (p.row_coeff != 0) {                                // (scalar; the `ones` fragment of the kernel above, rebuilt per unit: four
+      //  registers held across the loop cost this flavour its third wave per SIMD)
+      int32_t nr = nreal;
+      asm volatile("" : "+v"(nr));                         // (or hipcc hoists the fragment out of the loop again)
+      const v4i ones = {static_cast<int>(byte_range_mask(0, nr) & 0x01010101u), static_cast<int>(byte_range_mask(-4, nr - 4) & 0x01010101u),
+                        static_cast<int>(byte_range_mask(-8, nr - 8) & 0x01010101u), static_cast<int>(byte_range_mask(-12, nr - 12) & 0x01010101u)};
+      v16i racc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int kb = 0; kb < KR; kb++) racc = __builtin_amdgcn_mfma_i32_32x32x32_i8(ones, x[kb], racc, 0, 0, 0);
+      rowterm = with_rq_offset<SEQ>(p.row_coeff * racc[0]);
+    }
+    uint64_t row_addend = 0;
+    if constexpr (rq_is_lane<SEQ>()) row_addend = lane_addend(rowterm, p.lane);
+    v4i outv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[nb][0], x[0], bias[nb], 0, 0, 0);
+#pragma unroll
+      for (int kb = 1; kb < KR; kb++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[nb][kb], x[kb], acc, 0, 0, 0);
+      uint32_t pk[4];
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        if constexpr (rq_is_lane<SEQ>()) {
+          pk[rg] = q31_requantize_pack4_lane<SEQ, FULL>(
+              static_cast<uint32_t>(acc[rg * 4 + 0]), static_cast<uint32_t>(acc[rg * 4 + 1]),
+              static_cast<uint32_t>(acc[rg * 4 + 2]), static_cast<uint32_t>(acc[rg * 4 + 3]), row_addend, p.lane, p.rq);
+        } else {
+          pk[rg] = q31_requantize_pack4<SEQ, FULL, false>(add_wrap(acc[rg * 4 + 0], rowterm), add_wrap(acc[rg * 4 + 1], rowterm),
+                                                         add_wrap(acc[rg * 4 + 2], rowterm), add_wrap(acc[rg * 4 + 3], rowterm), p.rq);
+        }
+      }
+      const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+      const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+      outv[nb] = v4i{static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
+    }
+    c3_store_unit<NB>(outv, out_rsrc, ((img * cg.OH + oy) * cg.OW + ox) * p.output_stride, cg.OW * p.output_stride, p.output_stride, p.n,
+                      oy < cg.OH, oy + 1u < cg.OH, ox + pcol < cg.OW, prow, pcol, h, p.stream_out != 0);
+    if (unit == wave) QNNP_TRACE_WAVE(p, blockIdx.x, wave, 3);
+  }
+  QNNP_TRACE_WAVE(p, blockIdx.x, wave, 4);
+}
+
+/* the band plan of the LDS flavour; false: the shape stays on the register-path kernel */
+bool c3lds_plan(const IgemmParams& p, const C3Geom& cg, C3LdsGeom* out)
+{
+  if ((cg.W * 3u) % 16u != 0 || (reinterpret_cast<uintptr_t>(p.input) & 15u) != 0 || p.image_stride % 16u != 0) return false;
+  C3LdsGeom lg;
+  lg.c0 = (cg.pad_left * 3u + 15u) / 16u;
+  lg.dchunks = cg.W * 3u / 16u;
+  // bytes a real tap can touch right of the data: the last window's end; + the 20 junk bytes a lane reads past its slot's real ones
+  const uint32_t last_end = ((cg.OW - 1u) * cg.sw + cg.KW) * 3u;                       // relative to column -pad_left
+  const uint32_t data_end = (cg.pad_left + cg.W) * 3u;
+  const uint32_t right = last_end > data_end ? last_end - data_end : 0u;
+  lg.cpr = lg.c0 + lg.dchunks + (right + 15u) / 16u + 1u;
+  if ((lg.cpr & 1u) == 0u) lg.cpr++;
+  lg.pitch = lg.cpr * 16u;
+  lg.inv_cpr = static_cast<uint32_t>(((UINT64_C(1) << 32) + lg.cpr - 1) / lg.cpr);
+  // pairs per band: as many as keep a band under 24 KiB (several workgroups per CU), units per band a multiple of the waves if possible
+  uint32_t best = 0;
+  for (uint32_t ppb = 1; ppb <= cg.pairs && ppb <= 16u; ppb++) {
+    const uint32_t nrows = (2u * ppb - 1u) * cg.sh + cg.KH;
+    if (nrows * lg.pitch > 24u * 1024u) break;
+    if (best == 0 || (ppb * cg.segs) % kC3Waves == 0 || (best * cg.segs) % kC3Waves != 0) best = ppb;
+  }
+#ifdef QNNP_ENABLE_ABLATION
+  if (const char* env = getenv("QNNP_C3L_PPB")) {          // measurement builds: pairs per band by hand
+    const uint32_t ppb = static_cast<uint32_t>(atoi(env));
+    if (ppb >= 1 && ppb <= cg.pairs && ((2u * ppb - 1u) * cg.sh + cg.KH) * lg.pitch <= 60u * 1024u) best = ppb;
+  }
+#endif
+  if (best == 0) return false;
+  lg.ppb = best;
+  lg.nrows = (2u * best - 1u) * cg.sh + cg.KH;
+  lg.bands = (cg.pairs + best - 1u) / best;
+  lg.inv_bands = lg.bands > 1 ? static_cast<uint32_t>(((UINT64_C(1) << 32) + lg.bands - 1) / lg.bands) : 0u;
+  const uint64_t wgs = static_cast<uint64_t>(p.rows / (cg.OH * cg.OW)) * lg.bands;
+  if (wgs * lg.bands >= (UINT64_C(1) << 32) || static_cast<uint64_t>(lg.nrows) * lg.cpr * lg.cpr >= (UINT64_C(1) << 32)) return false;
+  *out = lg;
+  return true;
+}
+
+template <int NB, int KR>
+int launch_c3rows32_lds(const IgemmParams& p, const C3Geom& cg, const C3LdsGeom& lg, hipStream_t stream)
+{
+  const uint32_t grid = (p.rows / (cg.OH * cg.OW)) * lg.bands;
+  // (slack behind the last row: lanes of positions past the image's edge read on, at most 16 columns and a slot further)
+  const uint32_t lds_bytes = lg.nrows * lg.pitch + 16u * cg.sw * 3u + 64u;
+  requant_dispatch_lane(p.rq, p.lane, [&](auto seq, auto full) {
+    hipLaunchKernelGGL((q8_conv_c3rows32_lds_kernel<NB, KR, decltype(seq)::value, decltype(full)::value>), dim3(grid),
+                       dim3(kC3Threads), lds_bytes, stream, p, cg, lg);
   });
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
@@ -654,7 +904,9 @@ bool conv_c3rows32_supported(const IgemmParams& p, const ConvGeom& g, uint32_t g
   return true;
 }
 
-int conv_c3rows32_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_rows32, hipStream_t stream, const char** name)
+/* flavour: 0 = auto (the LDS-staged kernel where its plan takes the shape), 1 = the register-path kernel, 2 = the LDS-staged kernel or
+ * QNNP_HIP_EINVAL */
+int conv_c3rows32_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_rows32, hipStream_t stream, const char** name, int flavour)
 {
   C3Geom cg;
   cg.H = g.H; cg.W = g.W; cg.OH = g.OH; cg.OW = g.OW; cg.KH = g.KH; cg.KW = g.KW; cg.sh = g.sh; cg.sw = g.sw;
@@ -665,8 +917,19 @@ int conv_c3rows32_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* 
   cg.inv_pairs = cg.pairs > 1 ? static_cast<uint32_t>(((UINT64_C(1) << 32) + cg.pairs - 1) / cg.pairs) : 0u;
   cg.w_rows16 = w_rows32;
   cg.abl = 0;
-  *name = "q8_conv_c3rows32_mfma";
   const bool two = p.n_pad > 32;
+  C3LdsGeom lg;
+  // (auto: three channel blocks stay on the register-path kernel -- 232 registers leave the LDS flavour two waves per SIMD and nothing
+  //  to run under a workgroup's staging: 224x224 7x7 stride 2, 3 -> 96: 67 against 88 us, profiles/r06/conv7x7_lds_staged_ab_r06v.txt)
+  const bool lds = flavour != 1 && !(flavour == 0 && p.n_pad > 64) && c3lds_plan(p, cg, &lg);
+  if (flavour == 2 && !lds) return QNNP_HIP_EINVAL;
+  if (lds) {
+    *name = "q8_conv_c3rows32_lds_mfma";
+    if (g.KH == 7 && p.n_pad > 64) return launch_c3rows32_lds<3, 7>(p, cg, lg, stream);
+    if (g.KH == 7) return two ? launch_c3rows32_lds<2, 7>(p, cg, lg, stream) : launch_c3rows32_lds<1, 7>(p, cg, lg, stream);
+    return two ? launch_c3rows32_lds<2, 5>(p, cg, lg, stream) : launch_c3rows32_lds<1, 5>(p, cg, lg, stream);
+  }
+  *name = "q8_conv_c3rows32_mfma";
   if (g.KH == 7 && p.n_pad > 64) return launch_c3rows32<3, 7>(p, cg, stream);
   if (g.KH == 7) return two ? launch_c3rows32<2, 7>(p, cg, stream) : launch_c3rows32<1, 7>(p, cg, stream);
   return two ? launch_c3rows32<2, 5>(p, cg, stream) : launch_c3rows32<1, 5>(p, cg, stream);

@@ -682,7 +682,7 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   // (store_mode 1 with channels % 8 == 0: ShuffleNet's 3 -> 24 layer -- the kernel checks the 8-byte alignment it needs itself)
   const bool rows16_ok = pad3 && (p.store_mode == 2 || (p.store_mode == 1 && a->n % 8u == 0)) &&
       qnnp::conv_c3rows_supported(p, geom, a->groups, a->packed_w_rows16, a->kc);
-  if (a->variant == 14 && !rows16_ok && !(pad3 && p.store_mode == 2 && qnnp::conv_c3rows32_supported(p, geom, a->groups, a->packed_w_rows16, a->kc))) return QNNP_HIP_EINVAL;
+  if ((a->variant == 14 || a->variant == 30) && !rows16_ok && !(pad3 && p.store_mode == 2 && qnnp::conv_c3rows32_supported(p, geom, a->groups, a->packed_w_rows16, a->kc))) return QNNP_HIP_EINVAL;
   if (rows16_ok && (a->variant == 14 || (a->variant == 0 && a->rows >= 2048))) {
     const int rc_r16 = qnnp::conv_c3rows_launch(p, geom, a->packed_w_rows16, stream, &name);
     if (kernel_name != nullptr) *kernel_name = name;
@@ -690,8 +690,17 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   }
   // ... and its 32-byte-slot flavour for 5- and 7-row windows (ResNet's 7x7 entry layer); "gemm_kernel" = 14 forces it too
   const bool rows32_ok = pad3 && p.store_mode == 2 && qnnp::conv_c3rows32_supported(p, geom, a->groups, a->packed_w_rows16, a->kc);
-  if (rows32_ok && (a->variant == 14 || (a->variant == 0 && a->rows >= 2048))) {
-    const int rc_r32 = qnnp::conv_c3rows32_launch(p, geom, a->packed_w_rows16, stream, &name);
+  // (30 = its LDS-staged flavour or nothing; 14 = the register-path kernel; auto: the LDS-staged one where its plan takes the shape)
+  if (a->variant == 30 && !rows32_ok) return QNNP_HIP_EINVAL;
+  if (rows32_ok && (a->variant == 14 || a->variant == 30 || (a->variant == 0 && a->rows >= 2048))) {
+    qnnp::IgemmParams p32 = p;
+    if (a->bias2_rows != nullptr) {          // the image is centred on kernel zero point 127: its own bias pair, no row term
+      p32.bias2 = a->bias2_rows;
+      p32.bias2u = a->bias2_rows + a->n_pad;
+      p32.row_coeff = 0;
+      p32.a_flip = 0x7F7F7F7Fu;
+    }
+    const int rc_r32 = qnnp::conv_c3rows32_launch(p32, geom, a->packed_w_rows16, stream, &name, a->variant == 14 ? 1 : (a->variant == 30 ? 2 : 0));
     if (kernel_name != nullptr) *kernel_name = name;
     return rc_r32;
   }

@@ -136,6 +136,8 @@ struct qnnp_hip_igemm_args {
   uint8_t* output;
   const int8_t* packed_w;     /* MFMA-fragment panels, see pack.h */
   const int8_t* packed_w_rows16; /* 3-channel first layers: the row-slot image (pack.h qnnp_pack_conv_rows16), or NULL */
+  const int32_t* bias2_rows;  /* NULL, or: the row-slot image is centred on kernel zero point 127 (element 127 - w; the kernel re-centres the
+                               * activations with ^ 0x7F and needs no row term) and this is its bias pair table [2][n_pad] */
   const int32_t* bias2;       /* [groups][n_pad] */
   const int32_t* offsets;     /* conv: [rows_per_image][ks]; NULL for gemm */
   uint32_t rows;              /* batch * output pixels */

@@ -22,6 +22,7 @@ enum qnnp_status qnnp_delete_operator(qnnp_operator_t op)
   const int token = qnnp_hip_enter(op->device);
   qnnp_hip_free(op->d_weights);
   qnnp_hip_free(op->d_weights_rows16);
+  qnnp_hip_free(op->d_bias_rows);
   qnnp_hip_free(op->d_bias);
   qnnp_hip_free(op->d_weights_centred);
   qnnp_hip_free(op->d_strip);

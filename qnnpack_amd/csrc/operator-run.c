@@ -228,6 +228,7 @@ static int launch_kernel(struct qnnp_operator* op, const void* input, const void
         .output = (uint8_t*) output,
         .packed_w = (const int8_t*) op->d_weights,
         .packed_w_rows16 = is_conv ? (const int8_t*) op->d_weights_rows16 : NULL,
+        .bias2_rows = is_conv ? op->d_bias_rows : NULL,
         .bias2 = op->d_bias,
         .bias2_pair = 1,
         .offsets = is_conv ? op->d_offsets : NULL,

@@ -124,6 +124,8 @@ struct qnnp_operator {
   /* ---- device-side state owned by the operator ---- */
   void* d_weights;        /* igemm: int8 fragment panels; dwconv: int16 [taps][c_pad] */
   void* d_weights_rows16; /* igemm, 3-channel first layers: the [ky][16-byte row slot] fragment image (pack.h), or NULL */
+  int32_t* d_bias_rows;   /* its bias pair table when that image is the zero-point-centred one (32-byte slots, kernel zero point 127:
+                           * pack.h qnnp_pack_conv_rows32_centred127), else NULL: the image goes with d_bias and the row term */
   int32_t* d_bias;        /* igemm: bias2 [groups][n_pad]; dwconv: bias1 [c_pad] */
   uint32_t streaming_mode;  /* streaming-store hint of this operator's launches: 0 = the process default, 1 = off, 2 = on
                              * (qnnp_gfx950_operator_set_streaming_stores) */

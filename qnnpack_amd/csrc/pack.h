@@ -146,6 +146,43 @@ static inline void qnnp_pack_conv_rows32(
   }
 }
 
+/*
+ * The same image centred on kernel zero point 127 (hip/q8convc3.hip with IgemmParams.a_flip = 0x7F7F7F7F): element 127 - w
+ * (= w ^ 0x7F read as int8), the kernel re-centres the activations with the same mask (a ^ 0x7F = 127 - a; padding pixels hold
+ * izp ^ 0x7F), so that
+ *   bias + sum (a - izp)(w - 127) = biasc + sum (127 - a)(127 - w),   biasc[n] = bias[n] + (127 - izp) * sum_k (w(n, k) - 127)
+ * and the per-pixel row term -- a third of the kernel's matrix instructions -- disappears (qnnp_pack_igemm_w_centred127 below is
+ * the same algebra for the GEMM image).
+ */
+static inline void qnnp_pack_conv_rows32_centred127(
+    uint32_t n, uint32_t kh, uint32_t kw, uint32_t kc, uint32_t n_pad, uint8_t izp,
+    const uint8_t* kernel, const int32_t* bias, int8_t* packed /* [n_pad / 32][kh][64][16] */, int32_t* biasc /* [n_pad] */)
+{
+  memset(packed, 0, qnnp_conv_rows32_size(n_pad, kh));
+  const uint32_t a_off = (uint32_t) (127 - (int32_t) izp);
+  for (uint32_t col = 0; col < n_pad; col++) {
+    uint32_t b = 0;
+    if (col < n) {
+      const uint32_t nb = col / 32;
+      const uint32_t lane_lo = col % 32;
+      uint32_t wsum = 0;                                   /* sum (w - 127), mod 2^32 */
+      for (uint32_t ky = 0; ky < kh; ky++) {
+        for (uint32_t kx = 0; kx < kw; kx++) {
+          for (uint32_t c = 0; c < kc; c++) {
+            const int32_t w = (int32_t) kernel[(((size_t) col * kh + ky) * kw + kx) * kc + c];
+            wsum += (uint32_t) (w - 127);
+            const uint32_t kp = kx * kc + c;
+            const uint32_t lane = lane_lo + 32 * (kp / 16);
+            packed[((((size_t) nb * kh + ky) * 64) + lane) * 16 + (kp % 16)] = (int8_t) (127 - w);
+          }
+        }
+      }
+      b = (uint32_t) bias[col] + a_off * wsum;
+    }
+    biasc[col] = (int32_t) b;
+  }
+}
+
 static inline void qnnp_pack_igemm_w(
     uint32_t groups, uint32_t n, uint32_t k_total,
     uint32_t n_pad, uint32_t k_pad,

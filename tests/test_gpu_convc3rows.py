@@ -133,8 +133,73 @@ def test_wide_row_slot_kernel_matches_oracle(rows16, case):
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 
 
+# ---- its LDS-staged flavour (q8_conv_c3rows32_lds_kernel, round 6; "gemm_kernel" = 30): image rows of whole 16-byte chunks
+#      (W % 16 == 0), a band of output-row pairs per workgroup with its input rows -- padding materialised -- in LDS ----
+KERNEL32L = "q8_conv_c3rows32_lds_mfma"
+CASES32L = [
+    ConvCase("l_7x7_s2_resnet_entry", (224, 224), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=64),
+    ConvCase("l_7x7_s2_small", (32, 32), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=64, batch=2),
+    ConvCase("l_7x7_s1", (12, 16), (7, 7), _pad(3, 3), gic=3, goc=64, batch=3),
+    ConvCase("l_7x7_nopad", (12, 16), (7, 7), gic=3, goc=32),
+    ConvCase("l_7x7_pad_right_bottom_only", (10, 16), (7, 7), (0, 6, 6, 0), gic=3, goc=64, batch=2),
+    ConvCase("l_7x7_pad_left_top_only", (10, 16), (7, 7), (6, 0, 0, 6), gic=3, goc=64, batch=2),
+    ConvCase("l_7x7_odd_output_rows", (30, 32), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=64, batch=5),
+    ConvCase("l_7x7_one_output_row", (2, 16), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=32, batch=9),
+    ConvCase("l_7x7_s3", (20, 32), (7, 7), _pad(3, 3), subsampling=(3, 3), gic=3, goc=48),
+    ConvCase("l_7x7_s2x1", (20, 32), (7, 7), _pad(3, 3), subsampling=(2, 1), gic=3, goc=32, batch=2),
+    ConvCase("l_7x10_widest_row", (16, 16), (7, 10), (3, 5, 3, 4), gic=3, goc=32),                     # 30-byte window rows
+    ConvCase("l_7x6_row_of_18", (16, 16), (7, 6), (3, 3, 3, 2), gic=3, goc=16, batch=2),
+    ConvCase("l_7x7_wide_left_pad", (16, 16), (7, 7), (3, 1, 3, 6), gic=3, goc=32, batch=2),           # 18 bytes of left padding: two chunks
+    ConvCase("l_5x5_s1", (14, 16), (5, 5), _pad(2, 2), gic=3, goc=32, batch=2),
+    ConvCase("l_5x5_s2_n64", (28, 32), (5, 5), _pad(2, 2), subsampling=(2, 2), gic=3, goc=64),
+    ConvCase("l_5x3", (12, 16), (5, 3), (2, 1, 2, 1), gic=3, goc=32),
+    ConvCase("l_5x9", (12, 16), (5, 9), (2, 4, 2, 4), gic=3, goc=32),
+    ConvCase("l_7x7_out_stride", (8, 16), (7, 7), _pad(3, 3), gic=3, goc=32, output_pixel_stride=48),
+    ConvCase("l_7x7_zp", (10, 16), (7, 7), _pad(3, 3), gic=3, goc=64, izp=9, kzp=200, batch=2),
+    ConvCase("l_7x7_zp_extremes", (10, 16), (7, 7), _pad(3, 3), gic=3, goc=64, izp=255, kzp=0, batch=2),
+    ConvCase("l_7x7_zp_extremes2", (10, 16), (7, 7), _pad(3, 3), gic=3, goc=64, izp=0, kzp=255, batch=2),
+    ConvCase("l_7x7_kzp128_no_row_term", (10, 16), (7, 7), _pad(3, 3), gic=3, goc=64, kzp=128, batch=2),
+    ConvCase("l_7x7_clamp", (10, 16), (7, 7), _pad(3, 3), gic=3, goc=64, qmin=90, qmax=160, batch=2),
+    ConvCase("l_7x7_many_bands", (96, 48), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=64, batch=24),
+    ConvCase("l_7x7_s1_tall_many_bands", (70, 16), (7, 7), _pad(3, 3), gic=3, goc=32, batch=3),
+    ConvCase("l_7x7_s2_96_channels", (48, 48), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=96, batch=3),
+    ConvCase("l_7x7_80_channels_zp", (10, 16), (7, 7), _pad(3, 3), gic=3, goc=80, izp=9, kzp=200, batch=2),
+    ConvCase("l_7x7_nopad_96", (64, 64), (7, 7), subsampling=(2, 2), gic=3, goc=96, batch=2),
+    ConvCase("l_7x7_widest_image_of_the_plan", (9, 512), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=32),
+]
+
+
+@pytest.fixture()
+def rows32lds(qnnp):
+    qnnp.set_option("gemm_kernel", 30)
+    yield qnnp
+    qnnp.set_option("gemm_kernel", 0)
+
+
+@pytest.mark.parametrize("case", CASES32L, ids=lambda c: c.name)
+def test_lds_staged_wide_row_slot_kernel_matches_oracle(rows32lds, case):
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(rows32lds, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == KERNEL32L, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+def test_lds_staged_flavour_refuses_rows_that_are_not_whole_chunks(rows32lds):
+    """W * 3 % 16 != 0: the staging's 16-byte loads would straddle rows -- forced, the flavour refuses; auto keeps the register-path kernel"""
+    from qnnpack_amd import QnnpackError
+    case = ConvCase("l_bad_w20", (12, 20), (7, 7), _pad(3, 3), gic=3, goc=32)
+    _, quant, out_hw = conv_expected(case)
+    with pytest.raises(QnnpackError):
+        conv_run(rows32lds, case, quant, out_hw, to_device=to_device, from_device=from_device)
+
+
 def test_automatic_dispatch_takes_the_wide_row_slot_kernel_for_a_7x7_entry_layer(qnnp):
     case = ConvCase("w_auto_7x7", (64, 64), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=64, batch=2)
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == KERNEL32L, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} (automatic) vs oracle")
+    case = ConvCase("w_auto_7x7_w40", (64, 40), (7, 7), _pad(3, 3), subsampling=(2, 2), gic=3, goc=64, batch=4)
     expected, quant, out_hw = conv_expected(case)
     out, kname = conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
     assert kname == KERNEL32, kname

@@ -66,7 +66,7 @@ def kernels(tmp_path_factory):
 DEFAULT_PATH = ["q8_gemm_mfma_256x256_c16_kernel", "q8_gemm_mfma_128xN_c16_kernel", "q8_gemm_mfma_128xN_u16_kernel", "q8_conv_wave_ws16_kernel", "q8_gemm_mfma_256x256_c_kernel", "q8_gemm_mfma_256x256_kernelILb0ELi4E", "q8_gemm_mfma_256x256_kernelILb1ELi4E", "q8_pw_stream_staged_kernel", "q8_pw_stream_longk_kernel",
                 "q8_pw_stream_gw_kernel", "q8_pw_stream_gwk_kernel", "q8_conv_stream_c3s_kernel",
                 "q8_dwconv_col3x3_kernel", "q8_conv_wave_reg_kernel", "q8_conv_wave_ws_kernel", "q8_conv_lds_mfma", "q8_vadd", "q8_gavgpool",
-                "q8_conv_patch_kernel", "q8_conv_c3rows32_kernel"]
+                "q8_conv_patch_kernel", "q8_conv_c3rows32_kernel", "q8_conv_c3rows32_lds_kernel"]
 
 
 def test_default_path_kernels_do_not_spill(kernels):
@@ -96,6 +96,8 @@ def test_default_path_kernels_do_not_spill(kernels):
     ("20q8_conv_patch_kernelILi8ELi4E", 128, "patch kernel, 256 positions x 128 channels: TWO 8-wave workgroups per CU (4 waves per SIMD)"),
     ("20q8_conv_patch_kernelILi4ELi8E", 256, "patch kernel, 128 positions x 256 channels: 2 waves per SIMD"),
     ("23q8_conv_c3rows32_kernel", 256, "7x7 / 5x5 first-layer kernel: 2 waves per SIMD"),
+    ("27q8_conv_c3rows32_lds_kernelILi2E", 168, "its LDS-staged flavour, 64 channels: 3 waves per SIMD (one workgroup's staging runs under two others' units)"),
+    ("27q8_conv_c3rows32_lds_kernelILi1E", 168, "... 32 channels"),
 ])
 def test_register_budgets_of_the_occupancy_critical_kernels(kernels, fragment, max_vgpr, why):
     hits = {n: k for n, k in kernels.items() if fragment in n}
@@ -162,6 +164,7 @@ def test_streaming_store_flavours_survive_the_compiler(tmp_path):
     want = {"q8_pw_stream_staged_kernel": 0, "q8_pw_stream_longk_kernel": 0, "q8_vadd_flat_kernel": 0,
             "q8_gemm_mfma_256x256_kernelILb0ELi4ELi256ELi0ELb0ELb1E": 0,
             "q8_dwconv_col3x3_kernel": 0, "q8_dwconv_col5x5_kernel": 0, "q8_conv_c3rows_kernel": 0, "q8_conv_c3rows32_kernel": 0,
+            "q8_conv_c3rows32_lds_kernel": 0,
             "q8_conv_wave_ws_kernelILi2ELi2E": 0,        # (round 5: whole-line stores of the 64 -> 64 weight-stationary 3x3 kernel)
             "q8_gemm_mfma_256x256_c_kernel": 0}
     for k, elf in enumerate(_code_objects(blob)):
