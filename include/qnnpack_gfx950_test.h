@@ -39,7 +39,10 @@ extern "C" {
  *                    takes its 16x16x64 flavour since round 6), 28 = the 16x16x64 GEMM with kernel-zero-point row sums (any kernel
  *                    zero point; what auto picks where 15 ran before),
  *                    29 = the 128-row GEMM for 1x1 / fully-connected shapes with NO alignment (hip/q8gemm128u.hip: grouped, odd channel
- *                    counts, unaligned pixels; what auto picks where 1 ran for them).
+ *                    counts, unaligned pixels; what auto picks where 1 ran for them),
+ *                    30 = the LDS-staged flavour of the 7x7 / 5x5 first-layer kernel (hip/q8convc3.hip; 14 keeps the register-path one),
+ *                    31 = grouped 1x1 convolutions as ONE dense GEMM (block-diagonal weights, the kernel zero point off the diagonal:
+ *                    convolution.c; auto takes it from 65536 rows up; the dense problem's kernel is chosen automatically).
  *   "fused_kernel":  fused inverted-residual blocks: 0 = auto (the strip kernel, hip/q8fusedstrip.hip, where it takes the
  *                    block -- kernel zero points 127 / 128 in all three members -- else the tile kernel of rounds 1-3),
  *                    1 = the tile kernel only, 2 = the strip kernel only (unsupported_parameter at setup otherwise)
@@ -56,6 +59,9 @@ extern "C" {
  *                    (1 keeps the byte-per-thread direct kernel; auto takes its four-channel flavour for C >= 4)
  * Unknown family or code -> invalid_parameter. 0 = the automatic choice, always. */
 enum qnnp_status qnnp_gfx950_test_force_kernel(const char* family, int code);
+
+/* 1: the operator's last run took the dense image of a grouped 1x1 convolution ("gemm_kernel" 31 / its automatic rule) */
+int qnnp_gfx950_test_operator_ran_dense(qnnp_operator_t op);
 
 #ifdef __cplusplus
 }

@@ -329,6 +329,8 @@ class Gfx950Library(QnnpackLibrary):
         L.qnnp_gfx950_set_option.argtypes = [c_char_p, c_int]
         L.qnnp_gfx950_test_force_kernel.restype = c_int           # include/qnnpack_gfx950_test.h
         L.qnnp_gfx950_test_force_kernel.argtypes = [c_char_p, c_int]
+        L.qnnp_gfx950_test_operator_ran_dense.restype = c_int
+        L.qnnp_gfx950_test_operator_ran_dense.argtypes = [c_void_p]
         L.qnnp_gfx950_operator_set_streaming_stores.restype = c_int
         L.qnnp_gfx950_operator_set_streaming_stores.argtypes = [c_void_p, c_int]
         L.qnnp_gfx950_operator_kernel.restype = c_char_p
@@ -463,6 +465,10 @@ class Gfx950Library(QnnpackLibrary):
     def operator_set_streaming_stores(self, op, value: int) -> None:
         """1 / 0: the streaming-store hint of this operator's launches; -1: follow the process-wide option again."""
         self._check("qnnp_gfx950_operator_set_streaming_stores", self.lib.qnnp_gfx950_operator_set_streaming_stores(op, value))
+
+    def operator_ran_dense(self, op) -> bool:
+        """include/qnnpack_gfx950_test.h: the operator's last run took the dense image of a grouped 1x1 convolution"""
+        return bool(self.lib.qnnp_gfx950_test_operator_ran_dense(op))
 
     def operator_kernel(self, op) -> Optional[str]:
         name = self.lib.qnnp_gfx950_operator_kernel(op)

@@ -273,6 +273,52 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
       qnnp_log_error("device allocation or upload failed: %zu bytes of packed weights on the device", w_bytes + 2 * b_bytes);
       goto error;
     }
+    /* Grouped 1x1 as one dense GEMM (round 6). A group of 12 ... 68 channels fills a fifth ... a half of a 64-byte K step and a
+     * 128-channel tile, every group's tile stages its own copy of the rows, and its output pieces are 12 ... 68 bytes; the dense
+     * [groups * GOC][groups * GIC] matrix with the groups' blocks on its diagonal and the KERNEL ZERO POINT everywhere else
+     * ((w - kzp) = 0: the grouped result bit for bit) reads every input byte once and writes whole pixels, at `groups` times the
+     * multiplies -- which these layers do not notice: ShuffleNet v1's 28x28 layers at batch 128 run 15 ... 59 us grouped and 12 ... 27
+     * dense (profiles/r06/grouped_1x1_dense_equivalents_r06v.txt); from 14x14 down the two are level or the grouped form leads, so
+     * operator-run.c takes this image from 65536 rows up. Built for up to 1024 channels on either side (<= 1 MiB of weights). */
+    if (ukernel_type == qnnp_ukernel_type_gemm && groups > 1 && (size_t) groups * group_input_channels <= 1024 &&
+        (size_t) groups * group_output_channels <= 1024) {
+      const uint32_t cin = (uint32_t) (groups * group_input_channels), cout = (uint32_t) (groups * group_output_channels);
+      const uint32_t n_pad_d = qnnp_round_up_u32(cout, 32), k_pad_d = qnnp_round_up_u32(cin, 64);
+      const size_t wd_bytes = qnnp_igemm_packed_weights_size(1, n_pad_d, k_pad_d);
+      uint8_t* dense = (uint8_t*) malloc((size_t) cout * cin);
+      int8_t* host_wd = (int8_t*) malloc(wd_bytes);
+      int32_t* host_bd = (int32_t*) malloc(sizeof(int32_t) * n_pad_d);
+      int placed = dense != NULL && host_wd != NULL && host_bd != NULL;
+      if (placed) {
+        memset(dense, kernel_zero_point, (size_t) cout * cin);
+        for (uint32_t g = 0; g < groups; g++) {
+          for (uint32_t oc = 0; oc < group_output_channels; oc++) {
+            memcpy(dense + ((size_t) g * group_output_channels + oc) * cin + (size_t) g * group_input_channels,
+                   kernel + ((size_t) g * group_output_channels + oc) * group_input_channels, group_input_channels);
+          }
+        }
+        qnnp_pack_igemm_w_slots(1, cout, 1, cin, cin, n_pad_d, k_pad_d, input_zero_point, kernel_zero_point, dense, bias,
+            host_wd, host_bd);
+        op->d_weights_dense = qnnp_hip_alloc(wd_bytes);
+        op->d_bias_dense = qnnp_upload_bias_pair(host_bd, n_pad_d);
+        placed = op->d_weights_dense != NULL && op->d_bias_dense != NULL &&
+            qnnp_hip_h2d(op->d_weights_dense, host_wd, wd_bytes, 0) == QNNP_HIP_OK;
+      }
+      free(dense);
+      free(host_wd);
+      free(host_bd);
+      if (placed) {
+        op->dense_n_pad = n_pad_d;
+        op->dense_k_pad = k_pad_d;
+      } else {
+        /* an optimisation, not a requirement: the operator keeps its grouped image */
+        qnnp_log_warning("no room for %zu bytes of dense weights on the device: the operator keeps the grouped image", wd_bytes);
+        qnnp_hip_free(op->d_weights_dense);
+        qnnp_hip_free(op->d_bias_dense);
+        op->d_weights_dense = NULL;
+        op->d_bias_dense = NULL;
+      }
+    }
     /* Zero-point-centred image (pack.h qnnp_pack_igemm_w_centred127; hip/q8gemm256c.hip, the weight-stationary 3x3
      * kernel of hip/q8convwave.hip): single group, whole 32-deep K blocks, kernel zero point 128 (the standard image IS the centred
      * one) or 127 (a second image + bias pair). The [output channel][kh][kw][input channel] kernel tensor is the GEMM

@@ -72,10 +72,14 @@ __device__ __forceinline__ uint32_t a_swizzle(uint32_t row) { return (row & 8u) 
 
 #define QNNP_PIN() __builtin_amdgcn_sched_barrier(0)
 
-/* DWORD_OUT: every row's channel run of the group starts dword-aligned and N % 4 == 0: one dword store per lane and tile.
+/* OUT: 2 = every row's channel run of the group starts dword-aligned and N % 4 == 0; 1 = the same for 2 bytes (58 / 122 channels); 0 = no
+ * alignment at all. 2 and 1 transpose the requantized dwords over the four lanes of a row (v_permlane32_swap / v_permlane16_swap) so that
+ * a lane holds SIXTEEN consecutive channels of its row and writes them with one 16-byte store (2; rows of 2 mod 4: a short, three dwords
+ * shifted by v_alignbyte, a short) -- 16 TN contiguous bytes per row and instruction instead of 16-byte pieces (one dword per lane and
+ * tile, the first build) or single bytes; 0 keeps the byte stores.
  * TN: 16-channel MFMA tiles per wave: 4 / 2 / 1 = 128- / 64- / 32-channel workgroup tiles (groups of 12 ... 62 channels would leave
  * most of a wide tile empty: ShuffleNet v1's 8 groups of 48 -> 12). */
-template <int SEQ, int CLAMP, bool DWORD_OUT, int TN>
+template <int SEQ, int CLAMP, int OUT, int TN>
 __global__ __launch_bounds__(kThreads, 2)
 void q8_gemm_mfma_128xN_u16_kernel(const IgemmParams p)
 {
@@ -251,6 +255,15 @@ void q8_gemm_mfma_128xN_u16_kernel(const IgemmParams p)
   const uint32_t out_group = g * p.n;
   const int32_t row_coeff = p.row_coeff;
   const int32_t staged = static_cast<int32_t>(128u * ktiles * kBK);          // sum over the staged bytes of 128
+  auto transpose4 = [&](uint32_t (&q)[4]) __attribute__((always_inline)) {
+    const auto s02 = __builtin_amdgcn_permlane32_swap(q[0], q[2], false, false);
+    const auto s13 = __builtin_amdgcn_permlane32_swap(q[1], q[3], false, false);
+    const auto lo = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+    q[0] = lo[0]; q[1] = lo[1]; q[2] = hi[0]; q[3] = hi[1];
+  };
+  typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
+  typedef int v3i_a4 __attribute__((ext_vector_type(3), aligned(4)));
 #pragma unroll
   for (int tm = 0; tm < kTM; tm++) {
     const uint32_t r = tm * 16 + frow;
@@ -258,19 +271,53 @@ void q8_gemm_mfma_128xN_u16_kernel(const IgemmParams p)
     const uint32_t term = static_cast<uint32_t>(row_coeff) * static_cast<uint32_t>(s2.x + s2.y - staged);
     const bool row_ok = m0 + r < p.rows;
     uint8_t* out_row = p.output + static_cast<uint64_t>(m0 + r) * p.output_stride + out_group;
+    uint32_t q[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int tn = 0; tn < kTN; tn++) {
-      const uint32_t q = q31_requantize_pack4_clamp<SEQ, CLAMP>(
+      q[tn] = q31_requantize_pack4_clamp<SEQ, CLAMP>(
           static_cast<int>(static_cast<uint32_t>(acc[tm][tn][0]) + term), static_cast<int>(static_cast<uint32_t>(acc[tm][tn][1]) + term),
           static_cast<int>(static_cast<uint32_t>(acc[tm][tn][2]) + term), static_cast<int>(static_cast<uint32_t>(acc[tm][tn][3]) + term), p.rq);
-      const uint32_t n = n0 + tn * 16 + fg * 4;
+    }
+    if constexpr (OUT == 0 || (OUT == 2 && kTN == 1)) {
       if (!row_ok) continue;
-      if constexpr (DWORD_OUT) {
-        if (n < p.n) *reinterpret_cast<uint32_t*>(out_row + n) = q;
-      } else {
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-          if (n + b < p.n) out_row[n + b] = static_cast<uint8_t>(q >> (8 * b));
+      for (int tn = 0; tn < kTN; tn++) {
+        const uint32_t n = n0 + tn * 16 + fg * 4;
+        if constexpr (OUT == 2) {
+          if (n < p.n) *reinterpret_cast<uint32_t*>(out_row + n) = q[tn];
+        } else {
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            if (n + b < p.n) out_row[n + b] = static_cast<uint8_t>(q[tn] >> (8 * b));
+          }
+        }
+      }
+    } else {
+      transpose4(q);               // lane (row, g): channels 16 g .. 16 g + 15 of its row within the wave's 16 TN (g < TN)
+      const uint32_t n = n0 + fg * 16;
+      if (!row_ok || fg >= static_cast<uint32_t>(kTN) || n >= p.n) continue;
+      uint8_t* dst = out_row + n;
+      if (n + 16 <= p.n) {
+        if (OUT == 2 || (reinterpret_cast<uintptr_t>(dst) & 2u) == 0) {
+          *reinterpret_cast<v4i_a4*>(dst) = v4i_a4{static_cast<int>(q[0]), static_cast<int>(q[1]), static_cast<int>(q[2]), static_cast<int>(q[3])};
+        } else {
+          *reinterpret_cast<uint16_t*>(dst) = static_cast<uint16_t>(q[0]);
+          *reinterpret_cast<v3i_a4*>(dst + 2) = v3i_a4{static_cast<int>(__builtin_amdgcn_alignbyte(q[1], q[0], 2)),
+                                                       static_cast<int>(__builtin_amdgcn_alignbyte(q[2], q[1], 2)),
+                                                       static_cast<int>(__builtin_amdgcn_alignbyte(q[3], q[2], 2))};
+          *reinterpret_cast<uint16_t*>(dst + 14) = static_cast<uint16_t>(q[3] >> 16);
+        }
+      } else {                     // the group's last channels: what is left of the piece, dword by dword (2) or byte by byte
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          if constexpr (OUT == 2) {
+            if (n + 4 * d < p.n) *reinterpret_cast<uint32_t*>(dst + 4 * d) = q[d];
+          } else {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+              if (n + 4 * d + b < p.n) dst[4 * d + b] = static_cast<uint8_t>(q[d] >> (8 * b));
+            }
+          }
         }
       }
     }
@@ -303,12 +350,14 @@ int launch_u(const IgemmParams& p, uint32_t groups, hipStream_t stream)
   IgemmParams pm = p;
   pm.tiles_n_magic = tiles_n == 1 ? 0u : static_cast<uint32_t>((1ull << 32) / tiles_n) + 1u;
   const bool dword_out = p.n % 4 == 0 && p.output_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(p.output) & 3u) == 0;
+  const bool even_out = p.n % 2 == 0 && p.output_stride % 2 == 0 && (reinterpret_cast<uintptr_t>(p.output) & 1u) == 0;
   int rc = QNNP_HIP_EINVAL;
   auto launch = [&](auto seq, auto clamp) {
     constexpr int kSeq = decltype(seq)::value;
     constexpr int kClamp = decltype(clamp)::value;
-    if (dword_out) hipLaunchKernelGGL((q8_gemm_mfma_128xN_u16_kernel<kSeq, kClamp, true, TN>), grid, dim3(kThreads), 0, stream, pm);
-    else hipLaunchKernelGGL((q8_gemm_mfma_128xN_u16_kernel<kSeq, kClamp, false, TN>), grid, dim3(kThreads), 0, stream, pm);
+    if (dword_out) hipLaunchKernelGGL((q8_gemm_mfma_128xN_u16_kernel<kSeq, kClamp, 2, TN>), grid, dim3(kThreads), 0, stream, pm);
+    else if (even_out) hipLaunchKernelGGL((q8_gemm_mfma_128xN_u16_kernel<kSeq, kClamp, 1, TN>), grid, dim3(kThreads), 0, stream, pm);
+    else hipLaunchKernelGGL((q8_gemm_mfma_128xN_u16_kernel<kSeq, kClamp, 0, TN>), grid, dim3(kThreads), 0, stream, pm);
     rc = hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
   };
   using C0 = std::integral_constant<int, 0>;

@@ -739,7 +739,10 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   if (a->variant == 0 && mid_ok && a->offsets != nullptr && a->rows <= 32768u && a->k_total >= 128u && a->k_total <= 256u && a->rows >= 2048u) return launch_mid();
   // (round 6: pointwise layers whose channel count forces BYTE stores on the streaming kernel -- ShuffleNet v2's 24 -> 58 / 122 at 56 x 56:
   //  56.3 / 122.1 us -- run on the register-staged 128-row GEMM instead: 36.3 / 78.6 us, profiles/r06/ugemm_by_forced_kernel_r06p.txt)
-  if (a->variant == 0 && !pad3 && p.store_mode == 0 && a->rows >= 2048u && p.d2s_sh == 0 && qnnp::gemm128u_supported(p)) {
+  // (... and, with the transposed 16-byte stores of that kernel, the dword-store shapes with more than 32 channels: 56 x 56 24 -> 60 / 68
+  //  20.9 / 24.5 -> 17.1 / 22.4 us; 24 -> 24 stays, 7.1 against 9.7: profiles/r06/ugemm_transposed_stores_r06v.txt)
+  if (a->variant == 0 && !pad3 && (p.store_mode == 0 || (p.store_mode == 1 && a->n > 32u)) && a->rows >= 2048u && p.d2s_sh == 0 &&
+      a->residual == nullptr && qnnp::gemm128u_supported(p)) {
     const int rc_u = qnnp::gemm128u_launch(p, a->groups, stream, &name, 0u);
     if (kernel_name != nullptr) *kernel_name = name;
     return rc_u;
@@ -748,6 +751,16 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   const bool pw_ok = !pad3 && qnnp::pwstream_supported(p, a->groups, vec) && (p.d2s_sh == 0 || vec == 16);
   if ((a->variant == 5 || p.d2s_sh != 0) && !pw_ok) return QNNP_HIP_EINVAL;   /* depth-to-space exists in this kernel only */
   if (p.d2s_sh != 0 && a->variant != 5) return QNNP_HIP_EINVAL;
+  // (round 6: few rows x many channels -- ShuffleNet's last 1x1, 7x7 192 -> 1024 at 6 k rows: the streaming kernel runs one chain per
+  //  wave, 8.3 us; the 128-row GEMMs 6.0 (centred image) / 6.8 us (standard image): profiles/r06/ugemm_transposed_stores_r06v.txt)
+  const bool few_rows_wide = a->variant == 0 && !pad3 && a->rows >= 2048u && a->rows <= 8192u && a->n >= 512u && a->k_total >= 192u &&
+      p.d2s_sh == 0 && a->residual == nullptr && a->offsets == nullptr;
+  if (few_rows_wide && pw_ok && mid_ok) return launch_mid();
+  if (few_rows_wide && pw_ok && qnnp::gemm128u_supported(p)) {
+    const int rc_u = qnnp::gemm128u_launch(p, a->groups, stream, &name, 0u);
+    if (kernel_name != nullptr) *kernel_name = name;
+    return rc_u;
+  }
   if (pw_ok && (a->variant == 5 || (a->variant == 0 && a->rows >= 2048))) {
     const int rc_pw = qnnp::pwstream_launch(p, vec, stream, &name);
     if (kernel_name != nullptr) *kernel_name = name;
@@ -777,6 +790,12 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   // (round 6: what the long-K kernel took automatically goes to the 128-row centred GEMM where that exists -- MobileNetV2's 14x14 project
   //  layers 7.2 -> 5.6, 8.1 -> 6.2, 9.7 -> 7.3 us, 7x7x320 -> 1280 12.4 -> 7.9, ResNet-50's 28x28 512 -> 128 32.6 -> 21.2)
   if (a->variant == 0 && lk_ok && lk_auto && mid_ok && a->rows >= 2048u) return launch_mid();
+  // (... and without a centred image -- K = 464: ShuffleNet v2 x1.0's 7x7 464 -> 1024 -- to the register-staged one: 13.5 -> 10.7 us)
+  if (few_rows_wide && lk_ok && lk_auto && qnnp::gemm128u_supported(p)) {
+    const int rc_u = qnnp::gemm128u_launch(p, a->groups, stream, &name, 0u);
+    if (kernel_name != nullptr) *kernel_name = name;
+    return rc_u;
+  }
   if (lk_ok && (a->variant == 9 || (a->variant == 0 && lk_auto))) {
     const int rc_lk = qnnp::pwstream_longk_launch(p, stream, &name);
     if (kernel_name != nullptr) *kernel_name = name;

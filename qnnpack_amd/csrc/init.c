@@ -185,7 +185,7 @@ enum qnnp_status qnnp_gfx950_set_option(const char* key, int value)
 enum qnnp_status qnnp_gfx950_test_force_kernel(const char* key, int value)
 {
   if (key == NULL) return qnnp_status_invalid_parameter;
-  if (strcmp(key, "gemm_kernel") == 0 && value >= 0 && value <= 30 && !(value >= 17 && value <= 19)) {
+  if (strcmp(key, "gemm_kernel") == 0 && value >= 0 && value <= 31 && !(value >= 17 && value <= 19)) {
     qnnp_state.opt_gemm_kernel = value;
     return qnnp_status_success;
   }
@@ -206,6 +206,12 @@ enum qnnp_status qnnp_gfx950_test_force_kernel(const char* key, int value)
     return qnnp_status_success;
   }
   return qnnp_status_invalid_parameter;
+}
+
+/* include/qnnpack_gfx950_test.h */
+int qnnp_gfx950_test_operator_ran_dense(qnnp_operator_t op)
+{
+  return op != NULL && op->ran_dense != 0;
 }
 
 enum qnnp_status qnnp_gfx950_operator_set_streaming_stores(qnnp_operator_t op, int value)

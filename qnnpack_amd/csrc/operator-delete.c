@@ -23,6 +23,8 @@ enum qnnp_status qnnp_delete_operator(qnnp_operator_t op)
   qnnp_hip_free(op->d_weights);
   qnnp_hip_free(op->d_weights_rows16);
   qnnp_hip_free(op->d_bias_rows);
+  qnnp_hip_free(op->d_weights_dense);
+  qnnp_hip_free(op->d_bias_dense);
   qnnp_hip_free(op->d_bias);
   qnnp_hip_free(op->d_weights_centred);
   qnnp_hip_free(op->d_strip);

@@ -272,6 +272,30 @@ static int launch_kernel(struct qnnp_operator* op, const void* input, const void
         .centre_flip = op->centre_flip,
         .streaming_mode = op->streaming_mode,
       };
+      /* grouped 1x1 with a dense image (convolution.c): many rows -> the dense GEMM; "gemm_kernel" 31 forces it, any other
+       * forced kernel keeps the grouped image */
+      op->ran_dense = 0;
+      if (op->variant == 31 && op->d_weights_dense == NULL) return QNNP_HIP_EINVAL;
+      if (op->d_weights_dense != NULL && op->residual == NULL &&
+          (op->variant == 31 || (op->variant == 0 && (uint64_t) op->batch_size * output_size >= 65536u))) {
+        struct qnnp_hip_igemm_args dargs = args;
+        dargs.packed_w = (const int8_t*) op->d_weights_dense;
+        dargs.bias2 = op->d_bias_dense;
+        dargs.groups = 1;
+        dargs.n = (uint32_t) (op->groups * op->group_output_channels);
+        dargs.n_pad = op->dense_n_pad;
+        dargs.kc = (uint32_t) (op->groups * op->group_input_channels);
+        dargs.kc_slot = dargs.kc;
+        dargs.k_total = dargs.kc;
+        dargs.k_pad = op->dense_k_pad;
+        dargs.variant = 0;
+        dargs.packed_w_centred = dargs.packed_w;
+        dargs.bias2_centred = dargs.bias2;
+        dargs.centre_flip = 0;
+        op->ran_dense = 1;
+        return qnnp_hip_igemm_run(&dargs, &op->kernel_name);
+      }
+      if (op->variant == 31) return QNNP_HIP_EINVAL;
       return qnnp_hip_igemm_run(&args, &op->kernel_name);
     }
     case qnnp_ukernel_type_fused_block:

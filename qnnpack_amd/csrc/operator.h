@@ -124,6 +124,13 @@ struct qnnp_operator {
   /* ---- device-side state owned by the operator ---- */
   void* d_weights;        /* igemm: int8 fragment panels; dwconv: int16 [taps][c_pad] */
   void* d_weights_rows16; /* igemm, 3-channel first layers: the [ky][16-byte row slot] fragment image (pack.h), or NULL */
+  /* grouped 1x1 convolutions (ukernel gemm, groups > 1): the same operator as ONE dense GEMM -- the groups' weight blocks on the diagonal of
+   * a [groups * output channels][groups * input channels] matrix whose other elements are the kernel zero point (w - kzp = 0: bit for
+   * bit the grouped result) -- packed like any single-group image; operator-run.c takes it for many rows (convolution.c) */
+  void* d_weights_dense;
+  int32_t* d_bias_dense;  /* bias pair table [2][dense_n_pad] */
+  uint32_t dense_n_pad, dense_k_pad;
+  uint32_t ran_dense;     /* 1: the last run took the dense image (include/qnnpack_gfx950_test.h) */
   int32_t* d_bias_rows;   /* its bias pair table when that image is the zero-point-centred one (32-byte slots, kernel zero point 127:
                            * pack.h qnnp_pack_conv_rows32_centred127), else NULL: the image goes with d_bias and the row term */
   int32_t* d_bias;        /* igemm: bias2 [groups][n_pad]; dwconv: bias1 [c_pad] */
