@@ -56,7 +56,10 @@ extern "C" {
  *                    6 = column-sliding register window (3x3, stride 1 | 2): tap pairs shared between output rows,
  *                    7 = matrix-core kernel on v_mfma_i32_16x16x64_i8 without data transposition (3x3, stride 1, channels % 16 == 0;
  *                        a negative result kept for its A/B: slower than 6 on every layer)
- *                    (1 keeps the byte-per-thread direct kernel; auto takes its four-channel flavour for C >= 4)
+ *                    8 = the register sliding-window kernel (3) on UNALIGNED dwords: 3x3 windows, any channel count >= 4, any pixel
+ *                        stride / base address (what auto picks where nothing aligned takes the shape), 9 = the four-channel generic
+ *                        kernel kept for such shapes (A/B)
+ *                    (1 keeps the byte-per-thread direct kernel; auto takes its four-channel flavour for C >= 4 and windows other than 3x3)
  * Unknown family or code -> invalid_parameter. 0 = the automatic choice, always. */
 enum qnnp_status qnnp_gfx950_test_force_kernel(const char* family, int code);
 

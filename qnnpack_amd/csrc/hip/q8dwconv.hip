@@ -415,13 +415,25 @@ void q8_dwconv_lds_kernel(const DwParams p)
  */
 constexpr int kRowThreads = 256;
 
-template <int SW>
+/* UNAL (round 6): any channel count >= 4 and pixels / tensors of any alignment -- ShuffleNet v2's 58 / 122 / 244 / 488-channel depthwise
+ * layers (bench/convolution.cc:338-426), which ran on the generic q8_dwconv_direct4 at 0.05-0.13 of their bound. A pixel's channels are
+ * cut into (C + 3) / 4 groups of four, the last one starting at C - 4 (it recomputes up to three channels of its neighbour: the same
+ * bytes, written twice); every load and store is a dword at whatever address it falls on (the hardware takes unaligned dwords from
+ * global memory; the weight and bias tables are read the same way), everything else is the kernel's. */
+template <typename T>
+struct __attribute__((packed)) DwAnyAligned { T v; };
+template <typename T>
+__device__ __forceinline__ T dw_load_any(const void* ptr) { return reinterpret_cast<const DwAnyAligned<T>*>(ptr)->v; }
+template <typename T>
+__device__ __forceinline__ void dw_store_any(void* ptr, T v) { reinterpret_cast<DwAnyAligned<T>*>(ptr)->v = v; }
+
+template <int SW, bool UNAL = false>
 __global__ __launch_bounds__(kRowThreads)
 void q8_dwconv_row3x3_kernel(const DwParams p)
 {
   constexpr int PAIRS = 5;
   QNNP_DW_TRACE(p, 0);
-  const uint32_t q4 = p.C / 4;
+  const uint32_t q4 = UNAL ? (p.C + 3u) / 4u : p.C / 4;
   const uint32_t t = blockIdx.x * kRowThreads + threadIdx.x;       // host checked: fits 32 bits
   const uint32_t c4 = t % q4;
   uint32_t r = t / q4;
@@ -430,23 +442,23 @@ void q8_dwconv_row3x3_kernel(const DwParams p)
   const uint32_t n = r / p.slabs;
   const bool live = n < p.batch;
   const uint32_t nn = live ? n : 0u;
-  const uint32_t cg = c4 * 4;
+  const uint32_t cg = UNAL ? min(c4 * 4u, p.C - 4u) : c4 * 4;
 
   // tap weights as (tap 2i, tap 2i+1) int16 pairs, bias
   uint32_t wpair[PAIRS][4];
   int32_t bias[4];
 #pragma unroll
   for (int i = 0; i < PAIRS; i++) {
-    const uint2 lo = *reinterpret_cast<const uint2*>(p.wadj + (2 * i) * p.c_pad + cg);   // 4 x int16
+    const uint2 lo = dw_load_any<uint2>(p.wadj + (2 * i) * p.c_pad + cg);   // 4 x int16
     uint2 hi = make_uint2(0u, 0u);
-    if (2 * i + 1 < 9) hi = *reinterpret_cast<const uint2*>(p.wadj + (2 * i + 1) * p.c_pad + cg);
+    if (2 * i + 1 < 9) hi = dw_load_any<uint2>(p.wadj + (2 * i + 1) * p.c_pad + cg);
     wpair[i][0] = (lo.x & 0xFFFFu) | (hi.x << 16);
     wpair[i][1] = (lo.x >> 16) | (hi.x & 0xFFFF0000u);
     wpair[i][2] = (lo.y & 0xFFFFu) | (hi.y << 16);
     wpair[i][3] = (lo.y >> 16) | (hi.y & 0xFFFF0000u);
   }
   {
-    const int4 bv = *reinterpret_cast<const int4*>(p.bias1 + cg);
+    const int4 bv = dw_load_any<int4>(p.bias1 + cg);
     bias[0] = bv.x; bias[1] = bv.y; bias[2] = bv.z; bias[3] = bv.w;
   }
 
@@ -476,14 +488,14 @@ void q8_dwconv_row3x3_kernel(const DwParams p)
       const uint32_t coff = (col_ok ? static_cast<uint32_t>(ix) : 0u) * p.in_stride;
 #pragma unroll
       for (int ky = 0; ky < 3; ky++) {
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(p.input + (voff[ky] + coff));
+        const uint32_t v = dw_load_any<uint32_t>(p.input + (voff[ky] + coff));
         col[ky] = (col_ok && row_ok[ky]) ? v : fill;
       }
     } else {
       const uint32_t coff = static_cast<uint32_t>(ix) * p.in_stride;
 #pragma unroll
       for (int ky = 0; ky < 3; ky++) {
-        col[ky] = *reinterpret_cast<const uint32_t*>(p.input + (voff[ky] + coff));
+        col[ky] = dw_load_any<uint32_t>(p.input + (voff[ky] + coff));
       }
     }
   };
@@ -535,7 +547,7 @@ void q8_dwconv_row3x3_kernel(const DwParams p)
       }
       const uint32_t packed = qnnp::q31_requantize_pack4<decltype(shift0)::value, decltype(full)::value>(
           acc0, acc1, acc2, acc3, p.rq);
-      *reinterpret_cast<uint32_t*>(out_ptr) = packed;
+      dw_store_any<uint32_t>(out_ptr, packed);
       out_ptr += p.out_stride;
       // slide the window by SW columns (register renaming once the loop is unrolled)
 #pragma unroll
@@ -552,9 +564,9 @@ void q8_dwconv_row3x3_kernel(const DwParams p)
 }
 
 // geometry of kernel C: `slabs` = column segments per output row, `TOH` = outputs per segment
-bool plan_row(DwParams& p)
+bool plan_row(DwParams& p, bool unaligned = false)
 {
-  if (p.C % 4 != 0 || p.KH != 3 || p.KW != 3 || p.dh != 1 || p.dw != 1) return false;
+  if ((unaligned ? p.C < 4 : p.C % 4 != 0) || p.KH != 3 || p.KW != 3 || p.dh != 1 || p.dw != 1) return false;
   if (p.sh != p.sw || (p.sw != 1 && p.sw != 2)) return false;
   if (p.pad_left > 2 || p.pad_top > 2) return false;
   // 32-bit input offsets
@@ -567,7 +579,7 @@ bool plan_row(DwParams& p)
 #ifdef QNNP_ENABLE_ABLATION
   if (const char* env = getenv("QNNP_DW_ROW_WAVES")) waves = static_cast<uint32_t>(atoi(env));
 #endif
-  const uint64_t base_threads = static_cast<uint64_t>(p.batch) * p.OH * (p.C / 4);
+  const uint64_t base_threads = static_cast<uint64_t>(p.batch) * p.OH * ((p.C + 3u) / 4u);
   const uint64_t target = static_cast<uint64_t>(p.cu_count) * 4u * waves * 64u;
   uint32_t segs = static_cast<uint32_t>((target + base_threads - 1) / base_threads);
   const uint32_t max_segs = p.OW >= 8 ? p.OW / 8 : 1u;
@@ -578,11 +590,16 @@ bool plan_row(DwParams& p)
   return true;
 }
 
-int launch_row(const DwParams& p, hipStream_t stream)
+int launch_row(const DwParams& p, hipStream_t stream, bool unaligned = false)
 {
-  const uint64_t threads = static_cast<uint64_t>(p.batch) * p.slabs * p.OH * (p.C / 4);
+  const uint64_t threads = static_cast<uint64_t>(p.batch) * p.slabs * p.OH * ((p.C + 3u) / 4u);
   const uint64_t blocks = (threads + kRowThreads - 1) / kRowThreads;
   if (blocks * kRowThreads > 0xFFFFFFFFull) return QNNP_HIP_EINVAL;
+  if (unaligned) {
+    if (p.sw == 1) hipLaunchKernelGGL((q8_dwconv_row3x3_kernel<1, true>), dim3(static_cast<uint32_t>(blocks)), dim3(kRowThreads), 0, stream, p);
+    else hipLaunchKernelGGL((q8_dwconv_row3x3_kernel<2, true>), dim3(static_cast<uint32_t>(blocks)), dim3(kRowThreads), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+  }
   if (p.sw == 1) {
     hipLaunchKernelGGL(q8_dwconv_row3x3_kernel<1>, dim3(static_cast<uint32_t>(blocks)), dim3(kRowThreads), 0, stream, p);
   } else {
@@ -2518,7 +2535,7 @@ int launch_m16(const DwParams& geometry, hipStream_t stream)
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
-enum : uint32_t { kPlanDirect = 1, kPlanLds33, kPlanLds55, kPlanRow, kPlanMfma, kPlanMfmaLds, kPlanCol, kPlanCol5, kPlanM16, kPlanDirect4 };
+enum : uint32_t { kPlanDirect = 1, kPlanLds33, kPlanLds55, kPlanRow, kPlanMfma, kPlanMfmaLds, kPlanCol, kPlanCol5, kPlanM16, kPlanDirect4, kPlanRowAny };
 
 // measurement knob, read once: LDS budget per workgroup of the LDS-tiled kernel in KiB
 uint32_t lds_budget()
@@ -2545,7 +2562,11 @@ int make_plan(DwParams& p, const struct qnnp_hip_dwconv_args* a, uintptr_t in_ad
   else if (p.C % 4 == 0 && p.out_stride % 4 == 0 && out_addr % 4 == 0) p.store_mode = 1;
   plan->vec16 = 0;
   plan->kernel = 0;
-  if (a->variant == 7) {
+  if (a->variant == 8) {
+    // (round 6) the sliding-window kernel on unaligned dwords, forced (auto: below, where nothing aligned takes the shape)
+    if (!k33 || a->c_pad % 4 != 0 || !plan_row(p, true)) return QNNP_HIP_EINVAL;
+    plan->kernel = kPlanRowAny;
+  } else if (a->variant == 7) {
     // (round 6) the 16x16x64 matrix-core walk, forced
     if (!k33 || !plan_m16(p, in_addr, out_addr)) return QNNP_HIP_EINVAL;
     plan->kernel = kPlanM16;
@@ -2587,6 +2608,14 @@ int make_plan(DwParams& p, const struct qnnp_hip_dwconv_args* a, uintptr_t in_ad
       plan->vec16 = (p.CS % 16 == 0 && p.in_stride % 16 == 0 && in_addr % 16 == 0) ? 1u : 0u;
       plan->kernel = k33 ? kPlanLds33 : kPlanLds55;
     } else {
+      // (round 6) 3x3 windows of any channel count >= 4 and any alignment: the sliding-window kernel on unaligned dwords
+      // ("dwconv_kernel" 8 forces it -- on aligned tensors too --, 1 / 9 keep the generic kernels below)
+      if (a->variant == 0 && k33 && a->c_pad % 4 == 0 && plan_row(p, true)) {
+        plan->kernel = kPlanRowAny;
+        plan->CS = p.CS; plan->TOH = p.TOH; plan->IR = p.IR; plan->IC = p.IC; plan->PP = p.PP;
+        plan->bands = p.bands; plan->slabs = p.slabs; plan->store_mode = p.store_mode;
+        return QNNP_HIP_OK;
+      }
       // (round 6) four channels per thread where the tensors allow 32-bit offsets; "dwconv_kernel" 1 keeps the byte-per-thread kernel
       const uint64_t ib = static_cast<uint64_t>(p.batch) * p.H * p.W * p.in_stride;
       const uint64_t groups4 = static_cast<uint64_t>(p.batch) * p.OH * p.OW * ((p.C + 3u) / 4u);
@@ -2667,6 +2696,9 @@ extern "C" int qnnp_hip_dwconv_run(const struct qnnp_hip_dwconv_args* a, const c
     case kPlanRow:
       if (kernel_name != nullptr) *kernel_name = "q8_dwconv_row_3x3";
       return launch_row(p, stream);
+    case kPlanRowAny:
+      if (kernel_name != nullptr) *kernel_name = "q8_dwconv_row_3x3_any";
+      return launch_row(p, stream, true);
     case kPlanCol:
       if (kernel_name != nullptr) {
         *kernel_name = (p.dh != 1 || p.dw != 1) ? "q8_dwconv_col_3x3_dot4_dilated" : (col_uses_dot4(p) ? "q8_dwconv_col_3x3_dot4" : "q8_dwconv_col_3x3");

@@ -739,9 +739,10 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   if (a->variant == 0 && mid_ok && a->offsets != nullptr && a->rows <= 32768u && a->k_total >= 128u && a->k_total <= 256u && a->rows >= 2048u) return launch_mid();
   // (round 6: pointwise layers whose channel count forces BYTE stores on the streaming kernel -- ShuffleNet v2's 24 -> 58 / 122 at 56 x 56:
   //  56.3 / 122.1 us -- run on the register-staged 128-row GEMM instead: 36.3 / 78.6 us, profiles/r06/ugemm_by_forced_kernel_r06p.txt)
-  // (... and, with the transposed 16-byte stores of that kernel, the dword-store shapes with more than 32 channels: 56 x 56 24 -> 60 / 68
-  //  20.9 / 24.5 -> 17.1 / 22.4 us; 24 -> 24 stays, 7.1 against 9.7: profiles/r06/ugemm_transposed_stores_r06v.txt)
-  if (a->variant == 0 && !pad3 && (p.store_mode == 0 || (p.store_mode == 1 && a->n > 32u)) && a->rows >= 2048u && p.d2s_sh == 0 &&
+  // (... and, with the transposed 16-byte stores of that kernel, the streaming kernel's DWORD-store shapes -- channel counts of 4 mod 8 --
+  //  from 56 channels up: 56 x 56 24 -> 60 / 68 20.9 / 24.5 -> 17.1 / 22.4 us (profiles/r06/ugemm_transposed_stores_r06v.txt); 24 -> 36
+  //  stays, 12.0 against 13.8, and so do multiples of 8 -- 24 -> 88 12.9 against 23.8, 88 -> 88 8.2 against 10.0: run r06w's lists)
+  if (a->variant == 0 && !pad3 && (p.store_mode == 0 || (p.store_mode == 1 && a->n % 8u != 0u && a->n >= 56u)) && a->rows >= 2048u && p.d2s_sh == 0 &&
       a->residual == nullptr && qnnp::gemm128u_supported(p)) {
     const int rc_u = qnnp::gemm128u_launch(p, a->groups, stream, &name, 0u);
     if (kernel_name != nullptr) *kernel_name = name;

@@ -201,7 +201,7 @@ enum qnnp_status qnnp_gfx950_test_force_kernel(const char* key, int value)
     qnnp_state.opt_fused_rows = value;
     return qnnp_status_success;
   }
-  if (strcmp(key, "dwconv_kernel") == 0 && value >= 0 && value <= 7) {
+  if (strcmp(key, "dwconv_kernel") == 0 && value >= 0 && value <= 9) {
     qnnp_state.opt_dwconv_kernel = value;
     return qnnp_status_success;
   }

@@ -32,9 +32,16 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant,kernel", [(0, "q8_dwconv_direct4"), (1, "q8_dwconv_direct")], ids=["auto", "byte_per_thread"])
+def _auto_kernel(case):
+    """3x3 windows (dilation 1, equal strides 1 | 2, padding <= 2) of >= 4 channels: the sliding-window kernel on unaligned dwords (round 6)"""
+    k33 = case.kernel_size == (3, 3) and case.dilation == (1, 1) and case.subsampling in ((1, 1), (2, 2))
+    return "q8_dwconv_row_3x3_any" if k33 and case.groups >= 4 and max(case.padding) <= 2 else "q8_dwconv_direct4"
+
+
+@pytest.mark.parametrize("variant", [0, 9, 1], ids=["auto", "four_channels_per_thread", "byte_per_thread"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
-def test_generic_depthwise_matches_oracle(qnnp, case, variant, kernel):
+def test_generic_depthwise_matches_oracle(qnnp, case, variant):
+    kernel = {0: _auto_kernel(case), 9: "q8_dwconv_direct4", 1: "q8_dwconv_direct"}[variant]
     inp, kern, bias = conv_tensors(case)
     expected, quant, out_hw = conv_expected(case, inp, kern, bias)
     qnnp.set_option("dwconv_kernel", variant)
@@ -44,3 +51,58 @@ def test_generic_depthwise_matches_oracle(qnnp, case, variant, kernel):
         qnnp.set_option("dwconv_kernel", 0)
     assert kname == kernel, kname
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+# ---- the sliding-window kernel on unaligned dwords ("dwconv_kernel" 8; q8_dwconv_row3x3_kernel<SW, true>) ----
+ANY_CASES = [
+    _dw("ra_c58_28", (28, 28), 58, batch=3),
+    _dw("ra_c58_56_s2", (56, 56), 58, subsampling=(2, 2), batch=2),
+    _dw("ra_c122_28", (28, 28), 122, batch=2),
+    _dw("ra_c244_14_s2", (14, 14), 244, subsampling=(2, 2), batch=3),
+    _dw("ra_c488_7", (7, 7), 488, batch=2),
+    _dw("ra_c50_odd_image_s2", (29, 31), 50, subsampling=(2, 2), batch=2),
+    _dw("ra_c27", (9, 11), 27, batch=2),                                       # odd: groups start at odd bytes
+    _dw("ra_c4", (7, 7), 4, batch=3),
+    _dw("ra_c5", (7, 7), 5, batch=3),                                          # two groups, the second recomputes three channels
+    _dw("ra_c7_s2", (10, 12), 7, subsampling=(2, 2), batch=2),
+    _dw("ra_c58_strided_pixels", (9, 9), 58, input_pixel_stride=61, output_pixel_stride=59, batch=2),
+    _dw("ra_c58_nopad", (9, 9), 58, padding=(0, 0, 0, 0), batch=2),
+    _dw("ra_c58_pad2", (9, 9), 58, padding=(2, 2, 2, 2), batch=2),
+    _dw("ra_c58_pad_asym", (9, 12), 58, padding=(0, 2, 1, 0), batch=2),
+    _dw("ra_c22_zp_clamp", (9, 9), 22, izp=3, kzp=250, qmin=40, qmax=200, batch=2),
+    _dw("ra_c22_zp_extremes", (9, 9), 22, izp=255, kzp=0, batch=2),
+    _dw("ra_c58_1x1img", (1, 1), 58, batch=5),
+    _dw("ra_c58_wide_row_segments", (5, 200), 58, batch=1),
+    _dw("ra_c32_aligned_too", (14, 14), 32, batch=2),
+]
+
+
+@pytest.mark.parametrize("case", ANY_CASES, ids=lambda c: c.name)
+def test_sliding_window_on_unaligned_dwords_matches_oracle(qnnp, case):
+    inp, kern, bias = conv_tensors(case)
+    expected, quant, out_hw = conv_expected(case, inp, kern, bias)
+    qnnp.set_option("dwconv_kernel", 8)
+    try:
+        out, kname = conv_run(qnnp, case, quant, out_hw, inp, kern, bias, to_device, from_device)
+    finally:
+        qnnp.set_option("dwconv_kernel", 0)
+    assert kname == "q8_dwconv_row_3x3_any", kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("case", [
+    _dw("ra_bad_3_channels", (9, 9), 3, batch=2),
+    _dw("ra_bad_5x5", (9, 9), 58, k=(5, 5), batch=2),
+    _dw("ra_bad_dilated", (12, 12), 58, dilation=(2, 2), padding=(2, 2, 2, 2), batch=2),
+    _dw("ra_bad_stride_3", (12, 12), 58, subsampling=(3, 3), batch=2),
+], ids=lambda c: c.name)
+def test_sliding_window_on_unaligned_dwords_refuses_what_it_cannot_take(qnnp, case):
+    from qnnpack_amd import QnnpackError
+    inp, kern, bias = conv_tensors(case)
+    expected, quant, out_hw = conv_expected(case, inp, kern, bias)
+    qnnp.set_option("dwconv_kernel", 8)
+    try:
+        with pytest.raises(QnnpackError):
+            conv_run(qnnp, case, quant, out_hw, inp, kern, bias, to_device, from_device)
+    finally:
+        qnnp.set_option("dwconv_kernel", 0)
