@@ -42,7 +42,9 @@ extern "C" {
  *                    counts, unaligned pixels; what auto picks where 1 ran for them),
  *                    30 = the LDS-staged flavour of the 7x7 / 5x5 first-layer kernel (hip/q8convc3.hip; 14 keeps the register-path one),
  *                    31 = grouped 1x1 convolutions as ONE dense GEMM (block-diagonal weights, the kernel zero point off the diagonal:
- *                    convolution.c; auto takes it from 65536 rows up; the dense problem's kernel is chosen automatically).
+ *                    convolution.c; auto takes it from 65536 rows up; the dense problem's kernel is chosen automatically),
+ *                    32 = the weight-stationary 3x3 kernel for 16 / 32 / 48 / 64 input channels (hip/q8convws16s.hip; what auto picks for
+ *                    SqueezeNet's fire modules).
  *   "fused_kernel":  fused inverted-residual blocks: 0 = auto (the strip kernel, hip/q8fusedstrip.hip, where it takes the
  *                    block -- kernel zero points 127 / 128 in all three members -- else the tile kernel of rounds 1-3),
  *                    1 = the tile kernel only, 2 = the strip kernel only (unsupported_parameter at setup otherwise)

@@ -323,13 +323,16 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
      * kernel of hip/q8convwave.hip): single group, whole 32-deep K blocks, kernel zero point 128 (the standard image IS the centred
      * one) or 127 (a second image + bias pair). The [output channel][kh][kw][input channel] kernel tensor is the GEMM
      * layout the packer takes. */
-    if (groups == 1 && kc_slot == (uint32_t) group_input_channels && k_total % 32 == 0) {
+    /* (round 6: hip/q8convws16s.hip -- 3x3 windows over 16 / 32 / 48 / 64 input channels, SqueezeNet's fire modules -- takes the image
+     * WITH K padding: 9 x 16 and 9 x 48 bytes are not whole 32-byte blocks; the padding meets zero weights in either image) */
+    const int small_3x3 = kernel_height == 3 && kernel_width == 3 && group_input_channels % 16 == 0 && group_input_channels <= 64 &&
+        group_output_channels % 16 == 0 && group_output_channels <= 256;
+    if (groups == 1 && kc_slot == (uint32_t) group_input_channels && (k_total % 32 == 0 || small_3x3)) {
       if (kernel_zero_point == 128) {
         op->centre_flip = 0x80;
       } else if (kernel_zero_point == 127 &&
                  /* (a second image only where a kernel takes it: the 3x3 weight-stationary kernel, the 256x256 GEMM) */
-                 ((kernel_height == 3 && kernel_width == 3 && (group_input_channels == 32 || group_input_channels == 64) &&
-                   (group_output_channels == 32 || group_output_channels == 64)) ||
+                 (small_3x3 ||
                   (kernel_size == 1 && k_total == k_pad && k_total >= 512 && n_pad % 256 == 0) ||
                   /* ... and the 128-wide tiling of hip/q8gemm128x.hip: any K % 64 == 0 */
                   (kernel_size == 1 && k_total == k_pad && k_total % 64 == 0 && group_output_channels % 16 == 0))) {

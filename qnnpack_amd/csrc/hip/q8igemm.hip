@@ -661,6 +661,30 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
     if (kernel_name != nullptr) *kernel_name = name;
     return rc_wave;
   }
+  // (round 6) dense 3x3 / stride 1 with 16 / 32 / 48 / 64 input channels and a centred image (SqueezeNet's fire modules): the weight-stationary
+  // kernel with the channel count as a template argument (q8convws16s.hip); "gemm_kernel" = 32 forces it, 1 / 3 / 22 keep what it replaces
+  {
+    IgemmParams ps = p;
+    const bool centred = a->centre_flip != 0 && a->packed_w_centred != nullptr && a->bias2_centred != nullptr &&
+        a->bias2_pair != 0 && a->groups == 1;
+    if (centred) {
+      ps.packed_w = a->packed_w_centred;
+      ps.bias2 = a->bias2_centred;
+      ps.bias2u = a->bias2_centred + static_cast<size_t>(a->groups) * a->n_pad;
+      ps.a_flip = (a->centre_flip & 0xFFu) * 0x01010101u;
+      ps.row_coeff = 0;
+    }
+    const bool s_ok = centred && a->offsets != nullptr && !pad3 && a->rows_per_image > 0 &&
+        qnnp::convws16s_supported(ps, geom, a->groups, vec, a->rows / a->rows_per_image);
+    if (a->variant == 32 && !s_ok) return QNNP_HIP_EINVAL;
+    // (auto: everything but 64 -> 32 / 64, which the block above has taken; 64 -> 256 leaves the patch kernel: 27 x 27 24.7 -> 19.5 us,
+    //  13 x 13 9.4 -> 9.0: profiles/r06/conv3x3_small_channels_r06y.txt)
+    if (s_ok && (a->variant == 32 || (a->variant == 0 && a->rows >= 16384u))) {
+      const int rc_s = qnnp::convws16s_launch(ps, geom, a->rows / a->rows_per_image, stream, &name);
+      if (kernel_name != nullptr) *kernel_name = name;
+      return rc_s;
+    }
+  }
   // Dense 3x3 with many channels (ResNet's 128 / 256 / 512-channel layers): patch in LDS, weights streamed (q8convpatch.hip);
   // "gemm_kernel" = 22 forces it, 1 / 2 / 3 keep the kernels it replaces.
   const bool patch_ok = a->offsets != nullptr && !pad3 && a->rows_per_image > 0 &&

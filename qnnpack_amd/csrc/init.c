@@ -185,7 +185,7 @@ enum qnnp_status qnnp_gfx950_set_option(const char* key, int value)
 enum qnnp_status qnnp_gfx950_test_force_kernel(const char* key, int value)
 {
   if (key == NULL) return qnnp_status_invalid_parameter;
-  if (strcmp(key, "gemm_kernel") == 0 && value >= 0 && value <= 31 && !(value >= 17 && value <= 19)) {
+  if (strcmp(key, "gemm_kernel") == 0 && value >= 0 && value <= 32 && !(value >= 17 && value <= 19)) {
     qnnp_state.opt_gemm_kernel = value;
     return qnnp_status_success;
   }
