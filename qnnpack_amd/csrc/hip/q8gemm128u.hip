@@ -76,7 +76,8 @@ __device__ __forceinline__ uint32_t a_swizzle(uint32_t row) { return (row & 8u) 
  * alignment at all. 2 and 1 transpose the requantized dwords over the four lanes of a row (v_permlane32_swap / v_permlane16_swap) so that
  * a lane holds SIXTEEN consecutive channels of its row and writes them with one 16-byte store (2; rows of 2 mod 4: a short, three dwords
  * shifted by v_alignbyte, a short) -- 16 TN contiguous bytes per row and instruction instead of 16-byte pieces (one dword per lane and
- * tile, the first build) or single bytes; 0 keeps the byte stores.
+ * tile, the first build) or single bytes; 0 keeps the byte stores. 3 = FLAT: dense pixels, one group, one channel tile -- the workgroup's 128
+ * rows are one contiguous run of memory: staged in LDS as memory holds them, written as whole 16-byte chunks (any N).
  * TN: 16-channel MFMA tiles per wave: 4 / 2 / 1 = 128- / 64- / 32-channel workgroup tiles (groups of 12 ... 62 channels would leave
  * most of a wide tile empty: ShuffleNet v1's 8 groups of 48 -> 12). */
 template <int SEQ, int CLAMP, int OUT, int TN>
@@ -278,7 +279,20 @@ void q8_gemm_mfma_128xN_u16_kernel(const IgemmParams p)
           static_cast<int>(static_cast<uint32_t>(acc[tm][tn][0]) + term), static_cast<int>(static_cast<uint32_t>(acc[tm][tn][1]) + term),
           static_cast<int>(static_cast<uint32_t>(acc[tm][tn][2]) + term), static_cast<int>(static_cast<uint32_t>(acc[tm][tn][3]) + term), p.rq);
     }
-    if constexpr (OUT == 0 || (OUT == 2 && kTN == 1)) {
+    if constexpr (OUT == 3) {
+      // FLAT: dense pixels (stride == N) and one channel tile -- the workgroup's 128 output rows are ONE contiguous run of 128 N bytes
+      // that starts on a 128-byte boundary. The requantized bytes go to LDS where memory will hold them (the stage buffers are free:
+      // every wave is past the barrier behind the K loop) and leave as whole 16-byte chunks below, whatever N is a multiple of.
+      const uint32_t rflat = (wm * 64u + r) * p.n;
+#pragma unroll
+      for (int tn = 0; tn < kTN; tn++) {
+        const uint32_t n = n0 + tn * 16 + fg * 4;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          if (n + b < p.n) lds[rflat + n + b] = static_cast<uint8_t>(q[tn] >> (8 * b));
+        }
+      }
+    } else if constexpr (OUT == 0 || (OUT == 2 && kTN == 1)) {
       if (!row_ok) continue;
 #pragma unroll
       for (int tn = 0; tn < kTN; tn++) {
@@ -322,6 +336,18 @@ void q8_gemm_mfma_128xN_u16_kernel(const IgemmParams p)
       }
     }
   }
+  if constexpr (OUT == 3) {
+    __syncthreads();
+    const uint32_t row0 = m_tile * kBM;
+    const uint32_t rows_here = min(static_cast<uint32_t>(kBM), p.rows - row0);
+    const uint32_t total = rows_here * p.n;
+    uint8_t* dst = p.output + static_cast<uint64_t>(row0) * p.n;                     // (launcher: a multiple of 16 bytes from a 16-byte aligned base)
+    for (uint32_t c = tid * 16u; c + 16u <= total; c += kThreads * 16u) {
+      *reinterpret_cast<v4i*>(dst + c) = *reinterpret_cast<const v4i*>(lds + c);
+    }
+    const uint32_t tail = total & 15u;                                                // (the last tile of a tensor whose size is no multiple of 16)
+    if (tid < tail) dst[(total & ~15u) + tid] = lds[(total & ~15u) + tid];
+  }
 }
 #undef QNNP_PIN
 
@@ -351,11 +377,15 @@ int launch_u(const IgemmParams& p, uint32_t groups, hipStream_t stream)
   pm.tiles_n_magic = tiles_n == 1 ? 0u : static_cast<uint32_t>((1ull << 32) / tiles_n) + 1u;
   const bool dword_out = p.n % 4 == 0 && p.output_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(p.output) & 3u) == 0;
   const bool even_out = p.n % 2 == 0 && p.output_stride % 2 == 0 && (reinterpret_cast<uintptr_t>(p.output) & 1u) == 0;
+  // (flat rows: dense pixels, one group, one channel tile, rows that are not whole 16-byte pieces anyway)
+  const bool flat_out = groups == 1 && tiles_n == 1 && p.output_stride == p.n && p.n % 16 != 0 &&
+      (reinterpret_cast<uintptr_t>(p.output) & 15u) == 0 && static_cast<uint64_t>(p.rows) * p.n < (1ull << 32);
   int rc = QNNP_HIP_EINVAL;
   auto launch = [&](auto seq, auto clamp) {
     constexpr int kSeq = decltype(seq)::value;
     constexpr int kClamp = decltype(clamp)::value;
-    if (dword_out) hipLaunchKernelGGL((q8_gemm_mfma_128xN_u16_kernel<kSeq, kClamp, 2, TN>), grid, dim3(kThreads), 0, stream, pm);
+    if (flat_out) hipLaunchKernelGGL((q8_gemm_mfma_128xN_u16_kernel<kSeq, kClamp, 3, TN>), grid, dim3(kThreads), 0, stream, pm);
+    else if (dword_out) hipLaunchKernelGGL((q8_gemm_mfma_128xN_u16_kernel<kSeq, kClamp, 2, TN>), grid, dim3(kThreads), 0, stream, pm);
     else if (even_out) hipLaunchKernelGGL((q8_gemm_mfma_128xN_u16_kernel<kSeq, kClamp, 1, TN>), grid, dim3(kThreads), 0, stream, pm);
     else hipLaunchKernelGGL((q8_gemm_mfma_128xN_u16_kernel<kSeq, kClamp, 0, TN>), grid, dim3(kThreads), 0, stream, pm);
     rc = hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
