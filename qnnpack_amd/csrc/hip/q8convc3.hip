@@ -336,6 +336,36 @@ void q8_conv_c3rows_kernel(const IgemmParams p, const C3Geom cg)
       const v4i v = {static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
       outv[nb] = v;
       if (whole_lines) continue;                                // (wave-uniform)
+      if constexpr (NB == 1) {
+        // (round 6) 24 output channels, dense pixels -- ShuffleNet's 3 -> 24 first layer, in nine of the reference's lists: a unit row's
+        // sixteen pixels are 384 contiguous bytes that left as 16-byte and 8-byte pieces 24 bytes apart. Through the wave's own 768 bytes
+        // of LDS they leave as 48 whole 16-byte chunks (lane = chunk: 24 per unit row), one store instruction for both rows.
+        if (p.n == 24u && p.output_stride == 24u && u.cols_left >= 16u) {      // (wave-uniform)
+          __shared__ __attribute__((aligned(16))) uint8_t c3flat[kC3Waves * 768];
+          uint8_t* mine = c3flat + wave * 768u;
+          const uint32_t o = prow * 384u + pcol * 24u + h * 16u;
+          *reinterpret_cast<uint2*>(mine + o) = make_uint2(static_cast<uint32_t>(v.x), static_cast<uint32_t>(v.y));
+          if (h == 0u) *reinterpret_cast<uint2*>(mine + o + 8u) = make_uint2(static_cast<uint32_t>(v.z), static_cast<uint32_t>(v.w));
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const uint32_t lane48 = (h << 5) | px;                  // this lane's index in the wave
+          const uint32_t crow = lane48 >= 24u ? 1u : 0u;
+          const uint32_t cj = lane48 - crow * 24u;
+          const v4i c = *reinterpret_cast<const v4i*>(mine + min(lane48, 47u) * 16u);
+          const bool cok = lane48 < 48u && crow < u.rows_left;
+#ifdef QNNP_ENABLE_ABLATION
+          const bool cok2 = cok && !((cg.abl & 2u) && c.x != 0x12345678);
+#else
+          const bool cok2 = cok;
+#endif
+          const auto cbits = __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, c);
+          const uint32_t coff = cok2 ? u.out0 + crow * cg.OW * 24u + cj * 16u : 0xFFFFFFF0u;
+          if (p.stream_out) __builtin_amdgcn_raw_buffer_store_b128(cbits, out_rsrc, coff, 0, 2);
+          else __builtin_amdgcn_raw_buffer_store_b128(cbits, out_rsrc, coff, 0, 0);
+          __builtin_amdgcn_wave_barrier();                        // (the next unit's pieces must not overtake this unit's reads)
+          continue;
+        }
+      }
       bool ok = pixel_ok && nb * 32u + h * 16u + 16u <= p.n;   // (n % 8 == 0: launcher)
 #ifdef QNNP_ENABLE_ABLATION
       if (cg.abl & 2u) ok = ok && v.x == 0x12345678;

@@ -32,6 +32,8 @@ CASES = [
     ConvCase("r_2x2_s2", (10, 12), (2, 2), subsampling=(2, 2), gic=3, goc=16, batch=3),
     # round 6: channel counts in multiples of 8 (the last half piece leaves by an 8-byte store): ShuffleNet's 3 -> 24 first layer
     ConvCase("r_3x3_s2_24_channels", (40, 36), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=24, batch=3),
+    ConvCase("r_3x3_s2_24_channels_flat_rows_odd_height", (41, 64), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=24, batch=3),
+    ConvCase("r_3x3_s1_24_channels_strided_pixels", (12, 20), (3, 3), _pad(1, 1), gic=3, goc=24, output_pixel_stride=32, batch=2),
     ConvCase("r_3x3_s1_8_channels", (13, 11), (3, 3), _pad(1, 1), gic=3, goc=8, batch=2),
     ConvCase("r_3x3_s2_56_channels_zp", (17, 19), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=56, izp=9, kzp=200, batch=2),
     ConvCase("r_4x4_pad", (11, 10), (4, 4), (1, 2, 2, 1), gic=3, goc=64),
