@@ -335,7 +335,7 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
                  (small_3x3 ||
                   (kernel_size == 1 && k_total == k_pad && k_total >= 512 && n_pad % 256 == 0) ||
                   /* ... and the 128-wide tiling of hip/q8gemm128x.hip: any K % 64 == 0 */
-                  (kernel_size == 1 && k_total == k_pad && k_total % 64 == 0 && group_output_channels % 16 == 0))) {
+                  (kernel_size == 1 && k_total == k_pad && k_total % 64 == 0 && group_output_channels % 4 == 0))) {
         int8_t* host_wc = (int8_t*) malloc(w_bytes);
         int32_t* host_bc = (int32_t*) malloc(b_bytes);
         int placed = host_wc != NULL && host_bc != NULL;

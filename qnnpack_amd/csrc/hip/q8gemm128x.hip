@@ -19,7 +19,7 @@
  * Algebra, weight image, bias pair and re-centring mask: q8gemm256c.hip (kernel zero point 127 or 128).
  *
  * Requirements (gemm128x_supported): single GEMM (or a strided 1x1 convolution through the dense offset table), K % 64 == 0,
- * 16-byte aligned rows and outputs (store_mode 2), a centred image and its bias pair table.
+ * 16-byte aligned input rows, dword-aligned output rows (store_mode >= 1), a centred image and its bias pair table.
  */
 #include <hip/hip_runtime.h>
 
@@ -308,11 +308,21 @@ void q8_gemm_mfma_128xN_c16_kernel(const IgemmParams p)
       q[j] = q31_requantize_pack4_clamp<SEQ, CLAMP>(acc[tm][j][0], acc[tm][j][1], acc[tm][j][2], acc[tm][j][3], p.rq);
     }
     transpose4(q);         // lane (row, g): channels 16 g .. 16 g + 15 of its row within the wave's 16 TN (g < TN)
-    typedef int nt_v4i __attribute__((ext_vector_type(4)));
+    // (round 6: rows that are whole dwords but not whole 16-byte pieces -- SqueezeNet's 512 -> 1000 classifier convolution: the store is a
+    //  dword-aligned 16-byte one, the group's last piece may be 4 / 8 / 12 bytes)
+    typedef int nt_v4i __attribute__((ext_vector_type(4), aligned(4)));
+    typedef int nt_v2i __attribute__((ext_vector_type(2), aligned(4)));
     const nt_v4i x = {static_cast<int>(q[0]), static_cast<int>(q[1]), static_cast<int>(q[2]), static_cast<int>(q[3])};
     const uint32_t r = tm * 16 + frow;
-    nt_v4i* dst = reinterpret_cast<nt_v4i*>(out0 + static_cast<uint64_t>(r) * p.output_stride + fg * 16);
-    if (m0 + r < p.rows && col_ok && fg < static_cast<uint32_t>(kTN)) *dst = x;
+    uint8_t* dst = out0 + static_cast<uint64_t>(r) * p.output_stride + fg * 16;
+    if (m0 + r < p.rows && col_ok && fg < static_cast<uint32_t>(kTN)) {
+      const uint32_t left = p.n - (n0 + fg * 16);                 // bytes of the group behind this piece's first one (> 0: col_ok)
+      if (left >= 16u) *reinterpret_cast<nt_v4i*>(dst) = x;
+      else {
+        if (left >= 8u) *reinterpret_cast<nt_v2i*>(dst) = nt_v2i{x.x, x.y};
+        if ((left & 4u) != 0u) *reinterpret_cast<int*>(dst + (left & 8u)) = left >= 8u ? x.z : x.x;
+      }
+    }
   }
 }
 #undef QNNP_PIN
@@ -327,8 +337,8 @@ bool gemm128x_supported(const IgemmParams& p, uint32_t vec)
     const uint64_t images = (static_cast<uint64_t>(p.rows) + p.rows_per_image - 1) / p.rows_per_image;
     if (images * p.image_stride + p.k_pad >= (1ull << 32)) return false;
   }
-  return vec == 16 && p.a_flip != 0 && p.bias2u != nullptr && p.store_mode == 2 &&
-         p.k_total == p.k_pad && p.k_pad % kBK == 0 && p.k_pad >= kBK && p.n_pad % 32 == 0 && p.n % 16 == 0 &&
+  return vec == 16 && p.a_flip != 0 && p.bias2u != nullptr && p.store_mode >= 1 &&
+         p.k_total == p.k_pad && p.k_pad % kBK == 0 && p.k_pad >= kBK && p.n_pad % 32 == 0 && p.n % 4 == 0 &&
          p.k_pad <= (1u << 22) && static_cast<uint64_t>(p.input_stride) * kBM < (1ull << 32) &&
          p.residual == nullptr && p.rows >= 1;
 }

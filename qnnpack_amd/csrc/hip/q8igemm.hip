@@ -766,6 +766,8 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   // (... and, with the transposed 16-byte stores of that kernel, the streaming kernel's DWORD-store shapes -- channel counts of 4 mod 8 --
   //  from 56 channels up: 56 x 56 24 -> 60 / 68 20.9 / 24.5 -> 17.1 / 22.4 us (profiles/r06/ugemm_transposed_stores_r06v.txt); 24 -> 36
   //  stays, 12.0 against 13.8, and so do multiples of 8 -- 24 -> 88 12.9 against 23.8, 88 -> 88 8.2 against 10.0: run r06w's lists)
+  // (SqueezeNet's 13 x 13 512 -> 1000 with a centred image: the 128-row centred GEMM with dword-aligned stores, 25.7 against 27.8 us)
+  if (a->variant == 0 && mid_ok && p.store_mode == 1 && a->n >= 256u && a->k_total >= 256u && a->rows >= 2048u && a->offsets == nullptr) return launch_mid();
   // (... and wide ones: a channel run of 360 -- ShuffleNet v1 g8's 12 -> 45 as a dense 96 -> 360 -- 31.3 us on the streaming kernel, 21.0 here;
   //  SqueezeNet's 13 x 13 512 -> 1000 35.1 us on the 256-wide GEMM's padding path, 25.5 here: run r06z's lists against r06w's)
   if (a->variant == 0 && !pad3 && (p.store_mode == 0 || (p.store_mode == 1 && ((a->n % 8u != 0u && a->n >= 56u) || a->n >= 256u))) && a->rows >= 2048u && p.d2s_sh == 0 &&

@@ -107,6 +107,21 @@ def test_strided_pointwise_convolutions(mid, case):
     assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
 
 
+@pytest.mark.parametrize("case", [
+    ConvCase("x_1x1_13x13_512_1000", (13, 13), (1, 1), gic=512, goc=1000, batch=2),        # SqueezeNet's classifier convolution
+    ConvCase("x_1x1_n72", (9, 9), (1, 1), gic=128, goc=72, batch=3),                       # last piece 8 bytes
+    ConvCase("x_1x1_n20", (9, 9), (1, 1), gic=64, goc=20, batch=3),                        # 4 bytes
+    ConvCase("x_1x1_n44", (9, 9), (1, 1), gic=192, goc=44, batch=3, kzp=128),              # 12 bytes
+    ConvCase("x_1x1_n128_rows_of_132", (9, 9), (1, 1), gic=128, goc=128, batch=3, output_pixel_stride=132),
+], ids=lambda c: c.name)
+def test_rows_of_whole_dwords_that_are_not_whole_16_byte_pieces(mid, case):
+    """round 6: dword-aligned 16-byte stores, the group's last piece 4 / 8 / 12 bytes"""
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(mid, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == KERNEL, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
 @pytest.mark.parametrize("kw", [dict(kzp=126), dict(kzp=0)], ids=lambda d: f"kzp{d['kzp']}")
 def test_other_zero_points_have_no_centred_image(mid, kw):
     case = FcCase("x_refused_kzp", 300, 320, 128, **kw)
@@ -115,7 +130,7 @@ def test_other_zero_points_have_no_centred_image(mid, kw):
         fc_run(mid, case, quant, to_device=to_device, from_device=from_device)
 
 
-@pytest.mark.parametrize("k,n,stride", [(96, 128, 0), (320, 100, 0), (320, 128, 132)])
+@pytest.mark.parametrize("k,n,stride", [(96, 128, 0), (320, 100, 0), (320, 128, 130)])
 def test_refuses_what_it_cannot_take(mid, k, n, stride):
     case = FcCase(f"x_refused_k{k}_n{n}", 300, k, n, output_stride=stride)
     _, quant = fc_expected(case)
