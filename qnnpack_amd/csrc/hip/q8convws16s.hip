@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -313,7 +314,16 @@ inline bool make_sargs(const IgemmParams& p, const ConvGeom& g, uint32_t batch, 
   a->n_tiles = (p.n + 63u) / 64u;
   a->inv_n_tiles = a->n_tiles > 1 ? static_cast<uint32_t>(((UINT64_C(1) << 32) + a->n_tiles - 1) / a->n_tiles) : 0u;
   const uint32_t want = (a->units + kSWaves - 1) / kSWaves;
-  uint32_t ranges = (p.cu_count + a->n_tiles - 1) / a->n_tiles;      // ~ one workgroup per CU in all
+  // workgroups per CU the unit ranges are cut for, measured per channel count (profiles/r06/conv3x3_small_channels_per_cu_r06zd.txt):
+  // 16 channels (<= 122 registers: two 8-wave workgroups share a CU) 2 -- 55x55 16 -> 64 10.8 -> 10.3 us; 48 channels 3 -- one
+  // workgroup at a time by registers, but shorter ranges even out the tail: 27x27 48 -> 192 22.4 -> 19.3, 13x13 11.7 -> 10.4; 32 and 64
+  // channels 1 (55x55 32 -> 128 22.3 against 24.7 / 25.8, 27x27 64 -> 256 18.3 against 20.7 / 24.1)
+  const uint32_t cpp = p.kc / 16u;
+  uint32_t per_cu = cpp == 1u ? 2u : (cpp == 3u ? 3u : 1u);
+#ifdef QNNP_ENABLE_ABLATION
+  if (const char* env = getenv("QNNP_WS16S_PER_CU")) per_cu = static_cast<uint32_t>(atoi(env));
+#endif
+  uint32_t ranges = (p.cu_count * per_cu + a->n_tiles - 1) / a->n_tiles;
   if (ranges > want) ranges = want;
   if (ranges < 1) ranges = 1;
   a->ranges = ranges;
