@@ -367,7 +367,11 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
   PT_STAMP(3);
 
   // ---- this lane's positions (one per position block): patch pixel of tap (0, 0), output offset
-  uint32_t q0[2], out_off[2], abase0[2];
+  // (round 6) the stores: after the requantization this lane holds 16 channels of ITS position for each of the wave's two channel blocks --
+  // 32-byte pieces per position and instruction. The 16-lane rows trade pieces instead (v_permlane16_swap, q8convc3.hip c3_store_unit):
+  // the first instruction of a position block then writes positions 0..15 with all 64 channels of the wave, the second one 16..31, so
+  // `out_off[mi][half]` is the offset of position 16 half + (lane & 15) plus this lane's piece: 32 (row & 1) + 16 (row >> 1), row = lane >> 4
+  uint32_t q0[2], out_off[2][2], abase0[2];
 #pragma unroll
   for (int mi = 0; mi < 2; mi++) {
     const uint32_t pos = (wm * 2u + mi) * 32u + (lane & 31u);
@@ -375,13 +379,22 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
     const uint32_t rem = pos - il * (a.rows * g.OW);
     const uint32_t r = pt_div(rem, a.inv_ow);
     const uint32_t x = rem - r * g.OW;
-    const bool ok = pos < a.pos && img0 + il < a.batch && row0 + r < g.OH;
     q0[mi] = pos < a.pos ? il * a.pimg + r * g.sh * a.pw + x * g.sw : 0u;
     abase0[mi] = lds0 + q0[mi] * ps + khalf * 16u;
-    out_off[mi] = ok ? (((img0 + il) * g.OH + row0 + r) * g.OW + x) * p.output_stride + nb_tile * 32u + wn * 64u + khalf * 16u
-                     : 0xFFFFFF00u;                 // (beyond the descriptor: the store is dropped)
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const uint32_t spos = (wm * 2u + mi) * 32u + half * 16u + (lane & 15u);
+      const uint32_t sil = pt_div(spos, a.inv_rw);
+      const uint32_t srem = spos - sil * (a.rows * g.OW);
+      const uint32_t sr = pt_div(srem, a.inv_ow);
+      const uint32_t sx = srem - sr * g.OW;
+      const bool ok = spos < a.pos && img0 + sil < a.batch && row0 + sr < g.OH;
+      const uint32_t row16 = lane >> 4;
+      out_off[mi][half] = ok ? (((img0 + sil) * g.OH + row0 + sr) * g.OW + sx) * p.output_stride + nb_tile * 32u + wn * 64u +
+                                   (row16 & 1u) * 32u + (row16 >> 1) * 16u
+                             : 0xFFFFFF00u;         // (beyond the descriptor: the store is dropped)
+    }
   }
-
   // ---- accumulators start at the folded bias
   v16i acc[2][2];
 #pragma unroll
@@ -531,6 +544,7 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
     const int32_t rowterm = with_rq_offset<SEQ>(p.row_coeff * s);
     uint64_t row_addend = 0;
     if constexpr (rq_is_lane<SEQ>()) row_addend = lane_addend(rowterm, p.lane);
+    v4i outv[2];
 #pragma unroll
     for (int ni = 0; ni < 2; ni++) {
       uint32_t pk[4];
@@ -549,10 +563,19 @@ void q8_conv_patch_kernel(const IgemmParams p, const ConvGeom g, const PatchArgs
       const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
       const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
       // this lane now holds 16 consecutive channels of ITS position: (2 wn + ni) * 32 + khalf * 16 .. + 15
-      const v4i v = {static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
+      outv[ni] = v4i{static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
+    }
+    // row 1 of block 0 <-> row 0 of block 1, row 3 <-> row 2: outv[0] = positions 0..15 of the block x the wave's 64 channels, outv[1] = 16..31
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const auto sw = __builtin_amdgcn_permlane16_swap(static_cast<uint32_t>(outv[0][d]), static_cast<uint32_t>(outv[1][d]), false, false);
+      outv[0][d] = static_cast<int>(sw[0]); outv[1][d] = static_cast<int>(sw[1]);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
       __builtin_amdgcn_raw_buffer_store_b128(
-          __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc,
-          (abl & 64u) ? 0xFFFFFF00u : out_off[mi] + ni * 32u, 0, 0);
+          __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, outv[half]), out_rsrc,
+          (abl & 64u) ? 0xFFFFFF00u : out_off[mi][half], 0, 0);
     }
   }
   PT_STAMP(5);
