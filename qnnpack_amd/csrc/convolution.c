@@ -371,9 +371,23 @@ static enum qnnp_status qnnp_create_convolution2d_nhwc_q8_impl(
         qnnp_log_error("out of host memory: %zu bytes for packed weights", r_bytes);
         goto error;
       }
-      qnnp_pack_conv_rows16((uint32_t) group_output_channels, kernel_height, kernel_width, 3, n_pad, kernel, host_rows);
+      int placed = 1;
+      if (kernel_zero_point == 127) {
+        /* centred on the kernel zero point: no row term in the kernel (pack.h) */
+        int32_t* host_bc = (int32_t*) malloc((size_t) n_pad * sizeof(int32_t));
+        placed = host_bc != NULL;
+        if (placed) {
+          qnnp_pack_conv_rows16_centred127((uint32_t) group_output_channels, kernel_height, kernel_width, 3, n_pad, input_zero_point,
+              kernel, bias, host_rows, host_bc);
+          op->d_bias_rows = qnnp_upload_bias_pair(host_bc, n_pad);
+          placed = op->d_bias_rows != NULL;
+        }
+        free(host_bc);
+      } else {
+        qnnp_pack_conv_rows16((uint32_t) group_output_channels, kernel_height, kernel_width, 3, n_pad, kernel, host_rows);
+      }
       op->d_weights_rows16 = qnnp_hip_alloc(r_bytes);
-      const int placed = op->d_weights_rows16 != NULL && qnnp_hip_h2d(op->d_weights_rows16, host_rows, r_bytes, 0) == QNNP_HIP_OK;
+      placed = placed && op->d_weights_rows16 != NULL && qnnp_hip_h2d(op->d_weights_rows16, host_rows, r_bytes, 0) == QNNP_HIP_OK;
       free(host_rows);
       if (!placed) {
         qnnp_log_error("device allocation or upload failed: %zu bytes of packed weights on the device", r_bytes);

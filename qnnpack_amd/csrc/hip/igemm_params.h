@@ -125,7 +125,7 @@ int pwstream_gw_launch(const IgemmParams& p, hipStream_t stream, const char** na
 
 /* q8convc3.hip */
 bool conv_c3rows_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, const int8_t* w_rows16, uint32_t real_kc);
-int conv_c3rows_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_rows16, hipStream_t stream, const char** name);
+int conv_c3rows_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_rows16, hipStream_t stream, const char** name, int flavour);
 /* q8convws16s.hip: dense 3x3 / stride 1 with 16 / 32 / 48 / 64 input channels, weights in registers (p: the centred parameters) */
 bool convws16s_supported(const IgemmParams& p, const ConvGeom& g, uint32_t groups, uint32_t vec, uint32_t batch);
 int convws16s_launch(const IgemmParams& p, const ConvGeom& g, uint32_t batch, hipStream_t stream, const char** name);

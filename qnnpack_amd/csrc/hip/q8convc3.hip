@@ -308,8 +308,11 @@ void q8_conv_c3rows_kernel(const IgemmParams p, const C3Geom cg)
     }
 #pragma unroll
     for (int kb = 0; kb < 2; kb++) {
-      s.x[kb].x ^= static_cast<int>(kFlip); s.x[kb].y ^= static_cast<int>(kFlip);
-      s.x[kb].z ^= static_cast<int>(kFlip); s.x[kb].w ^= static_cast<int>(kFlip);
+      // (0x7F7F7F7F: the image is centred on kernel zero point 127 -- pack.h qnnp_pack_conv_rows16_centred127; the row-term fragments
+      //  are zero then)
+      const int flip = static_cast<int>(p.a_flip != 0u ? p.a_flip : kFlip);
+      s.x[kb].x ^= flip; s.x[kb].y ^= flip;
+      s.x[kb].z ^= flip; s.x[kb].w ^= flip;
     }
     const bool pixel_ok = prow < u.rows_left && pcol < u.cols_left;
     const uint32_t out_off = u.out0 + lane_out;
@@ -865,6 +868,188 @@ int launch_c3rows32_lds(const IgemmParams& p, const C3Geom& cg, const C3LdsGeom&
   return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
 }
 
+
+/*
+ * The 16-byte-slot kernel with the band staged in LDS (round 6; q8_conv_c3rows32_lds_kernel's scheme for windows of <= 4 rows of <= 16
+ * bytes: MobileNet's / ShuffleNet's 224 x 224 3x3 stride-2 first layers, in eleven of the reference's lists and in the sweep). The
+ * register-path kernel above spends ~200 instructions per unit of 32 pixels -- address arithmetic, two unaligned fetches with their
+ * tails, border surgery, re-centring -- around FOUR useful matrix instructions; here a unit is 2 x (ds_read2_b32 x 2 + ds_read_b32) + 8
+ * v_alignbyte + 2 MFMAs per channel block + the requantization. Needs a row term of zero (kernel zero point 128, or 127 with the centred
+ * image convolution.c builds) and image rows of whole 16-byte chunks; everything else stays on the kernel above.
+ * Lane (pixel p, half h): K block kb holds window row ky = 2 kb + h (row 3 of a 3-row window meets zero weights).
+ */
+template <int NB, int SEQ, bool FULL>
+__global__ __launch_bounds__(kC3Threads, NB == 1 ? 4 : 3)
+void q8_conv_c3rows_lds_kernel(const IgemmParams p, const C3Geom cg, const C3LdsGeom lg)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t c3lds[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t px = lane & 31u;
+  const uint32_t h = lane >> 5;
+  const uint32_t prow = px >> 4, pcol = px & 15u;
+
+  const uint32_t img = div_magic(blockIdx.x, lg.inv_bands);
+  const uint32_t band = blockIdx.x - img * lg.bands;
+  const uint32_t pair0 = band * lg.ppb;
+
+  // ---- weights and bias to registers (L2-resident; their round trip runs under the staging) ----
+  v4i w[NB][2];
+  v16i bias[NB];
+  {
+    const int32_t* bias_tab = rq_is_lane<SEQ>() ? p.bias2u : p.bias2;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) w[nb][kb] = *reinterpret_cast<const v4i*>(cg.w_rows16 + ((nb * 2 + kb) * 64u + lane) * 16u);
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const v4i b = *reinterpret_cast<const v4i*>(bias_tab + nb * 32 + rg * 8 + h * 4);
+        bias[nb][rg * 4 + 0] = b.x; bias[nb][rg * 4 + 1] = b.y; bias[nb][rg * 4 + 2] = b.z; bias[nb][rg * 4 + 3] = b.w;
+      }
+    }
+  }
+
+  // ---- staging: chunk id = row * cpr + c, four per thread and trip, all loads of a trip in flight together ----
+  {
+    const uint32_t total = lg.nrows * lg.cpr;
+    const int32_t iy_first = static_cast<int32_t>(pair0 * 2u * cg.sh) - static_cast<int32_t>(cg.pad_top);
+    const uint8_t* img_base = p.input + static_cast<uint64_t>(img) * p.image_stride;
+    const uint32_t row_bytes = cg.W * 3u;
+    const int flip = static_cast<int>(p.a_flip != 0u ? p.a_flip : kFlip);
+    const int zp4 = static_cast<int>((p.izp_fill & 0xFFu) * 0x01010101u) ^ flip;
+    constexpr int kTrip = 4;
+    for (uint32_t id0 = tid; id0 < total; id0 += kTrip * kC3Threads) {
+      v4i v[kTrip];
+      uint32_t dst[kTrip];
+      bool in[kTrip];
+#pragma unroll
+      for (int i = 0; i < kTrip; i++) {
+        const uint32_t id = id0 + static_cast<uint32_t>(i) * kC3Threads;
+        const uint32_t r = div_magic(id, lg.inv_cpr);
+        const uint32_t c = id - r * lg.cpr;
+        const int32_t iy = iy_first + static_cast<int32_t>(r);
+        in[i] = id < total && static_cast<uint32_t>(iy) < cg.H && c - lg.c0 < lg.dchunks;
+        dst[i] = id < total ? id * 16u : 0xFFFFFFFFu;
+        if (in[i]) v[i] = *reinterpret_cast<const v4i*>(img_base + static_cast<uint32_t>(iy) * row_bytes + (c - lg.c0) * 16u);
+      }
+#pragma unroll
+      for (int i = 0; i < kTrip; i++) {
+        v4i y = {zp4, zp4, zp4, zp4};
+        if (in[i]) y = v4i{v[i].x ^ flip, v[i].y ^ flip, v[i].z ^ flip, v[i].w ^ flip};
+        if (dst[i] != 0xFFFFFFFFu) *reinterpret_cast<v4i*>(c3lds + dst[i]) = y;
+      }
+    }
+  }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.output, 0, static_cast<int>((p.rows - 1u) * p.output_stride + p.n), 0x00020000);
+  // this lane's slot of window row h of the band's first unit: row prow * sh + h, column pcol * sw - pad_left behind the data start
+  const uint32_t lane_lds = (prow * cg.sh + h) * lg.pitch + lg.c0 * 16u + pcol * cg.sw * 3u - cg.pad_left * 3u;
+
+  const uint32_t pairs_here = min(lg.ppb, cg.pairs - pair0);
+  const uint32_t nunits = pairs_here * cg.segs;
+  for (uint32_t unit = wave; unit < nunits; unit += kC3Waves) {
+    const uint32_t pl = div_magic(unit, cg.inv_segs);
+    const uint32_t seg = unit - pl * cg.segs;
+    const uint32_t oy = (pair0 + pl) * 2u, ox = seg * 16u;
+    const uint32_t off = lane_lds + pl * 2u * cg.sh * lg.pitch + ox * cg.sw * 3u;
+    const uint32_t shb = off & 3u;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(c3lds + (off & ~3u));
+    v4i x[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      const uint32_t* q = src + kb * 2 * (lg.pitch >> 2);
+      const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+      x[kb] = v4i{static_cast<int>(__builtin_amdgcn_alignbyte(d1, d0, shb)), static_cast<int>(__builtin_amdgcn_alignbyte(d2, d1, shb)),
+                  static_cast<int>(__builtin_amdgcn_alignbyte(d3, d2, shb)), static_cast<int>(__builtin_amdgcn_alignbyte(d4, d3, shb))};
+    }
+    const int32_t rowterm = with_rq_offset<SEQ>(0);
+    uint64_t row_addend = 0;
+    if constexpr (rq_is_lane<SEQ>()) row_addend = lane_addend(rowterm, p.lane);
+    const uint32_t unit_out0 = ((img * cg.OH + oy) * cg.OW + ox) * p.output_stride;
+    const bool row0_ok = oy < cg.OH, row1_ok = oy + 1u < cg.OH;
+    const uint32_t cols_left = cg.OW - ox;
+    v4i outv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[nb][0], x[0], bias[nb], 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[nb][1], x[1], acc, 0, 0, 0);
+      uint32_t pk[4];
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        if constexpr (rq_is_lane<SEQ>()) {
+          pk[rg] = q31_requantize_pack4_lane<SEQ, FULL>(
+              static_cast<uint32_t>(acc[rg * 4 + 0]), static_cast<uint32_t>(acc[rg * 4 + 1]),
+              static_cast<uint32_t>(acc[rg * 4 + 2]), static_cast<uint32_t>(acc[rg * 4 + 3]), row_addend, p.lane, p.rq);
+        } else {
+          pk[rg] = q31_requantize_pack4<SEQ, FULL, false>(add_wrap(acc[rg * 4 + 0], rowterm), add_wrap(acc[rg * 4 + 1], rowterm),
+                                                         add_wrap(acc[rg * 4 + 2], rowterm), add_wrap(acc[rg * 4 + 3], rowterm), p.rq);
+        }
+      }
+      const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+      const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+      outv[nb] = v4i{static_cast<int>(s02[0]), static_cast<int>(s02[1]), static_cast<int>(s13[0]), static_cast<int>(s13[1])};
+    }
+    const bool pixel_ok = (prow != 0u ? row1_ok : row0_ok) && pcol < cols_left;
+    if (NB == 2 && (p.n & 15u) == 0u && p.n > 32u) {            // (wave-uniform) two whole blocks: whole-line stores
+      if constexpr (NB == 2) {
+        c3_store_unit<2>(outv, out_rsrc, unit_out0, cg.OW * p.output_stride, p.output_stride, p.n, row0_ok, row1_ok, pcol < cols_left, prow,
+                         pcol, h, p.stream_out != 0);
+      }
+      continue;
+    }
+    if (NB == 1 && p.n == 24u && p.output_stride == 24u && cols_left >= 16u) {   // (wave-uniform) 24 channels: flat rows of 384 bytes
+      __shared__ __attribute__((aligned(16))) uint8_t c3flat_l[kC3Waves * 768];
+      uint8_t* mine = c3flat_l + wave * 768u;
+      const uint32_t o = prow * 384u + pcol * 24u + h * 16u;
+      *reinterpret_cast<uint2*>(mine + o) = make_uint2(static_cast<uint32_t>(outv[0].x), static_cast<uint32_t>(outv[0].y));
+      if (h == 0u) *reinterpret_cast<uint2*>(mine + o + 8u) = make_uint2(static_cast<uint32_t>(outv[0].z), static_cast<uint32_t>(outv[0].w));
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t crow = lane >= 24u ? 1u : 0u;
+      const v4i c = *reinterpret_cast<const v4i*>(mine + min(lane, 47u) * 16u);
+      const bool cok = lane < 48u && (crow != 0u ? row1_ok : row0_ok);
+      const auto cbits = __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, c);
+      const uint32_t coff = cok ? unit_out0 + crow * cg.OW * 24u + (lane - crow * 24u) * 16u : 0xFFFFFFF0u;
+      if (p.stream_out) __builtin_amdgcn_raw_buffer_store_b128(cbits, out_rsrc, coff, 0, 2);
+      else __builtin_amdgcn_raw_buffer_store_b128(cbits, out_rsrc, coff, 0, 0);
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
+    const uint32_t out_off = unit_out0 + (prow * cg.OW + pcol) * p.output_stride + h * 16u;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      const bool ok = pixel_ok && nb * 32u + h * 16u + 16u <= p.n;             // (n % 8 == 0: launcher)
+      if ((p.n & 8u) != 0u) {
+        const bool ok8 = pixel_ok && nb * 32u + h * 16u + 8u == p.n;
+        typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+        const u2 lo = {static_cast<unsigned int>(outv[nb].x), static_cast<unsigned int>(outv[nb].y)};
+        __builtin_amdgcn_raw_buffer_store_b64(lo, out_rsrc, ok8 ? out_off + nb * 32u : 0xFFFFFFF0u, 0, 0);
+      }
+      const auto bits = __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, outv[nb]);
+      if (p.stream_out) __builtin_amdgcn_raw_buffer_store_b128(bits, out_rsrc, ok ? out_off + nb * 32u : 0xFFFFFFF0u, 0, 2);
+      else __builtin_amdgcn_raw_buffer_store_b128(bits, out_rsrc, ok ? out_off + nb * 32u : 0xFFFFFFF0u, 0, 0);
+    }
+  }
+}
+
+template <int NB>
+int launch_c3rows_lds(const IgemmParams& p, const C3Geom& cg, const C3LdsGeom& lg, hipStream_t stream)
+{
+  const uint32_t grid = (p.rows / (cg.OH * cg.OW)) * lg.bands;
+  // (slack: lanes of positions past the image's edge read on -- at most 16 columns further -- and K block 1 of half 1 reads the row behind
+  //  the window, which the band's last unit does not have)
+  const uint32_t lds_bytes = (lg.nrows + 1u) * lg.pitch + 16u * cg.sw * 3u + 64u;
+  requant_dispatch_lane(p.rq, p.lane, [&](auto seq, auto full) {
+    hipLaunchKernelGGL((q8_conv_c3rows_lds_kernel<NB, decltype(seq)::value, decltype(full)::value>), dim3(grid),
+                       dim3(kC3Threads), lds_bytes, stream, p, cg, lg);
+  });
+  return hipGetLastError() == hipSuccess ? QNNP_HIP_OK : QNNP_HIP_ELAUNCH;
+}
+
 }  // namespace
 
 /* dense 3-byte pixels, one group, window rows of <= 16 bytes and <= 4 rows, 32 or 64 output channels in whole 16-byte
@@ -889,7 +1074,9 @@ bool conv_c3rows_supported(const IgemmParams& p, const ConvGeom& g, uint32_t gro
   return p.row_coeff >= -127 && p.row_coeff <= 128;
 }
 
-int conv_c3rows_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_rows16, hipStream_t stream, const char** name)
+/* flavour: 0 = auto (the LDS-staged kernel where there is no row term and its plan takes the shape), 1 = the register-path kernel,
+ * 2 = the LDS-staged kernel or QNNP_HIP_EINVAL */
+int conv_c3rows_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_rows16, hipStream_t stream, const char** name, int flavour)
 {
   C3Geom cg;
   cg.H = g.H; cg.W = g.W; cg.OH = g.OH; cg.OW = g.OW; cg.KH = g.KH; cg.KW = g.KW; cg.sh = g.sh; cg.sw = g.sw;
@@ -903,9 +1090,18 @@ int conv_c3rows_launch(const IgemmParams& p, const ConvGeom& g, const int8_t* w_
 #ifdef QNNP_ENABLE_ABLATION
   if (const char* env = getenv("QNNP_C3R_ABL")) cg.abl = static_cast<uint32_t>(atoi(env));
 #endif
+  const bool two = p.n_pad > 32;
+  {
+    C3LdsGeom lg;
+    const bool lds = flavour != 1 && p.row_coeff == 0 && c3lds_plan(p, cg, &lg);
+    if (flavour == 2 && !lds) return QNNP_HIP_EINVAL;
+    if (lds) {
+      *name = "q8_conv_c3rows_lds_mfma";
+      return two ? launch_c3rows_lds<2>(p, cg, lg, stream) : launch_c3rows_lds<1>(p, cg, lg, stream);
+    }
+  }
   *name = "q8_conv_c3rows_mfma";
   const bool wide = g.KW * 3u > 12u;
-  const bool two = p.n_pad > 32;
   if (p.row_coeff == 128) {         // kernel zero point 0: the row-term weight does not fit int8, applied as 64 + 64
     if (wide) return two ? launch_c3rows<2, 4, 2>(p, cg, stream) : launch_c3rows<1, 4, 2>(p, cg, stream);
     return two ? launch_c3rows<2, 3, 2>(p, cg, stream) : launch_c3rows<1, 3, 2>(p, cg, stream);

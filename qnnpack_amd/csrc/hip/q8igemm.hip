@@ -707,8 +707,15 @@ extern "C" int qnnp_hip_igemm_run(const struct qnnp_hip_igemm_args* a, const cha
   const bool rows16_ok = pad3 && (p.store_mode == 2 || (p.store_mode == 1 && a->n % 8u == 0)) &&
       qnnp::conv_c3rows_supported(p, geom, a->groups, a->packed_w_rows16, a->kc);
   if ((a->variant == 14 || a->variant == 30) && !rows16_ok && !(pad3 && p.store_mode == 2 && qnnp::conv_c3rows32_supported(p, geom, a->groups, a->packed_w_rows16, a->kc))) return QNNP_HIP_EINVAL;
-  if (rows16_ok && (a->variant == 14 || (a->variant == 0 && a->rows >= 2048))) {
-    const int rc_r16 = qnnp::conv_c3rows_launch(p, geom, a->packed_w_rows16, stream, &name);
+  if (rows16_ok && (a->variant == 14 || a->variant == 30 || (a->variant == 0 && a->rows >= 2048))) {
+    qnnp::IgemmParams p16 = p;
+    if (a->bias2_rows != nullptr) {          // the image is centred on kernel zero point 127: its own bias pair, no row term
+      p16.bias2 = a->bias2_rows;
+      p16.bias2u = a->bias2_rows + a->n_pad;
+      p16.row_coeff = 0;
+      p16.a_flip = 0x7F7F7F7Fu;
+    }
+    const int rc_r16 = qnnp::conv_c3rows_launch(p16, geom, a->packed_w_rows16, stream, &name, a->variant == 14 ? 1 : (a->variant == 30 ? 2 : 0));
     if (kernel_name != nullptr) *kernel_name = name;
     return rc_r16;
   }

@@ -118,6 +118,37 @@ static inline void qnnp_pack_conv_rows16(
   }
 }
 
+/* ... centred on kernel zero point 127 (element 127 - w, activations ^ 0x7F, no row term; qnnp_pack_conv_rows32_centred127 below has the algebra) */
+static inline void qnnp_pack_conv_rows16_centred127(
+    uint32_t n, uint32_t kh, uint32_t kw, uint32_t kc, uint32_t n_pad, uint8_t izp,
+    const uint8_t* kernel, const int32_t* bias, int8_t* packed /* [n_pad / 32][2][64][16] */, int32_t* biasc /* [n_pad] */)
+{
+  memset(packed, 0, (size_t) n_pad * 64);
+  const uint32_t a_off = (uint32_t) (127 - (int32_t) izp);
+  for (uint32_t col = 0; col < n_pad; col++) {
+    uint32_t b = 0;
+    if (col < n) {
+      const uint32_t nb = col / 32;
+      const uint32_t lane_lo = col % 32;
+      uint32_t wsum = 0;                                   /* sum (w - 127), mod 2^32 */
+      for (uint32_t ky = 0; ky < kh; ky++) {
+        for (uint32_t kx = 0; kx < kw; kx++) {
+          for (uint32_t c = 0; c < kc; c++) {
+            const int32_t w = (int32_t) kernel[(((size_t) col * kh + ky) * kw + kx) * kc + c];
+            wsum += (uint32_t) (w - 127);
+            const uint32_t kp = ky * 16 + kx * kc + c;
+            const uint32_t kb = kp / 32;
+            const uint32_t lane = lane_lo + 32 * ((kp % 32) / 16);
+            packed[((((size_t) nb * 2 + kb) * 64) + lane) * 16 + (kp % 16)] = (int8_t) (127 - w);
+          }
+        }
+      }
+      b = (uint32_t) bias[col] + a_off * wsum;
+    }
+    biasc[col] = (int32_t) b;
+  }
+}
+
 /*
  * The same with 32-byte row slots (hip/q8convc3.hip, q8_conv_c3rows32_kernel): windows whose rows are 17 .. 32 bytes of a dense
  * 3-channel image -- ResNet's 7x7 entry layer, bench/convolution.cc:646: 21 bytes -- or have more than four rows. Packed K index

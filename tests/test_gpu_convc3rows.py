@@ -90,8 +90,67 @@ def test_automatic_dispatch_takes_the_row_slot_kernel_for_the_first_layer(qnnp):
     case = ConvCase("r_auto_112", (112, 112), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=32, batch=2)
     expected, quant, out_hw = conv_expected(case)
     out, kname = conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
-    assert kname == KERNEL, kname
+    assert kname == KERNEL16L, kname                           # (rows of whole chunks, kernel zero point 127: the LDS-staged flavour)
     assert_bytes_equal(out, expected, f"gfx950 {kname} (automatic) vs oracle")
+    for case in (ConvCase("r_auto_100", (100, 100), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=32, batch=2),        # rows of 300 bytes
+                 ConvCase("r_auto_112_kzp9", (112, 112), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=32, batch=2, kzp=9)):   # a row term
+        expected, quant, out_hw = conv_expected(case)
+        out, kname = conv_run(qnnp, case, quant, out_hw, to_device=to_device, from_device=from_device)
+        assert kname == KERNEL, kname
+        assert_bytes_equal(out, expected, f"gfx950 {kname} (automatic) vs oracle")
+
+
+# ---- the LDS-staged flavour of the 16-byte-slot kernel (q8_conv_c3rows_lds_kernel, round 6; "gemm_kernel" = 30) ----
+KERNEL16L = "q8_conv_c3rows_lds_mfma"
+CASES16L = [
+    ConvCase("q_3x3_s2_224", (224, 224), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=32),
+    ConvCase("q_3x3_s2_first_layer", (32, 32), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=32, batch=2),
+    ConvCase("q_3x3_s1_pad", (13, 16), (3, 3), _pad(1, 1), gic=3, goc=32, batch=3),
+    ConvCase("q_3x3_nopad", (9, 16), (3, 3), gic=3, goc=32),
+    ConvCase("q_3x3_s2_odd_output_rows", (30, 32), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=32, batch=5),
+    ConvCase("q_3x3_pad_right_bottom_only", (10, 16), (3, 3), (0, 2, 2, 0), gic=3, goc=32, batch=2),
+    ConvCase("q_3x3_pad_left_top_2", (10, 16), (3, 3), (2, 0, 0, 2), gic=3, goc=32, batch=2),
+    ConvCase("q_3x3_s3", (17, 32), (3, 3), _pad(1, 1), subsampling=(3, 3), gic=3, goc=32),
+    ConvCase("q_3x3_s2x1", (16, 16), (3, 3), _pad(1, 1), subsampling=(2, 1), gic=3, goc=32),
+    ConvCase("q_1x1_s2", (9, 16), (1, 1), subsampling=(2, 2), gic=3, goc=32),
+    ConvCase("q_2x2_s2", (10, 16), (2, 2), subsampling=(2, 2), gic=3, goc=16, batch=3),
+    ConvCase("q_3x3_s2_24_channels", (40, 48), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=24, batch=3),
+    ConvCase("q_3x3_s2_24_channels_flat_rows_odd_height", (41, 64), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=24, batch=3),
+    ConvCase("q_3x3_s1_8_channels", (13, 16), (3, 3), _pad(1, 1), gic=3, goc=8, batch=2),
+    ConvCase("q_3x3_s2_56_channels_izp", (17, 32), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=56, izp=9, batch=2),
+    ConvCase("q_4x4_pad", (11, 16), (4, 4), (1, 2, 2, 1), gic=3, goc=64),
+    ConvCase("q_4x5_wide_window", (12, 16), (4, 5), (1, 2, 2, 2), gic=3, goc=48, batch=2),
+    ConvCase("q_1x5", (6, 32), (1, 5), (0, 2, 0, 2), gic=3, goc=32),
+    ConvCase("q_3x1_tall", (20, 16), (3, 1), (1, 0, 1, 0), gic=3, goc=32),
+    ConvCase("q_one_row_images", (1, 16), (3, 3), _pad(1, 1), gic=3, goc=32, batch=70),
+    ConvCase("q_3x3_n64_whole_lines", (9, 16), (3, 3), _pad(1, 1), gic=3, goc=64, batch=2),
+    ConvCase("q_3x3_s1_224_n64_vgg", (224, 224), (3, 3), _pad(1, 1), gic=3, goc=64),
+    ConvCase("q_3x3_out_stride", (8, 16), (3, 3), _pad(1, 1), gic=3, goc=32, output_pixel_stride=48),
+    ConvCase("q_3x3_kzp128", (10, 16), (3, 3), _pad(1, 1), gic=3, goc=32, kzp=128, izp=200),
+    ConvCase("q_3x3_izp_extremes", (10, 16), (3, 3), _pad(1, 1), gic=3, goc=32, izp=255),
+    ConvCase("q_3x3_izp_0", (10, 16), (3, 3), _pad(1, 1), gic=3, goc=32, izp=0),
+    ConvCase("q_3x3_clamp", (10, 16), (3, 3), _pad(1, 1), gic=3, goc=32, qmin=90, qmax=160),
+    ConvCase("q_3x3_many_bands", (96, 48), (3, 3), _pad(1, 1), subsampling=(2, 2), gic=3, goc=32, batch=24),
+]
+
+
+@pytest.mark.parametrize("case", CASES16L, ids=lambda c: c.name)
+def test_lds_staged_row_slot_kernel_matches_oracle(rows32lds, case):
+    expected, quant, out_hw = conv_expected(case)
+    out, kname = conv_run(rows32lds, case, quant, out_hw, to_device=to_device, from_device=from_device)
+    assert kname == KERNEL16L, kname
+    assert_bytes_equal(out, expected, f"gfx950 {kname} vs oracle [{case.name}]")
+
+
+@pytest.mark.parametrize("case", [
+    ConvCase("q_bad_row_term", (10, 16), (3, 3), _pad(1, 1), gic=3, goc=32, kzp=200),        # the LDS flavour has no row term
+    ConvCase("q_bad_w20", (12, 20), (3, 3), _pad(1, 1), gic=3, goc=32),                       # rows of 60 bytes
+], ids=lambda c: c.name)
+def test_lds_staged_row_slot_kernel_refuses_what_it_cannot_take(rows32lds, case):
+    from qnnpack_amd import QnnpackError
+    _, quant, out_hw = conv_expected(case)
+    with pytest.raises(QnnpackError):
+        conv_run(rows32lds, case, quant, out_hw, to_device=to_device, from_device=from_device)
 
 
 # ---- the 32-byte-slot flavour (q8_conv_c3rows32_kernel, round 5): 5- and 7-row windows of up to 32 bytes per row ----

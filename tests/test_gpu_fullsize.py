@@ -197,7 +197,7 @@ def test_c5_mobilenetv2_first_layer(qnnp):
         d_in, d_out = to_device(inp), to_device(np.full(expected.size, FILL, np.uint8))
         qnnp.setup_convolution2d_nhwc_q8(op, batch, 224, 224, d_in, 3, d_out, 32)
         qnnp.run_operator(op)
-        assert qnnp.operator_kernel(op) == "q8_conv_c3rows_mfma", qnnp.operator_kernel(op)
+        assert qnnp.operator_kernel(op) == "q8_conv_c3rows_lds_mfma", qnnp.operator_kernel(op)   # (round 6: W * 3 % 16 == 0, k_zp 127)
         assert_bytes_equal(from_device(d_out), expected, "C5 first layer vs oracle")
     finally:
         qnnp.delete_operator(op)

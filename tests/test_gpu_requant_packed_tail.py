@@ -21,7 +21,7 @@ CASES = [("pw_16_96",      56, 56, 1, 1, 1, 1, 16,  96,  4,  "q8_pw_stream_mfma"
          ("pw_96_24",      28, 28, 1, 1, 1, 1, 96,  24,  8,  "q8_pw_stream_mfma"),
          ("ws3x3_64",      56, 56, 3, 3, 1, 1, 64,  64,  8,  "q8_conv_wave_ws"),
          ("patch3x3_128",  28, 28, 3, 3, 1, 1, 128, 128, 8,  "q8_conv_patch_mfma"),
-         ("c3rows_3x3s2",  64, 64, 3, 3, 2, 1, 3,   32,  4,  "q8_conv_c3rows_mfma"),
+         ("c3rows_3x3s2",  64, 64, 3, 3, 2, 1, 3,   32,  4,  "q8_conv_c3rows_lds_mfma"),
          ("c3rows32_7x7",  64, 64, 7, 7, 2, 1, 3,   64,  4,  "q8_conv_c3rows32_lds_mfma")]
 # requantization scale -> shift: 0.3 -> 1, 0.12 -> 3, 0.05 -> 4, 0.02 -> 5, 0.0125 -> 6, 0.006 -> 7, 0.0031 -> 8
 SCALES = [0.3, 0.12, 0.05, 0.02, 0.0125, 0.006, 0.0031]
