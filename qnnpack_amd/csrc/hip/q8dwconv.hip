@@ -424,6 +424,19 @@ template <typename T>
 struct __attribute__((packed)) DwAnyAligned { T v; };
 template <typename T>
 __device__ __forceinline__ T dw_load_any(const void* ptr) { return reinterpret_cast<const DwAnyAligned<T>*>(ptr)->v; }
+// (HIP's vector types are not POD for the packed attribute: their unaligned loads are spelled out dword by dword)
+template <>
+__device__ __forceinline__ uint2 dw_load_any<uint2>(const void* ptr)
+{
+  const uint8_t* b = static_cast<const uint8_t*>(ptr);
+  return make_uint2(dw_load_any<uint32_t>(b), dw_load_any<uint32_t>(b + 4));
+}
+template <>
+__device__ __forceinline__ int4 dw_load_any<int4>(const void* ptr)
+{
+  const uint8_t* b = static_cast<const uint8_t*>(ptr);
+  return make_int4(dw_load_any<int32_t>(b), dw_load_any<int32_t>(b + 4), dw_load_any<int32_t>(b + 8), dw_load_any<int32_t>(b + 12));
+}
 template <typename T>
 __device__ __forceinline__ void dw_store_any(void* ptr, T v) { reinterpret_cast<DwAnyAligned<T>*>(ptr)->v = v; }
 
@@ -2246,7 +2259,7 @@ void q8_dwconv_mfma16_3x3_kernel(const DwParams p)
   // (layer 8: 64 us) -- re-centred, written to LDS lane-linearly and read back in the fragment pattern. Pixel pitch in LDS: 3 chunks
   // (an odd number: the sixteen pixels of a ds_read_b128 lane group fall into sixteen different bank quads).
   constexpr uint32_t kPitch = 3u;                  // 16-byte chunks per pixel in LDS
-  constexpr uint32_t kRowBytes = 18u * kPitch * 16u;              // 864
+  // (a row buffer: 18 pixels x kPitch chunks = 864 bytes of its 1 KiB slot)
   __shared__ __attribute__((aligned(16))) uint8_t lds[(kM16Threads / 64) * 4 * 1024];      // per wave: 3 row buffers + the output row image
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t fp = lane & 15u;                 // operand: position; result: position
